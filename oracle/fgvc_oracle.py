@@ -1,0 +1,528 @@
+"""CPU restatement of FGVC's label-propagation inference hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this module, and only as the
+checker / the reported CPU baseline.  The product path (`fgvc_amd`) never imports
+it and has no CPU fallback.
+
+Pinning: the reference ships no tests or golden vectors for this path
+(SURVEY.md section 4), so this restatement is pinned against OUTPUTS OF THE REFERENCE
+ITSELF: `tests/golden/gen_golden.py` imports the genuine reference operators from
+/root/reference in the build container (via oracle/ref_import.py) and commits
+their inputs/outputs as fixtures under tests/golden/; `tests/test_oracle.py`
+checks every function below against those fixtures, and
+`tests/test_oracle_vs_reference.py` re-checks live when /root/reference exists.
+Third-party arithmetic that is NOT under /root/reference and therefore stays
+"parity unpinned": mmcv-full==1.5.2 `ConvModule` (restated as Conv2d+BatchNorm2d+
+ReLU, exact given identical weights) and `mmcv.ops.Correlation` (restated from the
+reference's own torch-only twin `masked_attention_efficient_correlation_v2`).
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).  All tensors are torch CPU tensors; dtype follows the inputs
+(float32 = the reference's arithmetic, float64 = the "infinitely precise" arm
+used to find near-ties).
+
+Tie policy (torch.topk / np.argsort leave tie order unspecified):
+    top-k lists are in CANONICAL order = (score descending, index ascending);
+    the soft-argmax read-out prefers the HIGHER flat index among equal values
+    (what a stable ascending argsort followed by [-5:] yields).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+NEG_INF = float("-inf")
+
+
+# ----------------------------------------------------------------------------
+# A4  spatial neighbourhood mask
+# ----------------------------------------------------------------------------
+def neighbor_predicate(dy: torch.Tensor, dx: torch.Tensor, neighbor_range, mode: str = "circle") -> torch.Tensor:
+    """The mask predicate on integer offsets (key - query).
+
+    mmpt/models/common/affinity_utils.py:75-112: 'circle' keeps
+    sqrt(dy^2+dx^2) < neighbor_range//2 evaluated in float32 (:101-109);
+    'square' keeps |dy| <= nr_h//2 and |dx| <= nr_w//2 (:88-96).
+    """
+    if mode == "circle":
+        radius = neighbor_range // 2
+        d = (dy.to(torch.float32) ** 2 + dx.to(torch.float32) ** 2) ** 0.5
+        return d < radius
+    if mode == "square":
+        nr = (neighbor_range, neighbor_range) if isinstance(neighbor_range, int) else tuple(neighbor_range)
+        return (dy.abs() <= nr[0] // 2) & (dx.abs() <= nr[1] // 2)
+    raise ValueError(mode)
+
+
+def spatial_neighbor(height: int, width: int, neighbor_range, mode: str = "circle") -> torch.Tensor:
+    """(HW, HW) bool, mask[key, query]  (affinity_utils.py:75-112, dim=1 layout)."""
+    ys = torch.arange(height).view(height, 1).expand(height, width).reshape(-1)
+    xs = torch.arange(width).view(1, width).expand(height, width).reshape(-1)
+    dy = ys.view(-1, 1) - ys.view(1, -1)
+    dx = xs.view(-1, 1) - xs.view(1, -1)
+    return neighbor_predicate(dy, dx, neighbor_range, mode)
+
+
+def radius_predicate_r2max(radius: float) -> int:
+    """Largest integer d2 with float32 sqrt(d2) < radius (v2's `dist < radius`,
+    local_attention.py:463-467, and the circle mask above).  -1 if none."""
+    r = np.float32(radius)
+    d2 = int(math.ceil(float(radius) ** 2)) + 2
+    while d2 >= 0 and not (np.sqrt(np.float32(d2)) < r):
+        d2 -= 1
+    return d2
+
+
+# ----------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------
+def l2_normalize(x: torch.Tensor, dim: int = 1) -> torch.Tensor:
+    """F.normalize(p=2, eps=1e-12) (local_attention.py:308-310)."""
+    return x / x.norm(p=2, dim=dim, keepdim=True).clamp_min(1e-12)
+
+
+def topk_canonical(aff: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Top-k along dim 0 of an (M, S) slab in canonical order.
+
+    Restates `cur_affinity.topk(k, dim=1)` (local_attention.py:356) with the tie
+    order fixed to (score desc, index asc).  Returns (values (k,S), indices (k,S)).
+    """
+    M, S = aff.shape
+    k = min(k, M)
+    vals, _ = aff.topk(k, dim=0)
+    kth = vals[k - 1]                                   # (S,)
+    gt = aff > kth                                      # strictly better than the k-th value
+    need = k - gt.sum(0)                                # how many k-th-valued entries to take
+    eq = aff == kth
+    take = eq & (eq.cumsum(0) <= need)                  # lowest indices among the equals
+    sel = gt | take                                     # exactly k per column
+    idx_by_index = sel.t().nonzero()[:, 1].view(S, k)   # per column, ascending index
+    v = aff.t().gather(1, idx_by_index)
+    order = torch.sort(v, dim=1, descending=True, stable=True)[1]
+    idx = idx_by_index.gather(1, order).t().contiguous()
+    val = v.gather(1, order).t().contiguous()
+    return val, idx
+
+
+# ----------------------------------------------------------------------------
+# A5''  dense correlation volume
+# ----------------------------------------------------------------------------
+def corr_volume(query: torch.Tensor, key: torch.Tensor, temperature: float = 1.0,
+                normalize: bool = True, q_slice: Optional[slice] = None) -> torch.Tensor:
+    """A[t*HWk + j, i] = <k_hat[:,t,j], q_hat[:,i]> / temperature.
+
+    query (C,Hq,Wq), key (C,T,Hk,Wk) -> (T*HWk, HWq[q_slice]).
+    local_attention.py:321-323 (chunked), :231 (`masked_attention`),
+    affinity_utils.py:6-21 (`compute_affinity`, transposed operand roles).
+    """
+    if key.dim() == 3:
+        key = key.unsqueeze(1)
+    if normalize:
+        query = l2_normalize(query, 0)
+        key = l2_normalize(key, 0)
+    C = query.shape[0]
+    qv = query.reshape(C, -1)
+    kv = key.reshape(C, -1)
+    if q_slice is not None:
+        qv = qv[:, q_slice]
+    return torch.einsum("ci,cj->ij", kv, qv) / temperature
+
+
+def mask_slab(Hq: int, Wq: int, Hk: int, Wk: int, T: int, q_index: torch.Tensor,
+              neighbor_range, mode: str, non_mask_len: int = 0) -> torch.Tensor:
+    """(T*HkWk, len(q_index)) bool validity slab (local_attention.py:329-353)."""
+    assert (Hq, Wq) == (Hk, Wk), "the analytic mask is defined on equal grids"
+    qy, qx = q_index // Wq, q_index % Wq
+    ky = torch.arange(Hk).view(Hk, 1).expand(Hk, Wk).reshape(-1)
+    kx = torch.arange(Wk).view(1, Wk).expand(Hk, Wk).reshape(-1)
+    m = neighbor_predicate(ky.view(-1, 1) - qy.view(1, -1), kx.view(-1, 1) - qx.view(1, -1),
+                           neighbor_range, mode)              # (HkWk, S)
+    m = m.unsqueeze(0).expand(T, -1, -1).clone()
+    m[:non_mask_len] = True
+    return m.reshape(T * Hk * Wk, -1)
+
+
+# ----------------------------------------------------------------------------
+# A5  affinity top-k  +  propagation
+# ----------------------------------------------------------------------------
+def affinity_topk(query: torch.Tensor, key: torch.Tensor, topk: int, temperature: float = 1.0,
+                  neighbor_range=None, mask_mode: str = "circle", mask: Optional[torch.Tensor] = None,
+                  normalize: bool = True, non_mask_len: int = 0, step: int = 512,
+                  q_index: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per query pixel: canonical top-k (logit, flat key index t*HWk+j).
+
+    query (C,Hq,Wq), key (C,T,Hk,Wk).  Returns idx (S,k) int64, logit (S,k)
+    where S = HqWq or len(q_index).  Follows local_attention.py:308-356.
+    Either `neighbor_range`(+`mask_mode`) (analytic) or a dense `mask`
+    (HkWk, HqWq) bool, or neither (no mask).
+    """
+    if key.dim() == 3:
+        key = key.unsqueeze(1)
+    C, Hq, Wq = query.shape
+    _, T, Hk, Wk = key.shape
+    if normalize:
+        query = l2_normalize(query, 0)
+        key = l2_normalize(key, 0)
+    qv = query.reshape(C, -1)
+    kv = key.reshape(C, -1)
+    if q_index is None:
+        q_index = torch.arange(Hq * Wq)
+    idx_out, val_out = [], []
+    for p in range(0, q_index.numel(), step):
+        qi = q_index[p:p + step]
+        aff = torch.einsum("ci,cj->ij", kv, qv[:, qi]) / temperature      # :321-323
+        if mask is not None:
+            m = mask[:, qi].unsqueeze(0).expand(T, -1, -1).clone()
+            m[:non_mask_len] = True
+            aff = aff.masked_fill(~m.reshape(T * Hk * Wk, -1), NEG_INF)  # :353
+        elif neighbor_range is not None:
+            m = mask_slab(Hq, Wq, Hk, Wk, T, qi, neighbor_range, mask_mode, non_mask_len)
+            aff = aff.masked_fill(~m, NEG_INF)
+        v, i = topk_canonical(aff, topk)                                  # :356
+        idx_out.append(i.t())
+        val_out.append(v.t())
+    return torch.cat(idx_out, 0), torch.cat(val_out, 0)
+
+
+def topk_weights(logit: torch.Tensor, mode: str = "softmax") -> torch.Tensor:
+    """local_attention.py:368-373: softmax over the k, or clamp(min=0)**2."""
+    if mode == "softmax":
+        return logit.softmax(dim=-1)
+    if mode == "cosine":
+        return logit.clamp(min=0) ** 2
+    raise ValueError(mode)
+
+
+def propagate_topk(value: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """out[p, i] = sum_r weight[i, r] * value[p, idx[i, r]]  (local_attention.py:360-375).
+
+    value (P, T*HWk) (flattened), idx/weight (S,k) -> (P, S).
+    """
+    P = value.shape[0]
+    g = value.reshape(P, -1)[:, idx.reshape(-1)].reshape(P, *idx.shape)   # (P,S,k)
+    return (g * weight.unsqueeze(0)).sum(-1)
+
+
+def masked_attention_efficient(query, key, value, mask=None, temperature=1, topk=None, normalize=True,
+                               step=32, non_mask_len=0, mode="softmax", neighbor_range=None,
+                               mask_mode="circle"):
+    """Same contract as local_attention.py:267-389 for N=1, sim_mode='dot_product', topk given.
+
+    query (1,C,Hq,Wq), key (1,C,T,Hk,Wk), value (1,P,T,Hk,Wk) -> (1,P,Hq,Wq).
+    """
+    assert query.shape[0] == 1 and topk is not None
+    if key.dim() == 4:
+        key, value = key.unsqueeze(2), value.unsqueeze(2)
+    idx, logit = affinity_topk(query[0], key[0], topk, temperature, neighbor_range, mask_mode, mask,
+                               normalize, non_mask_len, step)
+    w = topk_weights(logit, mode)
+    out = propagate_topk(value[0].reshape(value.shape[1], -1), idx, w)
+    return out.reshape(1, value.shape[1], query.shape[2], query.shape[3])
+
+
+# ----------------------------------------------------------------------------
+# A7 / A7'  single-scale local-window correlation + top-k
+# ----------------------------------------------------------------------------
+def local_corr(query: torch.Tensor, keys: torch.Tensor, radius: int, normalize: bool = True) -> torch.Tensor:
+    """mmcv.ops.Correlation(max_displacement=R, kernel_size=1) semantics as relied on at
+    vanilla_tracker.py:435-443: out[k, dy*(2R+1)+dx, y, x] = sum_c q[c,y,x]*key[k,c,y+dy-R,x+dx-R],
+    zero outside.  query (C,H,W), keys (K,C,H,W) -> (K,(2R+1)^2,H,W).  (Twin: local_attention.py:1190-1198.)
+    """
+    if normalize:
+        query = l2_normalize(query, 0)
+        keys = l2_normalize(keys, 1)
+    K, C, H, W = keys.shape
+    L = 2 * radius + 1
+    unf = F.unfold(keys, kernel_size=L, padding=radius).reshape(K, C, L * L, H, W)
+    return (unf * query.view(1, C, 1, H, W)).sum(1)
+
+
+def local_corr_topk(query, keys, values, radius: int, topk: int, temperature: float = 1.0,
+                    normalize: bool = True):
+    """HRVanillaTracker.forward_test_main inner step (vanilla_tracker.py:547-566) /
+    masked_attention_efficient_correlation_v2 (local_attention.py:1190-1240).
+
+    query (C,H,W), keys (K,C,H,W), values (K,P,H,W) -> out (P,H,W), idx (HW,k), logit (HW,k)
+    where idx = k_slot*(2R+1)^2 + dy*(2R+1)+dx and logit = corr/temperature (divided AFTER top-k).
+    """
+    K, P, H, W = values.shape
+    L = 2 * radius + 1
+    corr = local_corr(query, keys, radius, normalize).reshape(K * L * L, H * W)
+    val, idx = topk_canonical(corr, topk)                           # :558 / :1229
+    unf_v = F.unfold(values, kernel_size=L, padding=radius).reshape(K, P, L * L, H * W)
+    unf_v = unf_v.permute(1, 0, 2, 3).reshape(P, K * L * L, H * W)  # :550-555
+    g = unf_v.gather(1, idx.unsqueeze(0).expand(P, -1, -1))         # :561
+    logit = val / temperature                                       # :563
+    w = logit.softmax(0)                                            # :564
+    out = (g * w.unsqueeze(0)).sum(1).reshape(P, H, W)              # :566
+    return out, idx.t().contiguous(), logit.t().contiguous()
+
+
+# ----------------------------------------------------------------------------
+# A6  coarse-to-fine refine
+# ----------------------------------------------------------------------------
+def c2f_attention(query, key, query_fine, key_fine, value, topk: int, temperature: float = 1.0,
+                  neighbor_range=None, mask_mode="circle", normalize: bool = True,
+                  radius_fine: int = 12, non_mask_len: int = 0, step: int = 512):
+    """masked_attention_efficient_c2f (local_attention.py:721-880), N=1.
+
+    query (C,H,W), key (C,T,H,W), query_fine (Cf,sH,sW), key_fine (Cf,T,sH,sW),
+    value (P,T,sH,sW) -> out (P,H,W), coarse argmax (T,HW), idx (HW,k), logit (HW,k).
+    """
+    C, H, W = query.shape
+    T = key.shape[1]
+    Cf, Hf, Wf = query_fine.shape
+    P = value.shape[0]
+    scale = key_fine.shape[2] // key.shape[2]                        # :769
+    if normalize:                                                    # :771-775
+        query, key = l2_normalize(query, 0), l2_normalize(key, 0)
+        query_fine, key_fine = l2_normalize(query_fine, 0), l2_normalize(key_fine, 0)
+    L = 2 * radius_fine + 1
+    qf = query_fine[:, ::scale, ::scale].reshape(Cf, -1)             # :785
+    kf_unf = F.unfold(key_fine.transpose(0, 1), kernel_size=L, padding=radius_fine,
+                      stride=scale).reshape(T, Cf, L * L, H * W)     # :790
+    v_unf = F.unfold(value.transpose(0, 1), kernel_size=L, padding=radius_fine,
+                     stride=scale).reshape(T, P, L * L, H * W)       # :793
+    qv, kv = query.reshape(C, -1), key.reshape(C, -1)
+    HW = H * W
+    outs, arg_all, idx_all, logit_all = [], [], [], []
+    for p in range(0, HW, step):
+        qi = torch.arange(p, min(HW, p + step))
+        s = qi.numel()
+        aff = torch.einsum("ci,cj->ij", kv, qv[:, qi]) / temperature            # :804-806
+        if neighbor_range is not None:
+            m = mask_slab(H, W, H, W, T, qi, neighbor_range, mask_mode, non_mask_len)
+            aff = aff.masked_fill(~m, NEG_INF)                                   # :832
+        aff = aff.reshape(T, HW, s).softmax(1)                                   # :835
+        am = aff.argmax(1)                                                       # :837 (T,s)
+        gi = am.view(T, 1, 1, s)
+        k_sel = kf_unf.gather(3, gi.expand(T, Cf, L * L, s))                     # :841
+        fine = (k_sel * qf[:, qi].view(1, Cf, 1, s)).sum(1) / temperature        # :847 (T,LL,s)
+        fine = fine.reshape(T * L * L, s)
+        v_sel = v_unf.gather(3, gi.expand(T, P, L * L, s))                       # :853
+        v_sel = v_sel.permute(1, 0, 2, 3).reshape(P, T * L * L, s)               # :855
+        val, idx = topk_canonical(fine, topk)                                    # :859
+        g = v_sel.gather(1, idx.unsqueeze(0).expand(P, -1, -1))                  # :862
+        w = val.softmax(0)                                                       # :865
+        outs.append((g * w.unsqueeze(0)).sum(1))                                 # :870
+        arg_all.append(am); idx_all.append(idx.t()); logit_all.append(val.t())
+    out = torch.cat(outs, 1).reshape(P, H, W)
+    return out, torch.cat(arg_all, 1), torch.cat(idx_all, 0), torch.cat(logit_all, 0)
+
+
+# ----------------------------------------------------------------------------
+# A3  initial Gaussian labels,  A8 upsample,  A9 soft-argmax read-out
+# ----------------------------------------------------------------------------
+def gaussian_labels(points_xy: torch.Tensor, h: int, w: int, stride: int, sigma: float = 6.0):
+    """vanilla_tracker.py:193-221.  points (P,2)=(x,y) -> full (P,h,w), feature-res (P,ceil(h/s),ceil(w/s))."""
+    xs = torch.arange(w, dtype=torch.float32).view(1, 1, w)
+    ys = torch.arange(h, dtype=torch.float32).view(1, h, 1)
+    cx = points_xy[:, 0].to(torch.float32).view(-1, 1, 1)
+    cy = points_xy[:, 1].to(torch.float32).view(-1, 1, 1)
+    g = torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * sigma ** 2))
+    return g, g[:, ::stride, ::stride]
+
+
+def upsample_bilinear(label: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """vanilla_tracker.py:396-400: F.interpolate(bilinear, align_corners=False). (P,Hf,Wf)->(P,h,w)."""
+    return F.interpolate(label.unsqueeze(0), size=(h, w), mode="bilinear", align_corners=False)[0]
+
+
+def img2coord(maps: np.ndarray, topk: int = 5) -> np.ndarray:
+    """vanilla_tracker.py:172-191.  maps (T,P,h,w) float32 -> coords (2,P,T) float64.
+
+    Canonical tie order: stable ascending argsort, last `topk` (higher index wins ties).
+    """
+    T, P, h, w = maps.shape
+    flat = maps.reshape(T, P, -1)
+    order = np.argsort(flat, axis=-1, kind="stable")[..., -topk:]           # :181
+    v = np.take_along_axis(flat, order, axis=-1)                             # :182
+    v = v / (np.sum(v, keepdims=True, axis=-1) + 1e-9)                       # :183 (stays float32)
+    x = order % w                                                            # :184
+    y = order // w                                                           # :185
+    coords = np.zeros((2, P, T), dtype=float)
+    coords[0] = np.sum(x * v, axis=-1).T                                     # :187 (int64*f32 -> f64)
+    coords[1] = np.sum(y * v, axis=-1).T
+    coords[:, np.sum(flat.transpose(1, 0, 2), axis=-1) == 0] = -1            # :189
+    return coords
+
+
+# ----------------------------------------------------------------------------
+# A1  ResNet-18 trunk (mmcv ConvModule naming)
+# ----------------------------------------------------------------------------
+class _CM(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+        self.act = act
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x) if self.act else x
+
+
+class _Block(nn.Module):
+    """BasicBlock (resnet.py:16-116): conv3x3(stride)-BN-ReLU, conv3x3-BN, +identity, ReLU."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = _CM(cin, cout, 3, stride, 1, True)
+        self.conv2 = _CM(cout, cout, 3, 1, 1, False)
+        self.downsample = _CM(cin, cout, 1, stride, 0, False) if (stride != 1 or cin != cout) else None
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        return F.relu(self.conv2(self.conv1(x)) + idt)
+
+
+class ResNet18(nn.Module):
+    """resnet.py:329-638 for depth=18, pool_type in {'none','max'}; returns stage out_index.
+
+    state_dict keys equal the reference's (conv1.conv.weight, layer1.0.conv1.bn.running_mean, ...).
+    Like the reference it builds all four stages; unlike it, forward stops after out_index
+    (the later stages do not influence the returned tensor, resnet.py:619-627).
+    """
+
+    def __init__(self, strides=(1, 2, 2, 2), out_index=3, pool_type="max"):
+        super().__init__()
+        self.conv1 = _CM(3, 64, 7, 2, 3, True)                       # resnet.py:457-466
+        self.pool = nn.MaxPool2d(3, 2, 1) if pool_type == "max" else None
+        cin = 64
+        for i, s in enumerate(strides):
+            planes = 64 * 2 ** i
+            setattr(self, f"layer{i + 1}", nn.Sequential(_Block(cin, planes, s), _Block(planes, planes, 1)))
+            cin = planes
+        self.out_index = out_index
+
+    def forward(self, x):
+        x = self.conv1(x)
+        if self.pool is not None:
+            x = self.pool(x)
+        for i in range(self.out_index + 1):
+            x = getattr(self, f"layer{i + 1}")(x)
+        return x
+
+
+def seeded_resnet_state(seed: int = 0, strides=(1, 1, 1, 4), pool_type="none"):
+    """Synthetic weights per SURVEY.md section 8d: kaiming-normal(fan_out) convs, BN gamma=1 beta=0,
+    running stats (0,1); the last BN of each block is NOT zeroed."""
+    g = torch.Generator().manual_seed(seed)
+    net = ResNet18(strides, 3, pool_type)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if k.endswith("conv.weight"):
+            fan_out = v.shape[0] * v.shape[2] * v.shape[3]
+            sd[k] = torch.randn(v.shape, generator=g) * math.sqrt(2.0 / fan_out)
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# A2/A10  tracker driver
+# ----------------------------------------------------------------------------
+def key_slots(frame_idx: int, precede_frames: int = 5, with_first: bool = True):
+    """Key/value frame list for query frame `frame_idx` (vanilla_tracker.py:346-362):
+    [0] + [max(0,idx-p) .. idx-1]; frame 0 appears twice while idx <= p."""
+    ks = list(range(max(0, frame_idx - precede_frames), frame_idx))
+    return ([0] + ks) if with_first else ks
+
+
+def forward_test_main(feats: torch.Tensor, query_xy: torch.Tensor, h: int, w: int, *, precede_frames=5,
+                      topk=10, temperature=0.07, neighbor_range=30, mask_mode="circle", with_first=True,
+                      with_first_neighbor=True, normalize=True, step=512, mode="softmax", return_all=False):
+    """VanillaTracker.forward_test_main after feature extraction (vanilla_tracker.py:321-412).
+
+    feats (T,C,Hf,Wf) encoder outputs, query_xy (P,2)=(x,y) at frame 0.
+    Returns trajectories_pred (1,T,P,2) float64 [+ per-frame internals].
+    """
+    T, C, Hf, Wf = feats.shape
+    stride = h // Hf                                                   # :197
+    full0, lab0 = gaussian_labels(query_xy, h, w, stride)
+    assert lab0.shape[-2:] == (Hf, Wf), (lab0.shape, Hf, Wf)
+    P = lab0.shape[0]
+    labels = [lab0]
+    preds = [full0]
+    idxs, logits = [], []
+    for f in range(1, T):
+        ks = key_slots(f, precede_frames, with_first)
+        key = feats[ks].transpose(0, 1)                                # (C,T',Hf,Wf)
+        val = torch.stack([labels[k] for k in ks], 1)                  # (P,T',Hf,Wf)
+        idx, logit = affinity_topk(feats[f], key, topk, temperature, neighbor_range, mask_mode, None,
+                                   normalize, 0 if with_first_neighbor else 1, step)
+        out = propagate_topk(val.reshape(P, -1), idx, topk_weights(logit, mode)).reshape(P, Hf, Wf)
+        labels.append(out)
+        preds.append(upsample_bilinear(out, h, w))
+        idxs.append(idx); logits.append(logit)
+    seg = torch.stack(preds, 0).numpy()                                # (T,P,h,w)  :404
+    coords = img2coord(seg)                                            # :406
+    traj = torch.from_numpy(coords).permute(2, 1, 0).unsqueeze(0)      # :407
+    if return_all:
+        return traj, dict(labels=torch.stack(labels, 0), idx=idxs, logit=logits)
+    return traj
+
+
+def forward_test(encode, rgbs: torch.Tensor, query_points: torch.Tensor, trajectories, visibilities, **cfg):
+    """VanillaTracker.forward_test regrouping by query time (vanilla_tracker.py:246-303).
+
+    encode(frames (T,3,h,w)) -> feats (T,C,Hf,Wf).  rgbs (1,T,3,h,w), query_points (1,P,3)=(t,x,y).
+    """
+    B, T, P = trajectories.shape[:3]
+    h, w = rgbs.shape[-2:]
+    if not cfg.get("with_first", True):
+        traj = forward_test_main(encode(rgbs[0]), query_points[0, :, 1:], h, w, **cfg)
+        return trajectories, visibilities, traj, torch.zeros_like(visibilities), query_points
+    ts = torch.unique(query_points[:, :, 0])
+    qp_r = torch.zeros_like(query_points)
+    tr_r, vi_r = torch.zeros_like(trajectories), torch.zeros_like(visibilities)
+    tp_r = torch.zeros_like(trajectories)
+    K = 0
+    for t in [int(v) for v in ts]:
+        sel = query_points[0, :, 0] == t
+        n = int(sel.sum())
+        qp = query_points[:, sel].clone()
+        qp_r[:, K:K + n] = qp
+        traj = forward_test_main(encode(rgbs[0, t:]), qp[0, :, 1:], h, w, **cfg)    # :284
+        tp_r[:, t:, K:K + n] = traj.to(tp_r.dtype)                                   # zero prefix :286
+        tr_r[:, :, K:K + n] = trajectories[:, :, sel]
+        vi_r[:, :, K:K + n] = visibilities[:, :, sel]
+        K += n
+    return tr_r, vi_r, tp_r, torch.zeros_like(visibilities), qp_r
+
+
+# ----------------------------------------------------------------------------
+# tolerance-aware comparison of a top-k result against a dense score slab
+# ----------------------------------------------------------------------------
+def check_topk(dense: torch.Tensor, idx: torch.Tensor, score: torch.Tensor, k: int,
+               tol: float = 1e-3, gap: float = 1e-5) -> dict:
+    """Validate (idx, score) (S,k) against the dense slab `dense` (M,S) (ideally float64).
+
+    * every reported score is within `tol` of dense[idx]                       (score parity)
+    * every selected index is a legitimate top-k member: dense[idx] >= kth_dense - tol
+    * on columns whose ranks 1..k+1 are separated by more than `gap` in `dense`,
+      idx must equal the canonical dense top-k EXACTLY (bit-exact index parity)
+    Returns counts; raises AssertionError on violation.
+    """
+    M, S = dense.shape
+    kk = min(k + 1, M)
+    dv, di = topk_canonical(dense, kk)
+    dv, di = dv.t(), di.t()                                       # (S,kk)
+    got = dense.t().gather(1, idx.clamp_min(0).long())            # (S,k)
+    finite = torch.isfinite(dv[:, :k])
+    err = (got - score.to(dense.dtype)).abs()
+    err = torch.where(finite & torch.isfinite(got), err, torch.zeros_like(err))
+    assert float(err.max()) <= tol, f"score error {float(err.max())} > {tol}"
+    kth = dv[:, k - 1:k]
+    legit = (got >= kth - tol) | ~finite
+    assert bool(legit.all()), "an index outside the tolerance top-k set was selected"
+    gaps = (dv[:, :-1] - dv[:, 1:]).abs()
+    gaps = torch.where(torch.isfinite(gaps), gaps, torch.full_like(gaps, float("inf")))
+    clear = (gaps.min(dim=1).values > gap) & finite.all(1)
+    exact = (idx.long() == di[:, :k]).all(1)
+    assert bool(exact[clear].all()), f"{int((~exact[clear]).sum())} clear-gap queries differ in index"
+    return dict(queries=S, clear=int(clear.sum()), exact=int(exact.sum()), max_score_err=float(err.max()))

@@ -1,0 +1,200 @@
+"""Generate golden vectors by RUNNING THE REFERENCE ITSELF (build container only).
+
+    python tests/golden/gen_golden.py
+
+Imports the genuine operator files from /root/reference through
+oracle/ref_import.py, feeds them seeded inputs and stores inputs + the
+reference's outputs as small .npz fixtures next to this script.  The fixtures
+are data only; no reference source travels.  While a reference operator runs,
+`torch.Tensor.topk` is spied on so the (values, indices) the reference's own
+top-k call produced are recorded too.
+
+Recorded torch version: see `meta.json` (tie order of torch.topk and GEMM rounding
+may differ between torch versions; the reference pins torch 1.9.1).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from oracle import fgvc_oracle as O  # noqa: E402  (only for seeded_resnet_state = input generation)
+
+
+class TopkSpy:
+    def __enter__(self):
+        self.calls = []
+        self._orig = torch.Tensor.topk
+        spy = self
+
+        def topk(t, *a, **k):
+            r = spy._orig(t, *a, **k)
+            spy.calls.append((r[0].clone(), r[1].clone()))
+            return r
+
+        torch.Tensor.topk = topk
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.topk = self._orig
+        return False
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"  {name}.npz  " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in out.items()))
+
+
+def rnd(g, *shape):
+    return torch.randn(*shape, generator=g)
+
+
+def main():
+    ref = ref_import.load()
+    torch.set_num_threads(8)
+    meta = {"torch": torch.__version__, "numpy": np.__version__, "cases": {}}
+
+    # ---- A4 spatial_neighbor ------------------------------------------------
+    for (H, W, nr, mode) in [(8, 12, 6, "circle"), (16, 16, 30, "circle"), (9, 7, 5, "square"), (20, 24, 14, "circle")]:
+        m = ref.spatial_neighbor(1, H, W, neighbor_range=nr, device="cpu", dtype=torch.float32, mode=mode)
+        m = m.reshape(H * W, H * W)
+        save(f"mask_{mode}_{H}x{W}_r{nr}", H=H, W=W, nr=nr, packed=np.packbits(m.numpy().astype(np.uint8), axis=None),
+             count=int(m.sum()))
+
+    # ---- A5 masked_attention_efficient (+ v2 twin, + reference's own top-k) --
+    cases = [
+        # name,      C,  T, H,  W,  P, nr, k,  step, nml, mode
+        ("mae_s8x12", 16, 2, 8, 12, 3, 6, 5, 32, 0, "softmax"),
+        ("mae_s16x16", 64, 6, 16, 16, 5, 30, 10, 128, 0, "softmax"),
+        ("mae_s32x32", 64, 3, 32, 32, 2, 14, 10, 512, 0, "softmax"),
+        ("mae_s20x24_nml1", 32, 3, 20, 24, 4, 14, 10, 100, 1, "softmax"),
+        ("mae_s12x20_cos", 32, 2, 12, 20, 3, 10, 4, 64, 0, "cosine"),
+        ("mae_s16x24_c256", 256, 3, 16, 24, 5, 30, 10, 512, 0, "softmax"),
+    ]
+    for i, (name, C, T, H, W, P, nr, k, step, nml, mode) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + i)
+        q, key, v = rnd(g, 1, C, H, W), rnd(g, 1, C, T, H, W), torch.rand(1, P, T, H, W, generator=g)
+        if name == "mae_s16x16":          # duplicate frame 0 in slots 0 and 1 like the tracker does (:353-362)
+            key[:, :, 1] = key[:, :, 0]
+            v[:, :, 1] = v[:, :, 0]
+        mask = ref.spatial_neighbor(1, H, W, neighbor_range=nr, device="cpu", dtype=torch.float32)
+        with TopkSpy() as spy:
+            out = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=k, step=step,
+                                                 non_mask_len=nml, mode=mode)
+        tv = torch.cat([c[0][0] for c in spy.calls], dim=1)       # (k, HW)
+        ti = torch.cat([c[1][0] for c in spy.calls], dim=1)
+        out2 = ref.masked_attention_efficient_v2(q, key, v, nr // 2, temperature=0.07, topk=k, step=step,
+                                                 non_mask_len=0, mode=mode) if nml == 0 else out
+        save(name, query=q, key=key, value=v, nr=nr, topk=k, step=step, non_mask_len=nml,
+             mode=np.array(mode), temperature=0.07, out=out, out_v2=out2,
+             ref_topk_val=tv.t().contiguous(), ref_topk_idx=ti.t().contiguous().to(torch.int32))
+        meta["cases"][name] = dict(C=C, T=T, H=H, W=W, P=P, nr=nr, topk=k)
+
+    # ---- no-mask (full-frame) variant ---------------------------------------
+    g = torch.Generator().manual_seed(200)
+    q, key, v = rnd(g, 1, 32, 10, 14), rnd(g, 1, 32, 2, 10, 14), torch.rand(1, 3, 2, 10, 14, generator=g)
+    with TopkSpy() as spy:
+        out = ref.masked_attention_efficient(q, key, v, None, temperature=0.07, topk=10, step=64)
+    save("mae_nomask_10x14", query=q, key=key, value=v, topk=10, temperature=0.07, out=out,
+         ref_topk_val=torch.cat([c[0][0] for c in spy.calls], 1).t().contiguous(),
+         ref_topk_idx=torch.cat([c[1][0] for c in spy.calls], 1).t().contiguous().to(torch.int32))
+
+    # ---- A5'' dense volume formulations --------------------------------------
+    g = torch.Generator().manual_seed(300)
+    q, key = rnd(g, 1, 32, 9, 11), rnd(g, 1, 32, 2, 9, 11)
+    v = torch.rand(1, 3, 2, 9, 11, generator=g)
+    mask = ref.spatial_neighbor(1, 9, 11, neighbor_range=8, device="cpu", dtype=torch.float32)
+    out = ref.masked_attention(q, key, v, mask, temperature=0.07, topk=5, step=40)
+    aff = ref.compute_affinity(key[:, :, 0], q, temperature=0.07)          # (1, HWsrc, HWdst)
+    att = ref.non_local_attention(q, key.transpose(1, 2), temprature=0.07, norm=True, att_only=True)
+    save("dense_9x11", query=q, key=key, value=v, nr=8, out_masked_attention=out,
+         compute_affinity=aff[0], non_local_att=att[0])
+
+    # ---- A6 coarse-to-fine ----------------------------------------------------
+    g = torch.Generator().manual_seed(400)
+    H, W, s, T, C, Cf, P, Rf = 8, 10, 4, 2, 32, 16, 3, 3
+    q, key = rnd(g, 1, C, H, W), rnd(g, 1, C, T, H, W)
+    qf, kf = rnd(g, 1, Cf, H * s, W * s), rnd(g, 1, Cf, T, H * s, W * s)
+    v = torch.rand(1, P, T, H * s, W * s, generator=g)
+    mask = ref.spatial_neighbor(1, H, W, neighbor_range=8, device="cpu", dtype=torch.float32)
+    with TopkSpy() as spy:
+        out = ref.masked_attention_efficient_c2f(q, key, qf, kf, v, mask, temperature=0.07, topk=5, step=32,
+                                                 radius_fine=Rf)
+    save("c2f_8x10", query=q, key=key, query_fine=qf, key_fine=kf, value=v, nr=8, topk=5, radius_fine=Rf,
+         temperature=0.07, out=out,
+         ref_topk_val=torch.cat([c[0][0] for c in spy.calls], 1).t().contiguous(),
+         ref_topk_idx=torch.cat([c[1][0] for c in spy.calls], 1).t().contiguous().to(torch.int32))
+
+    # ---- A7' local-window correlation (torch-only twin of mmcv Correlation) ---
+    g = torch.Generator().manual_seed(500)
+    H, W, K, C, P, R = 10, 12, 3, 32, 4, 3
+    qframe, kframes = rnd(g, 1, C, H, W), rnd(g, 1, C, K, H, W)
+    v = torch.rand(1, P, K, H, W, generator=g)
+    with TopkSpy() as spy:
+        out = ref.masked_attention_efficient_correlation_v2(qframe, kframes, v, R, None, lambda x: x,
+                                                            temperature=0.07, topk=6, sstep=50, tstep=2)
+    save("localcorr_10x12", query=qframe, key=kframes, value=v, radius=R, topk=6, temperature=0.07, out=out,
+         ref_topk_val=torch.cat([c[0][0] for c in spy.calls], 1).t().contiguous(),
+         ref_topk_idx=torch.cat([c[1][0] for c in spy.calls], 1).t().contiguous().to(torch.int32))
+
+    # ---- A1-A3, A8-A10 the whole tracker ---------------------------------------
+    cfg = ref.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512,
+                         with_first=True, with_first_neighbor=True)
+    model = ref.builder.build_model(
+        dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4),
+                                                  out_indices=(2,), pool_type="none")),
+        train_cfg=None, test_cfg=cfg)
+    sd = O.seeded_resnet_state(seed=7, strides=(1, 1, 1, 4), pool_type="none")
+    missing = model.backbone.load_state_dict(sd, strict=True)
+    model.eval()
+    g = torch.Generator().manual_seed(600)
+    T, h, w = 4, 64, 64
+    rgbs = rnd(g, 1, T, 3, h, w)
+    qp = torch.tensor([[[0., 10., 20.], [1., 33.5, 12.25], [0., 50., 40.], [2., 5., 60.], [1., 20., 20.]]])
+    P = qp.shape[1]
+    traj_gt = torch.rand(1, T, P, 2, generator=g) * 64
+    vis_gt = (torch.rand(1, T, P, generator=g) > 0.3).float()
+    with ref_import.cuda_as_cpu(), torch.no_grad():
+        outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj_gt, visibilities=vis_gt)
+        feats = model.backbone(rgbs[0])
+        # un-regrouped main path for the t=0 points only
+        main = model.forward_test_main(rgbs, qp[:, [0, 2]], torch.zeros(1, T, 2, 2), torch.zeros(1, T, 2))
+    wsum = float(sum(v.double().abs().sum() for k, v in sd.items() if v.dtype.is_floating_point))
+    save("tracker_4x64x64", rgbs=rgbs, query_points=qp, trajectories=traj_gt, visibilities=vis_gt,
+         seed=7, weight_abs_sum=wsum,
+         out_trajectories=outs[0], out_visibilities=outs[1], out_traj_pred=outs[2], out_vis_pred=outs[3],
+         out_query_points=outs[4], feats_sub=feats[:, ::16, ::4, ::4], feats_abs_sum=float(feats.double().abs().sum()),
+         main_traj_pred=main[2])
+
+    # ---- img2coord and gaussian maps on their own ------------------------------
+    g = torch.Generator().manual_seed(700)
+    maps = torch.rand(3, 4, 12, 16, generator=g).numpy().astype(np.float32)
+    maps[1, 2] = 0.0
+    coords = model.img2coord(maps, 4)
+    with ref_import.cuda_as_cpu():
+        grid, _, stride = model.get_coords_grid((1, 24, 32), (12, 16))
+        gfull, gres = model.draw_gaussion_map_online(torch.tensor([[[3.0, 4.0], [10.5, 7.25]]]), grid, stride=stride)
+    save("readout_small", maps=maps, coords=coords, gauss_points=np.array([[3.0, 4.0], [10.5, 7.25]], np.float32),
+         gauss_full=gfull[0], gauss_res=gres[0], stride=stride)
+
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print(f"total fixture bytes: {tot}")
+
+
+if __name__ == "__main__":
+    main()

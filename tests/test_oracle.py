@@ -1,0 +1,151 @@
+"""CPU: the oracle (oracle/fgvc_oracle.py) against golden vectors produced by the
+reference itself (tests/golden/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fgvc_oracle as O
+
+T = torch.from_numpy
+MAE_CASES = ["mae_s8x12", "mae_s16x16", "mae_s32x32", "mae_s20x24_nml1", "mae_s12x20_cos", "mae_s16x24_c256"]
+
+
+def canon_ref_topk(val, idx):
+    """Bring the reference's recorded top-k (tie order unspecified) to canonical order."""
+    val, idx = T(val).clone(), T(idx).long().clone()
+    key = torch.argsort(idx, dim=1, stable=True)
+    val, idx = val.gather(1, key), idx.gather(1, key)
+    o = torch.sort(val, dim=1, descending=True, stable=True)[1]
+    return val.gather(1, o), idx.gather(1, o)
+
+
+@pytest.mark.parametrize("name", ["mask_circle_8x12_r6", "mask_circle_16x16_r30", "mask_square_9x7_r5",
+                                  "mask_circle_20x24_r14"])
+def test_spatial_neighbor(golden, name):
+    g = golden(name)
+    H, W, nr = int(g["H"]), int(g["W"]), int(g["nr"])
+    mode = "square" if "square" in name else "circle"
+    m = O.spatial_neighbor(H, W, nr, mode)
+    ref = np.unpackbits(g["packed"])[: (H * W) ** 2].reshape(H * W, H * W).astype(bool)
+    assert int(m.sum()) == int(g["count"])
+    assert np.array_equal(m.numpy(), ref)
+
+
+def test_r2max():
+    assert O.radius_predicate_r2max(15) == 224
+    assert O.radius_predicate_r2max(3) == 8
+    assert O.radius_predicate_r2max(2.5) == 6
+    assert O.radius_predicate_r2max(0) == -1
+
+
+@pytest.mark.parametrize("name", MAE_CASES)
+def test_masked_attention_efficient(golden, name):
+    g = golden(name)
+    q, k, v = T(g["query"]), T(g["key"]), T(g["value"])
+    nr, topk, nml = int(g["nr"]), int(g["topk"]), int(g["non_mask_len"])
+    mode = str(g["mode"])
+    idx, logit = O.affinity_topk(q[0], k[0], topk, 0.07, neighbor_range=nr, non_mask_len=nml, step=int(g["step"]))
+    rv, ri = canon_ref_topk(g["ref_topk_val"], g["ref_topk_idx"])
+    # the reference's own top-k: identical scores (same torch ops) and, tie order aside, identical indices
+    assert torch.allclose(logit, rv, atol=1e-5, rtol=0)
+    same = (idx == ri).all(1)
+    if name == "mae_s16x16":
+        # slot 0 and slot 1 hold the same frame -> exact ties by construction; compare modulo the slot
+        HW = q.shape[2] * q.shape[3]
+        fold = lambda i: torch.where(i // HW == 1, i - HW, i)
+        a, b = fold(idx).sort(1)[0], fold(ri).sort(1)[0]
+        # the multiset of (slot-folded) indices may differ only on a tie at the k/k+1 boundary
+        assert (a == b).all(1).float().mean() > 0.95
+    else:
+        assert bool(same.all()), f"{int((~same).sum())} queries differ"
+    out = O.masked_attention_efficient(q, k, v, None, 0.07, topk, True, int(g["step"]), nml, mode, neighbor_range=nr)
+    assert torch.allclose(out, T(g["out"]), atol=2e-5, rtol=1e-5)
+    if nml == 0:
+        assert torch.allclose(out, T(g["out_v2"]), atol=2e-5, rtol=1e-5)
+    # dense-mask entry gives the same answer as the analytic predicate
+    m = O.spatial_neighbor(q.shape[2], q.shape[3], nr)
+    out_m = O.masked_attention_efficient(q, k, v, m, 0.07, topk, True, int(g["step"]), nml, mode)
+    assert torch.equal(out, out_m)
+
+
+def test_nomask(golden):
+    g = golden("mae_nomask_10x14")
+    q, k, v = T(g["query"]), T(g["key"]), T(g["value"])
+    idx, logit = O.affinity_topk(q[0], k[0], 10, 0.07)
+    rv, ri = canon_ref_topk(g["ref_topk_val"], g["ref_topk_idx"])
+    assert torch.allclose(logit, rv, atol=1e-5, rtol=0) and bool((idx == ri).all())
+    out = O.masked_attention_efficient(q, k, v, None, 0.07, 10)
+    assert torch.allclose(out, T(g["out"]), atol=2e-5)
+
+
+def test_dense_volume(golden):
+    g = golden("dense_9x11")
+    q, k, v = T(g["query"]), T(g["key"]), T(g["value"])
+    vol = O.corr_volume(q[0], k[0], 0.07)                      # (T*HW, HW)
+    HW = 99
+    # compute_affinity(src=key frame 0, dst=query) -> (HWsrc, HWdst)   affinity_utils.py:6-21
+    assert torch.allclose(vol[:HW], T(g["compute_affinity"]), atol=1e-5)
+    # non_local_attention(att_only) -> (T, HWq, HWk)                    correlation.py:32-66
+    att = T(g["non_local_att"])
+    assert torch.allclose(vol.reshape(2, HW, HW).transpose(1, 2), att, atol=1e-5)
+    out = O.masked_attention_efficient(q, k, v, None, 0.07, 5, neighbor_range=int(g["nr"]))
+    assert torch.allclose(out, T(g["out_masked_attention"]), atol=2e-5)
+
+
+def test_c2f(golden):
+    g = golden("c2f_8x10")
+    out, am, idx, logit = O.c2f_attention(T(g["query"])[0], T(g["key"])[0], T(g["query_fine"])[0],
+                                          T(g["key_fine"])[0], T(g["value"])[0], int(g["topk"]), 0.07,
+                                          neighbor_range=int(g["nr"]), radius_fine=int(g["radius_fine"]))
+    rv, ri = canon_ref_topk(g["ref_topk_val"], g["ref_topk_idx"])
+    assert torch.allclose(logit, rv, atol=1e-5) and bool((idx == ri).all())
+    assert torch.allclose(out, T(g["out"])[0], atol=2e-5)
+
+
+def test_local_corr(golden):
+    g = golden("localcorr_10x12")
+    q, k, v = T(g["query"])[0], T(g["key"])[0], T(g["value"])[0]
+    out, idx, logit = O.local_corr_topk(q, k.transpose(0, 1), v.transpose(0, 1), int(g["radius"]),
+                                        int(g["topk"]), 0.07)
+    rv, ri = canon_ref_topk(g["ref_topk_val"], g["ref_topk_idx"])
+    # the reference divides by temperature after top-k (local_attention.py:1235)
+    assert torch.allclose(logit * 0.07, rv, atol=1e-5)
+    assert (idx == ri).all(1).float().mean() > 0.99      # zero-padded taps tie at exactly 0
+    assert torch.allclose(out, T(g["out"])[0], atol=2e-5)
+
+
+def test_readout(golden):
+    g = golden("readout_small")
+    c = O.img2coord(g["maps"], topk=5)
+    assert np.allclose(c, g["coords"], atol=1e-6)
+    full, res = O.gaussian_labels(T(g["gauss_points"]), 24, 32, int(g["stride"]))
+    assert torch.allclose(full, T(g["gauss_full"]), atol=1e-6)
+    assert torch.allclose(res, T(g["gauss_res"]), atol=1e-6)
+
+
+def test_tracker(golden):
+    g = golden("tracker_4x64x64")
+    sd = O.seeded_resnet_state(int(g["seed"]), (1, 1, 1, 4), "none")
+    wsum = float(sum(v.double().abs().sum() for v in sd.values() if v.dtype.is_floating_point))
+    if abs(wsum - float(g["weight_abs_sum"])) > 1e-6 * wsum:
+        pytest.skip("torch RNG stream differs from the fixture's")
+    net = O.ResNet18((1, 1, 1, 4), 2, "none")
+    net.load_state_dict(sd)
+    net.eval()
+    rgbs, qp = T(g["rgbs"]), T(g["query_points"])
+    with torch.no_grad():
+        feats = net(rgbs[0])
+        assert torch.allclose(feats[:, ::16, ::4, ::4], T(g["feats_sub"]), atol=1e-4, rtol=1e-4)
+        main = O.forward_test_main(feats, qp[0, [0, 2], 1:], 64, 64)
+        assert torch.allclose(main, T(g["main_traj_pred"]).double(), atol=2e-3)
+        outs = O.forward_test(lambda x: net(x), rgbs, qp, T(g["trajectories"]), T(g["visibilities"]))
+    assert torch.equal(outs[0], T(g["out_trajectories"]))
+    assert torch.equal(outs[1], T(g["out_visibilities"]))
+    assert torch.equal(outs[4], T(g["out_query_points"]))
+    d = (outs[2].double() - T(g["out_traj_pred"]).double()).abs()
+    # query point (t=1, x=33.5, y=12.25) sits exactly between two pixels: its frame-1 Gaussian has two
+    # EQUAL values at the top-5 boundary and np.argsort's tie order is unspecified ->
+    # that single x-coordinate is excluded; everything else must agree.
+    d[0, 1, 2, 0] = 0
+    assert float(d.max()) < 2e-3
+    assert torch.equal(outs[3], T(g["out_vis_pred"]))
