@@ -1,0 +1,67 @@
+"""ctypes binding of libfgvc_hip.so (include/fgvc_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfgvc_hip.so")
+
+FGVC_OK = 0
+NO_LIMIT = 0x3FFFFFFF
+PAIR_MASKED = 1
+WEIGHT_SOFTMAX, WEIGHT_COSINE = 0, 1
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+# name -> (restype, argtypes); mirrors include/fgvc_hip.h one to one
+SIGNATURES = {
+    "fgvc_version": (C.c_char_p, []),
+    "fgvc_last_error": (C.c_char_p, []),
+    "fgvc_r2max_for_radius": (_i, [_f]),
+    "fgvc_normalize_chw_to_hwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "fgvc_pair_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "fgvc_merge_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
+    "fgvc_propagate_topk_f32": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "fgvc_corr_volume_f32": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
+    "fgvc_split_bf16": (_i, [_p, _p, C.c_int64, _i, _p]),
+    "fgvc_corr_volume_bf16x3": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
+    "fgvc_corr_volume_bf16": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
+    "fgvc_local_corr_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
+    "fgvc_c2f_refine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "fgvc_gaussian_labels_f32": (_i, [_p, _i, _i, _i, _i, _f, _p, _p]),
+    "fgvc_softargmax_top5_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _f, _p, _p]),
+}
+
+_lib = None
+
+
+class FgvcHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FgvcHipError(
+                f"{LIB_PATH} is missing: build it with `python -m fgvc_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != FGVC_OK:
+        raise FgvcHipError(f"{name} failed (code {rc}): {lib.fgvc_last_error().decode()}")

@@ -1,0 +1,196 @@
+// extern "C" surface of libfgvc_hip.so (see include/fgvc_hip.h): argument validation, then launch.
+// Shapes are validated HERE, on the host, before any hand-written kernel is enqueued: a grid that
+// does not match its operands can fault the GPU.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace fgvc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int pair_topk_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, int, int, int, int,
+                     int32_t*, float*, hipStream_t);
+int merge_topk_launch(const int32_t*, const float*, const int32_t*, int, int, int, int, int, float, int, int32_t*,
+                      float*, float*, hipStream_t);
+int normalize_launch(const float*, float*, int, int, int, int, hipStream_t);
+int propagate_launch(const float*, const int32_t*, int, const int32_t*, const float*, int, int, int, int, int, int,
+                     int, float*, hipStream_t);
+int gaussian_launch(const float*, int, int, int, int, float, float*, hipStream_t);
+int softargmax_launch(const float*, int, int, int, int, int, int, const float*, float, double*, hipStream_t);
+int corr_volume_f32_launch(const float*, const float*, int, int, int, float, float*, hipStream_t);
+int split_bf16_launch(const float*, uint16_t*, long long, int, hipStream_t);
+int corr_volume_bf16_launch(const uint16_t*, const uint16_t*, int, int, int, float, float*, int, hipStream_t);
+int local_merge_launch(const int32_t*, const float*, int, int, int, int, int, float, int32_t*, float*, float*,
+                       hipStream_t);
+int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, int, int, int, int, int, int, int,
+                      int, float, float*, int32_t*, float*, hipStream_t);
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace fgvc
+
+using namespace fgvc;
+
+extern "C" {
+
+const char* fgvc_version(void) { return "fgvc_hip 0.1 (gfx950)"; }
+const char* fgvc_last_error(void) { return g_err; }
+
+int fgvc_r2max_for_radius(float radius) {
+  if (!(radius > 0.f)) return -1;
+  long long d2 = (long long)ceil((double)radius * (double)radius) + 2;
+  if (d2 > FGVC_NO_LIMIT) return FGVC_NO_LIMIT;
+  while (d2 >= 0 && !(sqrtf((float)d2) < radius)) --d2;
+  return (int)d2;
+}
+
+int fgvc_normalize_chw_to_hwc_f32(const float* in, float* out, int n, int C, int HW, int normalize, void* stream) {
+  FGVC_REQUIRE(in && out, FGVC_ERR_INVALID_ARG, "fgvc_normalize_chw_to_hwc_f32: null pointer");
+  FGVC_REQUIRE(n >= 0 && C > 0 && HW > 0, FGVC_ERR_INVALID_ARG, "fgvc_normalize_chw_to_hwc_f32: bad shape n=%d C=%d HW=%d", n, C, HW);
+  FGVC_REQUIRE(C <= 1024, FGVC_ERR_UNSUPPORTED, "fgvc_normalize_chw_to_hwc_f32: C=%d > 1024 (LDS tile)", C);
+  FGVC_REQUIRE(n <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_normalize_chw_to_hwc_f32: n=%d > 65535 frames per call", n);
+  if (n == 0) return FGVC_OK;
+  return normalize_launch(in, out, n, C, HW, normalize, (hipStream_t)stream);
+}
+
+int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_pairs, int C, int Hq,
+                       int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int32_t* idx_out,
+                       float* score_out, void* stream) {
+  FGVC_REQUIRE(qfeat && kfeat && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f32: null pointer");
+  FGVC_REQUIRE(aligned16(qfeat) && aligned16(kfeat) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_f32: qfeat/kfeat/pairs must be 16-byte aligned");
+  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && n_pairs >= 0, FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_f32: bad shape Hq=%d Wq=%d Hk=%d Wk=%d n_pairs=%d", Hq, Wq, Hk, Wk, n_pairs);
+  FGVC_REQUIRE(topk >= 1 && topk <= 16, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f32: topk=%d outside 1..16", topk);
+  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f32: negative mask parameter");
+  FGVC_REQUIRE(n_pairs <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f32: n_pairs=%d > 65535 per call", n_pairs);
+  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
+  FGVC_REQUIRE(!any_limit || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_f32: a spatial mask needs equal query/key grids (local_attention.py:331)");
+  FGVC_REQUIRE((long long)Hk * Wk < (1ll << 30) && (long long)Hq * Wq < (1ll << 30), FGVC_ERR_UNSUPPORTED,
+               "fgvc_pair_topk_f32: grid too large");
+  if (n_pairs == 0) return FGVC_OK;
+  return pair_topk_launch(qfeat, kfeat, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, idx_out, score_out,
+                          (hipStream_t)stream);
+}
+
+int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, int n_out, int T,
+                        int HWq, int HWk, int topk, float temperature, int weight_mode, int32_t* idx_out,
+                        float* logit_out, float* weight_out, void* stream) {
+  FGVC_REQUIRE(pair_idx && pair_score && slot_pair && idx_out && logit_out && weight_out, FGVC_ERR_INVALID_ARG,
+               "fgvc_merge_topk_f32: null pointer");
+  FGVC_REQUIRE(n_out >= 0 && T >= 1 && HWq > 0 && HWk > 0, FGVC_ERR_INVALID_ARG, "fgvc_merge_topk_f32: bad shape");
+  FGVC_REQUIRE(topk >= 1 && topk <= 16, FGVC_ERR_UNSUPPORTED, "fgvc_merge_topk_f32: topk=%d outside 1..16", topk);
+  FGVC_REQUIRE((long long)T * HWk < (1ll << 31), FGVC_ERR_UNSUPPORTED, "fgvc_merge_topk_f32: T*HWk overflows int32");
+  FGVC_REQUIRE(temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_merge_topk_f32: temperature must be > 0");
+  FGVC_REQUIRE(weight_mode == FGVC_WEIGHT_SOFTMAX || weight_mode == FGVC_WEIGHT_COSINE, FGVC_ERR_INVALID_ARG,
+               "fgvc_merge_topk_f32: unknown weight mode %d", weight_mode);
+  FGVC_REQUIRE(n_out <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_merge_topk_f32: n_out=%d > 65535", n_out);
+  if (n_out == 0) return FGVC_OK;
+  return merge_topk_launch(pair_idx, pair_score, slot_pair, n_out, T, HWq, HWk, topk, temperature, weight_mode,
+                           idx_out, logit_out, weight_out, (hipStream_t)stream);
+}
+
+int fgvc_propagate_topk_f32(const float* labels, const int32_t* slot_frame, int T, const int32_t* idx,
+                            const float* weight, int Hq, int Wq, int Hk, int Wk, int P, int topk, int window_L,
+                            float* out, void* stream) {
+  FGVC_REQUIRE(labels && slot_frame && idx && weight && out, FGVC_ERR_INVALID_ARG, "fgvc_propagate_topk_f32: null pointer");
+  FGVC_REQUIRE(T >= 1 && Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && P > 0 && topk >= 1, FGVC_ERR_INVALID_ARG,
+               "fgvc_propagate_topk_f32: bad shape");
+  FGVC_REQUIRE(window_L == 0 || ((window_L & 1) && Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
+               "fgvc_propagate_topk_f32: window_L must be odd and the grids equal");
+  return propagate_launch(labels, slot_frame, T, idx, weight, Hq, Wq, Hk, Wk, P, topk, window_L, out,
+                          (hipStream_t)stream);
+}
+
+int fgvc_corr_volume_f32(const float* qfeat, const float* kfeat, int C, int HWq, int HWk, float temperature,
+                         float* vol, void* stream) {
+  FGVC_REQUIRE(qfeat && kfeat && vol, FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f32: null pointer");
+  FGVC_REQUIRE(aligned16(qfeat) && aligned16(kfeat), FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f32: features must be 16-byte aligned");
+  FGVC_REQUIRE(HWq > 0 && HWk > 0 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f32: bad shape");
+  return corr_volume_f32_launch(qfeat, kfeat, C, HWq, HWk, temperature, vol, (hipStream_t)stream);
+}
+
+int fgvc_split_bf16(const float* feat, uint16_t* hi_lo, int64_t n_pixels, int C, void* stream) {
+  FGVC_REQUIRE(feat && hi_lo, FGVC_ERR_INVALID_ARG, "fgvc_split_bf16: null pointer");
+  FGVC_REQUIRE(n_pixels >= 0 && C > 0 && C % 4 == 0, FGVC_ERR_INVALID_ARG, "fgvc_split_bf16: C must be a multiple of 4");
+  FGVC_REQUIRE(aligned16(feat) && aligned16(hi_lo), FGVC_ERR_INVALID_ARG, "fgvc_split_bf16: 16-byte alignment required");
+  if (n_pixels == 0) return FGVC_OK;
+  return split_bf16_launch(feat, hi_lo, n_pixels, C, (hipStream_t)stream);
+}
+
+static int corr_bf16_common(const char* who, const uint16_t* q, const uint16_t* k, int C, int HWq, int HWk,
+                            float temperature, float* vol, int nseg, void* stream) {
+  FGVC_REQUIRE(q && k && vol, FGVC_ERR_INVALID_ARG, "%s: null pointer", who);
+  FGVC_REQUIRE(aligned16(q) && aligned16(k), FGVC_ERR_INVALID_ARG, "%s: features must be 16-byte aligned", who);
+  FGVC_REQUIRE(C > 0 && C % 64 == 0, FGVC_ERR_UNSUPPORTED, "%s: C=%d must be a multiple of 64", who, C);
+  FGVC_REQUIRE(HWq > 0 && HWk > 0 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "%s: bad shape", who);
+  return corr_volume_bf16_launch(q, k, C, HWq, HWk, temperature, vol, nseg, (hipStream_t)stream);
+}
+
+int fgvc_corr_volume_bf16x3(const uint16_t* q, const uint16_t* k, int C, int HWq, int HWk, float temperature,
+                            float* vol, void* stream) {
+  return corr_bf16_common("fgvc_corr_volume_bf16x3", q, k, C, HWq, HWk, temperature, vol, 3, stream);
+}
+
+int fgvc_corr_volume_bf16(const uint16_t* q, const uint16_t* k, int C, int HWq, int HWk, float temperature,
+                          float* vol, void* stream) {
+  return corr_bf16_common("fgvc_corr_volume_bf16", q, k, C, HWq, HWk, temperature, vol, 1, stream);
+}
+
+int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_slots, int C, int H,
+                             int W, int R, int topk, float temperature, int32_t* pair_idx_ws, float* pair_score_ws,
+                             int32_t* idx_out, float* logit_out, float* weight_out, void* stream) {
+  FGVC_REQUIRE(pair_idx_ws && pair_score_ws && idx_out && logit_out && weight_out, FGVC_ERR_INVALID_ARG,
+               "fgvc_local_corr_topk_f32: null pointer");
+  FGVC_REQUIRE(R >= 0 && n_slots >= 1 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_local_corr_topk_f32: bad R/n_slots/temperature");
+  FGVC_REQUIRE((long long)n_slots * (2 * R + 1) * (2 * R + 1) < (1ll << 31), FGVC_ERR_UNSUPPORTED,
+               "fgvc_local_corr_topk_f32: index overflow");
+  int rc = fgvc_pair_topk_f32(qfeat, kfeat, pairs, n_slots, C, H, W, H, W, FGVC_NO_LIMIT, R, R, topk, pair_idx_ws,
+                              pair_score_ws, stream);
+  if (rc != FGVC_OK) return rc;
+  return local_merge_launch(pair_idx_ws, pair_score_ws, n_slots, H, W, R, topk, temperature, idx_out, logit_out,
+                            weight_out, (hipStream_t)stream);
+}
+
+int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const float* kfine, const float* vfine, int T,
+                        int H, int W, int scale, int Cf, int P, int Rf, int topk, float temperature, float* out,
+                        int32_t* idx_out, float* logit_out, void* stream) {
+  FGVC_REQUIRE(coarse_arg && qfine && kfine && vfine && out && idx_out && logit_out, FGVC_ERR_INVALID_ARG,
+               "fgvc_c2f_refine_f32: null pointer");
+  FGVC_REQUIRE(T >= 1 && H > 0 && W > 0 && scale >= 1 && P > 0 && Rf >= 0, FGVC_ERR_INVALID_ARG, "fgvc_c2f_refine_f32: bad shape");
+  FGVC_REQUIRE(Cf > 0 && Cf % 4 == 0, FGVC_ERR_UNSUPPORTED, "fgvc_c2f_refine_f32: Cf=%d must be a multiple of 4", Cf);
+  FGVC_REQUIRE(aligned16(qfine) && aligned16(kfine), FGVC_ERR_INVALID_ARG, "fgvc_c2f_refine_f32: 16-byte alignment required");
+  FGVC_REQUIRE(topk >= 1 && topk <= 16, FGVC_ERR_UNSUPPORTED, "fgvc_c2f_refine_f32: topk=%d outside 1..16", topk);
+  FGVC_REQUIRE(temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_c2f_refine_f32: temperature must be > 0");
+  return c2f_refine_launch(coarse_arg, qfine, kfine, vfine, T, H, W, scale, Cf, P, Rf, topk, temperature, out,
+                           idx_out, logit_out, (hipStream_t)stream);
+}
+
+int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int stride, float sigma, float* out,
+                             void* stream) {
+  FGVC_REQUIRE(points && out, FGVC_ERR_INVALID_ARG, "fgvc_gaussian_labels_f32: null pointer");
+  FGVC_REQUIRE(P > 0 && Hf > 0 && Wf > 0 && stride >= 1 && sigma > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_gaussian_labels_f32: bad shape");
+  return gaussian_launch(points, P, Hf, Wf, stride, sigma, out, (hipStream_t)stream);
+}
+
+int fgvc_softargmax_top5_f32(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
+                             const float* gauss_points, float sigma, double* coords, void* stream) {
+  FGVC_REQUIRE(labels && coords, FGVC_ERR_INVALID_ARG, "fgvc_softargmax_top5_f32: null pointer");
+  FGVC_REQUIRE(n_frames >= 0 && Hf > 0 && Wf > 0 && P > 0 && h > 0 && w > 0, FGVC_ERR_INVALID_ARG, "fgvc_softargmax_top5_f32: bad shape");
+  FGVC_REQUIRE((long long)h * w < (1ll << 31) && h * w >= 5, FGVC_ERR_UNSUPPORTED, "fgvc_softargmax_top5_f32: h*w out of range");
+  FGVC_REQUIRE(n_frames <= 65535 && sigma > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_softargmax_top5_f32: bad n_frames/sigma");
+  if (n_frames == 0) return FGVC_OK;
+  return softargmax_launch(labels, n_frames, Hf, Wf, P, h, w, gauss_points, sigma, coords, (hipStream_t)stream);
+}
+
+}  // extern "C"

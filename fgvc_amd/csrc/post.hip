@@ -1,0 +1,319 @@
+// Bandwidth-bound companions of the correlation kernels: L2-normalise + layout change,
+// per-slot list merge (+ temperature + softmax), label propagation, initial Gaussian labels and
+// the fused bilinear-upsample / top-5 soft-argmax read-out.
+#include "common.hpp"
+
+namespace fgvc {
+
+// ------------------------------------------------------------------------------------------
+// F.normalize(dim=1) + NCHW -> channels-last.   in [n][C][HW] -> out [n][HW][C]
+// One workgroup = 32 pixels x all channels through an LDS tile (row stride 33: conflict-free both ways).
+// Reads are 128-B row segments per (channel, 32 pixels); writes are fully contiguous (32*C floats).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalize_chw_to_hwc_kernel(const float* __restrict__ in,
+                                                                     float* __restrict__ out, int C, int HW,
+                                                                     int normalize) {
+  extern __shared__ float tile[];  // [C][33] + [8][32] partial sums + [32] inverse norms
+  float* part = tile + (size_t)C * 33;
+  float* inv = part + 8 * 32;
+  const int tid = threadIdx.x;
+  const int px = tid & 31, grp = tid >> 5;  // 8 channel groups
+  const int p0 = blockIdx.x * 32;
+  const size_t frame = blockIdx.y;
+  const float* src = in + frame * (size_t)C * HW;
+  float ss = 0.f;
+  const int p = p0 + px;
+  for (int c = grp; c < C; c += 8) {
+    const float v = (p < HW) ? src[(size_t)c * HW + p] : 0.f;
+    tile[c * 33 + px] = v;
+    ss = fmaf(v, v, ss);
+  }
+  part[grp * 32 + px] = ss;
+  __syncthreads();
+  if (tid < 32) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += part[g * 32 + tid];
+    // F.normalize: x / max(||x||, eps), eps = 1e-12
+    inv[tid] = normalize ? fmaxf(sqrtf(s), 1e-12f) : 1.0f;
+  }
+  __syncthreads();
+  float* dst = out + (frame * HW + p0) * (size_t)C;
+  const int npx = imin(32, HW - p0);
+  for (int i = tid; i < npx * C; i += 256) {
+    const int pp = i / C, c = i - pp * C;
+    dst[i] = tile[c * 33 + pp] / inv[pp];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// merge T per-pair top-k lists into the per-frame top-k, apply temperature, compute weights.
+// One thread per (output frame, query pixel); lists are 4*k-byte contiguous rows.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void merge_topk_kernel(const int32_t* __restrict__ pair_idx,
+                                                          const float* __restrict__ pair_score,
+                                                          const int32_t* __restrict__ slot_pair, int T, int HWq,
+                                                          int HWk, int kout, float temperature, int weight_mode,
+                                                          int32_t* __restrict__ idx_out,
+                                                          float* __restrict__ logit_out,
+                                                          float* __restrict__ weight_out) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (q >= HWq) return;
+  TopK<K> top;
+  top.init();
+  for (int t = 0; t < T; ++t) {
+    const int pid = slot_pair[f * T + t];
+    if (pid < 0) continue;
+    const size_t o = ((size_t)pid * HWq + q) * kout;
+    for (int j = 0; j < kout; ++j) {
+      const int id = pair_idx[o + j];
+      if (id < 0) break;  // lists are sorted; -1 marks the empty tail
+      const float s = pair_score[o + j];
+      const int gid = t * HWk + id;  // the reference's flat key index (local_attention.py:312)
+      if (!top.accepts(s, gid)) break;  // sorted input: nothing further down can enter either
+      top.insert(s, gid);
+    }
+  }
+  float lg[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) lg[j] = top.v[j] / temperature;  // einsum(...) / temperature, :321-323
+  float w[K];
+  if (weight_mode == FGVC_WEIGHT_SOFTMAX) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      w[j] = (j < kout) ? expf(lg[j] - lg[0]) : 0.f;
+      sum += w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) w[j] = w[j] / sum;
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float c = fmaxf(lg[j], 0.f);
+      w[j] = c * c;
+    }
+  }
+  const size_t o = ((size_t)f * HWq + q) * kout;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (j < kout) {
+      const bool e = top.ix[j] == IDX_EMPTY;
+      idx_out[o + j] = e ? -1 : top.ix[j];
+      logit_out[o + j] = lg[j];
+      weight_out[o + j] = w[j];
+    }
+  }
+}
+
+template <int K>
+static void launch_merge(const int32_t* pi, const float* ps, const int32_t* sp, int n_out, int T, int HWq, int HWk,
+                         int kout, float temp, int mode, int32_t* io, float* lo, float* wo, hipStream_t s) {
+  dim3 grid(cdiv(HWq, 256), n_out);
+  merge_topk_kernel<K><<<grid, 256, 0, s>>>(pi, ps, sp, T, HWq, HWk, kout, temp, mode, io, lo, wo);
+}
+
+int merge_topk_launch(const int32_t* pi, const float* ps, const int32_t* sp, int n_out, int T, int HWq, int HWk,
+                      int topk, float temp, int mode, int32_t* io, float* lo, float* wo, hipStream_t s) {
+  if (topk <= 1) launch_merge<1>(pi, ps, sp, n_out, T, HWq, HWk, topk, temp, mode, io, lo, wo, s);
+  else if (topk <= 5) launch_merge<5>(pi, ps, sp, n_out, T, HWq, HWk, topk, temp, mode, io, lo, wo, s);
+  else if (topk <= 10) launch_merge<10>(pi, ps, sp, n_out, T, HWq, HWk, topk, temp, mode, io, lo, wo, s);
+  else launch_merge<16>(pi, ps, sp, n_out, T, HWq, HWk, topk, temp, mode, io, lo, wo, s);
+  FGVC_CHECK_LAUNCH("fgvc_merge_topk_f32");
+  return FGVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// label propagation: out[q][p] = sum_r w[q][r] * labels[slot_frame[slot]][pixel][p]
+// thread = (query, label) with the label fastest: a query's P labels are one contiguous gather.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void propagate_kernel(const float* __restrict__ labels,
+                                                         const int32_t* __restrict__ slot_frame, int T,
+                                                         const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ weight, int Hq, int Wq, int Hk,
+                                                         int Wk, int P, int topk, int window_L,
+                                                         float* __restrict__ out) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int HWq = Hq * Wq, HWk = Hk * Wk;
+  if (gid >= (long long)HWq * P) return;
+  const int q = (int)(gid / P), pl = (int)(gid - (long long)q * P);
+  float acc = 0.f;
+  const int span = window_L > 0 ? window_L * window_L : HWk;
+  for (int r = 0; r < topk; ++r) {
+    const int id = idx[(size_t)q * topk + r];
+    if (id < 0) continue;
+    const float w = weight[(size_t)q * topk + r];
+    const int slot = id / span;
+    int pix = id - slot * span;
+    if (window_L > 0) {
+      const int R = window_L >> 1;
+      const int ky = q / Wq + pix / window_L - R, kx = q % Wq + pix % window_L - R;
+      if (ky < 0 || ky >= Hk || kx < 0 || kx >= Wk) continue;  // zero padding (F.unfold)
+      pix = ky * Wk + kx;
+    }
+    const float v = labels[((size_t)slot_frame[slot] * HWk + pix) * P + pl];
+    acc = fmaf(w, v, acc);
+  }
+  out[gid] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// initial labels on the feature grid (vanilla_tracker.py:204-221)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gaussian_labels_kernel(const float* __restrict__ points, int P, int Hf,
+                                                               int Wf, int stride, float two_sigma2,
+                                                               float* __restrict__ out) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)Hf * Wf * P) return;
+  const int pix = (int)(gid / P), pl = (int)(gid - (long long)pix * P);
+  const float x = (float)((pix % Wf) * stride), y = (float)((pix / Wf) * stride);
+  const float dx = x - points[2 * pl], dy = y - points[2 * pl + 1];
+  out[gid] = expf(-(dx * dx + dy * dy) / two_sigma2);
+}
+
+// ------------------------------------------------------------------------------------------
+// read-out: bilinear upsample (align_corners=False) + top-5 soft-argmax, one workgroup per (frame, label)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_index(int d, float scale, int in_size, int& i0, int& i1, float& l1) {
+  // PyTorch area_pixel_compute_source_index(align_corners=False): max(scale*(d+0.5)-0.5, 0)
+  float s = scale * ((float)d + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void softargmax_top5_kernel(const float* __restrict__ labels, int Hf, int Wf,
+                                                               int P, int h, int w,
+                                                               const float* __restrict__ gauss_points,
+                                                               float two_sigma2, double* __restrict__ coords) {
+  constexpr int K = 5;
+  __shared__ float sv[256 * K];
+  __shared__ int si[256 * K];
+  __shared__ float ssum[256];
+  const int tid = threadIdx.x;
+  const int pl = blockIdx.x, f = blockIdx.y;
+  const bool analytic = (gauss_points != nullptr) && f == 0;
+  const float* lab = labels + (size_t)f * Hf * Wf * P + pl;
+  const float sy = (float)Hf / (float)h, sx = (float)Wf / (float)w;
+  float cx = 0.f, cy = 0.f;
+  if (analytic) {
+    cx = gauss_points[2 * pl];
+    cy = gauss_points[2 * pl + 1];
+  }
+  TopKHi<K> top;
+  top.init();
+  float sum = 0.f;
+  for (int i = tid; i < h * w; i += 256) {
+    const int y = i / w, x = i - y * w;
+    float v;
+    if (analytic) {
+      const float dx = (float)x - cx, dy = (float)y - cy;
+      v = expf(-(dx * dx + dy * dy) / two_sigma2);
+    } else {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      src_index(y, sy, Hf, y0, y1, ly);
+      src_index(x, sx, Wf, x0, x1, lx);
+      const float v00 = lab[((size_t)y0 * Wf + x0) * P], v01 = lab[((size_t)y0 * Wf + x1) * P];
+      const float v10 = lab[((size_t)y1 * Wf + x0) * P], v11 = lab[((size_t)y1 * Wf + x1) * P];
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+    sum += v;
+    if (top.accepts(v, i)) top.insert(v, i);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    sv[tid * K + j] = top.v[j];
+    si[tid * K + j] = top.ix[j];
+  }
+  ssum[tid] = sum;
+  __syncthreads();
+  for (int stride = 128; stride >= 1; stride >>= 1) {
+    if (tid < stride) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float v = sv[(tid + stride) * K + j];
+        const int id = si[(tid + stride) * K + j];
+        if (id >= 0 && top.accepts(v, id)) top.insert(v, id);
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        sv[tid * K + j] = top.v[j];
+        si[tid * K + j] = top.ix[j];
+      }
+      ssum[tid] += ssum[tid + stride];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double* o = coords + ((size_t)f * P + pl) * 2;
+    if (ssum[0] == 0.f) {  // np.sum(map) == 0  (vanilla_tracker.py:189)
+      o[0] = -1.0;
+      o[1] = -1.0;
+    } else {
+      float tot = 0.f;
+#pragma unroll
+      for (int j = K - 1; j >= 0; --j) tot += top.v[j];       // ascending order like np.sum over argsort[-5:]
+      tot += 1e-9f;                                            // float32 + python float stays float32
+      double ax = 0.0, ay = 0.0;
+#pragma unroll
+      for (int j = K - 1; j >= 0; --j) {
+        const float wgt = top.v[j] / tot;                      // float32 weights (:183)
+        ax += (double)(top.ix[j] % w) * (double)wgt;           // int64 * float32 -> float64 (:187)
+        ay += (double)(top.ix[j] / w) * (double)wgt;
+      }
+      o[0] = ax;
+      o[1] = ay;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+int normalize_launch(const float* in, float* out, int n, int C, int HW, int normalize, hipStream_t s) {
+  dim3 grid(cdiv(HW, 32), n);
+  const size_t lds = ((size_t)C * 33 + 8 * 32 + 32) * sizeof(float);
+  if (lds > 48 * 1024) {  // opt in to the large-LDS carve-out (attribute set, no sync, capture-safe)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(normalize_chw_to_hwc_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("fgvc_normalize_chw_to_hwc_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return FGVC_ERR_LAUNCH;
+    }
+  }
+  normalize_chw_to_hwc_kernel<<<grid, 256, lds, s>>>(in, out, C, HW, normalize);
+  FGVC_CHECK_LAUNCH("fgvc_normalize_chw_to_hwc_f32");
+  return FGVC_OK;
+}
+
+int propagate_launch(const float* labels, const int32_t* slot_frame, int T, const int32_t* idx, const float* weight,
+                     int Hq, int Wq, int Hk, int Wk, int P, int topk, int window_L, float* out, hipStream_t s) {
+  const long long n = (long long)Hq * Wq * P;
+  propagate_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(labels, slot_frame, T, idx, weight, Hq, Wq, Hk, Wk, P,
+                                                               topk, window_L, out);
+  FGVC_CHECK_LAUNCH("fgvc_propagate_topk_f32");
+  return FGVC_OK;
+}
+
+int gaussian_launch(const float* points, int P, int Hf, int Wf, int stride, float sigma, float* out, hipStream_t s) {
+  const long long n = (long long)Hf * Wf * P;
+  gaussian_labels_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(points, P, Hf, Wf, stride,
+                                                                     2.f * sigma * sigma, out);
+  FGVC_CHECK_LAUNCH("fgvc_gaussian_labels_f32");
+  return FGVC_OK;
+}
+
+int softargmax_launch(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
+                      const float* gauss_points, float sigma, double* coords, hipStream_t s) {
+  dim3 grid(P, n_frames);
+  softargmax_top5_kernel<<<grid, 256, 0, s>>>(labels, Hf, Wf, P, h, w, gauss_points, 2.f * sigma * sigma, coords);
+  FGVC_CHECK_LAUNCH("fgvc_softargmax_top5_f32");
+  return FGVC_OK;
+}
+
+}  // namespace fgvc

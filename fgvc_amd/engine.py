@@ -1,0 +1,186 @@
+"""Label-propagation engine: the schedule the reference's driver runs frame by frame
+(vanilla_tracker.py:305-412), restated as three device phases.
+
+  phase 1  correlation + top-k for EVERY (query frame, key frame) pair of the clip in one launch
+           (indices/scores depend on features only, so all frames go in parallel);
+  phase 2  per output frame: merge its key slots' lists, temperature, softmax   (one launch);
+  phase 3  the only sequential part: label propagation frame by frame (tiny gathers), then the
+           fused upsample + soft-argmax read-out.
+
+`plan_*` are pure host functions (tested on CPU); `run_*` enqueue HIP work and never synchronise.
+
+De-duplication: the reference re-encodes and re-correlates the whole tail of
+the clip once per distinct query time t0 (vanilla_tracker.py:249-295).  A (query frame, key frame)
+pair's top-k does not depend on t0, and top-k of a union of slots == top-k of the union of the
+slots' top-k lists, so pairs are computed ONCE and every group merges the pairs it needs;
+frame t0 in slot 0 and again as a preceding frame (:353-362) costs one pair, not two.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .ops import MaskSpec
+
+
+@dataclass
+class TrackerConfig:
+    """test_cfg_<task> keys the path reads (configs/eval/res18_d1_eval.py:12-58, vanilla_tracker.py:330-378)."""
+    precede_frames: int = 5
+    topk: int = 10
+    temperature: float = 0.07
+    neighbor_range: Optional[int] = 30
+    mask_mode: str = "circle"
+    with_first: bool = True
+    with_first_neighbor: bool = True
+    with_norm: bool = True
+    mode: str = "softmax"
+    sigma: float = 6.0
+
+    @staticmethod
+    def from_test_cfg(cfg) -> "TrackerConfig":
+        g = cfg.get
+        return TrackerConfig(
+            precede_frames=g("precede_frames", 5), topk=g("topk", 10), temperature=g("temperature", 0.07),
+            neighbor_range=g("neighbor_range", None), mask_mode=g("mask_mode", "circle"),
+            with_first=g("with_first", True), with_first_neighbor=g("with_first_neighbor", True),
+            with_norm=g("with_norm", True))
+
+    @property
+    def mask(self) -> MaskSpec:
+        return MaskSpec.from_neighbor_range(self.neighbor_range, self.mask_mode)
+
+
+def key_slots(frame: int, start: int, precede_frames: int, with_first: bool) -> List[int]:
+    """Clip-absolute key frames of query frame `frame` in the group that starts at `start`
+    (vanilla_tracker.py:346-362 with frame numbers shifted by `start`)."""
+    ks = list(range(max(start, frame - precede_frames), frame))
+    return ([start] + ks) if with_first else ks
+
+
+@dataclass
+class Plan:
+    """Host-side schedule for one clip."""
+    n_frames: int
+    starts: List[int]                                   # distinct query times, ascending
+    pairs: List[Tuple[int, int, bool]]                  # unique (query frame, key frame, masked)
+    out_rows: Dict[Tuple[int, int], int]                # (start, frame) -> row of slot tables
+    slot_pair: List[List[int]]                          # row -> pair id per key slot (-1 pad)
+    slot_frame: List[List[int]]                         # row -> clip frame per key slot (0 pad)
+    t_max: int = 0
+
+
+def plan_clip(n_frames: int, starts: Sequence[int], cfg: TrackerConfig,
+              frame_range: Optional[Tuple[int, int]] = None) -> Plan:
+    """Build the pair list and slot tables.  `frame_range` = [lo, hi) restricts the QUERY frames
+    (clip sharding across GPUs: each rank plans only its own frames)."""
+    starts = sorted(set(int(s) for s in starts))
+    lo, hi = frame_range if frame_range is not None else (0, n_frames)
+    non_mask_len = 0 if cfg.with_first_neighbor else 1
+    pair_id: Dict[Tuple[int, int, bool], int] = {}
+    rows: Dict[Tuple[int, int], int] = {}
+    slot_pair, slot_frame = [], []
+    t_max = cfg.precede_frames + (1 if cfg.with_first else 0)
+    t_max = max(t_max, 1)
+    for s in starts:
+        for f in range(max(s + 1, lo), min(n_frames, hi)):
+            ks = key_slots(f, s, cfg.precede_frames, cfg.with_first)
+            sp, sf = [], []
+            for t, kf in enumerate(ks):
+                masked = not (t < non_mask_len) and not cfg.mask.is_none
+                key = (f, kf, masked)
+                if key not in pair_id:
+                    pair_id[key] = len(pair_id)
+                sp.append(pair_id[key])
+                sf.append(kf)
+            pad = t_max - len(ks)
+            rows[(s, f)] = len(slot_pair)
+            slot_pair.append(sp + [-1] * pad)
+            slot_frame.append(sf + [0] * pad)
+    pairs = [k for k, _ in sorted(pair_id.items(), key=lambda kv: kv[1])]
+    return Plan(n_frames, starts, pairs, rows, slot_pair, slot_frame, t_max)
+
+
+@dataclass
+class DeviceTopk:
+    """phase 1+2 results on the device."""
+    plan: Plan
+    idx: torch.Tensor        # (rows, HW, k) int32   slot*HW + pixel
+    logit: torch.Tensor      # (rows, HW, k)
+    weight: torch.Tensor     # (rows, HW, k)
+    slot_frame: torch.Tensor  # (rows, t_max) int32
+
+
+def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
+                 pair_chunk: int = 4096) -> DeviceTopk:
+    """Phases 1 and 2.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip."""
+    dev = feats_hwc.device
+    HW = Hf * Wf
+    k = cfg.topk
+    n = len(plan.pairs)
+    pidx = torch.empty((n, HW, k), device=dev, dtype=torch.int32)
+    pscore = torch.empty((n, HW, k), device=dev, dtype=torch.float32)
+    pairs_dev = ops.make_pairs(plan.pairs, dev)
+    for c0 in range(0, n, pair_chunk):
+        c1 = min(n, c0 + pair_chunk)
+        i, s = ops.pair_topk(feats_hwc, feats_hwc, pairs_dev[c0:c1], Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
+        pidx[c0:c1], pscore[c0:c1] = i, s
+    rows = len(plan.slot_pair)
+    slot_pair = torch.tensor(plan.slot_pair, dtype=torch.int32, device=dev).reshape(rows, plan.t_max)
+    slot_frame = torch.tensor(plan.slot_frame, dtype=torch.int32, device=dev).reshape(rows, plan.t_max)
+    if rows == 0:
+        e = torch.empty((0, HW, k), device=dev)
+        return DeviceTopk(plan, e.int(), e, e, slot_frame)
+    idx, logit, weight = ops.merge_topk(pidx, pscore, slot_pair, HW, k, cfg.temperature, cfg.mode, validate=False)
+    return DeviceTopk(plan, idx, logit, weight, slot_frame)
+
+
+def run_propagation(topk: DeviceTopk, start: int, points_xy: torch.Tensor, Hf: int, Wf: int, h: int, w: int,
+                    cfg: TrackerConfig, frames: Optional[Tuple[int, int]] = None,
+                    labels: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Phase 3 for the group that starts at `start`.  points_xy (P,2) on the device.
+    Returns (labels bank (T, HW, P) with frames < start untouched/zero, coords (T-start, P, 2) f64)."""
+    plan = topk.plan
+    T = plan.n_frames
+    dev = points_xy.device
+    P = points_xy.shape[0]
+    stride = h // Hf                                            # vanilla_tracker.py:197
+    if labels is None:
+        labels = torch.zeros((T, Hf * Wf, P), device=dev, dtype=torch.float32)
+    lo, hi = frames if frames is not None else (start + 1, T)
+    if lo <= start + 1:
+        ops.gaussian_labels(points_xy, Hf, Wf, stride, cfg.sigma, out=labels[start])
+    for f in range(max(lo, start + 1), hi):
+        row = plan.out_rows[(start, f)]
+        ops.propagate_topk(labels, topk.slot_frame[row], topk.idx[row], topk.weight[row], Hf, Wf, Hf, Wf,
+                           out=labels[f])
+    coords = ops.softargmax_top5(labels[start:], Hf, Wf, h, w, gauss_points=points_xy, sigma=cfg.sigma)
+    return labels, coords
+
+
+def track_points(feats_hwc: torch.Tensor, Hf: int, Wf: int, h: int, w: int, query_points: torch.Tensor,
+                 cfg: TrackerConfig):
+    """The whole post-encoder path for one clip.  query_points (P,3) = (t, x, y) (any device).
+    Returns traj_pred (T, P', 2) f64 on the device with points re-ordered by query time (the
+    reference's regrouping, vanilla_tracker.py:257-299) and `order` (P',) original indices."""
+    T = feats_hwc.shape[0]
+    dev = feats_hwc.device
+    qp = query_points.detach().to("cpu")
+    times = qp[:, 0].to(torch.int64)
+    starts = sorted(set(times.tolist())) if cfg.with_first else [0]
+    plan = plan_clip(T, starts, cfg)
+    topk = run_affinity(feats_hwc, Hf, Wf, plan, cfg)
+    traj = torch.zeros((T, qp.shape[0], 2), device=dev, dtype=torch.float64)
+    order = []
+    K = 0
+    for s in starts:
+        sel = (times == s).nonzero().flatten() if cfg.with_first else torch.arange(qp.shape[0])
+        pts = qp[sel, 1:].to(dev, torch.float32)
+        _, coords = run_propagation(topk, s, pts, Hf, Wf, h, w, cfg)
+        traj[s:, K:K + sel.numel()] = coords
+        order.extend(sel.tolist())
+        K += sel.numel()
+    return traj, torch.tensor(order, dtype=torch.int64)

@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the C ABI (include/fgvc_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every kernel is
+libfgvc_hip.so.  Inputs must live on a ROCm device; nothing falls back to torch ops.
+
+Layouts: features channels-last (frames, HW, C); labels pixel-major (frames, HW, P);
+top-k lists (…, HW, k) in canonical order (score desc, index asc).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import NO_LIMIT, PAIR_MASKED, WEIGHT_COSINE, WEIGHT_SOFTMAX  # noqa: F401
+
+
+@dataclass(frozen=True)
+class MaskSpec:
+    """keep <=> dy^2+dx^2 <= r2max and |dy| <= ry and |dx| <= rx   (offset = key - query)."""
+    r2max: int = NO_LIMIT
+    ry: int = NO_LIMIT
+    rx: int = NO_LIMIT
+
+    @property
+    def is_none(self) -> bool:
+        return self.r2max >= NO_LIMIT and self.ry >= NO_LIMIT and self.rx >= NO_LIMIT
+
+    @staticmethod
+    def none() -> "MaskSpec":
+        return MaskSpec()
+
+    @staticmethod
+    def circle(radius: float) -> "MaskSpec":
+        """sqrt(dy^2+dx^2) < radius in float32 (affinity_utils.py:98-109, local_attention.py:463-467)."""
+        return MaskSpec(r2max=max(_lib.load().fgvc_r2max_for_radius(float(radius)), 0) if radius > 0 else 0)
+
+    @staticmethod
+    def square(neighbor_range) -> "MaskSpec":
+        """|dy| <= nr_h//2, |dx| <= nr_w//2 (affinity_utils.py:86-96)."""
+        nr = (neighbor_range, neighbor_range) if isinstance(neighbor_range, int) else tuple(neighbor_range)
+        return MaskSpec(ry=nr[0] // 2, rx=nr[1] // 2)
+
+    @staticmethod
+    def from_neighbor_range(neighbor_range, mode: str = "circle") -> "MaskSpec":
+        if neighbor_range is None:
+            return MaskSpec.none()
+        if mode == "circle":
+            return MaskSpec.circle(neighbor_range // 2)
+        if mode == "square":
+            return MaskSpec.square(neighbor_range)
+        raise ValueError(mode)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.FgvcHipError(f"{name} must be on the GPU (fgvc_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def normalize_to_hwc(x: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    """(n, C, H, W) or (n, C, HW) f32 NCHW -> (n, HW, C) L2-normalised over C (eps 1e-12)."""
+    x = _chk(x, torch.float32, "x")
+    n, Cc = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    out = torch.empty((n, HW, Cc), device=x.device, dtype=torch.float32)
+    _lib.call("fgvc_normalize_chw_to_hwc_f32", _ptr(x), _ptr(out), n, Cc, HW, int(normalize), _stream(x))
+    return out
+
+
+def make_pairs(pairs, device, masked=True) -> torch.Tensor:
+    """[(query_frame, key_frame[, masked])...] -> int32 (n,4) device tensor."""
+    rows = []
+    for p in pairs:
+        m = masked if len(p) < 3 else p[2]
+        rows.append((int(p[0]), int(p[1]), PAIR_MASKED if m else 0, 0))
+    return torch.tensor(rows, dtype=torch.int32, device=device).reshape(-1, 4)
+
+
+def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
+              mask: MaskSpec, topk: int, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Windowed correlation + top-k per (query frame, key frame) pair.
+    qfeat (nq, HqWq, C), kfeat (nk, HkWk, C), pairs int32 (n,4).
+    Returns idx (n, HqWq, topk) int32 (key pixel, -1 = none), score (n, HqWq, topk) f32 raw dot."""
+    qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
+    pairs = _chk(pairs, torch.int32, "pairs")
+    assert qfeat.shape[1] == Hq * Wq and kfeat.shape[1] == Hk * Wk and qfeat.shape[2] == kfeat.shape[2]
+    n = pairs.shape[0]
+    if n and validate:
+        # host-side operand check before a hand-written kernel indexes with these (costs a sync;
+        # callers that built `pairs` on the host from known-good frame numbers pass validate=False)
+        lim = pairs[:, :2].amax(0).tolist()
+        assert lim[0] < qfeat.shape[0] and lim[1] < kfeat.shape[0] and int(pairs[:, :2].min()) >= 0, "pair out of range"
+    idx = torch.empty((n, Hq * Wq, topk), device=qfeat.device, dtype=torch.int32)
+    score = torch.empty((n, Hq * Wq, topk), device=qfeat.device, dtype=torch.float32)
+    _lib.call("fgvc_pair_topk_f32", _ptr(qfeat), _ptr(kfeat), _ptr(pairs), n, qfeat.shape[2], Hq, Wq, Hk, Wk,
+              mask.r2max, mask.ry, mask.rx, topk, _ptr(idx), _ptr(score), _stream(qfeat))
+    return idx, score
+
+
+def merge_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pair: torch.Tensor, HWk: int, topk: int,
+               temperature: float, mode: str = "softmax", validate: bool = True):
+    """slot_pair int32 (n_out, T): pair feeding key slot t of output frame f (-1 unused).
+    Returns idx (n_out, HWq, k) int32 = slot*HWk + pixel, logit, weight."""
+    pair_idx, pair_score = _chk(pair_idx, torch.int32, "pair_idx"), _chk(pair_score, torch.float32, "pair_score")
+    slot_pair = _chk(slot_pair, torch.int32, "slot_pair")
+    assert pair_idx.shape == pair_score.shape and pair_idx.shape[2] == topk
+    n_out, T = slot_pair.shape
+    if validate:
+        assert int(slot_pair.max()) < pair_idx.shape[0]
+    HWq = pair_idx.shape[1]
+    wm = {"softmax": WEIGHT_SOFTMAX, "cosine": WEIGHT_COSINE}[mode]
+    idx = torch.empty((n_out, HWq, topk), device=pair_idx.device, dtype=torch.int32)
+    logit = torch.empty((n_out, HWq, topk), device=pair_idx.device, dtype=torch.float32)
+    weight = torch.empty_like(logit)
+    _lib.call("fgvc_merge_topk_f32", _ptr(pair_idx), _ptr(pair_score), _ptr(slot_pair), n_out, T, HWq, HWk, topk,
+              float(temperature), wm, _ptr(idx), _ptr(logit), _ptr(weight), _stream(pair_idx))
+    return idx, logit, weight
+
+
+def propagate_topk(labels: torch.Tensor, slot_frame: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor,
+                   Hq: int, Wq: int, Hk: int, Wk: int, window_L: int = 0,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """labels (n_frames, HkWk, P), slot_frame int32 (T,), idx/weight (HqWq, k) -> (HqWq, P)."""
+    labels = _chk(labels, torch.float32, "labels")
+    slot_frame = _chk(slot_frame, torch.int32, "slot_frame")
+    idx, weight = _chk(idx, torch.int32, "idx"), _chk(weight, torch.float32, "weight")
+    P, k = labels.shape[2], idx.shape[-1]
+    assert labels.shape[1] == Hk * Wk and idx.shape[-2] == Hq * Wq and idx.shape == weight.shape
+    if out is None:
+        out = torch.empty((Hq * Wq, P), device=labels.device, dtype=torch.float32)
+    else:
+        assert out.is_contiguous() and out.shape == (Hq * Wq, P) and out.dtype == torch.float32
+    _lib.call("fgvc_propagate_topk_f32", _ptr(labels), _ptr(slot_frame), slot_frame.numel(), _ptr(idx), _ptr(weight),
+              Hq, Wq, Hk, Wk, P, k, window_L, _ptr(out), _stream(labels))
+    return out
+
+
+def split_bf16(feat: torch.Tensor) -> torch.Tensor:
+    """(…, C) f32 -> (…, 2, C) int16 holding bf16 bit patterns: hi = bf16(x), lo = bf16(x - hi)."""
+    feat = _chk(feat, torch.float32, "feat")
+    Cc = feat.shape[-1]
+    n = feat.numel() // Cc
+    out = torch.empty((*feat.shape[:-1], 2, Cc), device=feat.device, dtype=torch.int16)
+    _lib.call("fgvc_split_bf16", _ptr(feat), _ptr(out), n, Cc, _stream(feat))
+    return out
+
+
+def corr_volume(qfeat: torch.Tensor, kfeat: torch.Tensor, temperature: float = 1.0, precision: str = "f32",
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense volume vol[key j][query i] = <k_j, q_i>/temperature, (HWk, HWq) f32.
+    precision 'f32': qfeat (HWq,C), kfeat (HWk,C) f32.  'bf16x3' / 'bf16': the split_bf16() forms (HW,2,C)."""
+    HWq, HWk, Cc = qfeat.shape[0], kfeat.shape[0], qfeat.shape[-1]
+    if out is None:
+        out = torch.empty((HWk, HWq), device=qfeat.device, dtype=torch.float32)
+    else:
+        assert out.is_contiguous() and out.shape == (HWk, HWq) and out.dtype == torch.float32
+    if precision == "f32":
+        qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
+        _lib.call("fgvc_corr_volume_f32", _ptr(qfeat), _ptr(kfeat), Cc, HWq, HWk, float(temperature), _ptr(out),
+                  _stream(qfeat))
+    elif precision in ("bf16x3", "bf16"):
+        qfeat, kfeat = _chk(qfeat, torch.int16, "qfeat"), _chk(kfeat, torch.int16, "kfeat")
+        assert qfeat.dim() == 3 and qfeat.shape[1] == 2
+        _lib.call("fgvc_corr_volume_" + precision, _ptr(qfeat), _ptr(kfeat), Cc, HWq, HWk, float(temperature),
+                  _ptr(out), _stream(qfeat))
+    else:
+        raise ValueError(precision)
+    return out
+
+
+def local_corr_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, H: int, W: int, R: int, topk: int,
+                    temperature: float):
+    """A7: qfeat (1, HW, C), kfeat (K, HW, C) -> idx (HW,k) int32 = slot*(2R+1)^2 + tap, logit, weight."""
+    qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
+    K = kfeat.shape[0]
+    dev = qfeat.device
+    pairs = make_pairs([(0, t) for t in range(K)], dev)
+    ws_i = torch.empty((K, H * W, topk), device=dev, dtype=torch.int32)
+    ws_s = torch.empty((K, H * W, topk), device=dev, dtype=torch.float32)
+    idx = torch.empty((H * W, topk), device=dev, dtype=torch.int32)
+    logit = torch.empty((H * W, topk), device=dev, dtype=torch.float32)
+    weight = torch.empty_like(logit)
+    _lib.call("fgvc_local_corr_topk_f32", _ptr(qfeat), _ptr(kfeat), _ptr(pairs), K, qfeat.shape[-1], H, W, R, topk,
+              float(temperature), _ptr(ws_i), _ptr(ws_s), _ptr(idx), _ptr(logit), _ptr(weight), _stream(qfeat))
+    return idx, logit, weight
+
+
+def c2f_refine(coarse_arg: torch.Tensor, qfine: torch.Tensor, kfine: torch.Tensor, vfine: torch.Tensor, H: int,
+               W: int, scale: int, Rf: int, topk: int, temperature: float):
+    """A6 fine stage. coarse_arg int32 (T, HW); qfine (sHsW, Cf); kfine (T, sHsW, Cf); vfine (T, sHsW, P)."""
+    coarse_arg = _chk(coarse_arg, torch.int32, "coarse_arg")
+    qfine, kfine = _chk(qfine, torch.float32, "qfine"), _chk(kfine, torch.float32, "kfine")
+    vfine = _chk(vfine, torch.float32, "vfine")
+    T, Cf, P = kfine.shape[0], kfine.shape[-1], vfine.shape[-1]
+    assert coarse_arg.shape == (T, H * W) and kfine.shape[1] == H * W * scale * scale == vfine.shape[1]
+    assert int(coarse_arg.min()) >= 0 and int(coarse_arg.max()) < H * W
+    dev = qfine.device
+    out = torch.empty((H * W, P), device=dev, dtype=torch.float32)
+    idx = torch.empty((H * W, topk), device=dev, dtype=torch.int32)
+    logit = torch.empty((H * W, topk), device=dev, dtype=torch.float32)
+    _lib.call("fgvc_c2f_refine_f32", _ptr(coarse_arg), _ptr(qfine), _ptr(kfine), _ptr(vfine), T, H, W, scale, Cf, P,
+              Rf, topk, float(temperature), _ptr(out), _ptr(idx), _ptr(logit), _stream(qfine))
+    return out, idx, logit
+
+
+def gaussian_labels(points: torch.Tensor, Hf: int, Wf: int, stride: int, sigma: float = 6.0,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """points (P,2)=(x,y) -> (HfWf, P) initial labels (vanilla_tracker.py:204-221)."""
+    points = _chk(points.to(torch.float32), torch.float32, "points")
+    P = points.shape[0]
+    if out is None:
+        out = torch.empty((Hf * Wf, P), device=points.device, dtype=torch.float32)
+    _lib.call("fgvc_gaussian_labels_f32", _ptr(points), P, Hf, Wf, stride, float(sigma), _ptr(out), _stream(points))
+    return out
+
+
+def softargmax_top5(labels: torch.Tensor, Hf: int, Wf: int, h: int, w: int,
+                    gauss_points: Optional[torch.Tensor] = None, sigma: float = 6.0) -> torch.Tensor:
+    """labels (n_frames, HfWf, P) -> coords (n_frames, P, 2) float64 = (x, y)."""
+    labels = _chk(labels, torch.float32, "labels")
+    n, P = labels.shape[0], labels.shape[2]
+    assert labels.shape[1] == Hf * Wf
+    if gauss_points is not None:
+        gauss_points = _chk(gauss_points.to(torch.float32), torch.float32, "gauss_points")
+        assert gauss_points.shape == (P, 2)
+    coords = torch.empty((n, P, 2), device=labels.device, dtype=torch.float64)
+    _lib.call("fgvc_softargmax_top5_f32", _ptr(labels), n, Hf, Wf, P, h, w, _ptr(gauss_points), float(sigma),
+              _ptr(coords), _stream(labels))
+    return coords

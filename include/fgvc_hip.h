@@ -1,0 +1,154 @@
+/*
+ * fgvc_hip.h -- C ABI of libfgvc_hip.so: FGVC's label-propagation inference hot path
+ * as hand-written HIP kernels for MI355X (gfx950 / CDNA4).
+ *
+ * The reference (qianduoduolr/FGVC, "mmpt") is pure Python; its FFI for this path is
+ * "call these torch functions".  Each entry point below replaces the body of one reference
+ * function (cited as file:line relative to the reference tree); fgvc_amd/mmpt_api/ rebuilds the
+ * reference's Python signatures on top of them and INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; buffers are caller-owned
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it; nothing here allocates, frees or synchronises
+ *     (the functions are hipGraph-capturable)
+ *   - return value: FGVC_OK or an FGVC_ERR_* code; fgvc_last_error() gives the text
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - feature maps are CHANNELS-LAST ("hwc"): feat[frame][pixel][channel], pixel = y*W + x
+ *   - label maps are PIXEL-MAJOR ("hwp"):     lab[frame][pixel][label]
+ *   - top-k lists are in canonical order: score descending, index ascending among equals
+ *     (torch.topk leaves tie order unspecified; see DESIGN.md "tie policy")
+ */
+#ifndef FGVC_HIP_H
+#define FGVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGVC_OK 0
+#define FGVC_ERR_INVALID_ARG 1
+#define FGVC_ERR_UNSUPPORTED 2
+#define FGVC_ERR_LAUNCH 3
+
+/* mask predicate on the integer offset (dy,dx) = key pixel - query pixel
+ *   keep  <=>  dy*dy+dx*dx <= r2max  &&  |dy| <= ry  &&  |dx| <= rx
+ * circle (affinity_utils.py:98-109, local_attention.py:463-467): r2max = largest d2 with
+ *   sqrtf(d2) < radius (fgvc_r2max_for_radius), ry = rx = FGVC_NO_LIMIT
+ * square (affinity_utils.py:86-96): r2max = FGVC_NO_LIMIT, ry = nr_h/2, rx = nr_w/2
+ * none: all three FGVC_NO_LIMIT */
+#define FGVC_NO_LIMIT 0x3fffffff
+
+/* pairs[i] = {query_frame, key_frame, flags, reserved} */
+#define FGVC_PAIR_MASKED 1      /* apply the mask predicate to this pair (else full frame)   */
+
+/* weight modes of fgvc_merge_topk_f32 (local_attention.py:368-373) */
+#define FGVC_WEIGHT_SOFTMAX 0
+#define FGVC_WEIGHT_COSINE 1
+
+const char* fgvc_version(void);
+const char* fgvc_last_error(void);
+
+/* Largest integer d2 such that sqrtf((float)d2) < radius, -1 if none (host helper). */
+int fgvc_r2max_for_radius(float radius);
+
+/* ---- A5 step 0: F.normalize(dim=1) + NCHW -> channels-last -------------------------------
+ * replaces local_attention.py:308-313 (F.normalize(query/key, p=2, dim=1) and the .view()s).
+ * in [n][C][HW] f32 (the encoder's NCHW output)  ->  out [n][HW][C] f32,
+ * out = in / max(||in||_2 over C, 1e-12) when normalize != 0, plain transpose otherwise. */
+int fgvc_normalize_chw_to_hwc_f32(const float* in, float* out, int n, int C, int HW,
+                                  int normalize, void* stream);
+
+/* ---- A5 step 1: windowed correlation + running top-k, one (query frame, key frame) pair per
+ * grid.y.  Replaces the einsum / masked_fill_ / topk of local_attention.py:321-356 (and the
+ * per-chunk mask rebuild of masked_attention_efficient_v2, :452-475) for ONE key frame; the
+ * (T*HW x step) slab is never materialised.  f32 MFMA (v_mfma_f32_32x32x2_f32), exact f32.
+ *   qfeat [n_qframes][Hq*Wq][C], kfeat [n_kframes][Hk*Wk][C]   (normalised, channels-last)
+ *   pairs [n_pairs][4] int32 (device)
+ *   idx_out   [n_pairs][Hq*Wq][topk] int32   key pixel index ky*Wk+kx, -1 where fewer than topk
+ *                                            candidates exist
+ *   score_out [n_pairs][Hq*Wq][topk] f32     raw dot product (NOT yet divided by temperature),
+ *                                            descending; -inf where idx = -1
+ * C must be a multiple of 32, 32 <= C <= 256; 1 <= topk <= 16.  Masked pairs need Hq==Hk, Wq==Wk. */
+int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_pairs,
+                       int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk,
+                       int32_t* idx_out, float* score_out, void* stream);
+
+/* ---- A5 step 2: merge the per-pair lists of the T key slots of each query frame, divide by the
+ * temperature and turn the k logits into weights.  Replaces the global topk over T*HW
+ * (local_attention.py:356) and :368-371.
+ *   slot_pair [n_out][T] int32 (device): pair id feeding slot t of output frame f, -1 = unused
+ *   idx_out [n_out][HWq][topk] = slot*HWk + key pixel   (the reference's flat key index, :312)
+ *   logit_out, weight_out [n_out][HWq][topk] f32 */
+int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair,
+                        int n_out, int T, int HWq, int HWk, int topk, float temperature,
+                        int weight_mode, int32_t* idx_out, float* logit_out, float* weight_out,
+                        void* stream);
+
+/* ---- A5 step 3: label propagation  out[i][p] = sum_r weight[i][r] * labels[slot(idx)][pix(idx)][p]
+ * replaces the index_select + einsum of local_attention.py:360-375.
+ *   labels [n_label_frames][HWk][P]; slot_frame [T] int32 (device): label frame of each key slot
+ *   window_L = 0: idx = slot*HWk + pixel.   window_L = L > 0 (A7 local window, vanilla_tracker.py:550-566):
+ *   idx = slot*L*L + (dy+R)*L + (dx+R) relative to the query pixel, taps outside the image read 0. */
+int fgvc_propagate_topk_f32(const float* labels, const int32_t* slot_frame, int T,
+                            const int32_t* idx, const float* weight, int Hq, int Wq, int Hk, int Wk,
+                            int P, int topk, int window_L, float* out, void* stream);
+
+/* ---- A5'': dense correlation volume  vol[j][i] = <k_j, q_i> / temperature,  j key, i query
+ * replaces affinity_utils.py:6-21 (compute_affinity), local_attention.py:231 / :321-323 and
+ * correlation.py:51 for one (query, key) frame pair.  vol is [HWk][HWq] f32, row-major.
+ *   _f32    : exact f32 MFMA
+ *   _bf16x3 : inputs pre-split by fgvc_split_bf16 into hi+lo bf16, three bf16 MFMA products
+ *             (hi*hi + hi*lo + lo*hi), f32 accumulate; |error| <= ~2e-5 in cosine
+ *   _bf16   : hi part only (reduced precision, configs[4]) */
+int fgvc_corr_volume_f32(const float* qfeat, const float* kfeat, int C, int HWq, int HWk,
+                         float temperature, float* vol, void* stream);
+int fgvc_split_bf16(const float* feat, uint16_t* hi_lo /* [n][2][C] bf16: hi then lo */, int64_t n_pixels,
+                    int C, void* stream);
+int fgvc_corr_volume_bf16x3(const uint16_t* q_hi_lo, const uint16_t* k_hi_lo, int C, int HWq, int HWk,
+                            float temperature, float* vol, void* stream);
+int fgvc_corr_volume_bf16(const uint16_t* q_hi_lo, const uint16_t* k_hi_lo, int C, int HWq, int HWk,
+                          float temperature, float* vol, void* stream);
+
+/* ---- A7: single-scale local-window correlation + top-k (mmcv.ops.Correlation semantics as used at
+ * vanilla_tracker.py:435-443,547-566; torch twin local_attention.py:1190-1240).
+ * Same kernel as fgvc_pair_topk_f32 with a square window |dy|,|dx| <= R; additionally the zero-padded
+ * taps outside the image are candidates with score exactly 0.
+ *   idx_out [HW][topk] = slot*(2R+1)^2 + (dy+R)*(2R+1) + (dx+R);  logit = corr/temperature (divided after
+ *   top-k, :563); weight = softmax(logit). */
+int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_slots,
+                             int C, int H, int W, int R, int topk, float temperature,
+                             int32_t* pair_idx_ws, float* pair_score_ws,
+                             int32_t* idx_out, float* logit_out, float* weight_out, void* stream);
+
+/* ---- A6: coarse-to-fine refine (local_attention.py:721-880), fine stage.
+ *   coarse_arg [T][HW] int32: per key slot and query, the coarse cell picked by the coarse stage
+ *                             (fgvc_pair_topk_f32 with topk=1 on the coarse features)
+ *   qfine [sH*sW][Cf], kfine [T][sH*sW][Cf] normalised channels-last, vfine [T][sH*sW][P]
+ *   out [HW][P]; idx_out/logit_out [HW][topk] (idx = t*(2Rf+1)^2 + tap) */
+int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const float* kfine,
+                        const float* vfine, int T, int H, int W, int scale, int Cf, int P, int Rf,
+                        int topk, float temperature, float* out, int32_t* idx_out, float* logit_out,
+                        void* stream);
+
+/* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
+ * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).
+ *   points [P][2] f32 = (x, y);  out [Hf*Wf][P] */
+int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int stride, float sigma,
+                             float* out, void* stream);
+
+/* ---- A8 + A9: bilinear upsample (align_corners=False) fused with the top-5 soft-argmax read-out
+ * replaces vanilla_tracker.py:396-400 and :172-191 (no (T,P,h,w) tensor, no D2H copy, no argsort).
+ *   labels [n_frames][Hf*Wf][P];  gauss_points: if non-NULL, frame 0 is read out from the analytic
+ *   full-resolution Gaussian of these points instead (vanilla_tracker.py:329,322).
+ *   coords [n_frames][P][2] f64 = (x, y); (-1,-1) where the map is all zero. */
+int fgvc_softargmax_top5_f32(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
+                             const float* gauss_points, float sigma, double* coords, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGVC_HIP_H */
