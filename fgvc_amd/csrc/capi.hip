@@ -21,7 +21,7 @@ int pair_topk_launch(const float*, const float*, const int32_t*, int, int, int, 
                      int32_t*, float*, hipStream_t);
 int merge_topk_launch(const int32_t*, const float*, const int32_t*, int, int, int, int, int, float, int, int32_t*,
                       float*, float*, hipStream_t);
-int normalize_launch(const float*, float*, int, int, int, int, hipStream_t);
+int normalize_launch(const float*, float*, int, int, int, int, int, hipStream_t);
 int propagate_launch(const float*, const int32_t*, int, const int32_t*, const float*, int, int, int, int, int, int,
                      int, float*, hipStream_t);
 int gaussian_launch(const float*, int, int, int, int, float, float*, hipStream_t);
@@ -53,13 +53,15 @@ int fgvc_r2max_for_radius(float radius) {
   return (int)d2;
 }
 
-int fgvc_normalize_chw_to_hwc_f32(const float* in, float* out, int n, int C, int HW, int normalize, void* stream) {
+int fgvc_normalize_chw_to_hwc_f32(const float* in, float* out, int n, int C, int HW, int normalize, int c_out,
+                                  void* stream) {
   FGVC_REQUIRE(in && out, FGVC_ERR_INVALID_ARG, "fgvc_normalize_chw_to_hwc_f32: null pointer");
   FGVC_REQUIRE(n >= 0 && C > 0 && HW > 0, FGVC_ERR_INVALID_ARG, "fgvc_normalize_chw_to_hwc_f32: bad shape n=%d C=%d HW=%d", n, C, HW);
   FGVC_REQUIRE(C <= 1024, FGVC_ERR_UNSUPPORTED, "fgvc_normalize_chw_to_hwc_f32: C=%d > 1024 (LDS tile)", C);
   FGVC_REQUIRE(n <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_normalize_chw_to_hwc_f32: n=%d > 65535 frames per call", n);
+  FGVC_REQUIRE(c_out >= C, FGVC_ERR_INVALID_ARG, "fgvc_normalize_chw_to_hwc_f32: c_out=%d < C=%d", c_out, C);
   if (n == 0) return FGVC_OK;
-  return normalize_launch(in, out, n, C, HW, normalize, (hipStream_t)stream);
+  return normalize_launch(in, out, n, C, HW, normalize, c_out, (hipStream_t)stream);
 }
 
 int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_pairs, int C, int Hq,

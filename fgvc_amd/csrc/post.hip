@@ -12,7 +12,7 @@ namespace fgvc {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void normalize_chw_to_hwc_kernel(const float* __restrict__ in,
                                                                      float* __restrict__ out, int C, int HW,
-                                                                     int normalize) {
+                                                                     int normalize, int Cout) {
   extern __shared__ float tile[];  // [C][33] + [8][32] partial sums + [32] inverse norms
   float* part = tile + (size_t)C * 33;
   float* inv = part + 8 * 32;
@@ -38,11 +38,13 @@ __global__ __launch_bounds__(256) void normalize_chw_to_hwc_kernel(const float* 
     inv[tid] = normalize ? fmaxf(sqrtf(s), 1e-12f) : 1.0f;
   }
   __syncthreads();
-  float* dst = out + (frame * HW + p0) * (size_t)C;
+  // output rows are Cout >= C floats long; channels C..Cout-1 are written as zeros (they add
+  // nothing to any dot product) so the MFMA kernels can run on their supported channel counts
+  float* dst = out + (frame * HW + p0) * (size_t)Cout;
   const int npx = imin(32, HW - p0);
-  for (int i = tid; i < npx * C; i += 256) {
-    const int pp = i / C, c = i - pp * C;
-    dst[i] = tile[c * 33 + pp] / inv[pp];
+  for (int i = tid; i < npx * Cout; i += 256) {
+    const int pp = i / Cout, c = i - pp * Cout;
+    dst[i] = c < C ? tile[c * 33 + pp] / inv[pp] : 0.f;
   }
 }
 
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void softargmax_top5_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
-int normalize_launch(const float* in, float* out, int n, int C, int HW, int normalize, hipStream_t s) {
+int normalize_launch(const float* in, float* out, int n, int C, int HW, int normalize, int Cout, hipStream_t s) {
   dim3 grid(cdiv(HW, 32), n);
   const size_t lds = ((size_t)C * 33 + 8 * 32 + 32) * sizeof(float);
   if (lds > 48 * 1024) {  // opt in to the large-LDS carve-out (attribute set, no sync, capture-safe)
@@ -286,7 +288,7 @@ int normalize_launch(const float* in, float* out, int n, int C, int HW, int norm
       return FGVC_ERR_LAUNCH;
     }
   }
-  normalize_chw_to_hwc_kernel<<<grid, 256, lds, s>>>(in, out, C, HW, normalize);
+  normalize_chw_to_hwc_kernel<<<grid, 256, lds, s>>>(in, out, C, HW, normalize, Cout);
   FGVC_CHECK_LAUNCH("fgvc_normalize_chw_to_hwc_f32");
   return FGVC_OK;
 }

@@ -71,13 +71,25 @@ def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def normalize_to_hwc(x: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-    """(n, C, H, W) or (n, C, HW) f32 NCHW -> (n, HW, C) L2-normalised over C (eps 1e-12)."""
+MFMA_CHANNELS = (32, 64, 128, 256)   # channel counts fgvc_pair_topk_f32 / fgvc_corr_volume_f32 are built for
+
+
+def padded_channels(c: int) -> int:
+    for m in MFMA_CHANNELS:
+        if c <= m:
+            return m
+    raise _lib.FgvcHipError(f"C={c} > {MFMA_CHANNELS[-1]} channels is not supported by the correlation kernels")
+
+
+def normalize_to_hwc(x: torch.Tensor, normalize: bool = True, pad: bool = False) -> torch.Tensor:
+    """(n, C, H, W) or (n, C, HW) f32 NCHW -> (n, HW, C') L2-normalised over C (eps 1e-12).
+    pad=True rounds C' up to a kernel-supported channel count with zero channels."""
     x = _chk(x, torch.float32, "x")
     n, Cc = x.shape[0], x.shape[1]
     HW = x[0, 0].numel()
-    out = torch.empty((n, HW, Cc), device=x.device, dtype=torch.float32)
-    _lib.call("fgvc_normalize_chw_to_hwc_f32", _ptr(x), _ptr(out), n, Cc, HW, int(normalize), _stream(x))
+    Co = padded_channels(Cc) if pad else Cc
+    out = torch.empty((n, HW, Co), device=x.device, dtype=torch.float32)
+    _lib.call("fgvc_normalize_chw_to_hwc_f32", _ptr(x), _ptr(out), n, Cc, HW, int(normalize), Co, _stream(x))
     return out
 
 

@@ -57,10 +57,12 @@ int fgvc_r2max_for_radius(float radius);
 
 /* ---- A5 step 0: F.normalize(dim=1) + NCHW -> channels-last -------------------------------
  * replaces local_attention.py:308-313 (F.normalize(query/key, p=2, dim=1) and the .view()s).
- * in [n][C][HW] f32 (the encoder's NCHW output)  ->  out [n][HW][C] f32,
- * out = in / max(||in||_2 over C, 1e-12) when normalize != 0, plain transpose otherwise. */
+ * in [n][C][HW] f32 (the encoder's NCHW output)  ->  out [n][HW][c_out] f32, c_out >= C,
+ * out = in / max(||in||_2 over C, 1e-12) when normalize != 0, plain transpose otherwise;
+ * channels C..c_out-1 are written as zeros (zero padding does not change any dot product; it lets
+ * callers round C up to a channel count the MFMA kernels support). */
 int fgvc_normalize_chw_to_hwc_f32(const float* in, float* out, int n, int C, int HW,
-                                  int normalize, void* stream);
+                                  int normalize, int c_out, void* stream);
 
 /* ---- A5 step 1: windowed correlation + running top-k, one (query frame, key frame) pair per
  * grid.y.  Replaces the einsum / masked_fill_ / topk of local_attention.py:321-356 (and the

@@ -39,7 +39,7 @@ def gpu_affinity(dev, q, key, topk, temperature, neighbor_range, mask_mode="circ
     C, H, W = q.shape
     Tn = key.shape[1]
     frames = torch.cat([q.unsqueeze(0), key.permute(1, 0, 2, 3)], 0).to(dev)
-    feats = ops.normalize_to_hwc(frames)
+    feats = ops.normalize_to_hwc(frames, pad=True)
     mask = ops.MaskSpec.from_neighbor_range(neighbor_range, mask_mode)
     pairs = ops.make_pairs([(0, 1 + t, (t >= non_mask_len) and not mask.is_none) for t in range(Tn)], dev)
     pidx, pscore = ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, topk)
@@ -69,6 +69,9 @@ def test_normalize(dev):
         assert torch.allclose(out, ref, atol=1e-6, rtol=1e-5)
         raw = ops.normalize_to_hwc(x.to(dev), normalize=False).cpu()
         assert torch.equal(raw, x.flatten(2).transpose(1, 2))
+        padded = ops.normalize_to_hwc(x.to(dev), pad=True).cpu()
+        assert padded.shape[2] == ops.padded_channels(C)
+        assert torch.equal(padded[..., :C], out) and float(padded[..., C:].abs().max() if padded.shape[2] > C else 0) == 0
 
 
 MAE = ["mae_s8x12", "mae_s16x16", "mae_s32x32", "mae_s20x24_nml1", "mae_s12x20_cos", "mae_s16x24_c256"]
