@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int pair_topk_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, int, int, int, int,
-                     int32_t*, float*, hipStream_t);
+                     const uint8_t*, int32_t*, float*, hipStream_t);
 int merge_topk_launch(const int32_t*, const float*, const int32_t*, int, int, int, int, int, float, int, int32_t*,
                       float*, float*, hipStream_t);
 int normalize_launch(const float*, float*, int, int, int, int, int, hipStream_t);
@@ -65,8 +65,8 @@ int fgvc_normalize_chw_to_hwc_f32(const float* in, float* out, int n, int C, int
 }
 
 int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_pairs, int C, int Hq,
-                       int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int32_t* idx_out,
-                       float* score_out, void* stream) {
+                       int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, const uint8_t* dense_mask,
+                       int32_t* idx_out, float* score_out, void* stream) {
   FGVC_REQUIRE(qfeat && kfeat && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f32: null pointer");
   FGVC_REQUIRE(aligned16(qfeat) && aligned16(kfeat) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
                "fgvc_pair_topk_f32: qfeat/kfeat/pairs must be 16-byte aligned");
@@ -81,8 +81,10 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
   FGVC_REQUIRE((long long)Hk * Wk < (1ll << 30) && (long long)Hq * Wq < (1ll << 30), FGVC_ERR_UNSUPPORTED,
                "fgvc_pair_topk_f32: grid too large");
   if (n_pairs == 0) return FGVC_OK;
-  return pair_topk_launch(qfeat, kfeat, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, idx_out, score_out,
-                          (hipStream_t)stream);
+  FGVC_REQUIRE(dense_mask == nullptr || !any_limit, FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_f32: give either the analytic predicate or a dense mask, not both");
+  return pair_topk_launch(qfeat, kfeat, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, dense_mask, idx_out,
+                          score_out, (hipStream_t)stream);
 }
 
 int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, int n_out, int T,
@@ -157,8 +159,8 @@ int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32
   FGVC_REQUIRE(R >= 0 && n_slots >= 1 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_local_corr_topk_f32: bad R/n_slots/temperature");
   FGVC_REQUIRE((long long)n_slots * (2 * R + 1) * (2 * R + 1) < (1ll << 31), FGVC_ERR_UNSUPPORTED,
                "fgvc_local_corr_topk_f32: index overflow");
-  int rc = fgvc_pair_topk_f32(qfeat, kfeat, pairs, n_slots, C, H, W, H, W, FGVC_NO_LIMIT, R, R, topk, pair_idx_ws,
-                              pair_score_ws, stream);
+  int rc = fgvc_pair_topk_f32(qfeat, kfeat, pairs, n_slots, C, H, W, H, W, FGVC_NO_LIMIT, R, R, topk, nullptr,
+                              pair_idx_ws, pair_score_ws, stream);
   if (rc != FGVC_OK) return rc;
   return local_merge_launch(pair_idx_ws, pair_score_ws, n_slots, H, W, R, topk, temperature, idx_out, logit_out,
                             weight_out, (hipStream_t)stream);

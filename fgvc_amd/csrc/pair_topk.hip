@@ -29,6 +29,7 @@ struct PairParams {
   int reach_y, reach_x;  // largest |dy|, |dx| the predicate admits (host-computed)
   int n_ty, n_tx;
   int kout;           // entries written per query (<= K); rows of idx_out/score_out have this stride
+  const uint8_t* dense_mask;  // optional [HWk][HWq] bool: arbitrary user mask (full-frame traversal)
   int32_t* idx_out;
   float* score_out;
 };
@@ -154,10 +155,16 @@ __global__ __launch_bounds__(256, 2) void pair_topk_kernel(PairParams p) {
         const int ky = ky0 + (r >> 2), kx = kx0 + (r & 3) + 4 * hi;
         const int dy = ky - qy, dx = kx - qx;
         const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
-        const bool ok = ky < p.Hk && kx < p.Wk && dy * dy + dx * dx <= r2max && ady <= ry && adx <= rx;
+        bool ok = ky < p.Hk && kx < p.Wk && dy * dy + dx * dx <= r2max && ady <= ry && adx <= rx;
         const float s = acc[r];
         const int id = ky * p.Wk + kx;
-        if (ok && top.accepts(s, id)) top.insert(s, id);
+        if (ok && top.accepts(s, id)) {
+          // arbitrary dense mask (local_attention.py:329-353 with a user tensor): consulted only for
+          // candidates that would enter the list, so the byte gather stays off the common path
+          if (masked && p.dense_mask != nullptr && q_valid)
+            ok = p.dense_mask[(size_t)id * ((size_t)p.Hq * p.Wq) + (size_t)qy * p.Wq + qx] != 0;
+          if (ok) top.insert(s, id);
+        }
       }
     }
     if (bn < nb) stage_store(buf ^ 1);
@@ -211,7 +218,7 @@ static int dispatch_k(const PairParams& p, int n_pairs, int k, hipStream_t s) {
 
 int pair_topk_launch(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_pairs, int C,
                      int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk,
-                     int32_t* idx_out, float* score_out, hipStream_t s) {
+                     const uint8_t* dense_mask, int32_t* idx_out, float* score_out, hipStream_t s) {
   PairParams p;
   p.qfeat = qfeat; p.kfeat = kfeat; p.pairs = reinterpret_cast<const int4*>(pairs);
   p.Hq = Hq; p.Wq = Wq; p.Hk = Hk; p.Wk = Wk;
@@ -222,6 +229,7 @@ int pair_topk_launch(const float* qfeat, const float* kfeat, const int32_t* pair
   p.kout = topk;
   p.n_ty = cdiv(Hq, 2 * QBH); p.n_tx = cdiv(Wq, 2 * QBW);
   p.idx_out = idx_out; p.score_out = score_out;
+  p.dense_mask = dense_mask;
   switch (C) {
     case 32: return dispatch_k<32>(p, n_pairs, topk, s);
     case 64: return dispatch_k<64>(p, n_pairs, topk, s);

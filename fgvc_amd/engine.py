@@ -71,6 +71,19 @@ class Plan:
     slot_pair: List[List[int]]                          # row -> pair id per key slot (-1 pad)
     slot_frame: List[List[int]]                         # row -> clip frame per key slot (0 pad)
     t_max: int = 0
+    _dev: Dict[str, tuple] = field(default_factory=dict, repr=False)
+
+    def tables(self, dev):
+        """Device copies of the schedule (pairs int32 (n,4), slot_pair / slot_frame int32 (rows,t_max)).
+        A plan depends only on (n_frames, starts, cfg), so the tables are uploaded once and reused."""
+        key = str(dev)
+        if key not in self._dev:
+            rows = len(self.slot_pair)
+            self._dev[key] = (
+                ops.make_pairs(self.pairs, dev),
+                torch.tensor(self.slot_pair, dtype=torch.int32, device=dev).reshape(rows, self.t_max),
+                torch.tensor(self.slot_frame, dtype=torch.int32, device=dev).reshape(rows, self.t_max))
+        return self._dev[key]
 
 
 def plan_clip(n_frames: int, starts: Sequence[int], cfg: TrackerConfig,
@@ -115,22 +128,29 @@ class DeviceTopk:
 
 
 def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
-                 pair_chunk: int = 4096) -> DeviceTopk:
-    """Phases 1 and 2.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip."""
+                 pair_chunk: int = 16384, events=None) -> DeviceTopk:
+    """Phases 1 and 2.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip.
+    `events` = (start, end) torch.cuda.Events recorded around the pair top-k launch(es)."""
     dev = feats_hwc.device
     HW = Hf * Wf
     k = cfg.topk
     n = len(plan.pairs)
-    pidx = torch.empty((n, HW, k), device=dev, dtype=torch.int32)
-    pscore = torch.empty((n, HW, k), device=dev, dtype=torch.float32)
-    pairs_dev = ops.make_pairs(plan.pairs, dev)
-    for c0 in range(0, n, pair_chunk):
-        c1 = min(n, c0 + pair_chunk)
-        i, s = ops.pair_topk(feats_hwc, feats_hwc, pairs_dev[c0:c1], Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
-        pidx[c0:c1], pscore[c0:c1] = i, s
+    pairs_dev, slot_pair, slot_frame = plan.tables(dev)
     rows = len(plan.slot_pair)
-    slot_pair = torch.tensor(plan.slot_pair, dtype=torch.int32, device=dev).reshape(rows, plan.t_max)
-    slot_frame = torch.tensor(plan.slot_frame, dtype=torch.int32, device=dev).reshape(rows, plan.t_max)
+    if events is not None:
+        events[0].record()
+    if n <= pair_chunk:
+        pidx, pscore = ops.pair_topk(feats_hwc, feats_hwc, pairs_dev, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
+    else:
+        pidx = torch.empty((n, HW, k), device=dev, dtype=torch.int32)
+        pscore = torch.empty((n, HW, k), device=dev, dtype=torch.float32)
+        for c0 in range(0, n, pair_chunk):
+            c1 = min(n, c0 + pair_chunk)
+            i, s = ops.pair_topk(feats_hwc, feats_hwc, pairs_dev[c0:c1], Hf, Wf, Hf, Wf, cfg.mask, k,
+                                 validate=False)
+            pidx[c0:c1], pscore[c0:c1] = i, s
+    if events is not None:
+        events[1].record()
     if rows == 0:
         e = torch.empty((0, HW, k), device=dev)
         return DeviceTopk(plan, e.int(), e, e, slot_frame)

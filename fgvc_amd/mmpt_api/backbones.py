@@ -1,0 +1,160 @@
+"""ResNet trunk behind the reference's registry name and constructor keys
+(mmpt/models/backbones/resnet.py:329-638), run by PyTorch-ROCm / MIOpen -- the encoder is host
+plumbing in this project (BASELINE.json north_star), not a hand-written kernel.
+
+What must match the reference: the state_dict key names (mmcv ConvModule nesting:
+`conv1.conv.weight`, `layer2.0.downsample.bn.running_var`, ...), the strides/out_indices/pool_type
+semantics and the arithmetic (conv -> BN(eval) -> ReLU).  What deliberately differs: forward()
+stops after the last requested stage (the reference runs all four stages even when only stage 2 is
+returned, resnet.py:619-627 -- ~17 GFLOP/frame of dead work at 256x256).
+"""
+from __future__ import annotations
+
+import re
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import BACKBONES
+
+
+class ConvBN(nn.Module):
+    """conv(no bias) + BatchNorm2d [+ ReLU]; attribute names follow mmcv.cnn.ConvModule."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, relu=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, padding, dilation, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = ConvBN(cin, planes, 3, stride, dilation, dilation, relu=True)
+        self.conv2 = ConvBN(planes, planes, 3, 1, 1, 1, relu=False)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        return F.relu(self.conv2(self.conv1(x)) + idt, inplace=True)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = ConvBN(cin, planes, 1, 1, 0, 1, relu=True)
+        self.conv2 = ConvBN(planes, planes, 3, stride, dilation, dilation, relu=True)
+        self.conv3 = ConvBN(planes, planes * 4, 1, 1, 0, 1, relu=False)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        return F.relu(self.conv3(self.conv2(self.conv1(x))) + idt, inplace=True)
+
+
+def _stage(block, cin, planes, n, stride, dilation):
+    ds = None
+    if stride != 1 or cin != planes * block.expansion:
+        ds = ConvBN(cin, planes * block.expansion, 1, stride, 0, 1, relu=False)
+    first_dil = dilation if dilation == 1 else dilation // 2           # resnet.py:304
+    layers = [block(cin, planes, stride, first_dil, ds)]
+    layers += [block(planes * block.expansion, planes, 1, dilation) for _ in range(1, n)]
+    return nn.Sequential(*layers)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)),
+                     50: (Bottleneck, (3, 4, 6, 3)), 101: (Bottleneck, (3, 4, 23, 3)),
+                     152: (Bottleneck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, pretrained=None, torchvision_pretrain=True, in_channels=3, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(3,), planes_custom=None,
+                 pool_type="max", zero_init_residual=True, **unused):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f"invalid depth {depth} for resnet")
+        assert 1 <= num_stages <= 4 and len(strides) == len(dilations) == num_stages
+        assert max(out_indices) < num_stages
+        self.depth, self.pretrained, self.torchvision_pretrain = depth, pretrained, torchvision_pretrain
+        self.strides, self.dilations, self.out_indices = tuple(strides), tuple(dilations), tuple(out_indices)
+        self.zero_init_residual = zero_init_residual
+        block, counts = self.arch_settings[depth]
+        self.conv1 = ConvBN(in_channels, 64, 7, 2, 3, 1, relu=True)                 # resnet.py:457-466
+        self.pool = {"max": nn.MaxPool2d(3, 2, 1), "mean": nn.AvgPool2d(3, 2, 1)}.get(pool_type)
+        cin = 64
+        self.res_layers = []
+        for i, n in enumerate(counts[:num_stages]):
+            planes = planes_custom[i] if planes_custom is not None else 64 * 2 ** i
+            self.add_module(f"layer{i + 1}", _stage(block, cin, planes, n, strides[i], dilations[i]))
+            self.res_layers.append(f"layer{i + 1}")
+            cin = planes * block.expansion
+        self.feat_dim = cin
+
+    def init_weights(self):
+        """Random init as resnet.py:587-601 when no checkpoint is given; checkpoints are loaded with
+        load_state_dict / load_checkpoint (prefixes stripped like revise_keys at resnet.py:580)."""
+        if isinstance(self.pretrained, str):
+            load_checkpoint(self, self.pretrained)
+            return
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    nn.init.constant_(m.conv2.bn.weight, 0)
+                elif isinstance(m, Bottleneck):
+                    nn.init.constant_(m.conv3.bn.weight, 0)
+
+    def forward(self, x, out_idx=None):
+        want = tuple(out_idx) if out_idx is not None else self.out_indices
+        x = self.conv1(x)
+        if self.pool is not None:
+            x = self.pool(x)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            if i > max(want):
+                break                                  # later stages cannot influence the outputs
+            x = getattr(self, name)(x)
+            if i in want:
+                outs.append(x)
+        return outs[0] if len(outs) == 1 else tuple(outs)
+
+
+_PREFIXES = (r"^module\.", r"^backbone\.", r"^encoder\.", r"^backbone_fine\.")
+
+
+def load_checkpoint(module: nn.Module, filename_or_state, strict: bool = False, prefixes: Sequence[str] = _PREFIXES):
+    """Minimal stand-in for mmcv.runner.load_checkpoint: accepts a path or a state dict, unwraps
+    'state_dict', strips the prefixes the reference strips (resnet.py:580), loads non-strictly."""
+    sd = torch.load(filename_or_state, map_location="cpu") if isinstance(filename_or_state, str) else filename_or_state
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    own = module.state_dict()
+    out = {}
+    for k, v in sd.items():
+        kk = k
+        if kk not in own:
+            for p in prefixes:
+                k2 = re.sub(p, "", kk)
+                if k2 != kk and (k2 in own or not strict):
+                    kk = k2
+                    if kk in own:
+                        break
+        out[kk] = v
+    return module.load_state_dict({k: v for k, v in out.items() if k in own} if not strict else out, strict=strict)

@@ -1,0 +1,200 @@
+"""Trackers behind the reference's registry names and call contract
+(mmpt/models/trackers/base.py:24-60, vanilla_tracker.py:25-412, :417-585).
+
+`model(test_mode=True, rgbs=..., query_points=..., trajectories=..., visibilities=...)` returns the
+reference's 5-tuple.  Everything after the encoder runs in libfgvc_hip.so through fgvc_amd.engine:
+no feature map, label map or score slab visits the host (the reference parks features on the CPU
+and re-uploads them per frame, :145-147, :347-352, and ships T*P*h*w floats back for a numpy
+argsort, :404-406).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import engine, ops
+from .builder import build_backbone, build_components
+from .config import ConfigDict
+from .registry import MODELS
+
+
+class BaseModel(nn.Module):
+    """base.py:24-60: holds train_cfg/test_cfg, dispatches on test_mode."""
+
+    def __init__(self, train_cfg=None, test_cfg=None, init_cfg=None):
+        super().__init__()
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg if test_cfg is not None else ConfigDict()
+
+    def init_weights(self):
+        for m in self.children():
+            if hasattr(m, "init_weights"):
+                m.init_weights()
+
+    def forward_train(self, *a, **k):
+        raise NotImplementedError("fgvc_amd accelerates the inference path only")
+
+    def forward_test(self, *a, **k):
+        raise NotImplementedError
+
+    def forward(self, test_mode=False, **kwargs):
+        return self.forward_test(**kwargs) if test_mode else self.forward_train(**kwargs)
+
+
+@MODELS.register_module()
+class BaseTracker(BaseModel):
+    def __init__(self, backbone, head=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.backbone = build_backbone(backbone)
+        self.head = build_components(head) if head is not None else None
+        self.register_buffer("iteration", torch.tensor(0, dtype=torch.float))
+
+    def extract_feat(self, imgs):
+        x = self.backbone(imgs)
+        if self.head is not None:
+            x = self.head(x)
+        return x
+
+
+@MODELS.register_module()
+class VanillaTracker(BaseTracker):
+    """Label propagation with a dense (disc-masked) affinity and top-k softmax."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        g = self.test_cfg.get
+        self.stride_sample = g("stride_sample", False)
+
+    # ---- A1/A2: encoder, every frame exactly once, features stay on the device ------------------
+    def extract_feat(self, imgs):
+        x = self.backbone(imgs)
+        if self.stride_sample:
+            x = x[:, :, ::self.stride_sample, ::self.stride_sample]
+        if self.head is not None:
+            x = self.head(x)
+        return x
+
+    @torch.no_grad()
+    def get_feats_hwc(self, frames: torch.Tensor):
+        """frames (T,3,h,w) -> normalised channels-last (T, HfWf, C'), Hf, Wf.
+        batch_step frames per encoder call (vanilla_tracker.py:135-147)."""
+        step = int(self.test_cfg.get("batch_step", 5))
+        norm = bool(self.test_cfg.get("with_norm", True))
+        chunks = []
+        Hf = Wf = None
+        for i in range(0, frames.shape[0], step):
+            f = self.extract_feat(frames[i:i + step])
+            if isinstance(f, (tuple, list)):
+                f = f[0]
+            Hf, Wf = f.shape[-2:]
+            chunks.append(ops.normalize_to_hwc(f.float(), norm, pad=True))
+        return torch.cat(chunks, 0), Hf, Wf
+
+    def engine_config(self) -> engine.TrackerConfig:
+        return engine.TrackerConfig.from_test_cfg(self.test_cfg)
+
+    # ---- A10: regrouping by query time ----------------------------------------------------------
+    @torch.no_grad()
+    def forward_test(self, rgbs, query_points, trajectories, visibilities, save_image=False, save_path=None,
+                     iteration=None):
+        """rgbs (1,T,3,h,w), query_points (1,P,3)=(t,x,y), trajectories (1,T,P,2), visibilities (1,T,P)."""
+        if not rgbs.is_cuda:
+            raise RuntimeError("fgvc_amd.VanillaTracker runs on the GPU only (no CPU fallback)")
+        assert rgbs.shape[0] == 1, "batch size must be 1 (vanilla_tracker.py:134)"
+        cfg = self.engine_config()
+        T, h, w = rgbs.shape[1], rgbs.shape[-2], rgbs.shape[-1]
+        dev = rgbs.device
+        qp = query_points[0]
+        if not cfg.with_first:
+            # single group that starts at frame 0 regardless of the query times (vanilla_tracker.py:302-303)
+            feats, Hf, Wf = self.get_feats_hwc(rgbs[0])
+            plan = engine.plan_clip(T, [0], cfg)
+            tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
+            _, coords = engine.run_propagation(tk, 0, qp[:, 1:].to(dev, torch.float32), Hf, Wf, h, w, cfg)
+            traj_pred = coords.unsqueeze(0)                                   # float64, like torch.from_numpy(...)
+            return trajectories, visibilities, traj_pred, torch.zeros_like(visibilities), query_points
+        t_min = int(qp[:, 0].min().item())
+        # frames before the earliest query time are never used by any group
+        feats, Hf, Wf = self.get_feats_hwc(rgbs[0, t_min:])
+        qp_rel = qp.clone()
+        qp_rel[:, 0] -= t_min
+        traj, order = engine.track_points(feats, Hf, Wf, h, w, qp_rel, cfg)     # (T-t_min, P, 2) f64, regrouped
+        order = order.to(dev)
+        traj_pred = torch.zeros_like(trajectories)
+        traj_pred[0, t_min:] = traj.to(traj_pred.dtype)
+        return (trajectories[:, :, order], visibilities[:, :, order], traj_pred,
+                torch.zeros_like(visibilities), query_points[:, order])
+
+    @torch.no_grad()
+    def forward_test_main(self, rgbs, query_points, trajectories, visibilities):
+        """vanilla_tracker.py:305-412: all points are propagated from frame 0 of `rgbs`."""
+        cfg = self.engine_config()
+        T, h, w = rgbs.shape[1], rgbs.shape[-2], rgbs.shape[-1]
+        feats, Hf, Wf = self.get_feats_hwc(rgbs[0])
+        plan = engine.plan_clip(T, [0], cfg)
+        tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
+        pts = query_points[0, :, 1:].to(rgbs.device, torch.float32)
+        _, coords = engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)
+        return trajectories, visibilities, coords.unsqueeze(0), torch.zeros_like(visibilities), query_points
+
+
+@MODELS.register_module()
+class HRVanillaTracker(VanillaTracker):
+    """Single-scale local-window variant (vanilla_tracker.py:417-585): mmcv.ops.Correlation(max_displacement=R)
+    + F.unfold + top-k is one call to fgvc_local_corr_topk_f32 per frame."""
+
+    def __init__(self, stride=2, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.stride = stride
+        self.infer_radius = self.test_cfg.get("neighbor_range", 24) // 2
+        if self.test_cfg.get("dilations", 1) != 1:
+            raise NotImplementedError("fgvc_amd: Correlation dilation != 1 is not on the accelerated path")
+
+    @torch.no_grad()
+    def forward_test_main(self, rgbs, query_points, trajectories, visibilities):
+        g = self.test_cfg.get
+        T, h, w = rgbs.shape[1], rgbs.shape[-2], rgbs.shape[-1]
+        dev = rgbs.device
+        step = int(g("batch_step", 5))
+        norm = bool(g("withnorm", True))                                       # sic (vanilla_tracker.py:437)
+        chunks = []
+        for i in range(0, T, step):
+            f = self.extract_feat(rgbs[0, i:i + step])
+            Hf, Wf = f.shape[-2:]
+            chunks.append(ops.normalize_to_hwc(f.float(), norm, pad=True))
+        feats = torch.cat(chunks, 0)
+        pts = query_points[0, :, 1:].to(dev, torch.float32)
+        P = pts.shape[0]
+        labels = torch.zeros((T, Hf * Wf, P), device=dev)
+        ops.gaussian_labels(pts, Hf, Wf, h // Hf, 6.0, out=labels[0])
+        R, k, tau = self.infer_radius, int(g("topk", 10)), float(g("temperature", 1))
+        pre, with_first = int(g("precede_frames", 5)), bool(g("with_first", True))
+        for f in range(1, T):
+            ks = engine.key_slots(f, 0, pre, with_first)
+            kf = feats[ks]
+            idx, _, weight = ops.local_corr_topk(feats[f:f + 1], kf, Hf, Wf, R, k, tau)
+            ops.propagate_topk(labels, torch.tensor(ks, dtype=torch.int32, device=dev), idx, weight, Hf, Wf, Hf, Wf,
+                               window_L=2 * R + 1, out=labels[f])
+        coords = ops.softargmax_top5(labels, Hf, Wf, h, w, gauss_points=pts)
+        return trajectories, visibilities, coords.unsqueeze(0), torch.zeros_like(visibilities), query_points
+
+    @torch.no_grad()
+    def forward_test(self, rgbs, query_points, trajectories, visibilities, **kw):
+        if not self.test_cfg.get("with_first", False):
+            return self.forward_test_main(rgbs, query_points, trajectories, visibilities)
+        # inherited regrouping (vanilla_tracker.py:246-299), one main pass per distinct query time
+        B, T, P = trajectories.shape[:3]
+        times = query_points[0, :, 0].to(torch.int64)
+        order, col = [], 0
+        traj_pred = torch.zeros_like(trajectories)
+        for t in sorted(set(times.tolist())):
+            sel = (times == t).nonzero().flatten()
+            qp = query_points[:, sel].clone()
+            qp[:, :, 0] -= t
+            out = self.forward_test_main(rgbs[:, t:], qp, None, torch.zeros(1, T - t, sel.numel(), device=rgbs.device))
+            traj_pred[0, t:, col:col + sel.numel()] = out[2][0].to(traj_pred.dtype)
+            order.extend(sel.tolist())
+            col += sel.numel()
+        order = torch.tensor(order, device=rgbs.device)
+        return (trajectories[:, :, order], visibilities[:, :, order], traj_pred, torch.zeros_like(visibilities),
+                query_points[:, order])

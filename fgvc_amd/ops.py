@@ -103,7 +103,8 @@ def make_pairs(pairs, device, masked=True) -> torch.Tensor:
 
 
 def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
-              mask: MaskSpec, topk: int, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+              mask: MaskSpec, topk: int, validate: bool = True,
+              dense_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Windowed correlation + top-k per (query frame, key frame) pair.
     qfeat (nq, HqWq, C), kfeat (nk, HkWk, C), pairs int32 (n,4).
     Returns idx (n, HqWq, topk) int32 (key pixel, -1 = none), score (n, HqWq, topk) f32 raw dot."""
@@ -116,10 +117,13 @@ def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq:
         # callers that built `pairs` on the host from known-good frame numbers pass validate=False)
         lim = pairs[:, :2].amax(0).tolist()
         assert lim[0] < qfeat.shape[0] and lim[1] < kfeat.shape[0] and int(pairs[:, :2].min()) >= 0, "pair out of range"
+    if dense_mask is not None:
+        dense_mask = _chk(dense_mask.to(torch.bool), torch.bool, "dense_mask")
+        assert dense_mask.shape == (Hk * Wk, Hq * Wq) and mask.is_none
     idx = torch.empty((n, Hq * Wq, topk), device=qfeat.device, dtype=torch.int32)
     score = torch.empty((n, Hq * Wq, topk), device=qfeat.device, dtype=torch.float32)
     _lib.call("fgvc_pair_topk_f32", _ptr(qfeat), _ptr(kfeat), _ptr(pairs), n, qfeat.shape[2], Hq, Wq, Hk, Wk,
-              mask.r2max, mask.ry, mask.rx, topk, _ptr(idx), _ptr(score), _stream(qfeat))
+              mask.r2max, mask.ry, mask.rx, topk, _ptr(dense_mask), _ptr(idx), _ptr(score), _stream(qfeat))
     return idx, score
 
 

@@ -74,10 +74,13 @@ int fgvc_normalize_chw_to_hwc_f32(const float* in, float* out, int n, int C, int
  *                                            candidates exist
  *   score_out [n_pairs][Hq*Wq][topk] f32     raw dot product (NOT yet divided by temperature),
  *                                            descending; -inf where idx = -1
- * C must be a multiple of 32, 32 <= C <= 256; 1 <= topk <= 16.  Masked pairs need Hq==Hk, Wq==Wk. */
+ *   dense_mask: NULL, or an arbitrary [Hk*Wk][Hq*Wq] bool (uint8) mask tensor as accepted by
+ *               local_attention.py:329-353; then the analytic predicate must be off (all FGVC_NO_LIMIT)
+ *               and FGVC_PAIR_MASKED pairs traverse the full frame consulting the tensor
+ * C in {32, 64, 128, 256}; 1 <= topk <= 16.  An analytic mask needs Hq==Hk, Wq==Wk. */
 int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_pairs,
                        int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk,
-                       int32_t* idx_out, float* score_out, void* stream);
+                       const uint8_t* dense_mask, int32_t* idx_out, float* score_out, void* stream);
 
 /* ---- A5 step 2: merge the per-pair lists of the T key slots of each query frame, divide by the
  * temperature and turn the k logits into weights.  Replaces the global topk over T*HW
