@@ -61,12 +61,14 @@ def build_tracker(wl, dev):
 def cpu_baseline(wl, budget_s=25.0):
     """The oracle on the host cores, bounded sample of the same workload -> frames/s estimate."""
     from oracle import fgvc_oracle as O
-    cores = os.cpu_count() or 1
+    # torch CPU ops stop scaling (and then regress) long before 256 threads on these hosts: use up to 64
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     h, w, T = wl["h"], wl["w"], wl["frames"]
     net = O.ResNet18(wl["strides"], wl["out_indices"][0], "none").eval()
     with torch.no_grad():
+        net(torch.randn(1, 3, 64, 64, generator=g))                    # spin up the thread pool / oneDNN
         x = torch.randn(1, 3, h, w, generator=g)
         t0 = time.perf_counter(); f = net(x); t_enc = time.perf_counter() - t0
     C, Hf, Wf = f.shape[1:]
@@ -75,6 +77,7 @@ def cpu_baseline(wl, budget_s=25.0):
     key = torch.randn(C, 6, Hf, Wf, generator=g)
     val = torch.rand(wl["points"], 6 * HW, generator=g)
     step, n_chunks, t_aff = 512, 0, 0.0
+    O.affinity_topk(q[:, :8, :8], key[:, :, :8, :8], 10, 0.07, neighbor_range=30)   # warm-up
     while t_aff < budget_s * 0.6 and n_chunks * step < HW:
         qi = torch.arange(n_chunks * step, min(HW, (n_chunks + 1) * step))
         t0 = time.perf_counter()

@@ -48,6 +48,10 @@ class FgvcHipError(RuntimeError):
 def load() -> C.CDLL:
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64; it must be in the process BEFORE this library is dlopen'ed so
+        # that both resolve to ONE HIP runtime (otherwise the system runtime is loaded first and kernels
+        # launched from here see "no ROCm-capable device").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise FgvcHipError(
                 f"{LIB_PATH} is missing: build it with `python -m fgvc_amd.build` "
