@@ -1,0 +1,147 @@
+"""CPU, world_size 2, gloo: the clip-sharding choreography of fgvc_amd/dist.py (frame ranges, halo,
+first-frame broadcast, all_gather order, replicated sweep) with an ORACLE-backed compute backend,
+checked against the un-sharded oracle driver.  The HIP backend runs the same code on the GPUs."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import fgvc_oracle as O
+
+
+class OracleBackend:
+    """Same interface as fgvc_amd.dist.HipBackend, torch CPU arithmetic (test infrastructure)."""
+
+    def encode(self, frames):                       # "frames" are already feature maps (n,C,Hf,Wf) in this test
+        n, C, Hf, Wf = frames.shape
+        return O.l2_normalize(frames, 1).flatten(2).transpose(1, 2).contiguous(), Hf, Wf
+
+    def affinity(self, bank, Hf, Wf, plan, cfg):
+        C = bank.shape[-1]
+        idxs, ws = [], []
+        for row in range(len(plan.slot_pair)):
+            pids = [p for p in plan.slot_pair[row] if p >= 0]
+            q = plan.pairs[pids[0]][0]
+            ks = [plan.pairs[p][1] for p in pids]
+            qm = bank[q].t().reshape(C, Hf, Wf)
+            km = torch.stack([bank[k].t().reshape(C, Hf, Wf) for k in ks], 1)
+            idx, logit = O.affinity_topk(qm, km, cfg.topk, cfg.temperature, neighbor_range=cfg.neighbor_range,
+                                         normalize=False)
+            idxs.append(idx.to(torch.int32))
+            ws.append(O.topk_weights(logit))
+        return torch.stack(idxs, 0), torch.stack(ws, 0)
+
+    def sweep(self, idx, weight, slot_frame, plan, start, pts, Hf, Wf, h, w, cfg):
+        T = plan.n_frames
+        full0, lab0 = O.gaussian_labels(pts, h, w, h // Hf)
+        P = pts.shape[0]
+        labels = {start: lab0.reshape(P, -1)}
+        preds = [full0]
+        for f in range(start + 1, T):
+            row = plan.out_rows[(start, f)]
+            frames = slot_frame[row].tolist()
+            i = idx[row].long()
+            slot, pix = i // (Hf * Wf), i % (Hf * Wf)
+            zero = torch.zeros_like(lab0.reshape(P, -1))                                   # padded slots are never indexed
+            val = torch.stack([labels.get(frames[s], zero) for s in range(len(frames))], 0)  # (t_max,P,HW)
+            g = val[slot, :, pix]                                                          # (HW,k,P)
+            out = (g * weight[row].unsqueeze(-1)).sum(1).t()                               # (P,HW)
+            labels[f] = out
+            preds.append(O.upsample_bilinear(out.reshape(P, Hf, Wf), h, w))
+        coords = O.img2coord(torch.stack(preds, 0).numpy())
+        return torch.from_numpy(coords).permute(2, 1, 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, feats, qp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from fgvc_amd import dist as D
+    from fgvc_amd.engine import TrackerConfig
+    cfg = TrackerConfig(neighbor_range=8)
+    h, w = feats.shape[-2] * 2, feats.shape[-1] * 2
+    try:
+        traj, order = _run(D, OracleBackend(), feats, qp, cfg, h, w)
+        q.put((rank, traj, order))
+    except Exception as e:  # surface the failure instead of letting the parent time out
+        q.put((rank, repr(e), None))
+        raise
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(D, backend, feats, qp, cfg, h, w):
+    """track_points_sharded takes h,w from rgbs; wrap the feature clip so the last two dims read as the image."""
+    class Wrapped:
+        def __init__(self, f):
+            self.f = f
+            self.shape = (f.shape[0], 3, h, w)
+            self.device = f.device
+
+        def __getitem__(self, s):
+            class _S:
+                def __init__(s2, t):
+                    s2.t = t
+
+                def to(s2, dev):
+                    return s2.t
+            return _S(self.f[s])
+    return D.track_points_sharded(backend, Wrapped(feats), qp, cfg)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharding_matches_unsharded_oracle():
+    g = torch.Generator().manual_seed(21)
+    T, C, Hf, Wf = 11, 16, 10, 12
+    feats = torch.randn(T, C, Hf, Wf, generator=g)
+    qp = torch.tensor([[0., 5., 7.], [0., 17.3, 11.2], [4., 9.5, 3.25], [4., 20., 15.], [7., 2.2, 18.8]])
+    h, w = 2 * Hf, 2 * Wf
+    # un-sharded expectation
+    exp = torch.zeros(T, qp.shape[0], 2, dtype=torch.float64)
+    col = 0
+    for s in (0, 4, 7):
+        sel = (qp[:, 0] == s).nonzero().flatten()
+        exp[s:, col:col + sel.numel()] = O.forward_test_main(feats[s:], qp[sel, 1:], h, w, neighbor_range=8)[0]
+        col += sel.numel()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, feats, qp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    assert all(r[2] is not None for r in res), res
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, traj, order in res:
+        assert order.tolist() == [0, 1, 2, 3, 4]
+        assert torch.allclose(traj, exp, atol=1e-6), (rank, float((traj - exp).abs().max()))
+    assert torch.equal(res[0][1], res[1][1])          # replicated sweep is deterministic across ranks
+
+
+def test_single_process_path_equals_engine_semantics():
+    """world=1 (no process group): same function, no collectives."""
+    from fgvc_amd import dist as D
+    from fgvc_amd.engine import TrackerConfig
+    g = torch.Generator().manual_seed(3)
+    T, C, Hf, Wf = 6, 8, 8, 8
+    feats = torch.randn(T, C, Hf, Wf, generator=g)
+    qp = torch.tensor([[0., 3., 4.], [2., 10., 9.]])
+    cfg = TrackerConfig(neighbor_range=6)
+    traj, order = _run(D, OracleBackend(), feats, qp, cfg, 16, 16)
+    e0 = O.forward_test_main(feats, qp[:1, 1:], 16, 16, neighbor_range=6)[0]
+    e2 = O.forward_test_main(feats[2:], qp[1:, 1:], 16, 16, neighbor_range=6)[0]
+    assert torch.allclose(traj[:, :1], e0, atol=1e-6) and torch.allclose(traj[2:, 1:], e2, atol=1e-6)
+    assert float(traj[:2, 1:].abs().max()) == 0.0

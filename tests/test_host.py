@@ -1,0 +1,173 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fgvc_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "fgvc_hip.h")).read()
+    declared = set(re.findall(r"\b(fgvc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fgvc_version().startswith(b"fgvc_hip")
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any launch (error codes, no exceptions across the ABI)."""
+    from fgvc_amd import _lib
+    lib = _lib.load()
+    rc = lib.fgvc_pair_topk_f32(None, None, None, 1, 256, 4, 4, 4, 4, 1, 1, 1, 10, None, None, None, None)
+    assert rc == 1 and b"null pointer" in lib.fgvc_last_error()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.fgvc_pair_topk_f32(p, p, p, 1, 256, 4, 4, 4, 4, 1, 1, 1, 17, None, p, p, None)
+    assert rc == 2 and b"topk" in lib.fgvc_last_error()
+    rc = lib.fgvc_pair_topk_f32(p, p, p, 1, 256, 4, 4, 5, 4, 224, _lib.NO_LIMIT, _lib.NO_LIMIT, 10, None, p, p, None)
+    assert rc == 1 and b"equal query/key grids" in lib.fgvc_last_error()
+    rc = lib.fgvc_merge_topk_f32(p, p, p, 1, 1, 4, 4, 10, ctypes.c_float(0.0), 0, p, p, p, None)
+    assert rc == 1 and b"temperature" in lib.fgvc_last_error()
+    rc = lib.fgvc_corr_volume_bf16x3(p, p, 48, 4, 4, ctypes.c_float(1.0), p, None)
+    assert rc == 2 and b"multiple of 64" in lib.fgvc_last_error()
+
+
+def test_r2max_matches_oracle():
+    from fgvc_amd import _lib
+    from oracle import fgvc_oracle as O
+    lib = _lib.load()
+    for r in [0.5, 1, 1.5, 2, 2.5, 3, 7, 12, 15, 15.5, 24, 100]:
+        assert lib.fgvc_r2max_for_radius(r) == O.radius_predicate_r2max(r), r
+
+
+def test_ops_refuse_cpu_tensors():
+    from fgvc_amd import _lib, ops
+    with pytest.raises(_lib.FgvcHipError):
+        ops.normalize_to_hwc(torch.zeros(1, 32, 4, 4))
+
+
+def test_key_slots_and_plan():
+    from fgvc_amd import engine
+    from oracle import fgvc_oracle as O
+    cfg = engine.TrackerConfig()
+    for f in range(1, 12):
+        assert engine.key_slots(f, 0, 5, True) == O.key_slots(f, 5, True)
+        assert engine.key_slots(f + 3, 3, 5, True) == [k + 3 for k in O.key_slots(f, 5, True)]
+    plan = engine.plan_clip(8, [0], cfg)
+    assert len(plan.pairs) == 27 and len(plan.slot_pair) == 7 and plan.t_max == 6   # 32 slots, 5 duplicates of frame 0
+    assert sum(1 for row in plan.slot_pair for p in row if p >= 0) == 32
+    # frame 3: slots [0,0,1,2] -> the two frame-0 slots share one pair
+    row = plan.out_rows[(0, 3)]
+    assert plan.slot_frame[row][:4] == [0, 0, 1, 2] and plan.slot_pair[row][0] == plan.slot_pair[row][1]
+    assert all(m for (_, _, m) in plan.pairs)
+    # several query times: pairs are shared between groups
+    p2 = engine.plan_clip(12, [0, 4], cfg)
+    single = len(engine.plan_clip(12, [0], cfg).pairs) + len(engine.plan_clip(8, [0], cfg).pairs)
+    assert len(p2.pairs) < single
+    # with_first_neighbor=False: slot 0 is unmasked, and (f,0) may exist in both flavours
+    p3 = engine.plan_clip(4, [0], engine.TrackerConfig(with_first_neighbor=False))
+    assert (1, 0, False) in p3.pairs and (1, 0, True) in p3.pairs
+    # no mask at all
+    p4 = engine.plan_clip(4, [0], engine.TrackerConfig(neighbor_range=None))
+    assert not any(m for (_, _, m) in p4.pairs)
+    # frame_range restricts the query frames
+    p5 = engine.plan_clip(20, [0], cfg, frame_range=(10, 15))
+    assert sorted({q for (q, _, _) in p5.pairs}) == [10, 11, 12, 13, 14]
+
+
+def test_registry_builder_config(tmp_path):
+    import fgvc_amd.mmpt_api as api
+    assert {"VanillaTracker", "HRVanillaTracker", "BaseTracker"} <= set(api.MODELS.module_dict)
+    assert "ResNet" in api.BACKBONES
+    with pytest.raises(KeyError):
+        api.build_backbone(dict(type="NoSuchNet"))
+    base = tmp_path / "base.py"
+    base.write_text("data = dict(a=1, b=dict(c=2, d=3))\nx = 5\n")
+    child = tmp_path / "child.py"
+    child.write_text("_base_ = './base.py'\ndata = dict(b=dict(c=7))\nexp_name = 'e'\nwork_dir = f'./eval/{exp_name}'\n")
+    cfg = api.Config.fromfile(str(child))
+    assert cfg.data.b.c == 7 and cfg.data.b.d == 3 and cfg.x == 5 and cfg.work_dir == "./eval/e"
+    assert cfg.get("eval_arc", "VanillaTracker") == "VanillaTracker"
+
+
+def test_reference_eval_config_loads():
+    """the shipped eval config of the reference parses with our Config (only if the tree is present)."""
+    path = "/root/reference/configs/eval/res18_d1_eval.py"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    import fgvc_amd.mmpt_api as api
+    cfg = api.Config.fromfile(path)
+    assert cfg.model.type == "VanillaTracker" and cfg.test_cfg_davis.neighbor_range == 30
+    tc = cfg["test_cfg_davis"]
+    model = api.build_model(dict(type=cfg.get("eval_arc", "VanillaTracker"),
+                                 backbone=dict(cfg.model.backbone, out_indices=tc.out_indices, strides=tc.strides)),
+                            train_cfg=None, test_cfg=tc)
+    ec = model.engine_config()
+    assert (ec.precede_frames, ec.topk, ec.temperature, ec.neighbor_range) == (5, 10, 0.07, 30)
+
+
+def test_resnet_state_dict_names_and_arithmetic():
+    """key names equal the reference's (the oracle ResNet was loaded strict=True into the reference backbone
+    by the golden generator) and the forward pass equals the oracle's."""
+    import fgvc_amd.mmpt_api as api
+    from oracle import fgvc_oracle as O
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 1, 1, 4), out_indices=(2,), pool_type="none"))
+    ora = O.ResNet18((1, 1, 1, 4), 2, "none")
+    assert set(net.state_dict()) == set(ora.state_dict())
+    sd = O.seeded_resnet_state(3, (1, 1, 1, 4), "none")
+    net.load_state_dict(sd)
+    ora.load_state_dict(sd)
+    x = torch.randn(2, 3, 48, 64)
+    with torch.no_grad():
+        a, b = net.eval()(x), ora.eval()(x)
+    assert a.shape == (2, 256, 24, 32) and torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    # checkpoint with the tracker's `backbone.` prefix
+    api.load_checkpoint(net, {"state_dict": {"backbone." + k: v for k, v in sd.items()}})
+
+
+def test_neighbor_mask_dense_matches_reference_golden(golden):
+    import numpy as np
+    import fgvc_amd.mmpt_api as api
+    for name, mode in [("mask_circle_8x12_r6", "circle"), ("mask_square_9x7_r5", "square"),
+                       ("mask_circle_20x24_r14", "circle")]:
+        g = golden(name)
+        H, W, nr = int(g["H"]), int(g["W"]), int(g["nr"])
+        m = api.common.spatial_neighbor(1, H, W, nr, "cpu", torch.float32, mode=mode)
+        ref = np.unpackbits(g["packed"])[: (H * W) ** 2].reshape(H * W, H * W).astype(bool)
+        assert m.shape == (H * W, H * W)
+        assert np.array_equal(m.dense().numpy(), ref)
+
+
+def test_install_as_mmpt():
+    import subprocess
+    import sys
+    code = ("import fgvc_amd; fgvc_amd.install_as_mmpt();"
+            "from mmpt.models import build_model, MODELS;"
+            "from mmpt.models.common import masked_attention_efficient, spatial_neighbor;"
+            "from mmpt.models.registry import BACKBONES; from mmpt.apis import single_gpu_test, multi_gpu_test;"
+            "print(sorted(MODELS.module_dict))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr
+    assert "VanillaTracker" in out.stdout
+
+
+def test_shard_frames():
+    from fgvc_amd import dist as D
+    from fgvc_amd.engine import TrackerConfig
+    assert D.shard_frames(9, 2) == [(1, 5), (5, 9)]
+    assert D.shard_frames(3, 4) == [(1, 2), (2, 3), (3, 3), (3, 3)]
+    r = D.shard_frames(64, 8)
+    assert r[0][0] == 1 and r[-1][1] == 64 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    cfg = TrackerConfig()
+    assert D.encode_range(9, 17, [0], cfg) == (4, 17)
+    assert D.encode_range(1, 9, [0], cfg) == (0, 9)
+    assert D.encode_range(5, 5, [0], cfg) == (5, 5)
+    enc = [D.encode_range(lo, hi, [0, 20], cfg) for lo, hi in D.shard_frames(64, 8)]
+    assert D.owner_of(0, enc) == 0 and D.owner_of(20, enc) == 2
