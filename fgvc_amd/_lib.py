@@ -23,6 +23,7 @@ _f = C.c_float
 SIGNATURES = {
     "fgvc_version": (C.c_char_p, []),
     "fgvc_last_error": (C.c_char_p, []),
+    "fgvc_set_option": (_i, [C.c_char_p, _i]),
     "fgvc_r2max_for_radius": (_i, [_f]),
     "fgvc_normalize_chw_to_hwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_pair_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -34,6 +34,9 @@ int local_merge_launch(const int32_t*, const float*, int, int, int, int, int, fl
 int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, int, int, int, int, int, int, int,
                       int, float, float*, int32_t*, float*, hipStream_t);
 
+void set_pair_kernel(int);
+void set_pair_debug(int);
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace fgvc
@@ -44,6 +47,21 @@ extern "C" {
 
 const char* fgvc_version(void) { return "fgvc_hip 0.1 (gfx950)"; }
 const char* fgvc_last_error(void) { return g_err; }
+
+int fgvc_set_option(const char* name, int value) {
+  FGVC_REQUIRE(name != nullptr, FGVC_ERR_INVALID_ARG, "fgvc_set_option: null name");
+  if (strcmp(name, "pair_kernel") == 0) {
+    FGVC_REQUIRE(value == 1 || value == 2, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_kernel must be 1 or 2");
+    set_pair_kernel(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
+    set_pair_debug(value);
+    return FGVC_OK;
+  }
+  set_error("fgvc_set_option: unknown option '%s'", name);
+  return FGVC_ERR_INVALID_ARG;
+}
 
 int fgvc_r2max_for_radius(float radius) {
   if (!(radius > 0.f)) return -1;

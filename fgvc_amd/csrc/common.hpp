@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include "../../include/fgvc_hip.h"
+#include "sortnet.hpp"
 
 namespace fgvc {
 
@@ -66,6 +67,116 @@ struct TopK {
       s = b ? tv : s;
       id = b ? ti : id;
     }
+  }
+};
+
+// Branch-free list for the hot selection loops: strict float compare only (1 v_cmp + 4 v_cndmask per
+// position), every lane runs the network and `pred` masks the update.  Equal scores keep ARRIVAL order, so
+// callers that need the canonical (score desc, index asc) order among exact ties re-establish it when they
+// merge (TopK::insert does the index tie-break).  With nested divergent `if`s around the list hipcc copies
+// the whole list at every join (40 v_mov per level, ~1800 cycles per candidate measured) -- hence no branches.
+template <int K>
+struct TopKF {
+  float v[K];
+  int ix[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      v[j] = -INFINITY;
+      ix[j] = IDX_EMPTY;
+    }
+  }
+  __device__ __forceinline__ bool accepts(float s) const { return s > v[K - 1]; }
+  __device__ __forceinline__ void insert_if(bool pred, float s, int id) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const bool b = pred && s > v[j];
+      const float tv = v[j];
+      const int ti = ix[j];
+      v[j] = b ? s : tv;
+      ix[j] = b ? id : ti;
+      s = b ? tv : s;
+      id = b ? ti : id;
+    }
+  }
+
+  // Data-independent alternative for a whole 32x32 score tile (16 candidates per lane): sort the 16
+  // candidates with a Batcher network (63 compare-exchanges), take max(cand[i], list[K-1-i]) -- the top K
+  // of the union, a bitonic sequence -- and re-sort K wires.  ~(63 + K-net) x 5 VALU ops per tile, no
+  // branches, no thresholds: the per-candidate insertion network above costs 16 x K x 5 and is >90 %
+  // wasted on rejected candidates, which made selection (not the MFMAs) the bottleneck.
+  __device__ __forceinline__ void merge_tile(float (&cs)[16], int (&ci)[16]);
+};
+
+#define FGVC_CSWAP(A, I, J)                      \
+  {                                              \
+    const bool b_ = A##s[J] > A##s[I];           \
+    const float hs_ = b_ ? A##s[J] : A##s[I];    \
+    const float ls_ = b_ ? A##s[I] : A##s[J];    \
+    const int hi_ = b_ ? A##i[J] : A##i[I];      \
+    const int li_ = b_ ? A##i[I] : A##i[J];      \
+    A##s[I] = hs_; A##s[J] = ls_;                \
+    A##i[I] = hi_; A##i[J] = li_;                \
+  }
+
+template <int K>
+__device__ __forceinline__ void TopKF<K>::merge_tile(float (&cs)[16], int (&ci)[16]) {
+#define X(I, J) FGVC_CSWAP(c, I, J)
+  FGVC_SORTNET_16(X)
+#undef X
+  float (&ls)[K] = v;
+  int (&li)[K] = ix;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (K - 1 - j < 16) {
+      const bool b = cs[K - 1 - j] > ls[j];
+      ls[j] = b ? cs[K - 1 - j] : ls[j];
+      li[j] = b ? ci[K - 1 - j] : li[j];
+    }
+  }
+#define X(I, J) FGVC_CSWAP(l, I, J)
+  if constexpr (K == 16) { FGVC_SORTNET_16(X) }
+  else if constexpr (K == 10) { FGVC_SORTNET_10(X) }
+  else if constexpr (K == 5) { FGVC_SORTNET_5(X) }
+#undef X
+}
+
+// Same canonical order on packed 64-bit keys: high word = score mapped to an order-preserving unsigned
+// (negative floats bit-flipped, non-negative get the sign bit set), low word = ~index, so a larger key is
+// a better candidate (higher score, then LOWER index).  One v_cmp_gt_u64 + 4 v_cndmask per list position
+// and, more importantly, a branch-free predicated insertion: with nested divergent `if`s around a float
+// list hipcc copies the whole list at every join (40 v_mov per level, measured 1800 cycles/candidate).
+// Key 0 = empty slot (decodes to index -1, score -inf).  Scores must not be NaN.
+template <int K>
+struct TopK64 {
+  unsigned long long k[K];
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < K; ++j) k[j] = 0ull;
+  }
+  static __device__ __forceinline__ unsigned long long make_key(float s, int id) {
+    unsigned u = __builtin_bit_cast(unsigned, s + 0.0f);            // -0.0 -> +0.0
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)(~(unsigned)id);
+  }
+  __device__ __forceinline__ bool accepts(unsigned long long key) const { return key > k[K - 1]; }
+  // every lane runs the network; lanes with pred == false leave their list untouched
+  __device__ __forceinline__ void insert_if(bool pred, unsigned long long key) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const bool b = pred && key > k[j];
+      const unsigned long long t = k[j];
+      k[j] = b ? key : t;
+      key = b ? t : key;
+    }
+  }
+  __device__ __forceinline__ int index(int j) const { return (int)(~(unsigned)k[j]); }   // empty -> -1
+  __device__ __forceinline__ float score(int j) const {
+    if (k[j] == 0ull) return -INFINITY;
+    unsigned u = (unsigned)(k[j] >> 32);
+    u = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
+    return __builtin_bit_cast(float, u);
   }
 };
 

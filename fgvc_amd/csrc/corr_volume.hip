@@ -67,16 +67,20 @@ __global__ __launch_bounds__(256, 2) void corr_volume_f32_kernel(const float* __
   int buf = 0;
   for (int kb = kb0; kb < kb1; ++kb) {
     if (kb + 1 < kb1) stage_load(kb + 1);
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // two independent accumulator chains per wave x two waves per SIMD = four chains per matrix pipe:
+    // a dependent f32 MFMA chain alone retires one MFMA per ~200 cycles (issue interval is 64)
+    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc1 = acc0;
     const float* ka = &smem[buf * BUF + n * LDK + 4 * hi];
 #pragma unroll
     for (int j = 0; j < C / 8; ++j) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(ka + 8 * j);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * j + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * j + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * j + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * j + 3], acc, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * j + 0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * j + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * j + 2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * j + 3], acc1, 0, 0, 0);
     }
+    const f32x16 acc = acc0 + acc1;
     if (q < HWq) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -55,6 +55,11 @@ class MaskSpec:
         raise ValueError(mode)
 
 
+def set_option(name: str, value: int) -> None:
+    """fgvc_set_option: e.g. set_option("pair_kernel", 1) selects the non-specialised pair kernel."""
+    _lib.call("fgvc_set_option", name.encode(), int(value))
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 

@@ -52,6 +52,11 @@ extern "C" {
 const char* fgvc_version(void);
 const char* fgvc_last_error(void);
 
+/* Process-wide tuning knobs (host only, not thread-safe against concurrent launches).
+ *   "pair_kernel": 2 (default) = wave-specialised fgvc_pair_topk_f32 kernel (4 MFMA waves + 4 selection/loader
+ *                  waves per workgroup), 1 = the simpler 4-wave kernel.  Results are identical. */
+int fgvc_set_option(const char* name, int value);
+
 /* Largest integer d2 such that sqrtf((float)d2) < radius, -1 if none (host helper). */
 int fgvc_r2max_for_radius(float radius);
 

@@ -267,3 +267,22 @@ def test_engine_vs_oracle_tracker(dev):
         assert float(traj[:s, col:col + sel.numel()].abs().max() if s else 0.0) == 0.0
         col += sel.numel()
     assert order.tolist() == [0, 1, 2, 3, 4]
+
+
+def test_pair_kernel_variants_agree(dev):
+    """v1 (4-wave) and v2 (wave-specialised) kernels must produce bit-identical lists."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(77)
+    for (C, H, W, nr) in [(256, 37, 53, 30), (64, 9, 70, 12), (128, 20, 20, None)]:
+        f = ops.normalize_to_hwc(torch.randn(3, C, H, W, generator=g).to(dev))
+        mask = ops.MaskSpec.from_neighbor_range(nr)
+        pairs = ops.make_pairs([(2, 0, nr is not None), (2, 1, nr is not None), (1, 0, nr is not None)], dev)
+        try:
+            ops.set_option("pair_kernel", 1)
+            i1, s1 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+            ops.set_option("pair_kernel", 2)
+            i2, s2 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+        finally:
+            ops.set_option("pair_kernel", 2)
+        # v2 sums the channels in four interleaved chains: last-bit differences in the scores are expected
+        assert torch.allclose(s1, s2, atol=2e-6) and (i1 == i2).float().mean() > 0.999
