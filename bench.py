@@ -61,8 +61,8 @@ def build_tracker(wl, dev):
 def cpu_baseline(wl, budget_s=25.0):
     """The oracle on the host cores, bounded sample of the same workload -> frames/s estimate."""
     from oracle import fgvc_oracle as O
-    # torch CPU ops stop scaling (and then regress) long before 256 threads on these hosts: use up to 64
-    cores = min(os.cpu_count() or 1, 64)
+    # torch CPU ops stop scaling (and then regress) long before 256 threads on these hosts: use up to 32
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     h, w, T = wl["h"], wl["w"], wl["frames"]
@@ -73,15 +73,20 @@ def cpu_baseline(wl, budget_s=25.0):
         t0 = time.perf_counter(); f = net(x); t_enc = time.perf_counter() - t0
     C, Hf, Wf = f.shape[1:]
     HW = Hf * Wf
-    q = torch.randn(C, Hf, Wf, generator=g)
-    key = torch.randn(C, 6, Hf, Wf, generator=g)
+    q = O.l2_normalize(torch.randn(C, Hf, Wf, generator=g), 0).reshape(C, -1)
+    key = O.l2_normalize(torch.randn(C, 6, Hf, Wf, generator=g), 0).reshape(C, -1)
     val = torch.rand(wl["points"], 6 * HW, generator=g)
-    step, n_chunks, t_aff = 512, 0, 0.0
-    O.affinity_topk(q[:, :8, :8], key[:, :, :8, :8], 10, 0.07, neighbor_range=30)   # warm-up
-    while t_aff < budget_s * 0.6 and n_chunks * step < HW:
+    step, n_chunks, t_aff, t_mask = 512, 0, 0.0, 0.0
+    O.affinity_chunk(key[:, :4096], q[:, :64], None, 10, 0.07, canonical=False)          # warm-up
+    while t_aff < budget_s * 0.6 and n_chunks * step < HW and n_chunks < 8:
         qi = torch.arange(n_chunks * step, min(HW, (n_chunks + 1) * step))
         t0 = time.perf_counter()
-        idx, logit = O.affinity_topk(q, key, 10, 0.07, neighbor_range=30, step=step, q_index=qi)
+        m = O.mask_slab(Hf, Wf, Hf, Wf, 6, qi, 30, "circle")                             # the reference builds its
+        t_mask += time.perf_counter() - t0                                                # mask once per video
+        t0 = time.perf_counter()
+        # the reference's per-chunk op sequence (local_attention.py:321-375): einsum, masked_fill_, plain topk,
+        # gather, softmax, weighted sum
+        idx, logit = O.affinity_chunk(key, q[:, qi], m, 10, 0.07, canonical=False)
         O.propagate_topk(val, idx, O.topk_weights(logit))
         t_aff += time.perf_counter() - t0
         n_chunks += 1
@@ -93,11 +98,13 @@ def cpu_baseline(wl, budget_s=25.0):
     t_read = time.perf_counter() - t0
     chunks_per_frame = (HW + step - 1) // step
     slots = sum(len(O.key_slots(fi)) for fi in range(1, T))           # 32 key slots for an 8-frame clip
-    clip_s = T * t_enc + chunks_per_frame * t_chunk * slots / 6.0 + T * t_read
+    t_mask_video = t_mask / n_chunks * chunks_per_frame / 6.0                              # one (HW x HW) mask per video
+    clip_s = T * t_enc + chunks_per_frame * t_chunk * slots / 6.0 + T * t_read + t_mask_video
     return dict(value=T / clip_s, unit="frames/s", cores=cores, kind="port",
                 sample=(f"oracle/fgvc_oracle.py on {cores} host threads: 1 frame through ResNet-18 ({t_enc:.2f}s), "
                         f"{n_chunks} of {chunks_per_frame} 512-query chunks of affinity_topk+propagate at T=6 "
-                        f"({t_chunk:.3f}s each), 1 frame read-out ({t_read:.2f}s); extrapolated to the "
+                        f"({t_chunk:.3f}s each, plain torch.topk like the reference), mask build "
+                        f"{t_mask_video:.1f}s per video, 1 frame read-out ({t_read:.2f}s); extrapolated to the "
                         f"{T}-frame clip ({slots} key slots)"),
                 clip_seconds_est=clip_s)
 

@@ -36,6 +36,7 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
 
 void set_pair_kernel(int);
 void set_pair_debug(int);
+void set_corr_debug(int);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -53,6 +54,10 @@ int fgvc_set_option(const char* name, int value) {
   if (strcmp(name, "pair_kernel") == 0) {
     FGVC_REQUIRE(value == 1 || value == 2, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_kernel must be 1 or 2");
     set_pair_kernel(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "corr_debug") == 0) {   // profiling ablation: 1 = bf16 volume kernels skip their stores
+    set_corr_debug(value);
     return FGVC_OK;
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero

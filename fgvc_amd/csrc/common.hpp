@@ -219,6 +219,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
   return base + k;
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains vmcnt(0), and on CDNA4 vmcnt
+// counts stores: in a loop that streams results to HBM every iteration would wait for its stores to land.
+// Global loads feeding LDS are still waited for by the compiler-counted vmcnt at their ds_write.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }

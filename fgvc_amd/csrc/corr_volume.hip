@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256, 2) void corr_volume_f32_kernel(const float* __
       qreg[4 * j + 0] = t.x; qreg[4 * j + 1] = t.y; qreg[4 * j + 2] = t.z; qreg[4 * j + 3] = t.w;
     }
   }
+  // Force the query loads to be waited for HERE: left alone, hipcc waits for them lazily inside the loop
+  // (s_waitcnt vmcnt(29..0) between the MFMAs), and on every later iteration those small counts also
+  // wait for the freshly issued key loads and the previous tile's stores -- a memory round trip per tile.
+#pragma unroll
+  for (int j = 0; j < C / 2; ++j) asm volatile("" ::"v"(qreg[j]));
   const int kb0 = blockIdx.y * KCHUNK;
   const int kb1 = imin(kb0 + KCHUNK, cdiv(HWk, 32));
   f32x4 stage[NLD];
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void corr_volume_f32_kernel(const float* __
       }
     }
     if (kb + 1 < kb1) stage_store(buf ^ 1);
-    __syncthreads();
+    lds_barrier();   // not __syncthreads(): must not wait for the volume stores above
     buf ^= 1;
   }
 }
@@ -120,105 +125,179 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 MFMA GEMM, 128 (keys) x 128 (queries) tile per workgroup, 2x2 waves of 64x64,
-// K-step 64, LDS double buffered with register prefetch, rows padded to 144 B (conflict-free b128).
-// NSEG = 3: K runs over [hi*hi | hi*lo | lo*hi];  NSEG = 1: hi*hi only.
+// bf16 / split-bf16x3 volume.  Same decomposition as the f32 kernel above: a wave keeps its 32 query
+// vectors resident in VGPRs as the MFMA B operand (hi and lo parts: 2 x C/4 registers), key blocks of 32
+// pixels ([pixel][hi|lo][C] bf16 = one contiguous 4*C-byte row per pixel) are staged once per workgroup into
+// padded LDS rows and read as ds_read_b128 A fragments; the 32x32 f32 tile goes straight from the
+// accumulator to memory (query on the lane -> 128-B row segments, non-temporal).
+//   NSEG == 3:  acc = k_hi*q_lo + k_lo*q_hi + k_hi*q_hi  (small terms first), 3*C/16 chained
+//               v_mfma_f32_32x32x16_bf16 per tile -- the f32-accurate product at bf16 MFMA rate
+//   NSEG == 1:  acc = k_hi*q_hi
+// For a short K (= C = 256) this beats a classic LDS-tiled GEMM: there is no K loop to pipeline, the
+// per-tile work is one straight MFMA chain, and the only recurring memory traffic besides the output
+// stream is the key block (shared by the workgroup's four waves, L2-resident).
 // ------------------------------------------------------------------------------------------
-template <int NSEG>
-__global__ __launch_bounds__(256, 2) void corr_volume_bf16_kernel(const uint16_t* __restrict__ q_hl,
-                                                                   const uint16_t* __restrict__ k_hl, int C,
-                                                                   int HWq, int HWk, float temperature,
-                                                                   float* __restrict__ vol, int n_qt) {
-  constexpr int BK = 64;            // bf16 elements per K-step
-  constexpr int ROWB = BK * 2 + 16; // padded row bytes
-  constexpr int TILEB = 128 * ROWB;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILEB];  // [buf][A|B]
+template <int C, int NSEG, int NW, int SUB>
+__global__ __launch_bounds__(NW * 64, (NW == 8) ? 2 : 2) void corr_volume_bf16_kernel(const uint16_t* __restrict__ q_hl,
+                                                                   const uint16_t* __restrict__ k_hl, int HWq,
+                                                                   int HWk, float temperature,
+                                                                   float* __restrict__ vol, int debug) {
+  // C == 256: a key pixel's [hi|lo] row is exactly 1 KiB = one LDS-DMA wave instruction, so the whole row is
+  // staged (also for NSEG == 1, which then simply ignores the lo half) with zero staging registers.
+  constexpr bool DMA = (C == 256);
+  constexpr int PARTS = (NSEG == 3 || DMA) ? 2 : 1;   // parts of a key row that are staged (hi [, lo])
+  constexpr int ROWB = PARTS * C * 2;                 // bytes of one staged key row
+  constexpr int LDB = ROWB + 16;                      // padded LDS row (bytes): stride 16*odd -> conflict-free b128
+  constexpr int ROWS = 32 * SUB;                      // key rows per pipeline stage
+  constexpr int BUFB = ROWS * LDB;
+  constexpr int NT = NW * 64;
+  constexpr int NLD = DMA ? 1 : (ROWS * ROWB / 16) / NT;   // 16-byte register-staged loads per thread (non-DMA)
+  constexpr int KS = C / 16;                          // k16 steps per part
+  static_assert(DMA || (ROWS * ROWB / 16) % NT == 0, "staging does not divide");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int n = lane & 31, hi = lane >> 5;
+  const int q = blockIdx.x * (NW * 32) + wave * 32 + n;
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int kt = tile / n_qt, qt = tile - kt * n_qt;   // consecutive tiles share the key panel
-  const int k0 = kt * 128, q0 = qt * 128;
-
-  const int ksteps_per_seg = C / BK;
-  const int nsteps = NSEG * ksteps_per_seg;
-
-  // staging: 128 rows x 128 B per operand = 1024 x 16 B -> 4 per thread per operand
-  uint4 sa[4], sb[4];
-  auto stage_load = [&](int step) {
-    const int seg = step / ksteps_per_seg, kin = (step - seg * ksteps_per_seg) * BK;
-    const int a_part = (seg == 2) ? 1 : 0;   // keys:    hi, hi, lo
-    const int b_part = (seg == 1) ? 1 : 0;   // queries: hi, lo, hi
+  // query fragments: lane (n, hi) holds k = 16j + 8hi .. +7 of query n, hi part [and lo part]
+  bf16x8 qh[KS], ql[(NSEG == 3) ? KS : 1];
+  {
+    const uint16_t* qp = q_hl + (size_t)imin(q, HWq - 1) * 2 * C + 8 * hi;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      const int row = f >> 3, c16 = f & 7;
-      const int kp = imin(k0 + row, HWk - 1), qp = imin(q0 + row, HWq - 1);
-      sa[i] = *reinterpret_cast<const uint4*>(k_hl + ((size_t)kp * 2 + a_part) * C + kin + c16 * 8);
-      sb[i] = *reinterpret_cast<const uint4*>(q_hl + ((size_t)qp * 2 + b_part) * C + kin + c16 * 8);
+    for (int j = 0; j < KS; ++j) {
+      qh[j] = *reinterpret_cast<const bf16x8*>(qp + 16 * j);
+      if constexpr (NSEG == 3) ql[j] = *reinterpret_cast<const bf16x8*>(qp + C + 16 * j);
+    }
+  }
+  // wait for the query fragments before the loop, not lazily inside it (see the f32 kernel)
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    asm volatile("" ::"v"(qh[j]));
+    if constexpr (NSEG == 3) asm volatile("" ::"v"(ql[j]));
+  }
+  const int kb0 = blockIdx.y * KCHUNK;               // in units of 32-key blocks; a stage covers SUB of them
+  const int kb1 = imin(kb0 + KCHUNK, cdiv(HWk, 32));
+  uint4 stage[NLD];
+  auto stage_load = [&](int kb, int buf) {
+    if constexpr (DMA) {
+#pragma unroll
+      for (int i = 0; i < ROWS / NW; ++i) {
+        const int row = wave * (ROWS / NW) + i;
+        const int pix = imin(kb * 32 + row, HWk - 1);
+        const uint16_t* src = k_hl + (size_t)pix * 2 * C + 8 * lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB],
+                                         16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int f = tid + NT * i;
+        const int row = f / (ROWB / 16), c16 = f % (ROWB / 16);
+        const int pix = imin(kb * 32 + row, HWk - 1);
+        stage[i] = *reinterpret_cast<const uint4*>(k_hl + (size_t)pix * 2 * C + 8 * c16);   // hi part first, lo follows
+      }
     }
   };
   auto stage_store = [&](int buf) {
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      const int row = f >> 3, c16 = f & 7;
-      *reinterpret_cast<uint4*>(&smem[(buf * 2 + 0) * TILEB + row * ROWB + c16 * 16]) = sa[i];
-      *reinterpret_cast<uint4*>(&smem[(buf * 2 + 1) * TILEB + row * ROWB + c16 * 16]) = sb[i];
+      for (int i = 0; i < NLD; ++i) {
+        const int f = tid + NT * i;
+        const int row = f / (ROWB / 16), c16 = f % (ROWB / 16);
+        *reinterpret_cast<uint4*>(&smem[buf * BUFB + row * LDB + 16 * c16]) = stage[i];
+      }
     }
   };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  stage_load(0);
+  stage_load(kb0, 0);
   stage_store(0);
   __syncthreads();
   int buf = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    if (step + 1 < nsteps) stage_load(step + 1);
-    const unsigned char* A = &smem[(buf * 2 + 0) * TILEB + (wm * 64 + l31) * ROWB + hi * 16];
-    const unsigned char* B = &smem[(buf * 2 + 1) * TILEB + (wn * 64 + l31) * ROWB + hi * 16];
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        af[t] = *reinterpret_cast<const bf16x8*>(A + t * 32 * ROWB + kk * 32);
-        bfr[t] = *reinterpret_cast<const bf16x8*>(B + t * 32 * ROWB + kk * 32);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
-    }
-    if (step + 1 < nsteps) stage_store(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-  // epilogue: row (key) = (r&3) + 8*(r>>2) + 4*hi, column (query) = lane&31 -> 128 B contiguous per half-wave
   const float inv_t = 1.0f / temperature;
+  // wave-uniform: all 32 queries of this wave exist -> the 16 stores of a full key block are unconditional,
+  // so their count is known and the DMA can be waited for with a counted vmcnt that leaves them in flight
+  const bool wave_full = (blockIdx.x * (NW * 32) + wave * 32 + 31) < HWq;
+  for (int kb = kb0; kb < kb1; kb += SUB) {
+    const bool more = kb + SUB < kb1;
+    if (more) stage_load(kb + SUB, buf ^ 1);
+    bool all_full = true;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+    for (int sb = 0; sb < SUB; ++sb) {
+      if (kb + sb >= kb1) break;                       // wave-uniform (ragged tail of the chunk)
+      // three independent accumulator chains (hi*lo, lo*hi, hi*hi): a dependent v_mfma_f32_32x32x16_bf16 does not
+      // issue back to back here (PMC: pipe 45 % busy, waves 60 % in SQ_WAIT_INST_ANY with two chains);
+      // summing the small correction terms separately is also the better rounding order
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      f32x16 accx = acc, accy = acc;
+      const unsigned char* ka = &smem[buf * BUFB + (sb * 32 + n) * LDB + 16 * hi];   // A operand: key row
+      constexpr int G = 2;                               // k16 steps per pipeline stage
+      constexpr int NG = KS / G;
+      bf16x8 ah[2][G], al[2][(NSEG == 3) ? G : 1];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int qcol = q0 + wn * 64 + ni * 32 + l31;
-      if (qcol < HWq) {
+      for (int i = 0; i < G; ++i) {
+        ah[0][i] = *reinterpret_cast<const bf16x8*>(ka + 32 * i);
+        if constexpr (NSEG == 3) al[0][i] = *reinterpret_cast<const bf16x8*>(ka + C * 2 + 32 * i);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            ah[(g + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(ka + 32 * ((g + 1) * G + i));
+            if constexpr (NSEG == 3)
+              al[(g + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(ka + C * 2 + 32 * ((g + 1) * G + i));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int j = g * G + i;
+          if constexpr (NSEG == 3) {
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g & 1][i], ql[j], accx, 0, 0, 0);
+            accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g & 1][i], qh[j], accy, 0, 0, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g & 1][i], qh[j], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (NSEG == 3) acc += (accx + accy);
+      const int kbs = kb + sb;
+      const bool full = wave_full && (kbs * 32 + 32 <= HWk);               // wave-uniform
+      all_full = all_full && full;
+      if (debug & 1) {   // profiling ablation: no volume stores (results are not written)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
+        all_full = false;
+      } else if (full) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int krow = k0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (krow < HWk) __builtin_nontemporal_store(acc[mi][ni][r] * inv_t, &vol[(size_t)krow * HWq + qcol]);
+          const int row = kbs * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          __builtin_nontemporal_store(acc[r] * inv_t, &vol[(size_t)row * HWq + q]);
+        }
+      } else if (q < HWq) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = kbs * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (row < HWk) __builtin_nontemporal_store(acc[r] * inv_t, &vol[(size_t)row * HWq + q]);
         }
       }
     }
+    if constexpr (DMA) {
+      // a full stage issued exactly 16*SUB stores after this wave's DMA loads: the counted wait retires the
+      // DMA (and everything older) but leaves those stores in flight across the barrier
+      if (all_full && kb + SUB <= kb1) {
+        if constexpr (SUB == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    if (more) stage_store(buf ^ 1);
+    lds_barrier();   // not __syncthreads(): must not wait for the volume stores above
+    buf ^= 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -245,13 +324,35 @@ int split_bf16_launch(const float* feat, uint16_t* out, long long n_pixels, int 
   return FGVC_OK;
 }
 
+static int g_corr_debug = 0;
+void set_corr_debug(int v) { g_corr_debug = v; }
+
 int corr_volume_bf16_launch(const uint16_t* q, const uint16_t* k, int C, int HWq, int HWk, float temperature,
                             float* vol, int nseg, hipStream_t s) {
-  const int n_qt = cdiv(HWq, 128), n_kt = cdiv(HWk, 128);
-  if (nseg == 3)
-    corr_volume_bf16_kernel<3><<<n_qt * n_kt, 256, 0, s>>>(q, k, C, HWq, HWk, temperature, vol, n_qt);
-  else
-    corr_volume_bf16_kernel<1><<<n_qt * n_kt, 256, 0, s>>>(q, k, C, HWq, HWk, temperature, vol, n_qt);
+  // C == 256: 8-wave workgroups (256 queries), 64-key stages through LDS-DMA; narrower features keep the
+  // 4-wave / 32-key register-staged form
+  if (C == 256) {
+    dim3 grid(cdiv(HWq, 256), cdiv(cdiv(HWk, 32), KCHUNK));
+    if (nseg == 3)
+      corr_volume_bf16_kernel<256, 3, 8, 2><<<grid, 512, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug);
+    else
+      corr_volume_bf16_kernel<256, 1, 8, 2><<<grid, 512, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug);
+  } else {
+    dim3 grid(cdiv(HWq, 128), cdiv(cdiv(HWk, 32), KCHUNK));
+#define FGVC_BF(CC)                                                                                       \
+  if (nseg == 3)                                                                                          \
+    corr_volume_bf16_kernel<CC, 3, 4, 1><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug);         \
+  else                                                                                                    \
+    corr_volume_bf16_kernel<CC, 1, 4, 1><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug)
+    switch (C) {
+      case 64: FGVC_BF(64); break;
+      case 128: FGVC_BF(128); break;
+      default:
+        set_error("fgvc_corr_volume_bf16: C=%d unsupported (64, 128 or 256)", C);
+        return FGVC_ERR_UNSUPPORTED;
+    }
+#undef FGVC_BF
+  }
   FGVC_CHECK_LAUNCH("fgvc_corr_volume_bf16");
   return FGVC_OK;
 }

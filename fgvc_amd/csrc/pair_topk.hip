@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256, 2) void pair_topk_kernel(PairParams p) {
     }
   }
 
+  // wait for the query loads here, not lazily inside the block loop (see corr_volume.hip)
+#pragma unroll
+  for (int j = 0; j < C / 2; ++j) asm volatile("" ::"v"(qreg[j]));
+
   // ---- key block range that the workgroup tile can reach
   const int reach_y = masked ? p.reach_y : FGVC_NO_LIMIT;
   const int reach_x = masked ? p.reach_x : FGVC_NO_LIMIT;

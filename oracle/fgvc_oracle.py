@@ -154,13 +154,15 @@ def mask_slab(Hq: int, Wq: int, Hk: int, Wk: int, T: int, q_index: torch.Tensor,
 def affinity_topk(query: torch.Tensor, key: torch.Tensor, topk: int, temperature: float = 1.0,
                   neighbor_range=None, mask_mode: str = "circle", mask: Optional[torch.Tensor] = None,
                   normalize: bool = True, non_mask_len: int = 0, step: int = 512,
-                  q_index: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  q_index: Optional[torch.Tensor] = None, canonical: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Per query pixel: canonical top-k (logit, flat key index t*HWk+j).
 
     query (C,Hq,Wq), key (C,T,Hk,Wk).  Returns idx (S,k) int64, logit (S,k)
     where S = HqWq or len(q_index).  Follows local_attention.py:308-356.
     Either `neighbor_range`(+`mask_mode`) (analytic) or a dense `mask`
     (HkWk, HqWq) bool, or neither (no mask).
+    canonical=False uses plain `torch.topk` exactly as the reference does (tie order unspecified): that is
+    the form timed as the CPU baseline; canonical=True (default) is the form used as the checker.
     """
     if key.dim() == 3:
         key = key.unsqueeze(1)
@@ -176,18 +178,31 @@ def affinity_topk(query: torch.Tensor, key: torch.Tensor, topk: int, temperature
     idx_out, val_out = [], []
     for p in range(0, q_index.numel(), step):
         qi = q_index[p:p + step]
-        aff = torch.einsum("ci,cj->ij", kv, qv[:, qi]) / temperature      # :321-323
         if mask is not None:
             m = mask[:, qi].unsqueeze(0).expand(T, -1, -1).clone()
             m[:non_mask_len] = True
-            aff = aff.masked_fill(~m.reshape(T * Hk * Wk, -1), NEG_INF)  # :353
+            m = m.reshape(T * Hk * Wk, -1)
         elif neighbor_range is not None:
             m = mask_slab(Hq, Wq, Hk, Wk, T, qi, neighbor_range, mask_mode, non_mask_len)
-            aff = aff.masked_fill(~m, NEG_INF)
-        v, i = topk_canonical(aff, topk)                                  # :356
-        idx_out.append(i.t())
-        val_out.append(v.t())
+        else:
+            m = None
+        i, v = affinity_chunk(kv, qv[:, qi], m, topk, temperature, canonical)
+        idx_out.append(i)
+        val_out.append(v)
     return torch.cat(idx_out, 0), torch.cat(val_out, 0)
+
+
+def affinity_chunk(kv: torch.Tensor, qv_chunk: torch.Tensor, mask_chunk: Optional[torch.Tensor], topk: int,
+                   temperature: float, canonical: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One query chunk of the reference's loop body (local_attention.py:321-356): einsum / temperature,
+    masked_fill_(-inf), topk.  kv (C, T*HWk), qv_chunk (C, s), mask_chunk (T*HWk, s) bool or None.
+    Returns idx (s,k), logit (s,k).  This is also the unit the CPU baseline times (with a pre-built mask,
+    as the reference pre-builds its mask once per video, vanilla_tracker.py:332-340)."""
+    aff = torch.einsum("ci,cj->ij", kv, qv_chunk) / temperature          # :321-323
+    if mask_chunk is not None:
+        aff = aff.masked_fill_(~mask_chunk, NEG_INF)                      # :353
+    v, i = topk_canonical(aff, topk) if canonical else aff.topk(topk, dim=0)   # :356
+    return i.t(), v.t()
 
 
 def topk_weights(logit: torch.Tensor, mode: str = "softmax") -> torch.Tensor:

@@ -1,0 +1,18 @@
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fgvc_amd import ops
+from tools.microbench import timeit
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+H, W, C = 120, 214, 256; HW = H * W
+feats = ops.normalize_to_hwc(torch.randn(2, C, H, W, device=dev))
+hl = ops.split_bf16(feats)
+vol = torch.empty((HW, HW), device=dev)
+res = {}
+for dbg in (0, 1):
+    ops.set_option("corr_debug", dbg)
+    for prec in ("bf16x3", "bf16"):
+        m, _ = timeit(lambda: ops.corr_volume(hl[1], hl[0], 0.07, prec, out=vol), 5)
+        res[f"{prec}_{'nostore' if dbg else 'full'}_ms"] = round(m, 4)
+ops.set_option("corr_debug", 0)
+print(json.dumps(res))
