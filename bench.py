@@ -44,6 +44,17 @@ WORKLOADS = {
 }
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json): PMC counters
+    cannot be read from inside this process, so the figure is the offline measurement of the same kernel
+    at the same workload, corrected as MI355X_MICROARCH.md prescribes.  None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return float(json.load(f)[kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def build_tracker(wl, dev):
     import fgvc_amd.mmpt_api as api
     test_cfg = api.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512,
@@ -117,6 +128,8 @@ def main():
     ap.add_argument("--workload", default="cfg2_480p_8f", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr-volume", action="store_true")
+    ap.add_argument("--channels-last", type=int, default=0, help="run the MIOpen encoder in NHWC (experiment)")
+    ap.add_argument("--no-autotune", action="store_true", help="MIOpen immediate mode (clean profiles)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,8 +146,11 @@ def main():
     _lib.load()
     wl = WORKLOADS[a.workload]
     T, h, w, P = wl["frames"], wl["h"], wl["w"], wl["points"]
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = not a.no_autotune
     model = build_tracker(wl, dev)
+    if a.channels_last:
+        model.test_cfg["channels_last"] = True
+        model = model.to(memory_format=torch.channels_last)
     cfg = model.engine_config()
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
@@ -189,7 +205,9 @@ def main():
                    "parallelism": f"dp{world} (independent clips per rank, no data-path collective)"},
         "roofline": {"kernel": "fgvc_pair_topk_f32", "bound": "mfma", "achieved": ach_tf,
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "ms_per_launch": pair_ms, "pairs_per_launch": n_pairs,
+                     "traffic": measured_traffic("fgvc_pair_topk_f32") if a.workload == "cfg2_480p_8f" else None,
+                     "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                     "ms_per_launch": pair_ms, "pairs_per_launch": n_pairs,
                      "flops_per_pair": flops_per_pair, "ms_per_pair": pair_ms / n_pairs},
     }
 
@@ -214,7 +232,8 @@ def main():
                     "score bar, f32 is exact, bf16 is reduced precision (reported, not parity-grade)",
             "ms_per_corr_volume": res["bf16x3"]["ms"],
             "roofline": {"kernel": "fgvc_corr_volume_bf16x3", "bound": "hbm", "achieved": res["bf16x3"]["achieved"],
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": res["bf16x3"]["frac"], "traffic": None,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": res["bf16x3"]["frac"],
+                         "traffic": measured_traffic("fgvc_corr_volume_bf16x3") if a.workload == "cfg2_480p_8f" else None,
                          "bytes_per_launch": gbytes * 1e9},
             "variants": res,
         }

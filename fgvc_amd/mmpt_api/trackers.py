@@ -82,6 +82,9 @@ class VanillaTracker(BaseTracker):
         norm = bool(self.test_cfg.get("with_norm", True))
         chunks = []
         Hf = Wf = None
+        if self.test_cfg.get("channels_last", False):
+            # MIOpen's fastest f32 kernels on gfx950 are NHWC; feeding NHWC avoids its transposes
+            frames = frames.contiguous(memory_format=torch.channels_last)
         for i in range(0, frames.shape[0], step):
             f = self.extract_feat(frames[i:i + step])
             if isinstance(f, (tuple, list)):

@@ -1,0 +1,19 @@
+"""One launch each of the roofline kernels at the bench size (for rocprofv3 --pmc passes)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fgvc_amd import engine, ops
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+H, W, C, T = 120, 214, 256, 8; HW = H * W
+feats = ops.normalize_to_hwc(torch.randn(T, C, H, W, device=dev))
+cfg = engine.TrackerConfig()
+plan = engine.plan_clip(T, [0], cfg)
+pairs = ops.make_pairs(plan.pairs, dev)
+hl = ops.split_bf16(feats[:2])
+vol = torch.empty((HW, HW), device=dev)
+for _ in range(3):
+    ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False)
+    ops.corr_volume(hl[1], hl[0], 0.07, "bf16x3", out=vol)
+    ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol)
+    ops.corr_volume(feats[1], feats[0], 0.07, "f32", out=vol)
+torch.cuda.synchronize()
