@@ -198,3 +198,32 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def gen_tapvid_metrics():
+    """tests/golden/tapvid_metrics.npz: the reference's compute_tapvid_metrics (numpy only) is lifted out of its
+    module by AST (the module imports mediapy/absl, absent here) and run on seeded inputs."""
+    import ast
+    from typing import Iterable, Mapping
+    src = open(os.path.join(ref_import.REF_ROOT, "mmpt/datasets/tapvid_evaluation_datasets.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "compute_tapvid_metrics"][0]
+    ns = {"np": np, "Iterable": Iterable, "Mapping": Mapping}
+    exec(compile(ast.Module([fn], []), "ref", "exec"), ns)
+    rng = np.random.default_rng(0)
+    b, n, T = 3, 7, 12
+    gt_occ = rng.random((b, n, T)) < 0.3
+    gt_occ[:, :, 0] = False
+    qp = np.zeros((b, n, 3))
+    qp[..., 0] = rng.integers(0, 4, (b, n))
+    for i in range(b):
+        for j in range(n):
+            gt_occ[i, j, int(qp[i, j, 0])] = False
+    gt = rng.random((b, n, T, 2)) * 64
+    pred = gt + rng.normal(0, 3, (b, n, T, 2))
+    pred_occ = rng.random((b, n, T)) < 0.3
+    outs = {}
+    for mode in ("first", "strided"):
+        m = ns["compute_tapvid_metrics"](qp, gt_occ, gt, pred_occ, pred, mode, additional_pck_thresholds=[0.5, 3])
+        outs.update({f"{mode}__{k}": np.asarray(v) for k, v in m.items()})
+    save("tapvid_metrics", query_points=qp, gt_occluded=gt_occ, gt_tracks=gt, pred_occluded=pred_occ,
+         pred_tracks=pred, **outs)

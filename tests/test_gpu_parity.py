@@ -286,3 +286,28 @@ def test_pair_kernel_variants_agree(dev):
             ops.set_option("pair_kernel", 2)
         # v2 sums the channels in four interleaved chains: last-bit differences in the scores are expected
         assert torch.allclose(s1, s2, atol=2e-6) and (i1 == i2).float().mean() > 0.999
+
+
+def test_tracker_end_to_end_on_synthetic_tapvid(dev):
+    """tools/test.py path: registry-built VanillaTracker -> 5-tuple -> TAP-Vid metrics.  The synthetic clip is a
+    rigidly translating texture, so even a RANDOM-INIT ResNet's features match exactly between frames and label
+    propagation must track the points (a smoke test of the whole drop-in path, not an accuracy claim)."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import apis, metrics
+    from fgvc_amd.datasets import StridedLoader, SyntheticTapVid
+    test_cfg = api.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, with_first=True,
+                              with_first_neighbor=True)
+    model = api.build_model(dict(type="VanillaTracker",
+                                 backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4), out_indices=(2,),
+                                               pool_type="none", zero_init_residual=False)),
+                            train_cfg=None, test_cfg=test_cfg)
+    torch.manual_seed(0)
+    model.init_weights()
+    model = model.to(dev).eval()
+    ds = SyntheticTapVid(n_videos=2, frames=6, size=(128, 128), points=6, query_mode="strided", device=dev)
+    outs = apis.single_gpu_test(model, StridedLoader(ds))
+    assert len(outs) == 2 and outs[0][2].shape == (1, 6, 6, 2)
+    traj, vis, pred, vpred, qp = outs[0]
+    assert bool((qp[0, 1:, 0] >= qp[0, :-1, 0]).all())                # regrouped by query time
+    s = metrics.tapvid_evaluate(outs, "strided")
+    assert s["average_pts_within_thresh"] > 60.0, s

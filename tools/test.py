@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Evaluation entry point with the steps of the reference's tools/test.py:71-198, on fgvc_amd.
+
+    python tools/test.py CONFIG --task davis [--checkpoint CKPT] [--videos 4 --frames 8 --size 256 256]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/test.py CONFIG --launcher pytorch
+
+CONFIG may be the reference's own configs/eval/res18_d1_eval.py.  The TAP-Vid / JHMDB files are not available
+offline, so the dataset is `SyntheticTapVid` (same sample format); with `--data-root` pointing at real TAP-Vid
+pickles a loader can be plugged in at `build_dataset`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fgvc_amd.mmpt_api as api  # noqa: E402
+from fgvc_amd import apis, metrics  # noqa: E402
+from fgvc_amd.datasets import StridedLoader, SyntheticTapVid  # noqa: E402
+
+DEFAULT_CFG = dict(
+    model=dict(type="VanillaTracker",
+               backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4), out_indices=(2,), pool_type="none")),
+    test_cfg_davis=dict(precede_frames=5, topk=10, temperature=0.07, strides=(1, 1, 1, 4), out_indices=(2,),
+                        neighbor_range=30, step=512, with_first=True, with_first_neighbor=True),
+)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", nargs="?", default=None)
+    ap.add_argument("--task", default="davis")
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--launcher", choices=["none", "pytorch"], default="none")
+    ap.add_argument("--videos", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--size", type=int, nargs=2, default=(256, 256))
+    ap.add_argument("--points", type=int, default=8)
+    ap.add_argument("--query-mode", default="first")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+
+    cfg = api.Config.fromfile(a.config) if a.config else api.Config(DEFAULT_CFG)           # tools/test.py:75
+    distributed = a.launcher != "none"
+    rank, world = 0, 1
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if distributed:                                                                          # :106-110
+        dist.init_process_group("nccl", device_id=dev)
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+    dataset = SyntheticTapVid(a.videos, a.frames, tuple(a.size), a.points, a.query_mode, device=dev)   # :121-122
+    loader = StridedLoader(dataset, rank, world)                                             # :124-134
+    test_cfg = cfg["test_cfg_" + a.task]                                                     # :135
+    model_cfg = dict(type=cfg.get("eval_arc", "VanillaTracker"), backbone=dict(cfg.model.backbone))   # :139
+    for k in ("out_indices", "strides", "dilations"):                                        # :141-145
+        if k in test_cfg:
+            model_cfg["backbone"][k] = test_cfg[k]
+    model = api.build_model(model_cfg, train_cfg=None, test_cfg=test_cfg)                    # :152
+    model.init_weights()                                                                     # :153
+    if a.checkpoint:
+        api.load_checkpoint(model, a.checkpoint)                                             # :158-159
+    model = model.to(dev).eval()
+
+    outputs = apis.multi_gpu_test(model, loader) if distributed else apis.single_gpu_test(model, loader)   # :160-190
+    if rank == 0:
+        summary = metrics.tapvid_evaluate(outputs, a.query_mode)                             # :192-198
+        keep = ("average_pts_within_thresh", "average_jaccard", "occlusion_accuracy", "ade_visible")
+        print(json.dumps({k: round(summary[k], 3) for k in keep}))
+        if a.out:
+            with open(a.out, "w") as f:
+                json.dump(summary, f, indent=1)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
