@@ -52,7 +52,7 @@ const char* fgvc_last_error(void) { return g_err; }
 int fgvc_set_option(const char* name, int value) {
   FGVC_REQUIRE(name != nullptr, FGVC_ERR_INVALID_ARG, "fgvc_set_option: null name");
   if (strcmp(name, "pair_kernel") == 0) {
-    FGVC_REQUIRE(value == 1 || value == 2, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_kernel must be 1 or 2");
+    FGVC_REQUIRE(value >= 1 && value <= 3, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_kernel must be 1, 2 or 3");
     set_pair_kernel(value);
     return FGVC_OK;
   }

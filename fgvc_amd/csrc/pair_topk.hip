@@ -14,27 +14,9 @@
 //   the query on the lane and 16 keys in the accumulator registers, so the running top-k is a
 //   private per-lane sorted list (score desc, index asc) -- no cross-lane traffic until the two
 //   lanes that share a query merge their lists with one __shfl_xor(32) sweep at the end.
-#include "common.hpp"
+#include "pair_common.hpp"
 
 namespace fgvc {
-
-constexpr int QBH = 4, QBW = 8;  // pixel block = 4 rows x 8 cols = 32 = one MFMA tile edge
-
-struct PairParams {
-  const float* qfeat;
-  const float* kfeat;
-  const int4* pairs;
-  int Hq, Wq, Hk, Wk;
-  int r2max, ry, rx;  // mask predicate (FGVC_NO_LIMIT = off)
-  int reach_y, reach_x;  // largest |dy|, |dx| the predicate admits (host-computed)
-  int n_ty, n_tx;
-  int kout;           // entries written per query (<= K); rows of idx_out/score_out have this stride
-  const uint8_t* dense_mask;  // optional [HWk][HWq] bool: arbitrary user mask (full-frame traversal)
-  int debug;                  // ablation switches for profiling (results are WRONG when non-zero):
-                              // 1 = no selection, 2 = no MFMA, 4 = no key staging, 8 = no geometry (accept all in-bounds)
-  int32_t* idx_out;
-  float* score_out;
-};
 
 template <int C, int K>
 __global__ __launch_bounds__(256, 2) void pair_topk_kernel(PairParams p) {
@@ -201,29 +183,6 @@ __global__ __launch_bounds__(256, 2) void pair_topk_kernel(PairParams p) {
     }
   }
 }
-
-// Geometry shared by both roles of the v2 kernel (all members wave-uniform).
-struct HalfIter {
-  int by_lo, bxl[2], nbx[2], nb[2];
-  int TY0, TX0, r2max, ry, rx;
-
-  __device__ __forceinline__ bool reach(int wy0, int wx0, int ky0, int kx0) const {
-    const int dy = imax(0, imax(ky0 - (wy0 + QBH - 1), wy0 - (ky0 + QBH - 1)));
-    const int dx = imax(0, imax(kx0 - (wx0 + QBW - 1), wx0 - (kx0 + QBW - 1)));
-    return dy * dy + dx * dx <= r2max && dy <= ry && dx <= rx;
-  }
-  __device__ __forceinline__ int blk_y(int h, int b) const { return (by_lo + b / nbx[h]) * QBH; }
-  __device__ __forceinline__ int blk_x(int h, int b) const { return (bxl[h] + b % nbx[h]) * QBW; }
-  __device__ __forceinline__ bool half_need(int h, int b) const {
-    const int ky0 = blk_y(h, b), kx0 = blk_x(h, b), hx0 = TX0 + h * QBW;
-    return reach(TY0, hx0, ky0, kx0) || reach(TY0 + QBH, hx0, ky0, kx0);
-  }
-  __device__ __forceinline__ int next_block(int h, int b) const {
-    ++b;
-    while (b < nb[h] && !half_need(h, b)) ++b;
-    return b;
-  }
-};
 
 template <int C, int K>
 __global__ __launch_bounds__(512, 2) void pair_topk_kernel_v2(PairParams p) {
@@ -514,7 +473,10 @@ __global__ __launch_bounds__(512, 2) void pair_topk_kernel_v2(PairParams p) {
   }
 }
 
-static int g_pair_kernel = 2;   // 1 = v1 (4 waves, selection in the MFMA waves), 2 = wave-specialised
+int pair_topk_v3_launch(const PairParams& p, int n_pairs, int topk, hipStream_t s);
+
+static int g_pair_kernel = 3;   // 1 = v1 (4 waves, selection in the MFMA waves), 2 = wave-specialised,
+                                // 3 = wave-specialised + sort in the MFMA shadow (C=256, topk 2..10, analytic mask)
 static int g_pair_debug = 0;
 void set_pair_kernel(int v) { g_pair_kernel = v; }
 void set_pair_debug(int v) { g_pair_debug = v; }
@@ -554,6 +516,8 @@ int pair_topk_launch(const float* qfeat, const float* kfeat, const int32_t* pair
   p.idx_out = idx_out; p.score_out = score_out;
   p.dense_mask = dense_mask;
   p.debug = g_pair_debug;
+  if (g_pair_kernel == 3 && C == 256 && topk >= 2 && topk <= 10 && dense_mask == nullptr && g_pair_debug == 0)
+    return pair_topk_v3_launch(p, n_pairs, topk, s);
   switch (C) {
     case 32: return dispatch_k<32>(p, n_pairs, topk, s);
     case 64: return dispatch_k<64>(p, n_pairs, topk, s);

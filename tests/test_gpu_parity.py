@@ -282,10 +282,19 @@ def test_pair_kernel_variants_agree(dev):
             i1, s1 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
             ops.set_option("pair_kernel", 2)
             i2, s2 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+            ops.set_option("pair_kernel", 3)
+            i3, s3 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+            i3b, s3b = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 4)
         finally:
-            ops.set_option("pair_kernel", 2)
+            ops.set_option("pair_kernel", 3)
         # v2 sums the channels in four interleaved chains: last-bit differences in the scores are expected
         assert torch.allclose(s1, s2, atol=2e-6) and (i1 == i2).float().mean() > 0.999
+        # v3 uses one chain like v1 (for C=256; other C fall back to v2): identical bits
+        if C == 256:
+            assert torch.equal(i1, i3) and torch.equal(s1, s3)
+            assert torch.equal(i3[..., :4], i3b) and torch.equal(s3[..., :4], s3b)
+        else:
+            assert torch.equal(i2, i3) and torch.equal(s2, s3)
 
 
 def test_tracker_end_to_end_on_synthetic_tapvid(dev):

@@ -14,16 +14,16 @@ plan = engine.plan_clip(T, [0], cfg)
 pairs = ops.make_pairs(plan.pairs, dev)
 one = ops.make_pairs([(1, 0)], dev)
 res = {}
-for kern in (2, 1):
+for kern in (3, 2, 1):
     ops.set_option("pair_kernel", kern)
     for dbg, name in [(0, "full"), (1, "no_select"), (2, "no_mfma"), (4, "no_stage"), (3, "no_select_no_mfma"),
                       (7, "nothing")]:
-        if kern == 1 and dbg:
+        if kern != 2 and dbg:
             continue
         ops.set_option("pair_debug", dbg)
         m27, _ = timeit(lambda: ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False), 5)
         m1, _ = timeit(lambda: ops.pair_topk(feats, feats, one, H, W, H, W, cfg.mask, 10, validate=False), 5)
         res[f"v{kern}_{name}"] = {"27pairs_ms": round(m27, 3), "1pair_ms": round(m1, 3)}
 ops.set_option("pair_debug", 0)
-ops.set_option("pair_kernel", 2)
+ops.set_option("pair_kernel", 3)
 print(json.dumps(res, indent=1))
