@@ -516,7 +516,7 @@ int pair_topk_launch(const float* qfeat, const float* kfeat, const int32_t* pair
   p.idx_out = idx_out; p.score_out = score_out;
   p.dense_mask = dense_mask;
   p.debug = g_pair_debug;
-  if (g_pair_kernel == 3 && C == 256 && topk >= 2 && topk <= 10 && dense_mask == nullptr && g_pair_debug == 0)
+  if (g_pair_kernel == 3 && C == 256 && topk >= 2 && topk <= 10 && dense_mask == nullptr && (g_pair_debug & 15) == 0)
     return pair_topk_v3_launch(p, n_pairs, topk, s);
   switch (C) {
     case 32: return dispatch_k<32>(p, n_pairs, topk, s);
