@@ -25,7 +25,8 @@ int normalize_launch(const float*, float*, int, int, int, int, int, hipStream_t)
 int propagate_launch(const float*, const int32_t*, int, const int32_t*, const float*, int, int, int, int, int, int,
                      int, float*, hipStream_t);
 int gaussian_launch(const float*, int, int, int, int, float, float*, hipStream_t);
-int softargmax_launch(const float*, int, int, int, int, int, int, const float*, float, double*, hipStream_t);
+int softargmax_launch(const float*, int, int, int, int, int, int, const float*, float, double*, float*, hipStream_t);
+int softargmax_bands();
 int corr_volume_f32_launch(const float*, const float*, int, int, int, float, float*, hipStream_t);
 int split_bf16_launch(const float*, uint16_t*, long long, int, hipStream_t);
 int corr_volume_bf16_launch(const uint16_t*, const uint16_t*, int, int, int, float, float*, int, hipStream_t);
@@ -210,14 +211,23 @@ int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int str
   return gaussian_launch(points, P, Hf, Wf, stride, sigma, out, (hipStream_t)stream);
 }
 
+size_t fgvc_softargmax_workspace_bytes(int n_frames, int P) {
+  if (n_frames < 0 || P < 0) return 0;
+  return (size_t)n_frames * P * softargmax_bands() * (2 * 5 + 1) * sizeof(float);
+}
+
 int fgvc_softargmax_top5_f32(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
-                             const float* gauss_points, float sigma, double* coords, void* stream) {
+                             const float* gauss_points, float sigma, double* coords, void* workspace, void* stream) {
   FGVC_REQUIRE(labels && coords, FGVC_ERR_INVALID_ARG, "fgvc_softargmax_top5_f32: null pointer");
   FGVC_REQUIRE(n_frames >= 0 && Hf > 0 && Wf > 0 && P > 0 && h > 0 && w > 0, FGVC_ERR_INVALID_ARG, "fgvc_softargmax_top5_f32: bad shape");
   FGVC_REQUIRE((long long)h * w < (1ll << 31) && h * w >= 5, FGVC_ERR_UNSUPPORTED, "fgvc_softargmax_top5_f32: h*w out of range");
   FGVC_REQUIRE(n_frames <= 65535 && sigma > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_softargmax_top5_f32: bad n_frames/sigma");
+  FGVC_REQUIRE(workspace != nullptr || n_frames == 0, FGVC_ERR_INVALID_ARG,
+               "fgvc_softargmax_top5_f32: workspace of fgvc_softargmax_workspace_bytes() bytes required");
+  FGVC_REQUIRE(P <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_softargmax_top5_f32: P > 65535");
   if (n_frames == 0) return FGVC_OK;
-  return softargmax_launch(labels, n_frames, Hf, Wf, P, h, w, gauss_points, sigma, coords, (hipStream_t)stream);
+  return softargmax_launch(labels, n_frames, Hf, Wf, P, h, w, gauss_points, sigma, coords,
+                           static_cast<float*>(workspace), (hipStream_t)stream);
 }
 
 }  // extern "C"

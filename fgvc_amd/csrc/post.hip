@@ -187,16 +187,22 @@ __device__ __forceinline__ void src_index(int d, float scale, int in_size, int& 
   l1 = s - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void softargmax_top5_kernel(const float* __restrict__ labels, int Hf, int Wf,
-                                                               int P, int h, int w,
+// Stage 1: one workgroup per (label, frame, row band): top-5 candidates + partial sum of its band.
+// Stage 2: one wave per (label, frame) merges the bands and writes the coordinates.
+// (A single workgroup per map leaves half of the 256 CUs idle at 8 frames x 16 labels and runs 0.9 ms.)
+constexpr int RO_K = 5;
+
+__global__ __launch_bounds__(256) void softargmax_band_kernel(const float* __restrict__ labels, int Hf, int Wf,
+                                                               int P, int h, int w, int nbands,
                                                                const float* __restrict__ gauss_points,
-                                                               float two_sigma2, double* __restrict__ coords) {
-  constexpr int K = 5;
+                                                               float two_sigma2, float* __restrict__ part_v,
+                                                               int* __restrict__ part_i, float* __restrict__ part_sum) {
+  constexpr int K = RO_K;
   __shared__ float sv[256 * K];
   __shared__ int si[256 * K];
   __shared__ float ssum[256];
   const int tid = threadIdx.x;
-  const int pl = blockIdx.x, f = blockIdx.y;
+  const int pl = blockIdx.x, f = blockIdx.y, band = blockIdx.z;
   const bool analytic = (gauss_points != nullptr) && f == 0;
   const float* lab = labels + (size_t)f * Hf * Wf * P + pl;
   const float sy = (float)Hf / (float)h, sx = (float)Wf / (float)w;
@@ -205,10 +211,12 @@ __global__ __launch_bounds__(256) void softargmax_top5_kernel(const float* __res
     cx = gauss_points[2 * pl];
     cy = gauss_points[2 * pl + 1];
   }
+  const int rows = cdiv(h, nbands);
+  const int y_lo = band * rows, y_hi = imin(h, y_lo + rows);
   TopKHi<K> top;
   top.init();
   float sum = 0.f;
-  for (int i = tid; i < h * w; i += 256) {
+  for (int i = y_lo * w + tid; i < y_hi * w; i += 256) {
     const int y = i / w, x = i - y * w;
     float v;
     if (analytic) {
@@ -252,26 +260,54 @@ __global__ __launch_bounds__(256) void softargmax_top5_kernel(const float* __res
     __syncthreads();
   }
   if (tid == 0) {
-    double* o = coords + ((size_t)f * P + pl) * 2;
-    if (ssum[0] == 0.f) {  // np.sum(map) == 0  (vanilla_tracker.py:189)
-      o[0] = -1.0;
-      o[1] = -1.0;
-    } else {
-      float tot = 0.f;
+    const size_t o = (((size_t)f * P + pl) * nbands + band);
 #pragma unroll
-      for (int j = K - 1; j >= 0; --j) tot += top.v[j];       // ascending order like np.sum over argsort[-5:]
-      tot += 1e-9f;                                            // float32 + python float stays float32
-      double ax = 0.0, ay = 0.0;
-#pragma unroll
-      for (int j = K - 1; j >= 0; --j) {
-        const float wgt = top.v[j] / tot;                      // float32 weights (:183)
-        ax += (double)(top.ix[j] % w) * (double)wgt;           // int64 * float32 -> float64 (:187)
-        ay += (double)(top.ix[j] / w) * (double)wgt;
-      }
-      o[0] = ax;
-      o[1] = ay;
+    for (int j = 0; j < K; ++j) {
+      part_v[o * K + j] = top.v[j];
+      part_i[o * K + j] = top.ix[j];
+    }
+    part_sum[o] = ssum[0];
+  }
+}
+
+__global__ __launch_bounds__(64) void softargmax_merge_kernel(const float* __restrict__ part_v,
+                                                               const int* __restrict__ part_i,
+                                                               const float* __restrict__ part_sum, int nbands, int w,
+                                                               int n_maps, double* __restrict__ coords) {
+  constexpr int K = RO_K;
+  const int m = blockIdx.x * 64 + threadIdx.x;      // one thread per (frame, label) map: nbands*5 candidates
+  if (m >= n_maps) return;
+  TopKHi<K> top;
+  top.init();
+  float sum = 0.f;
+  for (int b = 0; b < nbands; ++b) {
+    const size_t o = (size_t)m * nbands + b;
+    sum += part_sum[o];
+    for (int j = 0; j < K; ++j) {
+      const int id = part_i[o * K + j];
+      const float v = part_v[o * K + j];
+      if (id >= 0 && top.accepts(v, id)) top.insert(v, id);
     }
   }
+  double* o = coords + (size_t)m * 2;
+  if (sum == 0.f) {  // np.sum(map) == 0  (vanilla_tracker.py:189)
+    o[0] = -1.0;
+    o[1] = -1.0;
+    return;
+  }
+  float tot = 0.f;
+#pragma unroll
+  for (int j = K - 1; j >= 0; --j) tot += top.v[j];       // ascending order like np.sum over argsort[-5:]
+  tot += 1e-9f;                                            // float32 + python float stays float32
+  double ax = 0.0, ay = 0.0;
+#pragma unroll
+  for (int j = K - 1; j >= 0; --j) {
+    const float wgt = top.v[j] / tot;                      // float32 weights (:183)
+    ax += (double)(top.ix[j] % w) * (double)wgt;           // int64 * float32 -> float64 (:187)
+    ay += (double)(top.ix[j] / w) * (double)wgt;
+  }
+  o[0] = ax;
+  o[1] = ay;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -310,10 +346,20 @@ int gaussian_launch(const float* points, int P, int Hf, int Wf, int stride, floa
   return FGVC_OK;
 }
 
+int softargmax_bands() { return 8; }
+
 int softargmax_launch(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
-                      const float* gauss_points, float sigma, double* coords, hipStream_t s) {
-  dim3 grid(P, n_frames);
-  softargmax_top5_kernel<<<grid, 256, 0, s>>>(labels, Hf, Wf, P, h, w, gauss_points, 2.f * sigma * sigma, coords);
+                      const float* gauss_points, float sigma, double* coords, float* ws, hipStream_t s) {
+  // workspace layout: part_v [maps][bands][5] f32 | part_i [maps][bands][5] i32 | part_sum [maps][bands] f32
+  const int nb = softargmax_bands();
+  const size_t maps = (size_t)n_frames * P;
+  float* part_v = ws;
+  int* part_i = reinterpret_cast<int*>(ws + maps * nb * RO_K);
+  float* part_sum = ws + 2 * maps * nb * RO_K;
+  dim3 grid(P, n_frames, nb);
+  softargmax_band_kernel<<<grid, 256, 0, s>>>(labels, Hf, Wf, P, h, w, nb, gauss_points, 2.f * sigma * sigma, part_v,
+                                              part_i, part_sum);
+  softargmax_merge_kernel<<<cdiv((int)maps, 64), 64, 0, s>>>(part_v, part_i, part_sum, nb, w, (int)maps, coords);
   FGVC_CHECK_LAUNCH("fgvc_softargmax_top5_f32");
   return FGVC_OK;
 }

@@ -259,6 +259,8 @@ def softargmax_top5(labels: torch.Tensor, Hf: int, Wf: int, h: int, w: int,
         gauss_points = _chk(gauss_points.to(torch.float32), torch.float32, "gauss_points")
         assert gauss_points.shape == (P, 2)
     coords = torch.empty((n, P, 2), device=labels.device, dtype=torch.float64)
+    ws_bytes = _lib.load().fgvc_softargmax_workspace_bytes(n, P)
+    ws = torch.empty((max(ws_bytes, 4) + 3) // 4, device=labels.device, dtype=torch.float32)
     _lib.call("fgvc_softargmax_top5_f32", _ptr(labels), n, Hf, Wf, P, h, w, _ptr(gauss_points), float(sigma),
-              _ptr(coords), _stream(labels))
+              _ptr(coords), _ptr(ws), _stream(labels))
     return coords

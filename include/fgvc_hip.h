@@ -23,6 +23,7 @@
 #ifndef FGVC_HIP_H
 #define FGVC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -154,9 +155,13 @@ int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int str
  * replaces vanilla_tracker.py:396-400 and :172-191 (no (T,P,h,w) tensor, no D2H copy, no argsort).
  *   labels [n_frames][Hf*Wf][P];  gauss_points: if non-NULL, frame 0 is read out from the analytic
  *   full-resolution Gaussian of these points instead (vanilla_tracker.py:329,322).
- *   coords [n_frames][P][2] f64 = (x, y); (-1,-1) where the map is all zero. */
+ *   coords [n_frames][P][2] f64 = (x, y); (-1,-1) where the map is all zero.
+ *   workspace: caller-owned device scratch of fgvc_softargmax_workspace_bytes(n_frames, P) bytes (each map is
+ *   reduced in row bands by many workgroups, then merged). */
+size_t fgvc_softargmax_workspace_bytes(int n_frames, int P);
 int fgvc_softargmax_top5_f32(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
-                             const float* gauss_points, float sigma, double* coords, void* stream);
+                             const float* gauss_points, float sigma, double* coords, void* workspace,
+                             void* stream);
 
 #ifdef __cplusplus
 }
