@@ -24,6 +24,8 @@ int merge_topk_launch(const int32_t*, const float*, const int32_t*, int, int, in
 int normalize_launch(const float*, float*, int, int, int, int, int, hipStream_t);
 int propagate_launch(const float*, const int32_t*, int, const int32_t*, const float*, int, int, int, int, int, int,
                      int, float*, hipStream_t);
+int bn_act_launch(const float*, const float*, const float*, const float*, const float*, const float*, float, int, float*,
+                  int, int, int, hipStream_t);
 int gaussian_launch(const float*, int, int, int, int, float, float*, hipStream_t);
 int softargmax_launch(const float*, int, int, int, int, int, int, const float*, float, double*, float*, hipStream_t);
 int softargmax_bands();
@@ -202,6 +204,14 @@ int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const flo
   FGVC_REQUIRE(temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_c2f_refine_f32: temperature must be > 0");
   return c2f_refine_launch(coarse_arg, qfine, kfine, vfine, T, H, W, scale, Cf, P, Rf, topk, temperature, out,
                            idx_out, logit_out, (hipStream_t)stream);
+}
+
+int fgvc_bn_act_f32(const float* x, const float* residual, const float* mean, const float* var, const float* gamma,
+                    const float* beta, float eps, int relu, float* out, int N, int C, int HW, void* stream) {
+  FGVC_REQUIRE(x && mean && var && gamma && beta && out, FGVC_ERR_INVALID_ARG, "fgvc_bn_act_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && C > 0 && HW > 0 && eps >= 0.f, FGVC_ERR_INVALID_ARG, "fgvc_bn_act_f32: bad shape");
+  if (N == 0) return FGVC_OK;
+  return bn_act_launch(x, residual, mean, var, gamma, beta, eps, relu, out, N, C, HW, (hipStream_t)stream);
 }
 
 int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int stride, float sigma, float* out,

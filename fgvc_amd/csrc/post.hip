@@ -311,6 +311,65 @@ __global__ __launch_bounds__(64) void softargmax_merge_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// Encoder glue: inference BatchNorm (+ residual add) (+ ReLU) in ONE pass over an NCHW tensor.
+// y = (x - mean[c]) * rsqrt(var[c] + eps) * gamma[c] + beta[c]  [+ residual]  [max(.,0)]
+// Replaces the separate BN / add / ReLU kernels PyTorch launches after every MIOpen convolution of the
+// ResNet (resnet.py:54-116: conv -> BN -> ReLU, conv -> BN, += identity, ReLU): 3 reads + 3 writes of the
+// activation become 1-2 reads + 1 write.  float4 accesses (HW % 4 == 0) or scalar tail-safe path.
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, int relu, float* __restrict__ out, int C, int HW,
+                                                      long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  if constexpr (VEC) {
+    const long long n4 = n >> 2;
+    const int HW4 = HW >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const int c = (int)((i / HW4) % C);
+      const float inv = 1.0f / sqrtf(var[c] + eps);
+      const float g = gamma[c], b = beta[c], m = mean[c];
+      f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+      v.x = (v.x - m) * inv * g + b; v.y = (v.y - m) * inv * g + b;
+      v.z = (v.z - m) * inv * g + b; v.w = (v.w - m) * inv * g + b;
+      if (res != nullptr) {
+        const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      const int c = (int)((i / HW) % C);
+      float v = (x[i] - mean[c]) * (1.0f / sqrtf(var[c] + eps)) * gamma[c] + beta[c];
+      if (res != nullptr) v += res[i];
+      if (relu) v = fmaxf(v, 0.f);
+      out[i] = v;
+    }
+  }
+}
+
+int bn_act_launch(const float* x, const float* res, const float* mean, const float* var, const float* gamma,
+                  const float* beta, float eps, int relu, float* out, int N, int C, int HW, hipStream_t s) {
+  const long long n = (long long)N * C * HW;
+  const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+                                      reinterpret_cast<uintptr_t>(res)) & 15u) == 0;
+  const long long work = vec ? n / 4 : n;
+  const int grid = (int)((work + 255) / 256 < 256 * 16 ? (work + 255) / 256 : 256 * 16);
+  if (vec)
+    bn_act_kernel<true><<<grid, 256, 0, s>>>(x, res, mean, var, gamma, beta, eps, relu, out, C, HW, n);
+  else
+    bn_act_kernel<false><<<grid, 256, 0, s>>>(x, res, mean, var, gamma, beta, eps, relu, out, C, HW, n);
+  FGVC_CHECK_LAUNCH("fgvc_bn_act_f32");
+  return FGVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
 int normalize_launch(const float* in, float* out, int n, int C, int HW, int normalize, int Cout, hipStream_t s) {

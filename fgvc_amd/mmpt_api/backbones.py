@@ -29,9 +29,18 @@ class ConvBN(nn.Module):
         self.bn = nn.BatchNorm2d(cout)
         self.relu = relu
 
-    def forward(self, x):
-        x = self.bn(self.conv(x))
-        return F.relu(x, inplace=True) if self.relu else x
+    def forward(self, x, residual=None, relu=None):
+        """conv -> BN [-> + residual] [-> ReLU].  On the GPU in eval mode the BN / add / ReLU tail is ONE
+        fgvc_bn_act_f32 launch (in place on the conv output); otherwise plain torch modules."""
+        relu = self.relu if relu is None else relu
+        y = self.conv(x)
+        if y.is_cuda and not self.training and y.dtype == torch.float32 and y.is_contiguous():
+            from .. import ops
+            return ops.bn_act(y, self.bn, residual, relu, inplace=True)
+        y = self.bn(y)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y, inplace=True) if relu else y
 
 
 class BasicBlock(nn.Module):
@@ -45,7 +54,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        return F.relu(self.conv2(self.conv1(x)) + idt, inplace=True)
+        return self.conv2(self.conv1(x), residual=idt, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -60,7 +69,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        return F.relu(self.conv3(self.conv2(self.conv1(x))) + idt, inplace=True)
+        return self.conv3(self.conv2(self.conv1(x)), residual=idt, relu=True)
 
 
 def _stage(block, cin, planes, n, stride, dilation):

@@ -238,6 +238,21 @@ def c2f_refine(coarse_arg: torch.Tensor, qfine: torch.Tensor, kfine: torch.Tenso
     return out, idx, logit
 
 
+def bn_act(x: torch.Tensor, bn: "torch.nn.BatchNorm2d", residual: Optional[torch.Tensor] = None, relu: bool = True,
+           inplace: bool = True) -> torch.Tensor:
+    """Inference BatchNorm2d (+ residual) (+ ReLU) in one pass over a contiguous NCHW f32 tensor."""
+    x = _chk(x, torch.float32, "x")
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    if residual is not None:
+        residual = _chk(residual, torch.float32, "residual")
+        assert residual.shape == x.shape
+    out = x if inplace else torch.empty_like(x)
+    _lib.call("fgvc_bn_act_f32", _ptr(x), _ptr(residual), _ptr(bn.running_mean), _ptr(bn.running_var),
+              _ptr(bn.weight), _ptr(bn.bias), float(bn.eps), int(relu), _ptr(out), N, Cc, HW, _stream(x))
+    return out
+
+
 def gaussian_labels(points: torch.Tensor, Hf: int, Wf: int, stride: int, sigma: float = 6.0,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """points (P,2)=(x,y) -> (HfWf, P) initial labels (vanilla_tracker.py:204-221)."""

@@ -145,6 +145,14 @@ int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const flo
                         int topk, float temperature, float* out, int32_t* idx_out, float* logit_out,
                         void* stream);
 
+/* ---- A1 glue: inference BatchNorm2d (+ residual) (+ ReLU) fused over an NCHW activation
+ * replaces the BN / `out += identity` / ReLU modules around every convolution of the ResNet
+ * (resnet.py:54-116, mmcv ConvModule conv->BN->ReLU).  y = (x-mean[c])*rsqrt(var[c]+eps)*gamma[c]+beta[c]
+ * [+ residual] [ReLU].  x, residual (nullable), out: [N][C][HW] f32; out may alias x. */
+int fgvc_bn_act_f32(const float* x, const float* residual, const float* mean, const float* var,
+                    const float* gamma, const float* beta, float eps, int relu, float* out, int N, int C,
+                    int HW, void* stream);
+
 /* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
  * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).
  *   points [P][2] f32 = (x, y);  out [Hf*Wf][P] */

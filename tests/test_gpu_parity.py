@@ -320,3 +320,40 @@ def test_tracker_end_to_end_on_synthetic_tapvid(dev):
     assert bool((qp[0, 1:, 0] >= qp[0, :-1, 0]).all())                # regrouped by query time
     s = metrics.tapvid_evaluate(outs, "strided")
     assert s["average_pts_within_thresh"] > 60.0, s
+
+
+def test_encoder_fused_bn_act_matches_torch(dev):
+    """A1: the ResNet with the fused BN(+residual)+ReLU kernel vs the same weights through plain torch modules
+    (the oracle ResNet on the CPU), including non-trivial BN statistics."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(4)
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none"))
+    ora = O.ResNet18((1, 2, 1, 1), 2, "none")
+    sd = O.seeded_resnet_state(5, (1, 2, 1, 1), "none")
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+        elif k.endswith("bn.weight"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+        elif k.endswith("bn.bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    net.load_state_dict(sd)
+    ora.load_state_dict(sd)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    with torch.no_grad():
+        a = net.to(dev).eval()(x.to(dev)).cpu()
+        b = ora.eval()(x)
+    assert a.shape == b.shape == (2, 256, 16, 24)
+    assert torch.allclose(a, b, atol=2e-4, rtol=1e-4), float((a - b).abs().max())
+    # odd spatial size -> scalar path of the kernel; residual + relu
+    y = torch.randn(2, 8, 5, 7, generator=g)
+    r = torch.randn(2, 8, 5, 7, generator=g)
+    bn = torch.nn.BatchNorm2d(8).eval()
+    bn.running_mean.normal_(generator=g); bn.running_var.uniform_(0.5, 2.0, generator=g)
+    bn.weight.data.uniform_(0.5, 1.5, generator=g); bn.bias.data.normal_(generator=g)
+    ref = torch.relu(bn(y) + r)
+    got = ops.bn_act(y.to(dev), bn.to(dev), r.to(dev), True, inplace=False).cpu()
+    assert torch.allclose(got, ref.detach(), atol=1e-5, rtol=1e-5)
