@@ -34,6 +34,7 @@ int split_bf16_launch(const float*, uint16_t*, long long, int, hipStream_t);
 int corr_volume_bf16_launch(const uint16_t*, const uint16_t*, int, int, int, float, float*, int, hipStream_t);
 int local_merge_launch(const int32_t*, const float*, int, int, int, int, int, float, int32_t*, float*, float*,
                        hipStream_t);
+int topk_coord_launch(const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
 int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, int, int, int, int, int, int, int,
                       int, float, float*, int32_t*, float*, hipStream_t);
 
@@ -190,6 +191,13 @@ int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32
   if (rc != FGVC_OK) return rc;
   return local_merge_launch(pair_idx_ws, pair_score_ws, n_slots, H, W, R, topk, temperature, idx_out, logit_out,
                             weight_out, (hipStream_t)stream);
+}
+
+int fgvc_topk_coord_f32(const int32_t* idx, const float* weight, int H, int W, int R, int topk, int scale, float* out,
+                        void* stream) {
+  FGVC_REQUIRE(idx && weight && out, FGVC_ERR_INVALID_ARG, "fgvc_topk_coord_f32: null pointer");
+  FGVC_REQUIRE(H > 0 && W > 0 && R >= 0 && topk >= 1 && scale >= 1, FGVC_ERR_INVALID_ARG, "fgvc_topk_coord_f32: bad shape");
+  return topk_coord_launch(idx, weight, H, W, R, topk, scale, out, (hipStream_t)stream);
 }
 
 int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const float* kfine, const float* vfine, int T,

@@ -69,6 +69,38 @@ __global__ __launch_bounds__(256) void local_merge_kernel(const int32_t* __restr
   }
 }
 
+// A7 get_coord (vanilla_tracker.py:445-488): expected coordinate of each query under its top-k window weights.
+// The reference gathers from F.unfold(grid[:, :, ::scale, ::scale], 2R+1, padding=R): tap (dy,dx) of query (y,x)
+// carries the image coordinate ((x+dx-R)*scale, (y+dy-R)*scale), and (0,0) where the tap is outside the grid
+// (zero padding).  out [HW][2] = (x, y).
+__global__ __launch_bounds__(256) void topk_coord_kernel(const int32_t* __restrict__ idx, const float* __restrict__ weight,
+                                                          int H, int W, int R, int topk, int scale,
+                                                          float* __restrict__ out) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= H * W) return;
+  const int L = 2 * R + 1, qy = q / W, qx = q - qy * W;
+  float ax = 0.f, ay = 0.f;
+  for (int r = 0; r < topk; ++r) {
+    const int id = idx[(size_t)q * topk + r];
+    if (id < 0) continue;
+    const int tap = id % (L * L);
+    const int ky = qy + tap / L - R, kx = qx + tap % L - R;
+    if (ky < 0 || ky >= H || kx < 0 || kx >= W) continue;
+    const float wv = weight[(size_t)q * topk + r];
+    ax = fmaf(wv, (float)(kx * scale), ax);
+    ay = fmaf(wv, (float)(ky * scale), ay);
+  }
+  out[2 * q] = ax;
+  out[2 * q + 1] = ay;
+}
+
+int topk_coord_launch(const int32_t* idx, const float* weight, int H, int W, int R, int topk, int scale, float* out,
+                      hipStream_t s) {
+  topk_coord_kernel<<<cdiv(H * W, 256), 256, 0, s>>>(idx, weight, H, W, R, topk, scale, out);
+  FGVC_CHECK_LAUNCH("fgvc_topk_coord_f32");
+  return FGVC_OK;
+}
+
 int local_merge_launch(const int32_t* pi, const float* ps, int T, int H, int W, int R, int topk, float temp,
                        int32_t* io, float* lo, float* wo, hipStream_t s) {
   const int grid = cdiv(H * W, 256);

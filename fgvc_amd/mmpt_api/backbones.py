@@ -1,6 +1,7 @@
 """ResNet trunk behind the reference's registry name and constructor keys
-(mmpt/models/backbones/resnet.py:329-638), run by PyTorch-ROCm / MIOpen -- the encoder is host
-plumbing in this project (BASELINE.json north_star), not a hand-written kernel.
+(mmpt/models/backbones/resnet.py:329-638).  Convolutions run in MIOpen (the encoder is host plumbing
+in this project, BASELINE.json north_star); the BN(eval) [+ residual] [+ ReLU] tail after every
+convolution is one hand-written launch (fgvc_bn_act_f32) on the GPU.
 
 What must match the reference: the state_dict key names (mmcv ConvModule nesting:
 `conv1.conv.weight`, `layer2.0.downsample.bn.running_var`, ...), the strides/out_indices/pool_type

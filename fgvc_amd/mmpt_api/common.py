@@ -16,7 +16,7 @@ from ..ops import MaskSpec
 __all__ = [
     "NeighborMask", "spatial_neighbor", "masked_attention_efficient", "masked_attention_efficient_v2",
     "masked_attention", "masked_attention_efficient_c2f", "masked_attention_efficient_correlation_v2",
-    "compute_affinity", "coords_grid", "cat", "video2images", "images2video",
+    "compute_affinity", "coords_grid", "cat", "video2images", "images2video", "bilinear_sample",
 ]
 
 
@@ -66,6 +66,18 @@ def coords_grid(batch: int, xx, yy):
     """(batch, 2, H, W), channel 0 = x, channel 1 = y (local_attention.py:20-35)."""
     gy, gx = torch.meshgrid(yy, xx, indexing="ij")
     return torch.stack([gx, gy], 0).float()[None].repeat(batch, 1, 1, 1)
+
+
+def bilinear_sample(feat, grid, mode="bilinear", padding_mode="zeros", align_corners=False, scale=True):
+    """corr_lookup.py:31-65: F.grid_sample at pixel coordinates (x,y); `scale` maps them to [-1,1]
+    (the reference rescales the caller's grid IN PLACE; this one works on a copy)."""
+    import torch.nn.functional as F
+    H, W = feat.shape[-2:]
+    if grid.shape[-1] != 2:
+        grid = grid.permute(0, 2, 3, 1)
+    if scale:
+        grid = torch.stack([grid[..., 0] * 2.0 / max(W - 1, 1) - 1.0, grid[..., 1] * 2.0 / max(H - 1, 1) - 1.0], -1)
+    return F.grid_sample(feat, grid, mode, padding_mode, align_corners)
 
 
 def video2images(imgs):

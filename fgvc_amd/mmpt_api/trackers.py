@@ -182,6 +182,39 @@ class HRVanillaTracker(VanillaTracker):
         return trajectories, visibilities, coords.unsqueeze(0), torch.zeros_like(visibilities), query_points
 
     @torch.no_grad()
+    def get_coord(self, query_feat, key_feats, shape, scale):
+        """vanilla_tracker.py:445-488: dense forward-warping field.  query_feat (1,C,H,W), key_feats (1,C,H,W) ->
+        (1,2,H,W) expected (x,y) image coordinate of each query pixel's match in the key frame."""
+        g = self.test_cfg.get
+        norm = bool(g("withnorm", True))
+        H, W = query_feat.shape[-2:]
+        qf = ops.normalize_to_hwc(query_feat.float(), norm, pad=True)
+        kf = ops.normalize_to_hwc(key_feats.float(), norm, pad=True)
+        idx, _, weight = ops.local_corr_topk(qf, kf[:1], H, W, self.infer_radius, int(g("topk", 10)),
+                                             float(g("temperature", 1)))
+        return ops.topk_coord(idx, weight, H, W, self.infer_radius, scale).t().reshape(1, 2, H, W)
+
+    @torch.no_grad()
+    def forward_test_forward(self, imgs, ref, **kw):
+        """vanilla_tracker.py:591-645 ("forward warpping"): push the points `ref` (1,P,2)=(y,x) through the chain of
+        frame-to-frame coordinate fields.  imgs (1,3,T,h,w).  Returns coords (1,P,2,T) as (x,y)."""
+        from .common import bilinear_sample
+        h, w = imgs.shape[-2:]
+        T = imgs.shape[2]
+        feats = [self.extract_feat(imgs[:, :, t]) for t in range(T)]
+        scale = w // feats[0].shape[-1]
+        coord = torch.flip(ref, (2,)).float()                                        # (1,P,2) -> (x,y)
+        coords = [coord]
+        pre = int(self.test_cfg.get("precede_frames", 5))
+        for f in range(1, T):
+            start = max(0, f - pre)
+            field = self.get_coord(feats[start], feats[f], (h, w), scale)            # query = frame `start`
+            pts = (coord.clone() / scale).unsqueeze(2)                               # (1,P,1,2) feature coordinates
+            coord = bilinear_sample(field, pts, align_corners=True).squeeze(-1).transpose(1, 2)
+            coords.append(coord)
+        return torch.stack(coords, -1)
+
+    @torch.no_grad()
     def forward_test(self, rgbs, query_points, trajectories, visibilities, **kw):
         if not self.test_cfg.get("with_first", False):
             return self.forward_test_main(rgbs, query_points, trajectories, visibilities)

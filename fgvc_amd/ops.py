@@ -220,6 +220,15 @@ def local_corr_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, H: int, W: int, R:
     return idx, logit, weight
 
 
+def topk_coord(idx: torch.Tensor, weight: torch.Tensor, H: int, W: int, R: int, scale: int) -> torch.Tensor:
+    """A7 get_coord: (HW,k) window lists of ONE key slot -> (HW,2) expected (x,y) image coordinates."""
+    idx, weight = _chk(idx, torch.int32, "idx"), _chk(weight, torch.float32, "weight")
+    assert idx.shape == weight.shape == (H * W, idx.shape[1])
+    out = torch.empty((H * W, 2), device=idx.device, dtype=torch.float32)
+    _lib.call("fgvc_topk_coord_f32", _ptr(idx), _ptr(weight), H, W, R, idx.shape[1], scale, _ptr(out), _stream(idx))
+    return out
+
+
 def c2f_refine(coarse_arg: torch.Tensor, qfine: torch.Tensor, kfine: torch.Tensor, vfine: torch.Tensor, H: int,
                W: int, scale: int, Rf: int, topk: int, temperature: float):
     """A6 fine stage. coarse_arg int32 (T, HW); qfine (sHsW, Cf); kfine (T, sHsW, Cf); vfine (T, sHsW, P)."""

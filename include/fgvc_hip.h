@@ -135,6 +135,13 @@ int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32
                              int32_t* pair_idx_ws, float* pair_score_ws,
                              int32_t* idx_out, float* logit_out, float* weight_out, void* stream);
 
+/* ---- A7 get_coord (vanilla_tracker.py:445-488): expected image coordinate of every query pixel under the top-k
+ * window weights of fgvc_local_corr_topk_f32 with ONE key slot (taps outside the grid contribute (0,0), like the
+ * zero-padded F.unfold of the coordinate grid).  idx/weight [H*W][topk] -> out [H*W][2] = (x, y) in image pixels
+ * (feature coordinate * scale). */
+int fgvc_topk_coord_f32(const int32_t* idx, const float* weight, int H, int W, int R, int topk, int scale,
+                        float* out, void* stream);
+
 /* ---- A6: coarse-to-fine refine (local_attention.py:721-880), fine stage.
  *   coarse_arg [T][HW] int32: per key slot and query, the coarse cell picked by the coarse stage
  *                             (fgvc_pair_topk_f32 with topk=1 on the coarse features)

@@ -279,6 +279,22 @@ def local_corr_topk(query, keys, values, radius: int, topk: int, temperature: fl
     return out, idx.t().contiguous(), logit.t().contiguous()
 
 
+def get_coord(query, key, radius: int, topk: int, temperature: float, scale: int, normalize: bool = True):
+    """HRVanillaTracker.get_coord (vanilla_tracker.py:445-488) for one key frame.
+    query, key (C,H,W) -> (2,H,W) expected (x,y) image coordinates (feature coordinate * scale)."""
+    C, H, W = query.shape
+    L = 2 * radius + 1
+    corr = local_corr(query, key.unsqueeze(0), radius, normalize).reshape(L * L, H * W)       # :450, :470
+    xs = (torch.arange(W, dtype=torch.float32) * scale).view(1, W).expand(H, W)
+    ys = (torch.arange(H, dtype=torch.float32) * scale).view(H, 1).expand(H, W)
+    grid = torch.stack([xs, ys], 0).unsqueeze(0)                                               # :461-464 (sampled grid)
+    grid_unf = F.unfold(grid, kernel_size=L, padding=radius).reshape(2, L * L, H * W)          # :467
+    val, idx = topk_canonical(corr, topk)                                                      # :476
+    g = grid_unf.gather(1, idx.unsqueeze(0).expand(2, -1, -1))                                 # :479
+    w = (val / temperature).softmax(0)                                                         # :481-482
+    return (g * w.unsqueeze(0)).sum(1).reshape(2, H, W)                                        # :485
+
+
 # ----------------------------------------------------------------------------
 # A6  coarse-to-fine refine
 # ----------------------------------------------------------------------------

@@ -357,3 +357,19 @@ def test_encoder_fused_bn_act_matches_torch(dev):
     ref = torch.relu(bn(y) + r)
     got = ops.bn_act(y.to(dev), bn.to(dev), r.to(dev), True, inplace=False).cpu()
     assert torch.allclose(got, ref.detach(), atol=1e-5, rtol=1e-5)
+
+
+def test_get_coord_vs_oracle(dev):
+    """A7 forward-warping field (vanilla_tracker.py:445-488)."""
+    import fgvc_amd.mmpt_api as api
+    g = torch.Generator().manual_seed(8)
+    C, H, W, R, scale = 64, 14, 18, 4, 4
+    q, k = torch.randn(1, C, H, W, generator=g), torch.randn(1, C, H, W, generator=g)
+    trk = api.build_model(dict(type="HRVanillaTracker",
+                               backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                             pool_type="none")),
+                          train_cfg=None, test_cfg=api.ConfigDict(neighbor_range=2 * R, topk=6, temperature=0.07))
+    field = trk.get_coord(q.to(dev), k.to(dev), (H * scale, W * scale), scale).cpu()
+    ref = O.get_coord(q[0], k[0], R, 6, 0.07, scale)
+    assert field.shape == (1, 2, H, W)
+    assert torch.allclose(field[0], ref, atol=2e-3), float((field[0] - ref).abs().max())
