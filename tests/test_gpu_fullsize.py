@@ -1,0 +1,225 @@
+"""Full-size (BASELINE.json configs[1]: 8-frame 480p clip -> 120x214x256 features) checks of the HIP path through
+size-independent properties, where the CPU oracle would take minutes per frame:
+
+  * top-k lists: every index inside the disc, (score desc, index asc) order, scores equal to re-computed dot
+    products, and -- on a random sample of queries -- the exact top-k of the full masked row;
+  * cross-kernel: unmasked pair top-k == top-k of the columns of the dense volume kernel's output;
+  * dense volume: sum of all entries == <sum k, sum q>/tau (linearity), sampled entries vs dot products,
+    bf16x3 within the 1e-3 score bar of f32;
+  * merge: weights sum to one, merged list = best k of the slot lists;
+  * propagation: linear in the labels, constant labels are reproduced (weights sum to 1);
+  * read-out: a Gaussian bump is read back at its centre.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+H, W, C, T_CLIP, K = 120, 214, 256, 8, 10
+HW = H * W
+TAU = 0.07
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fgvc_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def clip(dev):
+    """Normalised channels-last features of an 8-frame clip with spatial structure (smooth field + noise), so
+    neighbouring pixels correlate like real feature maps do."""
+    from fgvc_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(2024)
+    base = torch.randn(1, C, H // 8 + 1, W // 8 + 1, generator=g)
+    smooth = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+    frames = smooth + 0.6 * torch.randn(T_CLIP, C, H, W, generator=g)
+    return ops.normalize_to_hwc(frames.to(dev))
+
+
+@pytest.fixture(scope="module")
+def affinity(dev, clip):
+    from fgvc_amd import engine
+    cfg = engine.TrackerConfig()
+    plan = engine.plan_clip(T_CLIP, [0], cfg)
+    return cfg, plan, engine.run_affinity(clip, H, W, plan, cfg)
+
+
+def test_normalised_features(clip):
+    assert clip.shape == (T_CLIP, HW, C)
+    assert torch.allclose(clip.norm(dim=2), torch.ones_like(clip[..., 0]), atol=1e-5)
+
+
+def test_pair_lists_properties(dev, clip):
+    from fgvc_amd import engine, ops
+    cfg = engine.TrackerConfig()
+    plan = engine.plan_clip(T_CLIP, [0], cfg)
+    assert len(plan.pairs) == 27                         # BASELINE cfg2: 27 unique (query, key) frame pairs
+    pairs = ops.make_pairs(plan.pairs, dev)
+    idx, score = ops.pair_topk(clip, clip, pairs, H, W, H, W, cfg.mask, K)
+    assert idx.shape == (27, HW, K) and int(idx.min()) >= 0 and int(idx.max()) < HW      # disc always holds >= k pixels
+    # (a) inside the disc
+    qy = (torch.arange(HW, device=dev) // W).view(1, HW, 1)
+    qx = (torch.arange(HW, device=dev) % W).view(1, HW, 1)
+    d2 = (idx // W - qy) ** 2 + (idx % W - qx) ** 2
+    assert int(d2.max()) <= cfg.mask.r2max
+    # (b) canonical order
+    ds = score[..., 1:] - score[..., :-1]
+    assert float(ds.max()) <= 0.0
+    tie = ds == 0
+    assert bool((idx[..., 1:][tie] > idx[..., :-1][tie]).all())
+    # (c) scores are the dot products of the rows they point at
+    for p in (0, 13, 26):
+        qf, kf = int(pairs[p, 0]), int(pairs[p, 1])
+        dots = torch.einsum("qc,qkc->qk", clip[qf], clip[kf][idx[p].long()])
+        assert torch.allclose(dots, score[p], atol=2e-6)
+    # (d) exact top-k of the full masked row on a sample of queries (f64 scores; ranks separated by > 1e-6)
+    g = torch.Generator().manual_seed(5)
+    sample = torch.cat([torch.tensor([0, W - 1, HW - W, HW - 1, 60 * W + 107]), torch.randint(0, HW, (251,), generator=g)])
+    sample = sample.to(dev)
+    ky = (torch.arange(HW, device=dev) // W).view(-1, 1)
+    kx = (torch.arange(HW, device=dev) % W).view(-1, 1)
+    inside = ((ky - (sample // W).view(1, -1)) ** 2 + (kx - (sample % W).view(1, -1)) ** 2) <= cfg.mask.r2max
+    for p in (1, 20):
+        qf, kf = int(pairs[p, 0]), int(pairs[p, 1])
+        full = (clip[kf].double() @ clip[qf][sample].double().t()).masked_fill(~inside, float("-inf"))   # (HW, n)
+        tv, ti = full.topk(K + 1, dim=0)
+        clear = ((tv[:-1] - tv[1:]).min(0).values > 1e-6)
+        assert int(clear.sum()) > 200
+        got = idx[p][sample].t().long()
+        assert torch.equal(got[:, clear], ti[:K][:, clear])
+        assert torch.allclose(score[p][sample].t().double(), tv[:K], atol=1e-5)
+
+
+def test_pair_kernels_agree_full_size(dev, clip):
+    """The three pair kernels (4-wave, wave-specialised, single-chain wave-specialised) at full size."""
+    from fgvc_amd import engine, ops
+    cfg = engine.TrackerConfig()
+    pairs = ops.make_pairs([(3, 0, True), (3, 2, True)], dev)
+    out = {}
+    try:
+        for v in (1, 2, 3):
+            ops.set_option("pair_kernel", v)
+            out[v] = ops.pair_topk(clip, clip, pairs, H, W, H, W, cfg.mask, K)
+    finally:
+        ops.set_option("pair_kernel", 3)
+    assert torch.equal(out[1][0], out[3][0]) and torch.equal(out[1][1], out[3][1])
+    assert torch.allclose(out[1][1], out[2][1], atol=2e-6) and (out[1][0] == out[2][0]).float().mean() > 0.999
+
+
+def test_unmasked_pair_topk_equals_topk_of_dense_volume(dev, clip):
+    from fgvc_amd import ops
+    pairs = ops.make_pairs([(1, 0, False)], dev)
+    idx, score = ops.pair_topk(clip, clip, pairs, H, W, H, W, ops.MaskSpec.none(), K)
+    vol = ops.corr_volume(clip[1], clip[0], 1.0, "f32")                  # (HWk, HWq)
+    tv, ti = vol.topk(K + 1, dim=0)
+    clear = (tv[:-1] - tv[1:]).min(0).values > 2e-6
+    assert float(clear.float().mean()) > 0.9
+    assert torch.equal(idx[0].t().long()[:, clear], ti[:K][:, clear])
+    assert torch.allclose(score[0].t(), tv[:K], atol=2e-6)
+
+
+def test_dense_volume_linearity_and_samples(dev, clip):
+    from fgvc_amd import ops
+    q, k = clip[1], clip[0]
+    hl = ops.split_bf16(clip[:2])
+    vols = {"f32": ops.corr_volume(q, k, TAU, "f32")}
+    expect_sum = float((k.double().sum(0) * q.double().sum(0)).sum() / TAU)
+    g = torch.Generator().manual_seed(11)
+    kk = torch.randint(0, HW, (4096,), generator=g).to(dev)
+    qq = torch.randint(0, HW, (4096,), generator=g).to(dev)
+    ref = (k[kk].double() * q[qq].double()).sum(1) / TAU
+    for prec, tol in (("f32", 2e-5), ("bf16x3", 1e-3)):
+        vol = vols.get(prec)
+        if vol is None:
+            vol = ops.corr_volume(hl[1], hl[0], TAU, prec)
+        assert vol.shape == (HW, HW)
+        assert abs(float(vol.double().sum()) - expect_sum) <= 1e-6 * HW * HW * 0.2 + 1e-3 * abs(expect_sum)
+        assert float((vol[kk, qq].double() - ref).abs().max()) < tol
+        if prec != "f32":
+            assert float((vol - vols["f32"]).abs().max()) < 1e-3           # the north_star score bar, every entry
+        # first/last rows and columns (ragged tile edges)
+        for j in (0, HW - 1):
+            assert torch.allclose(vol[j].double(), (q.double() @ k[j].double()) / TAU, atol=tol)
+            assert torch.allclose(vol[:, j].double(), (k.double() @ q[j].double()) / TAU, atol=tol)
+        if prec != "f32":
+            del vol
+    del vols
+
+
+def test_merged_lists(affinity):
+    cfg, plan, tk = affinity
+    assert tk.idx.shape == (T_CLIP - 1, HW, K)
+    assert torch.allclose(tk.weight.sum(-1), torch.ones_like(tk.weight[..., 0]), atol=1e-5)
+    assert float((tk.logit[..., 1:] - tk.logit[..., :-1]).max()) <= 0.0
+    n_slots = tk.slot_frame.shape[1]
+    assert int(tk.idx.min()) >= 0 and int(tk.idx.max()) < n_slots * HW
+    # softmax of the logits
+    assert torch.allclose(torch.softmax(tk.logit, -1), tk.weight, atol=1e-5)
+
+
+def test_merge_is_best_k_of_slot_lists(dev, clip, affinity):
+    """Output frame 7 has six key slots [0, 2..6]: its list must be the best k of the union of its pair lists."""
+    from fgvc_amd import ops
+    cfg, plan, tk = affinity
+    row = plan.out_rows[(0, 7)]
+    slots = [int(s) for s in tk.slot_frame[row].tolist() if s >= 0]
+    pairs = ops.make_pairs([(7, s, True) for s in slots], dev)
+    pidx, pscore = ops.pair_topk(clip, clip, pairs, H, W, H, W, cfg.mask, K)
+    gid = pidx.long() + (torch.arange(len(slots), device=dev) * HW).view(-1, 1, 1)
+    allv = pscore.permute(1, 0, 2).reshape(HW, -1)
+    alli = gid.permute(1, 0, 2).reshape(HW, -1)
+    # canonical order: score desc then global index asc
+    order = torch.argsort(alli, dim=1, stable=True)
+    allv, alli = allv.gather(1, order), alli.gather(1, order)
+    order = torch.argsort(allv, dim=1, descending=True, stable=True)[:, :K]
+    assert torch.equal(alli.gather(1, order), tk.idx[row].long())
+    assert torch.allclose(allv.gather(1, order) / cfg.temperature, tk.logit[row], atol=1e-5)
+
+
+def test_propagation_linearity_and_constants(dev, affinity):
+    from fgvc_amd import ops
+    cfg, plan, tk = affinity
+    row = plan.out_rows[(0, 6)]
+    n_slots = int((tk.slot_frame[row] >= 0).sum())
+    g = torch.Generator().manual_seed(3)
+    P = 16
+    A = torch.rand(T_CLIP, HW, P, generator=g).to(dev)
+    B = torch.rand(T_CLIP, HW, P, generator=g).to(dev)
+    f = lambda L: ops.propagate_topk(L, tk.slot_frame[row], tk.idx[row], tk.weight[row], H, W, H, W)
+    assert torch.allclose(f(2.0 * A - 3.0 * B), 2.0 * f(A) - 3.0 * f(B), atol=1e-5)
+    assert torch.allclose(f(torch.full_like(A, 0.25)), torch.full((HW, P), 0.25, device=dev), atol=1e-6)
+    # against the definition
+    sf = tk.slot_frame[row].long()
+    slot, pix = tk.idx[row].long() // HW, tk.idx[row].long() % HW
+    want = (A[sf[slot], pix] * tk.weight[row].unsqueeze(-1)).sum(1)
+    assert torch.allclose(f(A), want, atol=1e-5)
+    assert n_slots == 6
+
+
+def test_readout_recovers_gaussian_centres(dev):
+    from fgvc_amd import ops
+    h, w = 480, 854
+    pts = torch.tensor([[100.0, 200.0], [4.0, 4.0], [848.0, 472.0], [427.0, 240.0]], device=dev)   # (x, y), multiples of 4
+    labels = torch.stack([ops.gaussian_labels(pts, H, W, 4, 6.0)])                                   # (1, HW, P)
+    coords = ops.softargmax_top5(labels, H, W, h, w)
+    assert coords.shape == (1, 4, 2)
+    # bilinear upsampling of a sampled Gaussian peaks within a pixel or two of the centre
+    assert float((coords[0].float() - pts).abs().max()) < 2.5
+
+
+def test_track_points_full_size(dev, clip):
+    """End to end at cfg2 size: stationary features (every frame identical) must keep every point where it started."""
+    from fgvc_amd import engine
+    cfg = engine.TrackerConfig()
+    still = clip[:1].expand(T_CLIP, HW, C).contiguous()
+    g = torch.Generator().manual_seed(9)
+    xy = torch.stack([torch.randint(8, 846, (12,), generator=g), torch.randint(8, 472, (12,), generator=g)], 1).float()
+    qp = torch.cat([torch.zeros(12, 1), xy], 1)
+    traj, order = engine.track_points(still, H, W, 480, 854, qp, cfg)
+    assert traj.shape == (T_CLIP, 12, 2)
+    drift = (traj.float() - xy[order].to(dev).unsqueeze(0)).abs().max()
+    assert float(drift) < 3.0, float(drift)
