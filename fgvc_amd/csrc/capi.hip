@@ -40,6 +40,10 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
 
 void set_pair_kernel(int);
 void set_pair_debug(int);
+void set_pair_v4_debug(int);
+void set_pair_v4_products(int);
+int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int32_t*,
+                        float*, hipStream_t);
 void set_corr_debug(int);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -66,6 +70,16 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
     set_pair_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "pair_bf16_products") == 0) {   // 4 (default): hi*hi + hi*lo + lo*hi + lo*lo.  3 drops lo*lo: 12 % faster, but
+                                                   // for similar vectors that term is a one-signed ~4e-6, not noise
+    FGVC_REQUIRE(value == 3 || value == 4, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_bf16_products must be 3 or 4");
+    set_pair_v4_products(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "pair_bf16_debug") == 0) {   // same for fgvc_pair_topk_bf16x4: 1 = no selection, 2 = no MFMA, 4 = no staging
+    set_pair_v4_debug(value);
     return FGVC_OK;
   }
   set_error("fgvc_set_option: unknown option '%s'", name);
@@ -112,6 +126,29 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
                "fgvc_pair_topk_f32: give either the analytic predicate or a dense mask, not both");
   return pair_topk_launch(qfeat, kfeat, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, dense_mask, idx_out,
                           score_out, (hipStream_t)stream);
+}
+
+int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq,
+                          int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int32_t* idx_out,
+                          float* score_out, void* stream) {
+  FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_bf16x4: null pointer");
+  FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_bf16x4: qsplit/ksplit/pairs must be 16-byte aligned");
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: C=%d unsupported (256 only; use fgvc_pair_topk_f32)", C);
+  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && n_pairs >= 0, FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_bf16x4: bad shape Hq=%d Wq=%d Hk=%d Wk=%d n_pairs=%d", Hq, Wq, Hk, Wk, n_pairs);
+  FGVC_REQUIRE(topk >= 1 && topk <= 10, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: topk=%d outside 1..10", topk);
+  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_bf16x4: negative mask parameter");
+  FGVC_REQUIRE(n_pairs <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: n_pairs=%d > 65535 per call", n_pairs);
+  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
+  FGVC_REQUIRE(!any_limit || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_bf16x4: a spatial mask needs equal query/key grids (local_attention.py:331)");
+  FGVC_REQUIRE(Hk < 32768 && Wk < 32768 && Hq < 32768 && Wq < 32768 && (long long)Hk * Wk < (1ll << 30) &&
+                   (long long)Hq * Wq < (1ll << 30),
+               FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: grid too large");
+  if (n_pairs == 0) return FGVC_OK;
+  return pair_topk_v4_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, idx_out, score_out,
+                             (hipStream_t)stream);
 }
 
 int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, int n_out, int T,

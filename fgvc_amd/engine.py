@@ -39,6 +39,7 @@ class TrackerConfig:
     with_norm: bool = True
     mode: str = "softmax"
     sigma: float = 6.0
+    pair_precision: str = "auto"   # ops.pair_topk_auto: "auto" | "f32" | "split" (not a reference key)
 
     @staticmethod
     def from_test_cfg(cfg) -> "TrackerConfig":
@@ -137,17 +138,23 @@ def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tra
     n = len(plan.pairs)
     pairs_dev, slot_pair, slot_frame = plan.tables(dev)
     rows = len(plan.slot_pair)
+    use_split = cfg.pair_precision == "split" or (
+        cfg.pair_precision == "auto" and ops.split_path_ok(feats_hwc.shape[2], Hf, Wf, k, cfg.with_norm))
+    if use_split:      # bf16 matrix pipe on the hi/lo split of the (normalised) features, f32-grade scores
+        split = ops.split_bf16(feats_hwc)
+        pair_fn = lambda prs: ops.pair_topk_split(split, split, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
+    else:
+        pair_fn = lambda prs: ops.pair_topk(feats_hwc, feats_hwc, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
     if events is not None:
         events[0].record()
     if n <= pair_chunk:
-        pidx, pscore = ops.pair_topk(feats_hwc, feats_hwc, pairs_dev, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
+        pidx, pscore = pair_fn(pairs_dev)
     else:
         pidx = torch.empty((n, HW, k), device=dev, dtype=torch.int32)
         pscore = torch.empty((n, HW, k), device=dev, dtype=torch.float32)
         for c0 in range(0, n, pair_chunk):
             c1 = min(n, c0 + pair_chunk)
-            i, s = ops.pair_topk(feats_hwc, feats_hwc, pairs_dev[c0:c1], Hf, Wf, Hf, Wf, cfg.mask, k,
-                                 validate=False)
+            i, s = pair_fn(pairs_dev[c0:c1])
             pidx[c0:c1], pscore[c0:c1] = i, s
     if events is not None:
         events[1].record()

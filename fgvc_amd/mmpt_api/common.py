@@ -124,7 +124,8 @@ def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk,
     if any_mask:
         assert same or dense_mask is not None
     pairs = ops.make_pairs([(0, t, any_mask and t >= non_mask_len) for t in range(T)], query.device)
-    pidx, pscore = ops.pair_topk(qf, kf, pairs, Hq, Wq, Hk, Wk, spec, topk, validate=False, dense_mask=dense_mask)
+    pidx, pscore = ops.pair_topk_auto(qf, kf, pairs, Hq, Wq, Hk, Wk, spec, topk, normalized=bool(normalize),
+                                      validate=False, dense_mask=dense_mask)
     slot_pair = torch.arange(T, dtype=torch.int32, device=query.device).view(1, T)
     idx, _, weight = ops.merge_topk(pidx, pscore, slot_pair, Hk * Wk, topk, temperature, mode, validate=False)
     labels = value[0].permute(1, 2, 3, 0).reshape(T, Hk * Wk, P).float().contiguous()

@@ -132,6 +132,56 @@ def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq:
     return idx, score
 
 
+def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int,
+                    Wk: int, mask: MaskSpec, topk: int, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pair_topk() on the bf16 matrix pipe (fgvc_pair_topk_bf16x4): qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256)
+    int16 = split_bf16() of L2-NORMALISED features.  Same outputs as pair_topk()."""
+    qsplit, ksplit = _chk(qsplit, torch.int16, "qsplit"), _chk(ksplit, torch.int16, "ksplit")
+    pairs = _chk(pairs, torch.int32, "pairs")
+    assert qsplit.dim() == 4 and ksplit.dim() == 4 and qsplit.shape[2] == 2 and ksplit.shape[2] == 2
+    assert qsplit.shape[1] == Hq * Wq and ksplit.shape[1] == Hk * Wk and qsplit.shape[3] == ksplit.shape[3]
+    n = pairs.shape[0]
+    if n and validate:
+        lim = pairs[:, :2].amax(0).tolist()
+        assert lim[0] < qsplit.shape[0] and lim[1] < ksplit.shape[0] and int(pairs[:, :2].min()) >= 0, "pair out of range"
+    idx = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.int32)
+    score = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.float32)
+    _lib.call("fgvc_pair_topk_bf16x4", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n, qsplit.shape[3], Hq, Wq, Hk, Wk,
+              mask.r2max, mask.ry, mask.rx, topk, _ptr(idx), _ptr(score), _stream(qsplit))
+    return idx, score
+
+
+V4_LIST_CAP = 4096   # key blocks (4x8 pixels) one query tile may visit in fgvc_pair_topk_bf16x4 (csrc/pair_topk_v4.hip)
+
+
+def split_path_ok(C: int, Hk: int, Wk: int, topk: int, normalized: bool, dense_mask=None) -> bool:
+    """Whether fgvc_pair_topk_bf16x4 applies: 256 channels, top-k <= 10, analytic mask, L2-normalised rows (its
+    fixed-point keys assume |q.k| <= 1) and a key grid of at most 4096 4x8-pixel blocks."""
+    return (normalized and C == 256 and 1 <= topk <= 10 and dense_mask is None
+            and -(-Hk // 4) * -(-Wk // 8) <= V4_LIST_CAP and Hk < 16384 and Wk < 32768)
+
+
+def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
+                   mask: MaskSpec, topk: int, normalized: bool, precision: str = "auto", validate: bool = True,
+                   dense_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pair_topk() with the kernel chosen by `precision`:
+      "f32"   fgvc_pair_topk_f32 (f32 MFMA);
+      "split" fgvc_pair_topk_bf16x4 on split_bf16() of the features (raises when it does not apply);
+      "auto"  "split" where split_path_ok(), else "f32".
+    qfeat/kfeat are the f32 channels-last features either way (the split costs one extra pass over them)."""
+    if precision not in ("auto", "f32", "split"):
+        raise ValueError(f"precision={precision!r}")
+    use_split = precision == "split" or (precision == "auto" and split_path_ok(qfeat.shape[2], Hk, Wk, topk, normalized,
+                                                                                dense_mask))
+    if not use_split:
+        return pair_topk(qfeat, kfeat, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, dense_mask)
+    if not split_path_ok(qfeat.shape[2], Hk, Wk, topk, normalized, dense_mask):
+        raise ValueError("fgvc_pair_topk_bf16x4 needs C == 256, topk <= 10, an analytic mask and normalised features")
+    ks = split_bf16(kfeat)
+    qs = ks if qfeat is kfeat else split_bf16(qfeat)
+    return pair_topk_split(qs, ks, pairs, Hq, Wq, Hk, Wk, mask, topk, validate)
+
+
 def merge_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pair: torch.Tensor, HWk: int, topk: int,
                temperature: float, mode: str = "softmax", validate: bool = True):
     """slot_pair int32 (n_out, T): pair feeding key slot t of output frame f (-1 unused).

@@ -88,6 +88,18 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
                        int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk,
                        const uint8_t* dense_mask, int32_t* idx_out, float* score_out, void* stream);
 
+/* Same operator and outputs as fgvc_pair_topk_f32 on the bf16 matrix pipe, f32-grade: the features are the
+ * [pixel][hi C | lo C] bf16 split that fgvc_split_bf16 writes (x = hi + lo up to 2^-18 |x|); all four partial
+ * products hi*hi + hi*lo + lo*hi + lo*lo are accumulated in f32 (v_mfma_f32_32x32x16_bf16), so a score differs from
+ * the f32 dot product by ~1e-7 (the size of f32 summation-order noise); selection runs on fixed-point keys with 24 fractional bits
+ * (scores closer than 6e-8 tie and are ordered by pixel index, like equal f32 scores).
+ * The default pair kernel of the engine for C == 256.
+ *   Precondition: feature rows L2-normalised (|q.k| <= 1), as fgvc_normalize_chw_to_hwc_f32(normalize=1) makes them.
+ *   C == 256; 1 <= topk <= 10; analytic mask only (a dense mask tensor needs fgvc_pair_topk_f32). */
+int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs,
+                          int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk,
+                          int32_t* idx_out, float* score_out, void* stream);
+
 /* ---- A5 step 2: merge the per-pair lists of the T key slots of each query frame, divide by the
  * temperature and turn the k logits into weights.  Replaces the global topk over T*HW
  * (local_attention.py:356) and :368-371.

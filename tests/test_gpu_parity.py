@@ -373,3 +373,109 @@ def test_get_coord_vs_oracle(dev):
     ref = O.get_coord(q[0], k[0], R, 6, 0.07, scale)
     assert field.shape == (1, 2, H, W)
     assert torch.allclose(field[0], ref, atol=2e-3), float((field[0] - ref).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fgvc_pair_topk_bf16x4: the same operator on the bf16 matrix pipe (hi/lo split features, fixed-point selection keys)
+# ---------------------------------------------------------------------------------------------------------------
+def split_affinity(dev, q, key, topk, temperature, neighbor_range, mask_mode="circle", products=3):
+    from fgvc_amd import ops
+    C, H, W = q.shape
+    Tn = key.shape[1]
+    frames = torch.cat([q.unsqueeze(0), key.permute(1, 0, 2, 3)], 0).to(dev)
+    feats = ops.normalize_to_hwc(frames)
+    hl = ops.split_bf16(feats)
+    mask = ops.MaskSpec.from_neighbor_range(neighbor_range, mask_mode)
+    pairs = ops.make_pairs([(0, 1 + t, not mask.is_none) for t in range(Tn)], dev)
+    ops.set_option("pair_bf16_products", products)
+    try:
+        pidx, pscore = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, topk)
+    finally:
+        ops.set_option("pair_bf16_products", 4)
+    fidx, fscore = ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, topk)
+    slot_pair = torch.arange(Tn, dtype=torch.int32, device=dev).view(1, Tn)
+    idx, logit, weight = ops.merge_topk(pidx, pscore, slot_pair, H * W, topk, temperature, "softmax")
+    return (pidx, pscore, fidx, fscore), idx[0], logit[0], weight[0]
+
+
+@pytest.mark.parametrize("shape", [(3, 30, 44, 30, "circle", 10, 3), (3, 30, 44, 30, "circle", 10, 4),
+                                   (2, 17, 23, 9, "square", 10, 3), (1, 33, 70, 30, "circle", 5, 3),
+                                   (2, 5, 3, 4, "circle", 5, 3), (2, 20, 20, None, "circle", 10, 3),
+                                   (1, 9, 130, 12, "circle", 3, 4), (6, 8, 8, 30, "circle", 10, 3)])
+def test_split_pair_topk_vs_oracle(dev, shape):
+    """Ragged grids, both mask modes, no mask, k in {3,5,10}, 3 and 4 partial products: indices exact wherever the f64
+    ranks are clear, scores within the north_star bar (and within 1e-5 of the f32-MFMA kernel)."""
+    Tn, H, W, nr, mm, topk, products = shape
+    g = torch.Generator().manual_seed(sum(v for v in shape if isinstance(v, int)))
+    q, key = torch.randn(256, H, W, generator=g), torch.randn(256, Tn, H, W, generator=g)
+    (pidx, pscore, fidx, fscore), idx, logit, weight = split_affinity(dev, q, key, topk, 0.07, nr, mm, products)
+    stats = O.check_topk(dense64(q, key, 0.07, nr, mm), idx.cpu().long(), logit.cpu(), topk, tol=TOL)
+    assert stats["exact"] >= stats["clear"]
+    assert stats["max_score_err"] < 5e-5                       # logit units (score / 0.07)
+    fin = torch.isfinite(fscore)
+    assert torch.equal(fin, torch.isfinite(pscore)) and torch.equal(pidx < 0, fidx < 0)
+    assert float((pscore - fscore)[fin].abs().max()) < 1e-5
+    assert float((pidx == fidx).all(-1).float().mean()) > 0.99
+    oi, ol = O.affinity_topk(q, key, topk, 0.07, neighbor_range=nr, mask_mode=mm)
+    assert torch.allclose(logit.cpu(), ol, atol=TOL) and torch.allclose(weight.cpu(), O.topk_weights(ol), atol=TOL)
+
+
+def test_split_pair_topk_exact_ties_and_identical_frames(dev):
+    """Key frame == query frame: every query's best match is itself with score 1 (fixed-point 2^30 exactly); a constant
+    feature map makes every in-window candidate tie -- any k of them is legitimate, but scores must all be 1."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(4)
+    H, W = 21, 37
+    f = ops.normalize_to_hwc(torch.randn(1, 256, H, W, generator=g).to(dev))
+    hl = ops.split_bf16(f)
+    mask = ops.MaskSpec.from_neighbor_range(30)
+    pairs = ops.make_pairs([(0, 0, True)], dev)
+    idx, score = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, 10)
+    assert torch.equal(idx[0, :, 0].cpu(), torch.arange(H * W, dtype=torch.int32))
+    self64 = (f[0].double() ** 2).sum(1)
+    assert float((score[0, :, 0].double() - self64).abs().max()) < 2.5e-6
+    const = torch.ones(1, 256, H, W)
+    fc = ops.normalize_to_hwc(const.to(dev))
+    idx, score = ops.pair_topk_split(ops.split_bf16(fc), ops.split_bf16(fc), pairs, H, W, H, W, mask, 10)
+    assert float((score.double() - float((fc[0, 0].double() ** 2).sum())).abs().max()) < 2.5e-6
+    assert float(score.max() - score.min()) == 0.0                 # identical operands -> identical fixed-point keys
+    qy, qx = torch.arange(H * W) // W, torch.arange(H * W) % W
+    ii = idx[0].cpu().long()
+    d2 = (ii // W - qy.view(-1, 1)) ** 2 + (ii % W - qx.view(-1, 1)) ** 2
+    assert int(d2.max()) <= mask.r2max and all(len(set(r.tolist())) == 10 for r in ii[:: 37])
+
+
+def test_split_pair_topk_rejects_what_it_cannot_do(dev):
+    from fgvc_amd import ops, _lib
+    f = ops.normalize_to_hwc(torch.randn(1, 128, 8, 8).to(dev))
+    hl = ops.split_bf16(f)
+    pairs = ops.make_pairs([(0, 0, True)], dev)
+    with pytest.raises(_lib.FgvcHipError):
+        ops.pair_topk_split(hl, hl, pairs, 8, 8, 8, 8, ops.MaskSpec.from_neighbor_range(6), 10)      # C != 256
+    f = ops.normalize_to_hwc(torch.randn(1, 256, 8, 8).to(dev))
+    hl = ops.split_bf16(f)
+    with pytest.raises(_lib.FgvcHipError):
+        ops.pair_topk_split(hl, hl, pairs, 8, 8, 8, 8, ops.MaskSpec.from_neighbor_range(6), 11)      # topk > 10
+    assert not ops.split_path_ok(256, 8, 8, 10, normalized=False)
+    assert not ops.split_path_ok(64, 8, 8, 10, normalized=True)
+    assert ops.split_path_ok(256, 120, 214, 10, normalized=True)
+    assert not ops.split_path_ok(256, 720, 1280, 10, normalized=True)         # more than 4096 key blocks per frame
+    # auto falls back to the f32 kernel where the split path does not apply
+    i, s = ops.pair_topk_auto(f, f, pairs, 8, 8, 8, 8, ops.MaskSpec.from_neighbor_range(6), 10, normalized=False)
+    i2, s2 = ops.pair_topk(f, f, pairs, 8, 8, 8, 8, ops.MaskSpec.from_neighbor_range(6), 10)
+    assert torch.equal(i, i2) and torch.equal(s, s2)
+
+
+def test_engine_split_and_f32_paths_agree(dev):
+    """The tracker's default pair kernel (split bf16) against the f32-MFMA kernel on a whole clip."""
+    from fgvc_amd import engine, ops
+    g = torch.Generator().manual_seed(12)
+    T_, H, W = 7, 24, 40
+    feats = ops.normalize_to_hwc(torch.randn(T_, 256, H, W, generator=g).to(dev))
+    qp = torch.tensor([[0, 40.0, 30.0], [0, 100.0, 60.0], [2, 80.0, 20.0]])
+    outs = {}
+    for prec in ("f32", "split", "auto"):
+        cfg = engine.TrackerConfig(pair_precision=prec)
+        outs[prec] = engine.track_points(feats, H, W, H * 4, W * 4, qp, cfg)[0]
+    assert torch.equal(outs["split"], outs["auto"])
+    assert float((outs["split"] - outs["f32"]).abs().max()) < 1e-3
