@@ -9,9 +9,11 @@ feats = ops.normalize_to_hwc(torch.randn(T, C, H, W, device=dev))
 cfg = engine.TrackerConfig()
 plan = engine.plan_clip(T, [0], cfg)
 pairs = ops.make_pairs(plan.pairs, dev)
-hl = ops.split_bf16(feats[:2])
+hl_all = ops.split_bf16(feats)
+hl = hl_all[:2]
 vol = torch.empty((HW, HW), device=dev)
 for _ in range(3):
+    ops.pair_topk_split(hl_all, hl_all, pairs, H, W, H, W, cfg.mask, 10, validate=False)
     ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False)
     ops.corr_volume(hl[1], hl[0], 0.07, "bf16x3", out=vol)
     ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol)
