@@ -38,6 +38,11 @@ int topk_coord_launch(const int32_t*, const float*, int, int, int, int, int, flo
 int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, int, int, int, int, int, int, int,
                       int, float, float*, int32_t*, float*, hipStream_t);
 
+int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
+                      int, int, int, int, hipStream_t);
+int nchw_to_split_nhwc_launch(const float*, uint16_t*, int, int, int, int, int, int, hipStream_t);
+int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+
 void set_pair_kernel(int);
 void set_pair_debug(int);
 void set_pair_v4_debug(int);
@@ -257,6 +262,48 @@ int fgvc_bn_act_f32(const float* x, const float* residual, const float* mean, co
   FGVC_REQUIRE(N >= 0 && C > 0 && HW > 0 && eps >= 0.f, FGVC_ERR_INVALID_ARG, "fgvc_bn_act_f32: bad shape");
   if (N == 0) return FGVC_OK;
   return bn_act_launch(x, residual, mean, var, gamma, beta, eps, relu, out, N, C, HW, (hipStream_t)stream);
+}
+
+static bool conv_pad_ok(int H, int W, int Hp, int Wp) {
+  return Hp >= 8 * cdiv(H, 8) + 2 && Wp >= 32 * cdiv(W, 32) + 8;
+}
+
+int fgvc_nchw_to_split_nhwc_f32(const float* in, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, void* stream) {
+  FGVC_REQUIRE(in && out, FGVC_ERR_INVALID_ARG, "fgvc_nchw_to_split_nhwc_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && C > 0 && C % 32 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG,
+               "fgvc_nchw_to_split_nhwc_f32: bad shape (C must be a multiple of 32)");
+  FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG,
+               "fgvc_nchw_to_split_nhwc_f32: padded size %dx%d too small for %dx%d (need >= 8*ceil(H/8)+2 x 32*ceil(W/32)+8)", Hp, Wp, H, W);
+  FGVC_REQUIRE(aligned16(out) && (long long)N * (C / 32) <= 65535 && H <= 65535, FGVC_ERR_INVALID_ARG,
+               "fgvc_nchw_to_split_nhwc_f32: alignment / grid limits");
+  if (N == 0) return FGVC_OK;
+  return nchw_to_split_nhwc_launch(in, out, N, C, H, W, Hp, Wp, (hipStream_t)stream);
+}
+
+int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
+                        float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu,
+                        void* stream) {
+  FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: bad shape");
+  FGVC_REQUIRE(KS == 1 || KS == 3, FGVC_ERR_UNSUPPORTED, "fgvc_conv_split_f32: kernel size %d (1 or 3, stride 1)", KS);
+  FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 256 == 0, FGVC_ERR_UNSUPPORTED,
+               "fgvc_conv_split_f32: Cin=%d must be a multiple of 32 and Cout=%d of 256", Cin, Cout);
+  FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
+  FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(y_split) && aligned16(y_f32),
+               FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: 16-byte alignment required");
+  FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: in-place not supported");
+  if (N == 0) return FGVC_OK;
+  return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, (hipStream_t)stream);
+}
+
+int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Hp, int Wp, int normalize,
+                            void* stream) {
+  FGVC_REQUIRE(in && out, FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0 && Hp >= H + 2 && Wp >= W + 2, FGVC_ERR_INVALID_ARG,
+               "fgvc_normalize_nhwc_f32: bad shape");
+  FGVC_REQUIRE(aligned16(in) && aligned16(out), FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: 16-byte alignment required");
+  if (N == 0) return FGVC_OK;
+  return normalize_nhwc_launch(in, out, N, C, H, W, Hp, Wp, normalize, (hipStream_t)stream);
 }
 
 int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int stride, float sigma, float* out,

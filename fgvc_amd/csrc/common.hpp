@@ -222,6 +222,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains vmcnt(0), and on CDNA4 vmcnt
 // counts stores: in a loop that streams results to HBM every iteration would wait for its stores to land.
 // Global loads feeding LDS are still waited for by the compiler-counted vmcnt at their ds_write.
+__device__ __forceinline__ uint16_t f2bf(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // RNE; inputs are finite
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }

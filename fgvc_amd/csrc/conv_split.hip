@@ -1,0 +1,269 @@
+// Convolution on the bf16 matrix pipe with f32-grade accuracy: the encoder's 3x3 / 1x1 stride-1 convolutions as an
+// implicit GEMM over activations and weights that are both stored as (hi, lo) bf16 pairs (x = hi + lo up to 2^-18 |x|).
+// Three partial products hi*hi + hi*lo + lo*hi accumulate in f32 (v_mfma_f32_32x32x16_bf16); the dropped lo*lo term is
+// 2^-18 relative and sign-random here (activations and weights are unrelated), i.e. below f32 rounding noise.
+// MIOpen's f32 Winograd kernel needs 2.4 ms for a 256->256 layer of a 480p clip; the bf16 pipe has ~16x the FLOP rate.
+//
+// Layouts (all chosen so that every LDS-DMA instruction moves 1 KiB that is contiguous in global memory):
+//   activations  x[n][Hp][Wp][C/32][hi 32 ch | lo 32 ch] bf16 -- "padded split NHWC": the image sits at (1,1) inside a
+//                zero border (Hp >= 8*ceil(H/8)+2, Wp >= 32*ceil(W/32)+8), so halos and ragged tiles need no predicates;
+//   weights      w[tap][Cin/32][Cout][hi 32 ci | lo 32 ci] bf16, BatchNorm folded in on the host;
+//   f32 side outputs / residuals: padded NHWC f32 [n][Hp][Wp][C].
+// Work split: a 512-thread workgroup owns 8 rows x 32 columns of output pixels x 256 output channels; wave (pr, ch) owns
+// pixel rows 2pr, 2pr+1 (two 32-pixel MFMA B operands) x channels ch*128..+128 (four 32-channel A operands): 8 accumulator
+// tiles.  K loop: for every 32-channel input chunk the (8+2) x 40 pixel patch is staged once (swizzled 128-byte pixel
+// rows: ds_read_b128 of a 3x3-shifted row segment is conflict-free for every shift), then the KS*KS taps stream their
+// 256 x 32 weight slab through a 3-slot ring; one barrier per tap = per 96 MFMAs per SIMD.
+#include "common.hpp"
+
+namespace fgvc {
+
+struct ConvSplitParams {
+  const uint16_t* x;
+  const uint16_t* w;
+  const float* bias;       // [Cout]
+  const float* residual;   // optional, padded NHWC f32 [N][Hp][Wp][Cout]
+  uint16_t* y_split;       // optional, padded split NHWC
+  float* y_f32;            // optional, padded NHWC f32
+  int N, H, W, Hp, Wp, Cin, Cout, relu;
+  int n_ty, n_tx;
+};
+
+__device__ __forceinline__ void conv_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_uniform) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
+constexpr int CV_PW = 40;                      // staged patch width in pixels (34 needed; DMA moves 8 pixels at a time)
+constexpr int CV_PH = 10;
+constexpr int CV_PATCHB = CV_PH * CV_PW * 128;  // 51200
+constexpr int CV_WSLOTB = 256 * 128;            // one tap's weight slab for 256 output channels: 32768
+constexpr int CV_NSLOT = 3;
+
+// physical byte offset of 16-byte slot `s` (0..7) of 128-byte row `row`: slot index XOR (row >> 1) & 7
+__device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^ ((row >> 1) & 7)) << 4); }
+
+template <int KS>
+__global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
+  constexpr int T = KS * KS;
+  constexpr int PADK = KS / 2;                  // 1 for 3x3, 0 for 1x1
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CV_PATCHB + CV_NSLOT * CV_WSLOTB];
+  unsigned char* patch = smem;
+  unsigned char* wring = smem + CV_PATCHB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pr = wave & 3, ch = wave >> 2;
+  const int n = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int nimg = bid / (p.n_ty * p.n_tx);
+  bid -= nimg * p.n_ty * p.n_tx;
+  const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
+  const int y0 = ty * 8, x0 = tx * 32;
+  const int co_base = blockIdx.y * 256;
+  const int nchunk = p.Cin / 32;
+  const size_t pix_bytes_in = (size_t)nchunk * 128;
+
+  // ---- staging helpers: lane L of a DMA instruction fills LDS bytes [16L, 16L+16) of a 1-KiB piece = 8 rows x 8 slots
+  const int d_row = lane >> 3, d_slot = lane & 7;
+  auto stage_patch = [&](int chunk) {
+    // (8 + 2 PADK) rows x (32 + 8 PADK) pixels in pieces of 8 pixels; piece i -> wave i % 8
+    constexpr int ROWS = 8 + 2 * PADK, PPR = 4 + PADK;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + (size_t)chunk * 128;
+    for (int i = wave; i < ROWS * PPR; i += 8) {
+      const int prow = i / PPR, pc0 = (i - prow * PPR) * 8;
+      const int P = prow * CV_PW + pc0 + d_row;                       // patch pixel of this lane
+      const int sl = d_slot ^ ((P >> 1) & 7);                         // logical slot that lives at this physical slot
+      const size_t gpix = ((size_t)nimg * p.Hp + (y0 + 1 - PADK + prow)) * p.Wp + (x0 + 1 - PADK + pc0 + d_row);
+      conv_lds_dma_16(xb + gpix * pix_bytes_in + sl * 16, lds_addr(patch + (prow * CV_PW + pc0) * 128));
+    }
+  };
+  auto stage_weights = [&](int q) {                                    // stage q = chunk * T + tap
+    const int chunk = q / T, tap = q - chunk * T;
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
+                              (((size_t)tap * nchunk + chunk) * p.Cout + co_base) * 128;
+    unsigned char* dst = wring + (q % CV_NSLOT) * CV_WSLOTB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c0 = (wave * 4 + j) * 8;                               // 8 output channels per piece
+      const int co = c0 + d_row;
+      const int sl = d_slot ^ ((co >> 1) & 7);
+      conv_lds_dma_16(wb + (size_t)co * 128 + sl * 16, lds_addr(dst + c0 * 128));
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int n_stage = nchunk * T;
+  stage_patch(0);
+  stage_weights(0);
+  if (n_stage > 1) stage_weights(1);
+  for (int q = 0; q < n_stage; ++q) {
+    const int chunk = q / T, tap = q - chunk * T;
+    if (tap == 0 && q > 0) {
+      __syncthreads();                            // everyone is done reading the previous chunk's patch
+      stage_patch(chunk);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (q + 1 < n_stage) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 pieces of stage q+1 have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+    if (q + 2 < n_stage) stage_weights(q + 2);      // its slot held stage q-1, which every wave has finished
+    const int dy = tap / KS, dx = tap - dy * KS;
+    const unsigned char* wslot = wring + (q % CV_NSLOT) * CV_WSLOTB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {                   // two k16 steps per 32-channel chunk
+      bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int co = ch * 128 + a * 32 + n;
+        ah[a] = *reinterpret_cast<const bf16x8*>(wslot + cv_swz(co, 2 * s + h));
+        al[a] = *reinterpret_cast<const bf16x8*>(wslot + cv_swz(co, 4 + 2 * s + h));
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int P = (2 * pr + b + dy) * CV_PW + n + dx;
+        bh[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 2 * s + h));
+        bl[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 4 + 2 * s + h));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: + bias [+ residual] [ReLU]; the C layout puts the pixel on the lane and, per register group of four,
+  //      four consecutive output channels in the registers -> 16-byte f32 / 8-byte bf16 stores
+  const int nco_chunk = p.Cout / 32;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int y = y0 + 2 * pr + b, x = x0 + n;
+    if (y >= p.H || x >= p.W) continue;
+    const size_t pix = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x + 1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co_base + ch * 128 + a * 32 + 8 * g + 4 * h;   // rows (r&3) + 8 (r>>2) + 4 h of the tile
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+        f32x4 v = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z,
+                   acc[a][b][4 * g + 3] + bv.w};
+        if (p.residual) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + pix * p.Cout + co);
+          v += rv;
+        }
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (p.y_f32) *reinterpret_cast<f32x4*>(p.y_f32 + pix * p.Cout + co) = v;
+        if (p.y_split) {
+          ushort4 hv, lv;
+          hv.x = f2bf(v.x); hv.y = f2bf(v.y); hv.z = f2bf(v.z); hv.w = f2bf(v.w);
+          lv.x = f2bf(v.x - bf2f(hv.x)); lv.y = f2bf(v.y - bf2f(hv.y));
+          lv.z = f2bf(v.z - bf2f(hv.z)); lv.w = f2bf(v.w - bf2f(hv.w));
+          uint16_t* o = p.y_split + (pix * nco_chunk + (co >> 5)) * 64 + (co & 31);
+          *reinterpret_cast<ushort4*>(o) = hv;
+          *reinterpret_cast<ushort4*>(o + 32) = lv;
+        }
+      }
+    }
+  }
+}
+
+// f32 NCHW -> padded split NHWC (interior only; the border must already be zero)
+__global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
+                                                                  int C, int H, int W, int Hp, int Wp) {
+  // one thread = one pixel x 32-channel chunk; consecutive threads = consecutive x -> coalesced reads per channel
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y, chunk = blockIdx.z % (C / 32), nimg = blockIdx.z / (C / 32);
+  if (x >= W) return;
+  const float* src = in + (((size_t)nimg * C + chunk * 32) * H + y) * W + x;
+  __attribute__((aligned(16))) uint16_t hv[32];
+  __attribute__((aligned(16))) uint16_t lv[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float v = src[(size_t)c * H * W];
+    hv[c] = f2bf(v);
+    lv[c] = f2bf(v - bf2f(hv[c]));
+  }
+  uint16_t* o = out + ((((size_t)nimg * Hp + (y + 1)) * Wp + (x + 1)) * (C / 32) + chunk) * 64;
+#pragma unroll
+  for (int c = 0; c < 32; c += 8) {
+    *reinterpret_cast<uint4*>(o + c) = *reinterpret_cast<const uint4*>(hv + c);
+    *reinterpret_cast<uint4*>(o + 32 + c) = *reinterpret_cast<const uint4*>(lv + c);
+  }
+}
+
+// padded NHWC f32 -> L2-normalised [n][H*W][C] f32 (the layout of fgvc_normalize_chw_to_hwc_f32's output); one wave
+// per pixel
+__global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                              int H, int W, int Hp, int Wp, int normalize, long long npix) {
+  const long long pixel = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (pixel >= npix) return;
+  const int nimg = (int)(pixel / ((long long)H * W));
+  const int rem = (int)(pixel - (long long)nimg * H * W);
+  const int y = rem / W, x = rem - y * W;
+  const float* src = in + (((size_t)nimg * Hp + (y + 1)) * Wp + (x + 1)) * C;
+  float ss = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+  const float inv = normalize ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;      // F.normalize: x / max(||x||, eps)
+  for (int c = lane * 4; c < C; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+    v *= inv;
+    *reinterpret_cast<f32x4*>(out + pixel * C + c) = v;
+  }
+}
+
+int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
+                      float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu,
+                      hipStream_t s) {
+  ConvSplitParams p;
+  p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
+  p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+  p.n_ty = cdiv(H, 8); p.n_tx = cdiv(W, 32);
+  dim3 grid(p.n_ty * p.n_tx * N, Cout / 256);
+  if (KS == 3)
+    conv_split_kernel<3><<<grid, 512, 0, s>>>(p);
+  else
+    conv_split_kernel<1><<<grid, 512, 0, s>>>(p);
+  FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
+  return FGVC_OK;
+}
+
+int nchw_to_split_nhwc_launch(const float* in, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, hipStream_t s) {
+  dim3 grid(cdiv(W, 256), H, N * (C / 32));
+  nchw_to_split_nhwc_kernel<<<grid, 256, 0, s>>>(in, out, C, H, W, Hp, Wp);
+  FGVC_CHECK_LAUNCH("fgvc_nchw_to_split_nhwc_f32");
+  return FGVC_OK;
+}
+
+int normalize_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int Hp, int Wp, int normalize,
+                          hipStream_t s) {
+  const long long npix = (long long)N * H * W;
+  normalize_nhwc_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, C, H, W, Hp, Wp, normalize, npix);
+  FGVC_CHECK_LAUNCH("fgvc_normalize_nhwc_f32");
+  return FGVC_OK;
+}
+
+}  // namespace fgvc

@@ -102,11 +102,6 @@ __global__ __launch_bounds__(256, 2) void corr_volume_f32_kernel(const float* __
 // ------------------------------------------------------------------------------------------
 // f32 -> (hi, lo) bf16 split.  out[pix][0][c] = bf16(x), out[pix][1][c] = bf16(x - hi)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint16_t f2bf(float x) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, x);
-  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // RNE; inputs are finite
-}
-__device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ feat,
                                                           uint16_t* __restrict__ out, long long n_vec4, int C) {

@@ -131,19 +131,103 @@ class ResNet(nn.Module):
                 elif isinstance(m, Bottleneck):
                     nn.init.constant_(m.conv3.bn.weight, 0)
 
-    def forward(self, x, out_idx=None):
-        want = tuple(out_idx) if out_idx is not None else self.out_indices
+    # ---- stages on the bf16 matrix pipe (fgvc_conv_split_f32) ------------------------------------------------------
+    use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_split_cache", None)        # folded / split weights are derived from the parameters
+        return super().load_state_dict(*args, **kwargs)
+
+    def _split_stage_ok(self, stage, x) -> bool:
+        """A stage runs on fgvc_conv_split_f32 when it is made of BasicBlocks with stride-1, dilation-1 convolutions,
+        Cin % 32 == 0 and Cout % 256 == 0, in eval mode on the GPU in f32."""
+        if not (self.use_split_conv and x.is_cuda and not self.training and x.dtype == torch.float32):
+            return False
+        for blk in stage:
+            if not isinstance(blk, BasicBlock):
+                return False
+            convs = [blk.conv1.conv, blk.conv2.conv] + ([blk.downsample.conv] if blk.downsample is not None else [])
+            for c in convs:
+                if (c.stride != (1, 1) or c.dilation != (1, 1) or c.groups != 1 or c.in_channels % 32
+                        or c.out_channels % 256 or c.kernel_size not in ((1, 1), (3, 3))):
+                    return False
+            if blk.downsample is None and blk.conv1.conv.in_channels != blk.conv2.conv.out_channels:
+                return False
+        return True
+
+    def _stage_split(self, si: int, x):
+        """Run stage `si` on NCHW f32 `x`; returns the stage output as padded NHWC f32 (N, Hp, Wp, C) plus (H, W)."""
+        from .. import ops
+        stage = getattr(self, self.res_layers[si])
+        N, Cin, H, W = x.shape
+        cache = self.__dict__.setdefault("_split_cache", {})
+        wkey = ("w", si, x.device)
+        if wkey not in cache:
+            cache[wkey] = [dict(c1=ops.prepare_conv_split(b.conv1.conv.weight.detach(), b.conv1.bn),
+                                c2=ops.prepare_conv_split(b.conv2.conv.weight.detach(), b.conv2.bn),
+                                ds=None if b.downsample is None else
+                                ops.prepare_conv_split(b.downsample.conv.weight.detach(), b.downsample.bn)) for b in stage]
+        Cout = stage[0].conv2.conv.out_channels
+        bkey = ("b", si, N, H, W, x.device)
+        if bkey not in cache:          # zero-bordered workspaces, reused by every call of this shape
+            cache[bkey] = dict(xin=ops.alloc_split_nhwc(N, Cin, H, W, x.device), a=ops.alloc_split_nhwc(N, Cout, H, W, x.device),
+                               ys=[ops.alloc_split_nhwc(N, Cout, H, W, x.device) for _ in range(2)],
+                               yf=[ops.alloc_padded_nhwc(N, Cout, H, W, x.device) for _ in range(2)],
+                               idt=ops.alloc_padded_nhwc(N, Cout, H, W, x.device))
+        buf, wts = cache[bkey], cache[wkey]
+        xs = ops.nchw_to_split_nhwc(x.contiguous(), out=buf["xin"])
+        prev_f32 = None
+        for bi, (blk, wt) in enumerate(zip(stage, wts)):
+            if wt["ds"] is not None:
+                ops.conv_split(xs, wt["ds"][0], wt["ds"][1], H, W, relu=False, out_f32=buf["idt"])
+                idt = buf["idt"]
+            elif prev_f32 is not None:
+                idt = prev_f32
+            else:                      # first block without a projection: identity = the stage input itself
+                idt = buf["idt"]
+                idt[:, 1:H + 1, 1:W + 1, :] = x.permute(0, 2, 3, 1)
+            ops.conv_split(xs, wt["c1"][0], wt["c1"][1], H, W, relu=True, out_split=buf["a"])
+            ys, yf = buf["ys"][bi & 1], buf["yf"][bi & 1]
+            ops.conv_split(buf["a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt, out_split=ys, out_f32=yf)
+            xs, prev_f32 = ys, yf
+        return prev_f32, H, W
+
+    def _trunk(self, x, last: int):
+        """Stem and stages 0..last; the last stage on the bf16 pipe where it qualifies.
+        Returns (list of NCHW outputs of stages < last, last stage output, padded-NHWC flag, H, W)."""
         x = self.conv1(x)
         if self.pool is not None:
             x = self.pool(x)
         outs = []
-        for i, name in enumerate(self.res_layers):
-            if i > max(want):
-                break                                  # later stages cannot influence the outputs
-            x = getattr(self, name)(x)
-            if i in want:
-                outs.append(x)
+        for i, name in enumerate(self.res_layers[:last + 1]):
+            stage = getattr(self, name)
+            if i == last and self._split_stage_ok(stage, x):
+                y, H, W = self._stage_split(i, x)
+                return outs, y, True, H, W
+            x = stage(x)
+            outs.append(x)
+        return outs[:-1], x, False, x.shape[-2], x.shape[-1]
+
+    def forward(self, x, out_idx=None):
+        want = tuple(out_idx) if out_idx is not None else self.out_indices
+        last = max(want)                               # later stages cannot influence the outputs
+        earlier, y, padded, H, W = self._trunk(x, last)
+        if padded:
+            y = y[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2)     # NCHW view of the padded NHWC buffer
+        stage_out = earlier + [y]
+        outs = [stage_out[i] for i in want]
         return outs[0] if len(outs) == 1 else tuple(outs)
+
+    def forward_hwc(self, x, normalize: bool = True):
+        """The tracker's fast path: features of the single requested stage as (N, H*W, C) f32 rows, L2-normalised if
+        `normalize` -- straight from the padded NHWC buffer when the stage ran on the bf16 pipe (no NCHW round trip).
+        Returns (feats, H, W)."""
+        from .. import ops
+        assert len(self.out_indices) == 1
+        _, y, padded, H, W = self._trunk(x, self.out_indices[0])
+        if padded:
+            return ops.normalize_nhwc(y, H, W, normalize), H, W
+        return ops.normalize_to_hwc(y.float(), normalize, pad=True), H, W
 
 
 _PREFIXES = (r"^module\.", r"^backbone\.", r"^encoder\.", r"^backbone_fine\.")

@@ -85,7 +85,13 @@ class VanillaTracker(BaseTracker):
         if self.test_cfg.get("channels_last", False):
             # MIOpen's fastest f32 kernels on gfx950 are NHWC; feeding NHWC avoids its transposes
             frames = frames.contiguous(memory_format=torch.channels_last)
+        fast = (hasattr(self.backbone, "forward_hwc") and self.head is None and not self.stride_sample
+                and len(getattr(self.backbone, "out_indices", ())) == 1)
         for i in range(0, frames.shape[0], step):
+            if fast:       # backbone writes normalised channels-last rows itself (no NCHW round trip)
+                f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm)
+                chunks.append(f)
+                continue
             f = self.extract_feat(frames[i:i + step])
             if isinstance(f, (tuple, list)):
                 f = f[0]

@@ -312,6 +312,79 @@ def bn_act(x: torch.Tensor, bn: "torch.nn.BatchNorm2d", residual: Optional[torch
     return out
 
 
+# ---- encoder convolutions on the bf16 pipe (fgvc_conv_split_f32) ---------------------------------------------------
+def conv_pad_dims(H: int, W: int) -> Tuple[int, int]:
+    """(Hp, Wp) of the zero-bordered "padded split NHWC" activation buffers for an H x W image."""
+    return 8 * (-(-H // 8)) + 2, 32 * (-(-W // 32)) + 8
+
+
+def _split_pair(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def prepare_conv_split(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fold eval-mode BatchNorm into a conv weight (Cout, Cin, KS, KS) and lay it out for fgvc_conv_split_f32:
+    returns (w int16 [KS*KS][Cin/32][Cout][64] = (hi 32 ci | lo 32 ci) bf16 bit patterns, bias f32 [Cout])."""
+    Cout, Cin, KS, _ = weight.shape
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float()
+    w = weight.float() * scale.view(-1, 1, 1, 1)
+    bias = (bn.bias - bn.running_mean * scale).float().contiguous()
+    w = w.permute(2, 3, 1, 0).reshape(KS * KS, Cin // 32, 32, Cout).permute(0, 1, 3, 2).contiguous()   # [tap][chunk][co][32 ci]
+    hi, lo = _split_pair(w)
+    packed = torch.cat([hi, lo], dim=-1).contiguous().view(torch.int16)
+    return packed, bias
+
+
+def alloc_split_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
+    Hp, Wp = conv_pad_dims(H, W)
+    return torch.zeros((N, Hp, Wp, C // 32, 64), device=device, dtype=torch.int16)
+
+
+def alloc_padded_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
+    Hp, Wp = conv_pad_dims(H, W)
+    return torch.zeros((N, Hp, Wp, C), device=device, dtype=torch.float32)
+
+
+def nchw_to_split_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f32 (N,C,H,W) -> padded split NHWC (N,Hp,Wp,C/32,64) int16; `out` must have a zero border (alloc_split_nhwc)."""
+    x = _chk(x, torch.float32, "x")
+    N, C, H, W = x.shape
+    if out is None:
+        out = alloc_split_nhwc(N, C, H, W, x.device)
+    Hp, Wp = out.shape[1], out.shape[2]
+    assert out.shape == (N, Hp, Wp, C // 32, 64) and out.dtype == torch.int16 and out.is_contiguous()
+    _lib.call("fgvc_nchw_to_split_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, Hp, Wp, _stream(x))
+    return out
+
+
+def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
+               residual: Optional[torch.Tensor] = None, out_split: Optional[torch.Tensor] = None,
+               out_f32: Optional[torch.Tensor] = None) -> None:
+    """fgvc_conv_split_f32: y = conv(x, w) + bias [+ residual] [ReLU] into out_split and/or out_f32 (interiors only)."""
+    x_split, w = _chk(x_split, torch.int16, "x_split"), _chk(w, torch.int16, "w")
+    bias = _chk(bias, torch.float32, "bias")
+    N, Hp, Wp, nch, _ = x_split.shape
+    taps, nch_w, Cout, _ = w.shape
+    assert nch_w == nch and taps in (1, 9) and bias.shape == (Cout,)
+    for t, dt, shape in ((residual, torch.float32, (N, Hp, Wp, Cout)), (out_f32, torch.float32, (N, Hp, Wp, Cout)),
+                         (out_split, torch.int16, (N, Hp, Wp, Cout // 32, 64))):
+        if t is not None:
+            assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv_split buffer"
+    _lib.call("fgvc_conv_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
+              N, H, W, Hp, Wp, nch * 32, Cout, 3 if taps == 9 else 1, int(relu), _stream(x_split))
+
+
+def normalize_nhwc(x: torch.Tensor, H: int, W: int, normalize: bool = True) -> torch.Tensor:
+    """padded NHWC f32 (N,Hp,Wp,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc)."""
+    x = _chk(x, torch.float32, "x")
+    N, Hp, Wp, C = x.shape
+    out = torch.empty((N, H * W, C), device=x.device, dtype=torch.float32)
+    _lib.call("fgvc_normalize_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, Hp, Wp, int(normalize), _stream(x))
+    return out
+
+
 def gaussian_labels(points: torch.Tensor, Hf: int, Wf: int, stride: int, sigma: float = 6.0,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """points (P,2)=(x,y) -> (HfWf, P) initial labels (vanilla_tracker.py:204-221)."""

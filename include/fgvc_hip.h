@@ -172,6 +172,27 @@ int fgvc_bn_act_f32(const float* x, const float* residual, const float* mean, co
                     const float* gamma, const float* beta, float eps, int relu, float* out, int N, int C,
                     int HW, void* stream);
 
+/* ---- A1 on the bf16 matrix pipe: the encoder's stride-1 3x3 / 1x1 convolutions (resnet.py:16-116, mmcv ConvModule =
+ * conv -> BN(eval) [-> + identity] [-> ReLU]) as an implicit GEMM over activations and weights stored as (hi, lo) bf16
+ * pairs; hi*hi + hi*lo + lo*hi accumulate in f32 (error ~1e-7 relative, the size of f32 rounding noise).
+ *   "padded split NHWC" activations: x[n][Hp][Wp][C/32][hi 32 ch | lo 32 ch] bf16, image at (1,1) inside a ZERO border
+ *       that the caller provides once (the kernels only ever write the H x W interior);
+ *       Hp >= 8*ceil(H/8)+2, Wp >= 32*ceil(W/32)+8.
+ *   weights w[KS*KS][Cin/32][Cout][hi 32 ci | lo 32 ci] bf16 with BatchNorm folded in (w * gamma / sqrt(var + eps)),
+ *       tap = ky*KS + kx; bias[Cout] = beta - mean * gamma / sqrt(var + eps)   (fgvc_amd/ops.py: prepare_conv_split).
+ *   residual: NULL or padded NHWC f32 [n][Hp][Wp][Cout];  outputs (either may be NULL): y_split (padded split NHWC,
+ *       the next convolution's input) and y_f32 (padded NHWC f32: residual of the next block / final features).
+ * Cin % 32 == 0, Cout % 256 == 0, KS in {1, 3}, stride 1, zero padding KS/2. */
+int fgvc_nchw_to_split_nhwc_f32(const float* in /* [N][C][H][W] */, uint16_t* out, int N, int C, int H, int W,
+                                int Hp, int Wp, void* stream);
+int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
+                        uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
+                        int KS, int relu, void* stream);
+/* padded NHWC f32 -> [n][H*W][C] f32, rows L2-normalised if `normalize` (the output layout of
+ * fgvc_normalize_chw_to_hwc_f32) */
+int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Hp, int Wp, int normalize,
+                            void* stream);
+
 /* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
  * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).
  *   points [P][2] f32 = (x, y);  out [Hf*Wf][P] */

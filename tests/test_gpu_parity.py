@@ -479,3 +479,107 @@ def test_engine_split_and_f32_paths_agree(dev):
         outs[prec] = engine.track_points(feats, H, W, H * 4, W * 4, qp, cfg)[0]
     assert torch.equal(outs["split"], outs["auto"])
     assert float((outs["split"] - outs["f32"]).abs().max()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# encoder convolutions on the bf16 pipe (fgvc_conv_split_f32)
+# ---------------------------------------------------------------------------------------------------------------
+def _padded_to_nchw(t, H, W):
+    return t[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).contiguous()
+
+
+def _split_to_nchw(t, H, W):
+    N, Hp, Wp, nch, _ = t.shape
+    v = t.view(torch.bfloat16).float().view(N, Hp, Wp, nch, 2, 32)
+    x = (v[..., 0, :] + v[..., 1, :]).reshape(N, Hp, Wp, nch * 32)
+    return _padded_to_nchw(x, H, W)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 256, 3, 19, 45, True, True), (1, 256, 256, 3, 8, 32, False, True),
+                                  (2, 128, 256, 1, 13, 70, False, False), (1, 64, 512, 3, 24, 33, True, True)])
+def test_conv_split_vs_torch(dev, case):
+    """conv -> BN(eval) [-> + identity] [-> ReLU] against torch in float64: ragged sizes, 3x3 and 1x1, Cout 256 / 512."""
+    import torch.nn.functional as F
+    from fgvc_amd import ops
+    N, Cin, Cout, KS, H, W, with_res, relu = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    wt = torch.randn(Cout, Cin, KS, KS, generator=g) * (2.0 / (Cin * KS * KS)) ** 0.5
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    bn.weight.data = torch.rand(Cout, generator=g) + 0.5
+    bn.bias.data = torch.randn(Cout, generator=g) * 0.1
+    bn.running_mean = torch.randn(Cout, generator=g) * 0.1
+    bn.running_var = torch.rand(Cout, generator=g) + 0.5
+    res = torch.randn(N, Cout, H, W, generator=g) if with_res else None
+    ref = F.conv2d(x.double(), wt.double(), padding=KS // 2)
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double().view(1, -1, 1, 1)
+    ref = (ref - bn.running_mean.double().view(1, -1, 1, 1)) * sc + bn.bias.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.clamp_min(0)
+
+    wp, bias = ops.prepare_conv_split(wt.to(dev), bn.to(dev))
+    xs = ops.nchw_to_split_nhwc(x.to(dev))
+    assert float((_split_to_nchw(xs.cpu(), H, W) - x).abs().max()) < 1e-5 * float(x.abs().max())
+    out_s = ops.alloc_split_nhwc(N, Cout, H, W, dev)
+    out_f = ops.alloc_padded_nhwc(N, Cout, H, W, dev)
+    resp = None
+    if with_res:
+        resp = ops.alloc_padded_nhwc(N, Cout, H, W, dev)
+        resp[:, 1:H + 1, 1:W + 1, :] = res.permute(0, 2, 3, 1).to(dev)
+    ops.conv_split(xs, wp, bias, H, W, relu, residual=resp, out_split=out_s, out_f32=out_f)
+    got_f = _padded_to_nchw(out_f.cpu(), H, W).double()
+    got_s = _split_to_nchw(out_s.cpu(), H, W).double()
+    scale = float(ref.detach().abs().max())
+    assert float((got_f - ref).abs().max()) < 2e-5 * scale, float((got_f - ref).abs().max()) / scale
+    assert float((got_s - ref).abs().max()) < 3e-5 * scale
+    # nothing outside the interior was touched
+    assert float(out_f[:, 0].abs().max()) == 0 and float(out_f[:, H + 1:].abs().max()) == 0
+    assert float(out_f[:, :, 0].abs().max()) == 0 and float(out_f[:, :, W + 1:].abs().max()) == 0
+    assert int(out_s[:, :, W + 1:].abs().max()) == 0 and int(out_s[:, H + 1:].abs().max()) == 0
+    # the normalised read-back
+    nf = ops.normalize_nhwc(out_f, H, W)
+    want = torch.nn.functional.normalize(got_f.float().permute(0, 2, 3, 1).reshape(N, H * W, Cout), dim=2)
+    assert torch.allclose(nf.cpu(), want, atol=1e-6)
+
+
+def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev):
+    """A1: layer 3 of the ResNet-18 trunk on fgvc_conv_split_f32 (the default on the GPU) against the same network with
+    every convolution in MIOpen, against the CPU oracle network, and through the tracker's forward_hwc fast path."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    g = torch.Generator().manual_seed(14)
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none"))
+    ora = O.ResNet18((1, 2, 1, 1), 2, "none")
+    sd = O.seeded_resnet_state(9, (1, 2, 1, 1), "none")
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+        elif k.endswith("bn.weight"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    net.load_state_dict(sd)
+    ora.load_state_dict(sd)
+    net = net.to(dev).eval()
+    x = torch.randn(3, 3, 76, 132, generator=g)              # features 19 x 33: ragged against the 8 x 32 tiles
+    with torch.no_grad():
+        assert net._split_stage_ok(net.layer3, torch.empty(1, 128, 4, 4, device=dev))
+        a = net(x.to(dev)).cpu()
+        hw, Hf, Wf = net.forward_hwc(x.to(dev), True)
+        try:
+            ResNet.use_split_conv = False
+            b = net(x.to(dev)).cpu()
+        finally:
+            ResNet.use_split_conv = True
+        c = ora.eval()(x)
+    assert a.shape == b.shape == c.shape == (3, 256, 19, 33) and (Hf, Wf) == (19, 33)
+    scale = float(c.abs().max())
+    assert float((a - b).abs().max()) < 2e-5 * scale and float((a - c).abs().max()) < 1e-4 * scale
+    want = torch.nn.functional.normalize(c, dim=1).flatten(2).transpose(1, 2)
+    assert hw.shape == (3, 19 * 33, 256) and torch.allclose(hw.cpu(), want, atol=5e-6)
+    # a second call reuses the cached workspaces (their zero borders must have stayed zero)
+    with torch.no_grad():
+        a2 = net(x.to(dev)).cpu()
+    assert torch.equal(a, a2)
