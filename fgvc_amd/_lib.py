@@ -28,7 +28,7 @@ SIGNATURES = {
     "fgvc_normalize_chw_to_hwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_pair_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "fgvc_pair_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "fgvc_nchw_to_split_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_nchw_to_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_merge_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),

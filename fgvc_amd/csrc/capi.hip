@@ -40,7 +40,7 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
                       int, int, int, int, hipStream_t);
-int nchw_to_split_nhwc_launch(const float*, uint16_t*, int, int, int, int, int, int, hipStream_t);
+int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
 
 void set_pair_kernel(int);
@@ -268,16 +268,17 @@ static bool conv_pad_ok(int H, int W, int Hp, int Wp) {
   return Hp >= 8 * cdiv(H, 8) + 2 && Wp >= 32 * cdiv(W, 32) + 8;
 }
 
-int fgvc_nchw_to_split_nhwc_f32(const float* in, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, void* stream) {
-  FGVC_REQUIRE(in && out, FGVC_ERR_INVALID_ARG, "fgvc_nchw_to_split_nhwc_f32: null pointer");
+int fgvc_nchw_to_split_nhwc_f32(const float* in, uint16_t* out, float* out_f32, int N, int C, int H, int W, int Hp, int Wp,
+                                void* stream) {
+  FGVC_REQUIRE(in && (out || out_f32), FGVC_ERR_INVALID_ARG, "fgvc_nchw_to_split_nhwc_f32: null pointer");
   FGVC_REQUIRE(N >= 0 && C > 0 && C % 32 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG,
                "fgvc_nchw_to_split_nhwc_f32: bad shape (C must be a multiple of 32)");
   FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG,
                "fgvc_nchw_to_split_nhwc_f32: padded size %dx%d too small for %dx%d (need >= 8*ceil(H/8)+2 x 32*ceil(W/32)+8)", Hp, Wp, H, W);
-  FGVC_REQUIRE(aligned16(out) && (long long)N * (C / 32) <= 65535 && H <= 65535, FGVC_ERR_INVALID_ARG,
+  FGVC_REQUIRE(aligned16(out) && aligned16(out_f32) && (long long)N * (C / 32) <= 65535 && H <= 65535, FGVC_ERR_INVALID_ARG,
                "fgvc_nchw_to_split_nhwc_f32: alignment / grid limits");
   if (N == 0) return FGVC_OK;
-  return nchw_to_split_nhwc_launch(in, out, N, C, H, W, Hp, Wp, (hipStream_t)stream);
+  return nchw_to_split_nhwc_launch(in, out, out_f32, N, C, H, W, Hp, Wp, (hipStream_t)stream);
 }
 
 int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
@@ -286,8 +287,8 @@ int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias,
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: null pointer");
   FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: bad shape");
   FGVC_REQUIRE(KS == 1 || KS == 3, FGVC_ERR_UNSUPPORTED, "fgvc_conv_split_f32: kernel size %d (1 or 3, stride 1)", KS);
-  FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 256 == 0, FGVC_ERR_UNSUPPORTED,
-               "fgvc_conv_split_f32: Cin=%d must be a multiple of 32 and Cout=%d of 256", Cin, Cout);
+  FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 64 == 0, FGVC_ERR_UNSUPPORTED,
+               "fgvc_conv_split_f32: Cin=%d must be a multiple of 32 and Cout=%d of 64", Cin, Cout);
   FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
   FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(y_split) && aligned16(y_f32),
                FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: 16-byte alignment required");

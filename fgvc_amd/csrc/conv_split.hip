@@ -39,17 +39,24 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 constexpr int CV_PW = 40;                      // staged patch width in pixels (34 needed; DMA moves 8 pixels at a time)
 constexpr int CV_PH = 10;
 constexpr int CV_PATCHB = CV_PH * CV_PW * 128;  // 51200
-constexpr int CV_WSLOTB = 256 * 128;            // one tap's weight slab for 256 output channels: 32768
-constexpr int CV_NSLOT = 3;
+constexpr int CV_RINGB = 96 * 1024;             // weight ring: NSLOT slots of TG taps x COT output channels x 128 B
 
 // physical byte offset of 16-byte slot `s` (0..7) of 128-byte row `row`: slot index XOR (row >> 1) & 7
 __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^ ((row >> 1) & 7)) << 4); }
 
-template <int KS>
+// COT = output channels per workgroup (256 / 128 / 64: wave (pr, ch) owns COT/2 of them = NA 32-channel A operands);
+// a pipeline stage = TG taps of one 32-channel input chunk (TG = 1 at COT = 256; a whole row of three taps for the
+// narrower layers, which would otherwise synchronise every 24 MFMAs per wave); NSLOT ring slots of TG*COT*128 bytes.
+template <int KS, int COT, int TG, int NSLOT>
 __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
   constexpr int T = KS * KS;
   constexpr int PADK = KS / 2;                  // 1 for 3x3, 0 for 1x1
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CV_PATCHB + CV_NSLOT * CV_WSLOTB];
+  constexpr int NA = COT / 64;                  // A operands (32 output channels each) per wave
+  constexpr int SPC = (T + TG - 1) / TG;        // stages per input chunk
+  constexpr int CV_WSLOTB = TG * COT * 128;
+  constexpr int PPW = TG * COT / 64;            // 1-KiB DMA pieces per wave per full stage
+  static_assert(NSLOT * CV_WSLOTB <= CV_RINGB && (TG * COT) % 64 == 0, "ring");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CV_PATCHB + NSLOT * CV_WSLOTB];
   unsigned char* patch = smem;
   unsigned char* wring = smem + CV_PATCHB;
 
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
   bid -= nimg * p.n_ty * p.n_tx;
   const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
   const int y0 = ty * 8, x0 = tx * 32;
-  const int co_base = blockIdx.y * 256;
+  const int co_base = blockIdx.y * COT;
   const int nchunk = p.Cin / 32;
   const size_t pix_bytes_in = (size_t)nchunk * 128;
 
@@ -80,70 +87,79 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
       conv_lds_dma_16(xb + gpix * pix_bytes_in + sl * 16, lds_addr(patch + (prow * CV_PW + pc0) * 128));
     }
   };
-  auto stage_weights = [&](int q) {                                    // stage q = chunk * T + tap
-    const int chunk = q / T, tap = q - chunk * T;
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
-                              (((size_t)tap * nchunk + chunk) * p.Cout + co_base) * 128;
-    unsigned char* dst = wring + (q % CV_NSLOT) * CV_WSLOTB;
+  auto stage_weights = [&](int q) {                                    // stage q = chunk * SPC + tap group
+    const int chunk = q / SPC, tap0 = (q - chunk * SPC) * TG;
+    unsigned char* dst = wring + (q % NSLOT) * CV_WSLOTB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c0 = (wave * 4 + j) * 8;                               // 8 output channels per piece
+    for (int j = 0; j < PPW; ++j) {                                    // always PPW pieces (a short last group re-reads
+      const int piece = wave * PPW + j;                                // its last tap): the vmcnt arithmetic stays fixed
+      const int tg = piece / (COT / 8), c0 = (piece - tg * (COT / 8)) * 8;   // 8 output channels per piece
+      const int tap = imin(tap0 + tg, T - 1);
+      const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
+                                (((size_t)tap * nchunk + chunk) * p.Cout + co_base) * 128;
       const int co = c0 + d_row;
       const int sl = d_slot ^ ((co >> 1) & 7);
-      conv_lds_dma_16(wb + (size_t)co * 128 + sl * 16, lds_addr(dst + c0 * 128));
+      conv_lds_dma_16(wb + (size_t)co * 128 + sl * 16, lds_addr(dst + (tg * COT + c0) * 128));
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[NA][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int n_stage = nchunk * T;
+  const int n_stage = nchunk * SPC;
+  constexpr int LA = NSLOT - 1;                  // stages in flight ahead of the one being multiplied
   stage_patch(0);
-  stage_weights(0);
-  if (n_stage > 1) stage_weights(1);
+#pragma unroll
+  for (int i = 0; i < LA; ++i)
+    if (i < n_stage) stage_weights(i);
   for (int q = 0; q < n_stage; ++q) {
-    const int chunk = q / T, tap = q - chunk * T;
-    if (tap == 0 && q > 0) {
+    const int chunk = q / SPC, sg = q - chunk * SPC;
+    if (sg == 0 && q > 0) {
       __syncthreads();                            // everyone is done reading the previous chunk's patch
       stage_patch(chunk);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (q + 1 < n_stage) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 pieces of stage q+1 have landed
+    } else if (q + LA - 1 < n_stage) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * PPW) : "memory");   // all but the stages after q have landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
-    if (q + 2 < n_stage) stage_weights(q + 2);      // its slot held stage q-1, which every wave has finished
-    const int dy = tap / KS, dx = tap - dy * KS;
-    const unsigned char* wslot = wring + (q % CV_NSLOT) * CV_WSLOTB;
+    if (q + LA < n_stage) stage_weights(q + LA);    // its slot held stage q-1, which every wave has finished
+    const unsigned char* wslot = wring + (q % NSLOT) * CV_WSLOTB;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {                   // two k16 steps per 32-channel chunk
-      bf16x8 ah[4], al[4], bh[2], bl[2];
+    for (int tg = 0; tg < TG; ++tg) {
+      const int tap = sg * TG + tg;
+      if (tap >= T) break;                          // wave-uniform: short last tap group
+      const int dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int co = ch * 128 + a * 32 + n;
-        ah[a] = *reinterpret_cast<const bf16x8*>(wslot + cv_swz(co, 2 * s + h));
-        al[a] = *reinterpret_cast<const bf16x8*>(wslot + cv_swz(co, 4 + 2 * s + h));
-      }
+      for (int s = 0; s < 2; ++s) {                 // two k16 steps per 32-channel chunk
+        bf16x8 ah[NA], al[NA], bh[2], bl[2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int P = (2 * pr + b + dy) * CV_PW + n + dx;
-        bh[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 2 * s + h));
-        bl[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 4 + 2 * s + h));
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a) {
+          const int co = ch * (COT / 2) + a * 32 + n;
+          ah[a] = *reinterpret_cast<const bf16x8*>(wslot + tg * COT * 128 + cv_swz(co, 2 * s + h));
+          al[a] = *reinterpret_cast<const bf16x8*>(wslot + tg * COT * 128 + cv_swz(co, 4 + 2 * s + h));
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          const int P = (2 * pr + b + dy) * CV_PW + n + dx;
+          bh[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 2 * s + h));
+          bl[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 4 + 2 * s + h));
         }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+      }
     }
   }
 
@@ -156,10 +172,10 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
     if (y >= p.H || x >= p.W) continue;
     const size_t pix = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x + 1);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NA; ++a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = co_base + ch * 128 + a * 32 + 8 * g + 4 * h;   // rows (r&3) + 8 (r>>2) + 4 h of the tile
+        const int co = co_base + ch * (COT / 2) + a * 32 + 8 * g + 4 * h;   // rows (r&3) + 8 (r>>2) + 4 h of the tile
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
         f32x4 v = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z,
                    acc[a][b][4 * g + 3] + bv.w};
@@ -185,9 +201,10 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
   }
 }
 
-// f32 NCHW -> padded split NHWC (interior only; the border must already be zero)
+// f32 NCHW -> padded split NHWC and/or padded NHWC f32 (interiors only; the borders must already be zero)
 __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
-                                                                  int C, int H, int W, int Hp, int Wp) {
+                                                                  float* __restrict__ out_f32, int C, int H, int W, int Hp,
+                                                                  int Wp) {
   // one thread = one pixel x 32-channel chunk; consecutive threads = consecutive x -> coalesced reads per channel
   const int x = blockIdx.x * 256 + threadIdx.x;
   const int y = blockIdx.y, chunk = blockIdx.z % (C / 32), nimg = blockIdx.z / (C / 32);
@@ -195,17 +212,27 @@ __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __
   const float* src = in + (((size_t)nimg * C + chunk * 32) * H + y) * W + x;
   __attribute__((aligned(16))) uint16_t hv[32];
   __attribute__((aligned(16))) uint16_t lv[32];
+  __attribute__((aligned(16))) float fv[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) {
     const float v = src[(size_t)c * H * W];
+    fv[c] = v;
     hv[c] = f2bf(v);
     lv[c] = f2bf(v - bf2f(hv[c]));
   }
-  uint16_t* o = out + ((((size_t)nimg * Hp + (y + 1)) * Wp + (x + 1)) * (C / 32) + chunk) * 64;
+  const size_t pix = ((size_t)nimg * Hp + (y + 1)) * Wp + (x + 1);
+  if (out) {
+    uint16_t* o = out + (pix * (C / 32) + chunk) * 64;
 #pragma unroll
-  for (int c = 0; c < 32; c += 8) {
-    *reinterpret_cast<uint4*>(o + c) = *reinterpret_cast<const uint4*>(hv + c);
-    *reinterpret_cast<uint4*>(o + 32 + c) = *reinterpret_cast<const uint4*>(lv + c);
+    for (int c = 0; c < 32; c += 8) {
+      *reinterpret_cast<uint4*>(o + c) = *reinterpret_cast<const uint4*>(hv + c);
+      *reinterpret_cast<uint4*>(o + 32 + c) = *reinterpret_cast<const uint4*>(lv + c);
+    }
+  }
+  if (out_f32) {
+    float* o = out_f32 + pix * C + chunk * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(fv + c);
   }
 }
 
@@ -242,18 +269,25 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   p.n_ty = cdiv(H, 8); p.n_tx = cdiv(W, 32);
-  dim3 grid(p.n_ty * p.n_tx * N, Cout / 256);
-  if (KS == 3)
-    conv_split_kernel<3><<<grid, 512, 0, s>>>(p);
-  else
-    conv_split_kernel<1><<<grid, 512, 0, s>>>(p);
+  const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
+  dim3 grid(p.n_ty * p.n_tx * N, Cout / cot);
+  if (KS == 3) {
+    if (cot == 256) conv_split_kernel<3, 256, 1, 3><<<grid, 512, 0, s>>>(p);
+    else if (cot == 128) conv_split_kernel<3, 128, 3, 2><<<grid, 512, 0, s>>>(p);
+    else conv_split_kernel<3, 64, 3, 3><<<grid, 512, 0, s>>>(p);
+  } else {
+    if (cot == 256) conv_split_kernel<1, 256, 1, 3><<<grid, 512, 0, s>>>(p);
+    else if (cot == 128) conv_split_kernel<1, 128, 1, 3><<<grid, 512, 0, s>>>(p);
+    else conv_split_kernel<1, 64, 1, 3><<<grid, 512, 0, s>>>(p);
+  }
   FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
   return FGVC_OK;
 }
 
-int nchw_to_split_nhwc_launch(const float* in, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, hipStream_t s) {
+int nchw_to_split_nhwc_launch(const float* in, uint16_t* out, float* out_f32, int N, int C, int H, int W, int Hp, int Wp,
+                              hipStream_t s) {
   dim3 grid(cdiv(W, 256), H, N * (C / 32));
-  nchw_to_split_nhwc_kernel<<<grid, 256, 0, s>>>(in, out, C, H, W, Hp, Wp);
+  nchw_to_split_nhwc_kernel<<<grid, 256, 0, s>>>(in, out, out_f32, C, H, W, Hp, Wp);
   FGVC_CHECK_LAUNCH("fgvc_nchw_to_split_nhwc_f32");
   return FGVC_OK;
 }

@@ -139,73 +139,111 @@ class ResNet(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def _split_stage_ok(self, stage, x) -> bool:
-        """A stage runs on fgvc_conv_split_f32 when it is made of BasicBlocks with stride-1, dilation-1 convolutions,
-        Cin % 32 == 0 and Cout % 256 == 0, in eval mode on the GPU in f32."""
+        """A stage runs on fgvc_conv_split_f32 when it is made of BasicBlocks with dilation-1 convolutions, Cin % 32 == 0
+        and Cout % 64 == 0, in eval mode on the GPU in f32.  Only the stage's first block may be strided: its strided
+        3x3 and 1x1 projection stay in MIOpen, everything after them is on the bf16 pipe."""
         if not (self.use_split_conv and x.is_cuda and not self.training and x.dtype == torch.float32):
             return False
-        for blk in stage:
+        for bi, blk in enumerate(stage):
             if not isinstance(blk, BasicBlock):
                 return False
             convs = [blk.conv1.conv, blk.conv2.conv] + ([blk.downsample.conv] if blk.downsample is not None else [])
             for c in convs:
-                if (c.stride != (1, 1) or c.dilation != (1, 1) or c.groups != 1 or c.in_channels % 32
-                        or c.out_channels % 256 or c.kernel_size not in ((1, 1), (3, 3))):
+                if (c.dilation != (1, 1) or c.groups != 1 or c.in_channels % 32 or c.out_channels % 64
+                        or c.kernel_size not in ((1, 1), (3, 3))):
                     return False
+            strided = blk.conv1.conv.stride != (1, 1)
+            if blk.conv2.conv.stride != (1, 1) or (strided and (bi > 0 or blk.downsample is None)):
+                return False
+            if blk.downsample is not None and blk.downsample.conv.stride != blk.conv1.conv.stride:
+                return False
             if blk.downsample is None and blk.conv1.conv.in_channels != blk.conv2.conv.out_channels:
                 return False
         return True
 
-    def _stage_split(self, si: int, x):
-        """Run stage `si` on NCHW f32 `x`; returns the stage output as padded NHWC f32 (N, Hp, Wp, C) plus (H, W)."""
+    def _split_buffers(self, key, N, C, H, W, device, names):
+        """Zero-bordered workspaces, allocated once per (stage, block, shape) and reused by every call."""
+        from .. import ops
+        cache = self.__dict__.setdefault("_split_cache", {})
+        k = ("b",) + key + (N, C, H, W, device)
+        if k not in cache:
+            mk = {"s": ops.alloc_split_nhwc, "f": ops.alloc_padded_nhwc}
+            cache[k] = {nm: mk[nm[0]](N, C, H, W, device) for nm in names}
+        return cache[k]
+
+    def _stage_split(self, si: int, cur):
+        """Run stage `si`.  `cur` = dict(nchw=f32 NCHW tensor or None, split=padded split NHWC or None, f32=padded NHWC f32
+        or None, H, W) describing the stage input in whichever forms exist; returns the same for the stage output
+        (split + f32 forms)."""
         from .. import ops
         stage = getattr(self, self.res_layers[si])
-        N, Cin, H, W = x.shape
         cache = self.__dict__.setdefault("_split_cache", {})
-        wkey = ("w", si, x.device)
+        dev = (cur["nchw"] if cur["nchw"] is not None else cur["split"]).device
+        wkey = ("w", si, dev)
         if wkey not in cache:
-            cache[wkey] = [dict(c1=ops.prepare_conv_split(b.conv1.conv.weight.detach(), b.conv1.bn),
+            cache[wkey] = [dict(c1=None if b.conv1.conv.stride != (1, 1) else
+                                ops.prepare_conv_split(b.conv1.conv.weight.detach(), b.conv1.bn),
                                 c2=ops.prepare_conv_split(b.conv2.conv.weight.detach(), b.conv2.bn),
-                                ds=None if b.downsample is None else
+                                ds=None if (b.downsample is None or b.downsample.conv.stride != (1, 1)) else
                                 ops.prepare_conv_split(b.downsample.conv.weight.detach(), b.downsample.bn)) for b in stage]
-        Cout = stage[0].conv2.conv.out_channels
-        bkey = ("b", si, N, H, W, x.device)
-        if bkey not in cache:          # zero-bordered workspaces, reused by every call of this shape
-            cache[bkey] = dict(xin=ops.alloc_split_nhwc(N, Cin, H, W, x.device), a=ops.alloc_split_nhwc(N, Cout, H, W, x.device),
-                               ys=[ops.alloc_split_nhwc(N, Cout, H, W, x.device) for _ in range(2)],
-                               yf=[ops.alloc_padded_nhwc(N, Cout, H, W, x.device) for _ in range(2)],
-                               idt=ops.alloc_padded_nhwc(N, Cout, H, W, x.device))
-        buf, wts = cache[bkey], cache[wkey]
-        xs = ops.nchw_to_split_nhwc(x.contiguous(), out=buf["xin"])
-        prev_f32 = None
-        for bi, (blk, wt) in enumerate(zip(stage, wts)):
-            if wt["ds"] is not None:
-                ops.conv_split(xs, wt["ds"][0], wt["ds"][1], H, W, relu=False, out_f32=buf["idt"])
-                idt = buf["idt"]
-            elif prev_f32 is not None:
-                idt = prev_f32
-            else:                      # first block without a projection: identity = the stage input itself
-                idt = buf["idt"]
-                idt[:, 1:H + 1, 1:W + 1, :] = x.permute(0, 2, 3, 1)
-            ops.conv_split(xs, wt["c1"][0], wt["c1"][1], H, W, relu=True, out_split=buf["a"])
-            ys, yf = buf["ys"][bi & 1], buf["yf"][bi & 1]
-            ops.conv_split(buf["a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt, out_split=ys, out_f32=yf)
-            xs, prev_f32 = ys, yf
-        return prev_f32, H, W
+        for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
+            Cin, Cout = blk.conv1.conv.in_channels, blk.conv2.conv.out_channels
+            H, W = cur["H"], cur["W"]
+            if blk.conv1.conv.stride != (1, 1):
+                # strided 3x3 + strided projection in MIOpen (NCHW), then back onto the bf16 pipe
+                x = cur["nchw"]
+                if x is None:
+                    x = cur["f32"][:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).contiguous()
+                t1 = blk.conv1(x)
+                idt_nchw = blk.downsample(x)
+                N, _, H, W = t1.shape
+                buf = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
+                ops.nchw_to_split_nhwc(t1.contiguous(), out=buf["s_a"])
+                ops.nchw_to_split_nhwc(idt_nchw.contiguous(), out=None, out_f32=buf["f_idt"], want_split=False)
+                idt = buf["f_idt"]
+            else:
+                if cur["split"] is None:           # stage input still NCHW (from the stem): both forms in one pass
+                    x = cur["nchw"].contiguous()
+                    N = x.shape[0]
+                    inb = self._split_buffers((si, bi, "in"), N, Cin, H, W, dev, ("s_x", "f_x"))
+                    need_f32 = blk.downsample is None
+                    ops.nchw_to_split_nhwc(x, out=inb["s_x"], out_f32=inb["f_x"] if need_f32 else None)
+                    cur = dict(nchw=None, split=inb["s_x"], f32=inb["f_x"] if need_f32 else None, H=H, W=W)
+                N = cur["split"].shape[0]
+                buf = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
+                if blk.downsample is not None:
+                    ops.conv_split(cur["split"], wt["ds"][0], wt["ds"][1], H, W, relu=False, out_f32=buf["f_idt"])
+                    idt = buf["f_idt"]
+                else:
+                    idt = cur["f32"]
+                ops.conv_split(cur["split"], wt["c1"][0], wt["c1"][1], H, W, relu=True, out_split=buf["s_a"])
+            ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt, out_split=buf["s_y"],
+                           out_f32=buf["f_y"])
+            cur = dict(nchw=None, split=buf["s_y"], f32=buf["f_y"], H=H, W=W)
+        return cur
 
     def _trunk(self, x, last: int):
-        """Stem and stages 0..last; the last stage on the bf16 pipe where it qualifies.
+        """Stem and stages 0..last, on the bf16 pipe from the first stage that qualifies (and all after it do).
         Returns (list of NCHW outputs of stages < last, last stage output, padded-NHWC flag, H, W)."""
         x = self.conv1(x)
         if self.pool is not None:
             x = self.pool(x)
         outs = []
+        cur = None
         for i, name in enumerate(self.res_layers[:last + 1]):
             stage = getattr(self, name)
-            if i == last and self._split_stage_ok(stage, x):
-                y, H, W = self._stage_split(i, x)
-                return outs, y, True, H, W
+            probe = x if cur is None else cur["f32"]
+            if cur is not None or all(self._split_stage_ok(getattr(self, nm), probe) for nm in self.res_layers[i:last + 1]):
+                if cur is None:
+                    cur = dict(nchw=x, split=None, f32=None, H=x.shape[-2], W=x.shape[-1])
+                cur = self._stage_split(i, cur)
+                H, W = cur["H"], cur["W"]
+                outs.append(cur["f32"][:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2))     # NCHW view
+                continue
             x = stage(x)
             outs.append(x)
+        if cur is not None:
+            return outs[:-1], cur["f32"], True, cur["H"], cur["W"]
         return outs[:-1], x, False, x.shape[-2], x.shape[-1]
 
     def forward(self, x, out_idx=None):

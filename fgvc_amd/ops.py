@@ -347,15 +347,20 @@ def alloc_padded_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
     return torch.zeros((N, Hp, Wp, C), device=device, dtype=torch.float32)
 
 
-def nchw_to_split_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """f32 (N,C,H,W) -> padded split NHWC (N,Hp,Wp,C/32,64) int16; `out` must have a zero border (alloc_split_nhwc)."""
+def nchw_to_split_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None,
+                       want_split: bool = True) -> Optional[torch.Tensor]:
+    """f32 (N,C,H,W) -> padded split NHWC (N,Hp,Wp,C/32,64) int16 [and/or padded NHWC f32 `out_f32` (N,Hp,Wp,C)];
+    the destination buffers must have zero borders (alloc_split_nhwc / alloc_padded_nhwc)."""
     x = _chk(x, torch.float32, "x")
     N, C, H, W = x.shape
-    if out is None:
+    if out is None and want_split:
         out = alloc_split_nhwc(N, C, H, W, x.device)
-    Hp, Wp = out.shape[1], out.shape[2]
-    assert out.shape == (N, Hp, Wp, C // 32, 64) and out.dtype == torch.int16 and out.is_contiguous()
-    _lib.call("fgvc_nchw_to_split_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, Hp, Wp, _stream(x))
+    Hp, Wp = conv_pad_dims(H, W)
+    if out is not None:
+        assert out.shape == (N, Hp, Wp, C // 32, 64) and out.dtype == torch.int16 and out.is_contiguous()
+    if out_f32 is not None:
+        assert out_f32.shape == (N, Hp, Wp, C) and out_f32.dtype == torch.float32 and out_f32.is_contiguous()
+    _lib.call("fgvc_nchw_to_split_nhwc_f32", _ptr(x), _ptr(out), _ptr(out_f32), N, C, H, W, Hp, Wp, _stream(x))
     return out
 
 

@@ -182,8 +182,9 @@ int fgvc_bn_act_f32(const float* x, const float* residual, const float* mean, co
  *       tap = ky*KS + kx; bias[Cout] = beta - mean * gamma / sqrt(var + eps)   (fgvc_amd/ops.py: prepare_conv_split).
  *   residual: NULL or padded NHWC f32 [n][Hp][Wp][Cout];  outputs (either may be NULL): y_split (padded split NHWC,
  *       the next convolution's input) and y_f32 (padded NHWC f32: residual of the next block / final features).
- * Cin % 32 == 0, Cout % 256 == 0, KS in {1, 3}, stride 1, zero padding KS/2. */
-int fgvc_nchw_to_split_nhwc_f32(const float* in /* [N][C][H][W] */, uint16_t* out, int N, int C, int H, int W,
+ * Cin % 32 == 0, Cout % 64 == 0, KS in {1, 3}, stride 1, zero padding KS/2. */
+int fgvc_nchw_to_split_nhwc_f32(const float* in /* [N][C][H][W] */, uint16_t* out_split /* or NULL */,
+                                float* out_f32 /* padded NHWC f32, or NULL */, int N, int C, int H, int W,
                                 int Hp, int Wp, void* stream);
 int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                         uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,

@@ -496,9 +496,13 @@ def _split_to_nchw(t, H, W):
 
 
 @pytest.mark.parametrize("case", [(2, 128, 256, 3, 19, 45, True, True), (1, 256, 256, 3, 8, 32, False, True),
-                                  (2, 128, 256, 1, 13, 70, False, False), (1, 64, 512, 3, 24, 33, True, True)])
+                                  (2, 128, 256, 1, 13, 70, False, False), (1, 64, 512, 3, 24, 33, True, True),
+                                  (2, 64, 64, 3, 21, 50, True, True), (1, 64, 128, 3, 9, 40, False, True),
+                                  (1, 128, 128, 3, 17, 31, True, True), (1, 64, 128, 1, 8, 8, False, False),
+                                  (1, 32, 192, 3, 10, 34, True, False)])
 def test_conv_split_vs_torch(dev, case):
-    """conv -> BN(eval) [-> + identity] [-> ReLU] against torch in float64: ragged sizes, 3x3 and 1x1, Cout 256 / 512."""
+    """conv -> BN(eval) [-> + identity] [-> ReLU] against torch in float64: ragged sizes, 3x3 and 1x1, every
+    output-channel tiling (64 / 128 / 192 = 3 x 64 / 256 / 512 = 2 x 256)."""
     import torch.nn.functional as F
     from fgvc_amd import ops
     N, Cin, Cout, KS, H, W, with_res, relu = case
@@ -518,6 +522,7 @@ def test_conv_split_vs_torch(dev, case):
         ref = ref + res.double()
     if relu:
         ref = ref.clamp_min(0)
+    ref = ref.detach()
 
     wp, bias = ops.prepare_conv_split(wt.to(dev), bn.to(dev))
     xs = ops.nchw_to_split_nhwc(x.to(dev))

@@ -21,8 +21,9 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
-N, H, W = 8, 120, 214
-for Cin, Cout, KS in [(256, 256, 3), (128, 256, 3), (128, 256, 1)]:
+N = 8
+for Cin, Cout, KS, H, W in [(256, 256, 3, 120, 214), (128, 256, 3, 120, 214), (128, 256, 1, 120, 214),
+                            (128, 128, 3, 120, 214), (64, 64, 3, 240, 427)]:
     x = torch.randn(N, Cin, H, W, device=dev)
     wt = torch.randn(Cout, Cin, KS, KS, device=dev) * 0.05
     bn = torch.nn.BatchNorm2d(Cout).eval().to(dev)
@@ -35,5 +36,5 @@ for Cin, Cout, KS in [(256, 256, 3), (128, 256, 3), (128, 256, 1)]:
     t_c2 = timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s, out_f32=out_f, residual=out_f))
     t_x = timeit(lambda: ops.nchw_to_split_nhwc(x, out=xs))
     fl = 2.0 * N * H * W * Cin * Cout * KS * KS
-    print(f"{Cin}->{Cout} {KS}x{KS}: MIOpen f32 {t_m:.3f} ms ({fl / t_m / 1e9:.0f} TF) | conv_split {t_c:.3f} ms "
+    print(f"{Cin}->{Cout} {KS}x{KS} @{H}x{W}: MIOpen f32 {t_m:.3f} ms ({fl / t_m / 1e9:.0f} TF) | conv_split {t_c:.3f} ms "
           f"({fl / t_c / 1e9:.0f} TF f32-eq, {3 * fl / t_c / 1e9:.0f} TF bf16) | +res+f32 out {t_c2:.3f} ms | nchw->split {t_x:.3f} ms", flush=True)
