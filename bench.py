@@ -6,7 +6,9 @@
            bench.py --gpus N --steps K --warmup W
 
 A "step" = one 8-frame 480x854 synthetic clip (BASELINE.json configs[1]) through the whole path, inputs
-resident in HBM: ResNet-18 encoder (PyTorch-ROCm/MIOpen, f32) -> L2-normalise/channels-last -> windowed
+resident in HBM: ResNet-18 encoder (stem and the two strided convolutions in PyTorch-ROCm/MIOpen f32; the 13 stride-1
+convolutions of layers 1-3 in fgvc_conv_split_f32: activations and weights as 2 x bf16, f32 accumulate, f32-grade)
+-> L2-normalise/channels-last -> windowed
 correlation + top-10 for all 27 unique (query, key) frame pairs (features split into bf16 hi + lo, four partial
 products on the bf16 matrix pipe with f32 accumulation: f32-grade scores; --pair-precision f32 selects the f32-MFMA
 kernel) -> slot merge + softmax ->
@@ -225,7 +227,9 @@ def main():
         "value": world * a.steps * T / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (correlation: 2 x bf16 split of f32, f32 accumulate)" if use_split else "f32", "data": "synthetic",
+        "dtype": "f32 (encoder stages and correlation: every f32 value as 2 x bf16, partial products on the bf16 MFMA pipe, "
+                 "f32 accumulate)" if use_split else "f32 (encoder stages: 2 x bf16 split, f32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"{a.workload}: {T}x{h}x{w} clip -> {Hf}x{Wf}x{C} features, {n_pairs} unique "
                                f"(query,key) pairs, top-10, radius 15, tau 0.07, P={P}, one clip per rank per step",
                    "parallelism": f"dp{world} (independent clips per rank, no data-path collective)"},
