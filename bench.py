@@ -45,6 +45,8 @@ WORKLOADS = {
     "cfg2_480p_8f": dict(frames=8, h=480, w=854, strides=(1, 2, 1, 1), out_indices=(2,), points=16),
     # configs[0] shape (CPU-runnable plumbing case), also handy for quick runs
     "cfg1_256_2f": dict(frames=2, h=256, w=256, strides=(1, 1, 1, 4), out_indices=(2,), points=8),
+    # configs[4] shape: 720p 24-frame clip (stride-4 features 180x320x256)
+    "cfg5_720p_24f": dict(frames=24, h=720, w=1280, strides=(1, 2, 1, 1), out_indices=(2,), points=16),
     # configs[3] shape: TAP-Vid-DAVIS-like clip
     "cfg4_davis_64f": dict(frames=64, h=256, w=256, strides=(1, 1, 1, 4), out_indices=(2,), points=32),
 }

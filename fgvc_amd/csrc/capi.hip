@@ -43,6 +43,7 @@ int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const floa
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
 
+void set_conv_cot_cap(int);
 void set_pair_kernel(int);
 void set_pair_debug(int);
 void set_pair_v4_debug(int);
@@ -75,6 +76,11 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
     set_pair_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "conv_cot_cap") == 0) {   // fgvc_conv_split_f32: at most this many output channels per workgroup (0, 64, 128)
+    FGVC_REQUIRE(value == 0 || value == 64 || value == 128, FGVC_ERR_INVALID_ARG, "fgvc_set_option: conv_cot_cap must be 0, 64 or 128");
+    set_conv_cot_cap(value);
     return FGVC_OK;
   }
   if (strcmp(name, "pair_bf16_products") == 0) {   // 4 (default): hi*hi + hi*lo + lo*hi + lo*lo.  3 drops lo*lo: 12 % faster, but

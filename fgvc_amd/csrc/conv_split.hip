@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
   }
 }
 
+static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
+void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
+
 int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                       float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu,
                       hipStream_t s) {
@@ -269,7 +272,8 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   p.n_ty = cdiv(H, 8); p.n_tx = cdiv(W, 32);
-  const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
+  int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
+  if (g_conv_cot_cap && cot > g_conv_cot_cap) cot = g_conv_cot_cap;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot);
   if (KS == 3) {
     if (cot == 256) conv_split_kernel<3, 256, 1, 3><<<grid, 512, 0, s>>>(p);

@@ -1,7 +1,8 @@
 """ResNet trunk behind the reference's registry name and constructor keys
-(mmpt/models/backbones/resnet.py:329-638).  Convolutions run in MIOpen (the encoder is host plumbing
-in this project, BASELINE.json north_star); the BN(eval) [+ residual] [+ ReLU] tail after every
-convolution is one hand-written launch (fgvc_bn_act_f32) on the GPU.
+(mmpt/models/backbones/resnet.py:329-638).  On the GPU in eval mode the stride-1 convolutions of the residual
+stages run in fgvc_conv_split_f32 (hi/lo bf16 split, f32-grade, BatchNorm folded, identity and ReLU in the epilogue);
+the stem and strided convolutions run in MIOpen with the BN(eval) [+ residual] [+ ReLU] tail as one hand-written
+launch (fgvc_bn_act_f32).  `ResNet.use_split_conv = False` sends every convolution through MIOpen.
 
 What must match the reference: the state_dict key names (mmcv ConvModule nesting:
 `conv1.conv.weight`, `layer2.0.downsample.bn.running_var`, ...), the strides/out_indices/pool_type

@@ -588,3 +588,39 @@ def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev):
     with torch.no_grad():
         a2 = net(x.to(dev)).cpu()
     assert torch.equal(a, a2)
+
+
+def test_sharded_tracker_hip_backend_single_rank(dev):
+    """fgvc_amd.dist.track_points_sharded with the product backend (HipBackend) under a real RCCL process group of one
+    rank: must reproduce the unsharded tracker (to 1e-3 px: MIOpen's stem convolution is not bit-reproducible from call
+    to call, 1e-6 on the features; the 2-rank choreography is covered on CPU with gloo)."""
+    import os
+    import torch.distributed as dist
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import dist as fdist, engine
+    g = torch.Generator().manual_seed(21)
+    model = api.build_model(dict(type="VanillaTracker",
+                                 backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                               pool_type="none")),
+                            train_cfg=None,
+                            test_cfg=api.ConfigDict(precede_frames=3, topk=10, temperature=0.07, neighbor_range=12,
+                                                    with_first=True, with_first_neighbor=True)).to(dev).eval()
+    rgbs = torch.randn(6, 3, 64, 96, generator=g)
+    qp = torch.tensor([[0, 20.0, 12.0], [0, 70.0, 40.0], [2, 33.0, 50.0]])
+    cfg = model.engine_config()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        traj_s, order_s = fdist.track_points_sharded(fdist.HipBackend(model), rgbs, qp, cfg, device=dev)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    feats, Hf, Wf = model.get_feats_hwc(rgbs.to(dev))
+    traj, order = engine.track_points(feats, Hf, Wf, 64, 96, qp, cfg)
+    assert torch.equal(order_s, order)
+    diff = float((traj_s.cpu() - traj.cpu()).abs().max())
+    assert diff < 1e-3, diff

@@ -1,0 +1,43 @@
+"""BASELINE.json configs[2]: coarse-to-fine two-scale local-window correlation (fine radius 6) and the single-scale
+local window, at 480p sizes (coarse 120x214x256 stride-4 features, fine 480x856x64 stride-1 features, 6 key slots)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fgvc_amd import ops
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+
+
+def timeit(fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+H, W, C, T, P, scale, Cf, Rf, k = 120, 214, 256, 6, 16, 4, 64, 6, 10
+HW = H * W
+coarse = ops.normalize_to_hwc(torch.randn(T + 1, C, H, W, device=dev))                 # frame 0 = query
+fine = ops.normalize_to_hwc(torch.randn(T + 1, Cf, H * scale, W * scale, device=dev))
+vfine = torch.rand(T, H * scale * W * scale, P, device=dev)
+mask = ops.MaskSpec.from_neighbor_range(30)
+pairs = ops.make_pairs([(0, 1 + t, True) for t in range(T)], dev)
+t_coarse = timeit(lambda: ops.pair_topk_auto(coarse, coarse, pairs, H, W, H, W, mask, 1, normalized=True))
+cidx, _ = ops.pair_topk_auto(coarse, coarse, pairs, H, W, H, W, mask, 1, normalized=True)
+arg = cidx[:, :, 0].clamp_min(0).contiguous()
+t_fine = timeit(lambda: ops.c2f_refine(arg, fine[0], fine[1:], vfine, H, W, scale, Rf, k, 0.07))
+cand = T * (2 * Rf + 1) ** 2
+print(f"c2f (A6) per query frame, {T} key slots: coarse arg-max stage {t_coarse:.3f} ms + fine stage {t_fine:.3f} ms "
+      f"({HW} queries x {cand} fine candidates x {Cf} ch = {2.0 * HW * cand * Cf / t_fine / 1e9:.1f} TFLOP/s f32 VALU)")
+R = 6
+lw = ops.normalize_to_hwc(torch.randn(T + 1, C, H, W, device=dev))
+t_local = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07))
+print(f"local window (A7) radius {R}, {T} key slots at {H}x{W}x{C}: {t_local:.3f} ms per query frame")
+R = 12
+t_local = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07))
+print(f"local window (A7) radius {R}: {t_local:.3f} ms per query frame")

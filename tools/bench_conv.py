@@ -33,8 +33,14 @@ for Cin, Cout, KS, H, W in [(256, 256, 3, 120, 214), (128, 256, 3, 120, 214), (1
     out_f = ops.alloc_padded_nhwc(N, Cout, H, W, dev)
     t_m = timeit(lambda: F.conv2d(x, wt, padding=KS // 2))
     t_c = timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s))
+    caps = {}
+    for cap in (128, 64):
+        if cap < Cout:
+            ops.set_option("conv_cot_cap", cap)
+            caps[cap] = round(timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s)), 3)
+    ops.set_option("conv_cot_cap", 0)
     t_c2 = timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s, out_f32=out_f, residual=out_f))
     t_x = timeit(lambda: ops.nchw_to_split_nhwc(x, out=xs))
     fl = 2.0 * N * H * W * Cin * Cout * KS * KS
     print(f"{Cin}->{Cout} {KS}x{KS} @{H}x{W}: MIOpen f32 {t_m:.3f} ms ({fl / t_m / 1e9:.0f} TF) | conv_split {t_c:.3f} ms "
-          f"({fl / t_c / 1e9:.0f} TF f32-eq, {3 * fl / t_c / 1e9:.0f} TF bf16) | +res+f32 out {t_c2:.3f} ms | nchw->split {t_x:.3f} ms", flush=True)
+          f"({fl / t_c / 1e9:.0f} TF f32-eq, {3 * fl / t_c / 1e9:.0f} TF bf16) | cot caps {caps} | +res+f32 out {t_c2:.3f} ms | nchw->split {t_x:.3f} ms", flush=True)
