@@ -238,6 +238,32 @@ def main():
         "roofline": pair_roof,
     }
 
+    if rank == 0 and C == 256 and getattr(type(model.backbone), "use_split_conv", False):
+        # the other big hand-written kernel of the step: one 256 -> 256 3x3 convolution of encoder layer 3 on this clip
+        # (4 such launches + 9 narrower ones per step), timed alone with HIP events
+        blk = model.backbone.layer3[-1]
+        wp, bs = ops.prepare_conv_split(blk.conv2.conv.weight.detach(), blk.conv2.bn)
+        xs_in = ops.nchw_to_split_nhwc(torch.relu(torch.randn(T, 256, Hf, Wf, device=dev)))     # post-ReLU-like activations
+        ys_out = ops.alloc_split_nhwc(T, 256, Hf, Wf, dev)
+        fn = lambda: ops.conv_split(xs_in, wp, bs, Hf, Wf, True, out_split=ys_out)
+        for _ in range(3):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for e0, e1 in evs:
+            e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        cms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+        cfl = 2.0 * T * Hf * Wf * 256 * 256 * 9
+        out["encoder_conv"] = {
+            "what": f"fgvc_conv_split_f32, 256->256 3x3 on {T}x{Hf}x{Wf} (one of 13 split-bf16 convolutions per clip)",
+            "ms_per_launch": cms,
+            "roofline": {"kernel": "fgvc_conv_split_f32", "bound": "mfma", "achieved": 3 * cfl / (cms * 1e-3) / 1e12,
+                         "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 3 * cfl / (cms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                         "note": "bf16 MFMA FLOPs = 3 partial products x the convolution's f32 FLOPs",
+                         "f32_equivalent_tflops": cfl / (cms * 1e-3) / 1e12,
+                         "traffic": measured_traffic("fgvc_conv_split_f32") if a.workload == "cfg2_480p_8f" else None}}
+        del xs_in, ys_out
     if rank == 0 and not a.no_corr_volume:
         vol = torch.empty((HW, HW), device=dev, dtype=torch.float32)
         gbytes = (HW * HW * 4 + 2 * HW * C * 4) / 1e9                  # volume write + both inputs

@@ -41,9 +41,11 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
                       int, int, int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
-int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, hipStream_t);
+int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
 
 void set_conv_cot_cap(int);
+void set_conv_debug(int);
 void set_pair_kernel(int);
 void set_pair_debug(int);
 void set_pair_v4_debug(int);
@@ -76,6 +78,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
     set_pair_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "conv_debug") == 0) {   // profiling ablations of fgvc_conv_split_f32; results are wrong when non-zero
+    set_conv_debug(value);
     return FGVC_OK;
   }
   if (strcmp(name, "conv_cot_cap") == 0) {   // fgvc_conv_split_f32: at most this many output channels per workgroup (0, 64, 128)
@@ -303,14 +309,23 @@ int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias,
   return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, (hipStream_t)stream);
 }
 
-int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Hp, int Wp, int normalize,
-                            void* stream) {
+int fgvc_nhwc_to_split_f32(float* x, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, int relu, void* stream) {
+  FGVC_REQUIRE(x && out, FGVC_ERR_INVALID_ARG, "fgvc_nhwc_to_split_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && C > 0 && C % 32 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG,
+               "fgvc_nhwc_to_split_f32: bad shape (C must be a multiple of 32)");
+  FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_nhwc_to_split_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
+  FGVC_REQUIRE(aligned16(x) && aligned16(out), FGVC_ERR_INVALID_ARG, "fgvc_nhwc_to_split_f32: 16-byte alignment required");
+  FGVC_REQUIRE((long long)N * H * W * C / 4 < (1ll << 31) * 256, FGVC_ERR_UNSUPPORTED, "fgvc_nhwc_to_split_f32: tensor too large");
+  if (N == 0) return FGVC_OK;
+  return nhwc_to_split_launch(x, out, N, C, H, W, Hp, Wp, relu, (hipStream_t)stream);
+}
+
+int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream) {
   FGVC_REQUIRE(in && out, FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: null pointer");
-  FGVC_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0 && Hp >= H + 2 && Wp >= W + 2, FGVC_ERR_INVALID_ARG,
-               "fgvc_normalize_nhwc_f32: bad shape");
+  FGVC_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: bad shape");
   FGVC_REQUIRE(aligned16(in) && aligned16(out), FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: 16-byte alignment required");
   if (N == 0) return FGVC_OK;
-  return normalize_nhwc_launch(in, out, N, C, H, W, Hp, Wp, normalize, (hipStream_t)stream);
+  return normalize_nhwc_launch(in, out, N, C, H, W, normalize, (hipStream_t)stream);
 }
 
 int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int stride, float sigma, float* out,

@@ -8,7 +8,8 @@
 //   activations  x[n][Hp][Wp][C/32][hi 32 ch | lo 32 ch] bf16 -- "padded split NHWC": the image sits at (1,1) inside a
 //                zero border (Hp >= 8*ceil(H/8)+2, Wp >= 32*ceil(W/32)+8), so halos and ragged tiles need no predicates;
 //   weights      w[tap][Cin/32][Cout][hi 32 ci | lo 32 ci] bf16, BatchNorm folded in on the host;
-//   f32 side outputs / residuals: padded NHWC f32 [n][Hp][Wp][C].
+//   f32 side outputs / residuals: dense NHWC f32 [n][H][W][C] (= a channels_last NCHW tensor: MIOpen reads and writes it
+//                without any layout conversion).
 // Work split: a 512-thread workgroup owns 8 rows x 32 columns of output pixels x 256 output channels; wave (pr, ch) owns
 // pixel rows 2pr, 2pr+1 (two 32-pixel MFMA B operands) x channels ch*128..+128 (four 32-channel A operands): 8 accumulator
 // tiles.  K loop: for every 32-channel input chunk the (8+2) x 40 pixel patch is staged once (swizzled 128-byte pixel
@@ -22,11 +23,12 @@ struct ConvSplitParams {
   const uint16_t* x;
   const uint16_t* w;
   const float* bias;       // [Cout]
-  const float* residual;   // optional, padded NHWC f32 [N][Hp][Wp][Cout]
+  const float* residual;   // optional, dense NHWC f32 [N][H][W][Cout]
   uint16_t* y_split;       // optional, padded split NHWC
-  float* y_f32;            // optional, padded NHWC f32
+  float* y_f32;            // optional, dense NHWC f32
   int N, H, W, Hp, Wp, Cin, Cout, relu;
   int n_ty, n_tx;
+  int debug;   // profiling ablations (results WRONG): 1 = patch staged once, 2 = no epilogue, 4 = no MFMA
 };
 
 __device__ __forceinline__ void conv_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
     if (i < n_stage) stage_weights(i);
   for (int q = 0; q < n_stage; ++q) {
     const int chunk = q / SPC, sg = q - chunk * SPC;
-    if (sg == 0 && q > 0) {
+    if (sg == 0 && q > 0 && (p.debug & 1) == 0) {
       __syncthreads();                            // everyone is done reading the previous chunk's patch
       stage_patch(chunk);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
           bh[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 2 * s + h));
           bl[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 4 + 2 * s + h));
         }
+        if (p.debug & 4) continue;
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -163,45 +166,108 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
     }
   }
 
-  // ---- epilogue: + bias [+ residual] [ReLU]; the C layout puts the pixel on the lane and, per register group of four,
-  //      four consecutive output channels in the registers -> 16-byte f32 / 8-byte bf16 stores
-  const int nco_chunk = p.Cout / 32;
+  // ---- epilogue: + bias [+ residual] [ReLU].  The C layout puts the pixel on the lane and four consecutive output
+  //      channels in a register group: stored straight from there every instruction would scatter 64 pieces of 8-16
+  //      bytes (measured: 23 % of the kernel).  Instead each wave transposes its 32-pixel x CW-channel tile through a
+  //      private LDS region (rows padded by 16 B: conflict-free both ways) and moves whole pixel rows -- CW*4 contiguous
+  //      bytes -- to and from global memory; the residual tile comes in the same way.
+  if (p.debug & 2) {
+    float sink = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) sink += acc[a][0][0] + acc[a][1][5];
+    if (sink == 123.456f) p.y_split[0] = 1;
+    return;
+  }
+  constexpr int CW = COT / 2;                     // output channels of this wave
+  constexpr int RB = CW * 4;                      // bytes of one pixel row of the tile (f32, or hi+lo bf16)
+  constexpr int RS = RB + 16;                     // padded LDS row stride
+  constexpr int LPR = RB / 16;                    // lanes that move one row (16 B each)
+  constexpr int RPI = 64 / LPR;                   // rows per wave instruction
+  static_assert(8 * 32 * RS <= CV_PATCHB + NSLOT * CV_WSLOTB, "epilogue staging");
+  __syncthreads();                                // patch and weight ring are dead: reuse them
+  unsigned char* tile = smem + wave * (32 * RS);
+  const int co_w = co_base + ch * CW;             // first output channel of this wave
+  const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const int y = y0 + 2 * pr + b, x = x0 + n;
-    if (y >= p.H || x >= p.W) continue;
-    const size_t pix = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x + 1);
+    const int y = y0 + 2 * pr + b;
+    if (y >= p.H) continue;                       // wave-uniform
+    const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);   // pixel of lane n = 0 in the padded split tensor
+    const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;                 // ... and in the dense f32 tensors
+    if (p.residual) {                             // rows of the residual tile -> LDS
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + mv_row;
+        if (x0 + row < p.W)
+          *reinterpret_cast<uint4*>(tile + row * RS + mv_col) =
+              *reinterpret_cast<const uint4*>(src + (size_t)row * p.Cout * 4 + mv_col);
+      }
+      wave_sync();
+    }
+    f32x4 v[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = co_base + ch * (COT / 2) + a * 32 + 8 * g + 4 * h;   // rows (r&3) + 8 (r>>2) + 4 h of the tile
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-        f32x4 v = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z,
+        const int cw = a * 32 + 8 * g + 4 * h;    // channel within the wave's CW: rows (r&3) + 8 (r>>2) + 4 h of the tile
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
+        v[a][g] = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z,
                    acc[a][b][4 * g + 3] + bv.w};
-        if (p.residual) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + pix * p.Cout + co);
-          v += rv;
-        }
+        if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
         if (p.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        if (p.y_f32) *reinterpret_cast<f32x4*>(p.y_f32 + pix * p.Cout + co) = v;
-        if (p.y_split) {
-          ushort4 hv, lv;
-          hv.x = f2bf(v.x); hv.y = f2bf(v.y); hv.z = f2bf(v.z); hv.w = f2bf(v.w);
-          lv.x = f2bf(v.x - bf2f(hv.x)); lv.y = f2bf(v.y - bf2f(hv.y));
-          lv.z = f2bf(v.z - bf2f(hv.z)); lv.w = f2bf(v.w - bf2f(hv.w));
-          uint16_t* o = p.y_split + (pix * nco_chunk + (co >> 5)) * 64 + (co & 31);
-          *reinterpret_cast<ushort4*>(o) = hv;
-          *reinterpret_cast<ushort4*>(o + 32) = lv;
+          v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
+          v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
         }
       }
+    if (p.y_f32) {
+      wave_sync();                                // residual reads done before the region is overwritten
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(tile + n * RS + (a * 32 + 8 * g + 4 * h) * 4) = v[a][g];
+      wave_sync();
+      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_f32 + fpix0 * p.Cout + co_w);
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + mv_row;
+        if (x0 + row < p.W)
+          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) =
+              *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
+      }
     }
+    if (p.y_split) {
+      wave_sync();
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 x = v[a][g];
+          ushort4 hv, lv;
+          hv.x = f2bf(x.x); hv.y = f2bf(x.y); hv.z = f2bf(x.z); hv.w = f2bf(x.w);
+          lv.x = f2bf(x.x - bf2f(hv.x)); lv.y = f2bf(x.y - bf2f(hv.y));
+          lv.z = f2bf(x.z - bf2f(hv.z)); lv.w = f2bf(x.w - bf2f(hv.w));
+          unsigned char* o = tile + n * RS + a * 128 + (8 * g + 4 * h) * 2;    // [chunk a][hi 64 B | lo 64 B]
+          *reinterpret_cast<ushort4*>(o) = hv;
+          *reinterpret_cast<ushort4*>(o + 64) = lv;
+        }
+      wave_sync();
+      // in global memory the wave's CW channels of a pixel are CW/32 consecutive 128-byte chunks = RB contiguous bytes
+      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * (p.Cout / 32) + (co_w >> 5)) * 128;
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + mv_row;
+        if (x0 + row < p.W)
+          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) =
+              *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
+      }
+    }
+    wave_sync();
   }
 }
 
-// f32 NCHW -> padded split NHWC and/or padded NHWC f32 (interiors only; the borders must already be zero)
+// f32 NCHW -> padded split NHWC (interior only; the border must already be zero) and/or dense NHWC f32
 __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
                                                                   float* __restrict__ out_f32, int C, int H, int W, int Hp,
                                                                   int Wp) {
@@ -230,23 +296,19 @@ __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __
     }
   }
   if (out_f32) {
-    float* o = out_f32 + pix * C + chunk * 32;
+    float* o = out_f32 + (((size_t)nimg * H + y) * W + x) * C + chunk * 32;
 #pragma unroll
     for (int c = 0; c < 32; c += 4) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(fv + c);
   }
 }
 
-// padded NHWC f32 -> L2-normalised [n][H*W][C] f32 (the layout of fgvc_normalize_chw_to_hwc_f32's output); one wave
-// per pixel
+// dense NHWC f32 -> L2-normalised [n][H*W][C] f32 (the layout of fgvc_normalize_chw_to_hwc_f32's output); one wave per pixel
 __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
-                                                              int H, int W, int Hp, int Wp, int normalize, long long npix) {
+                                                              int normalize, long long npix) {
   const long long pixel = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pixel >= npix) return;
-  const int nimg = (int)(pixel / ((long long)H * W));
-  const int rem = (int)(pixel - (long long)nimg * H * W);
-  const int y = rem / W, x = rem - y * W;
-  const float* src = in + (((size_t)nimg * Hp + (y + 1)) * Wp + (x + 1)) * C;
+  const float* src = in + (size_t)pixel * C;
   float ss = 0.f;
   for (int c = lane * 4; c < C; c += 256) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
@@ -262,6 +324,8 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
   }
 }
 
+static int g_conv_debug = 0;
+void set_conv_debug(int v) { g_conv_debug = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
 void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 
@@ -272,6 +336,7 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   p.n_ty = cdiv(H, 8); p.n_tx = cdiv(W, 32);
+  p.debug = g_conv_debug;
   int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
   if (g_conv_cot_cap && cot > g_conv_cot_cap) cot = g_conv_cot_cap;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot);
@@ -296,10 +361,41 @@ int nchw_to_split_nhwc_launch(const float* in, uint16_t* out, float* out_f32, in
   return FGVC_OK;
 }
 
-int normalize_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int Hp, int Wp, int normalize,
-                          hipStream_t s) {
+// dense NHWC f32 [n][H][W][C] -> padded split NHWC, optionally through a ReLU that is also written back in place
+__global__ __launch_bounds__(256) void nhwc_to_split_kernel(float* __restrict__ x, uint16_t* __restrict__ out, int C, int H,
+                                                             int W, int Hp, int Wp, int relu, long long n_vec4) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n_vec4) return;
+  const long long e = g * 4;
+  const long long pixel = e / C;
+  const int c = (int)(e - pixel * C);
+  const int nimg = (int)(pixel / ((long long)H * W));
+  const int rem = (int)(pixel - (long long)nimg * H * W);
+  const int y = rem / W, xx = rem - y * W;
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
+  if (relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    *reinterpret_cast<f32x4*>(x + e) = v;
+  }
+  ushort4 hv, lv;
+  hv.x = f2bf(v.x); hv.y = f2bf(v.y); hv.z = f2bf(v.z); hv.w = f2bf(v.w);
+  lv.x = f2bf(v.x - bf2f(hv.x)); lv.y = f2bf(v.y - bf2f(hv.y));
+  lv.z = f2bf(v.z - bf2f(hv.z)); lv.w = f2bf(v.w - bf2f(hv.w));
+  uint16_t* o = out + ((((size_t)nimg * Hp + (y + 1)) * Wp + (xx + 1)) * (C / 32) + (c >> 5)) * 64 + (c & 31);
+  *reinterpret_cast<ushort4*>(o) = hv;
+  *reinterpret_cast<ushort4*>(o + 32) = lv;
+}
+
+int nhwc_to_split_launch(float* x, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, int relu, hipStream_t s) {
+  const long long n4 = (long long)N * H * W * C / 4;
+  nhwc_to_split_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(x, out, C, H, W, Hp, Wp, relu, n4);
+  FGVC_CHECK_LAUNCH("fgvc_nhwc_to_split_f32");
+  return FGVC_OK;
+}
+
+int normalize_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int normalize, hipStream_t s) {
   const long long npix = (long long)N * H * W;
-  normalize_nhwc_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, C, H, W, Hp, Wp, normalize, npix);
+  normalize_nhwc_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, C, normalize, npix);
   FGVC_CHECK_LAUNCH("fgvc_normalize_nhwc_f32");
   return FGVC_OK;
 }

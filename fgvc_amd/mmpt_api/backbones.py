@@ -163,23 +163,44 @@ class ResNet(nn.Module):
         return True
 
     def _split_buffers(self, key, N, C, H, W, device, names):
-        """Zero-bordered workspaces, allocated once per (stage, block, shape) and reused by every call."""
+        """Workspaces, allocated once per (stage, block, shape) and reused by every call: "s_*" = zero-bordered padded
+        split NHWC, "f_*" = dense NHWC f32."""
         from .. import ops
         cache = self.__dict__.setdefault("_split_cache", {})
         k = ("b",) + key + (N, C, H, W, device)
         if k not in cache:
-            mk = {"s": ops.alloc_split_nhwc, "f": ops.alloc_padded_nhwc}
+            mk = {"s": ops.alloc_split_nhwc, "f": ops.alloc_nhwc}
             cache[k] = {nm: mk[nm[0]](N, C, H, W, device) for nm in names}
         return cache[k]
 
+    @staticmethod
+    def _fold(cb: "ConvBN"):
+        """conv weight and bias with the eval-mode BatchNorm folded in, channels_last (for MIOpen's NHWC kernels)."""
+        bn = cb.bn
+        scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+        w = (cb.conv.weight.detach() * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+        return w, (bn.bias - bn.running_mean * scale).detach().contiguous()
+
+    def _miopen_nhwc(self, key, cb: "ConvBN", x_cl):
+        """conv + folded BN in MIOpen on a channels_last input; returns the dense NHWC f32 result (N,H,W,C) (a view of the
+        channels_last output: no layout conversion on either side)."""
+        cache = self.__dict__.setdefault("_split_cache", {})
+        k = ("m",) + key + (x_cl.device,)
+        if k not in cache:
+            cache[k] = self._fold(cb)
+        w, b = cache[k]
+        c = cb.conv
+        y = F.conv2d(x_cl, w, b, c.stride, c.padding, c.dilation, c.groups)
+        y = y.contiguous(memory_format=torch.channels_last)          # already is, for MIOpen's NHWC solvers
+        return y.permute(0, 2, 3, 1)
+
     def _stage_split(self, si: int, cur):
-        """Run stage `si`.  `cur` = dict(nchw=f32 NCHW tensor or None, split=padded split NHWC or None, f32=padded NHWC f32
-        or None, H, W) describing the stage input in whichever forms exist; returns the same for the stage output
-        (split + f32 forms)."""
+        """Run stage `si`.  `cur` = dict(split = padded split NHWC input, f32 = dense NHWC f32 of the same tensor or None, H,
+        W); returns the same for the stage output."""
         from .. import ops
         stage = getattr(self, self.res_layers[si])
         cache = self.__dict__.setdefault("_split_cache", {})
-        dev = (cur["nchw"] if cur["nchw"] is not None else cur["split"]).device
+        dev = cur["split"].device
         wkey = ("w", si, dev)
         if wkey not in cache:
             cache[wkey] = [dict(c1=None if b.conv1.conv.stride != (1, 1) else
@@ -188,29 +209,19 @@ class ResNet(nn.Module):
                                 ds=None if (b.downsample is None or b.downsample.conv.stride != (1, 1)) else
                                 ops.prepare_conv_split(b.downsample.conv.weight.detach(), b.downsample.bn)) for b in stage]
         for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
-            Cin, Cout = blk.conv1.conv.in_channels, blk.conv2.conv.out_channels
+            Cout = blk.conv2.conv.out_channels
             H, W = cur["H"], cur["W"]
+            N = cur["split"].shape[0]
             if blk.conv1.conv.stride != (1, 1):
-                # strided 3x3 + strided projection in MIOpen (NCHW), then back onto the bf16 pipe
-                x = cur["nchw"]
-                if x is None:
-                    x = cur["f32"][:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).contiguous()
-                t1 = blk.conv1(x)
-                idt_nchw = blk.downsample(x)
-                N, _, H, W = t1.shape
-                buf = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
-                ops.nchw_to_split_nhwc(t1.contiguous(), out=buf["s_a"])
-                ops.nchw_to_split_nhwc(idt_nchw.contiguous(), out=None, out_f32=buf["f_idt"], want_split=False)
-                idt = buf["f_idt"]
+                # strided 3x3 and strided projection in MIOpen, NHWC in and out (the dense f32 tensors ARE channels_last
+                # tensors), then back onto the bf16 pipe: ReLU + split in one pass, the projection is the identity as it lies
+                x_cl = cur["f32"].permute(0, 3, 1, 2)
+                t1 = self._miopen_nhwc((si, bi, "c1"), blk.conv1, x_cl)
+                idt = self._miopen_nhwc((si, bi, "ds"), blk.downsample, x_cl)
+                _, H, W, _ = t1.shape
+                buf = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y"))
+                ops.nhwc_to_split(t1, buf["s_a"], relu=True)
             else:
-                if cur["split"] is None:           # stage input still NCHW (from the stem): both forms in one pass
-                    x = cur["nchw"].contiguous()
-                    N = x.shape[0]
-                    inb = self._split_buffers((si, bi, "in"), N, Cin, H, W, dev, ("s_x", "f_x"))
-                    need_f32 = blk.downsample is None
-                    ops.nchw_to_split_nhwc(x, out=inb["s_x"], out_f32=inb["f_x"] if need_f32 else None)
-                    cur = dict(nchw=None, split=inb["s_x"], f32=inb["f_x"] if need_f32 else None, H=H, W=W)
-                N = cur["split"].shape[0]
                 buf = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
                 if blk.downsample is not None:
                     ops.conv_split(cur["split"], wt["ds"][0], wt["ds"][1], H, W, relu=False, out_f32=buf["f_idt"])
@@ -220,52 +231,56 @@ class ResNet(nn.Module):
                 ops.conv_split(cur["split"], wt["c1"][0], wt["c1"][1], H, W, relu=True, out_split=buf["s_a"])
             ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt, out_split=buf["s_y"],
                            out_f32=buf["f_y"])
-            cur = dict(nchw=None, split=buf["s_y"], f32=buf["f_y"], H=H, W=W)
+            cur = dict(split=buf["s_y"], f32=buf["f_y"], H=H, W=W)
         return cur
 
     def _trunk(self, x, last: int):
-        """Stem and stages 0..last, on the bf16 pipe from the first stage that qualifies (and all after it do).
-        Returns (list of NCHW outputs of stages < last, last stage output, padded-NHWC flag, H, W)."""
+        """Stem and stages 0..last.  When every requested stage qualifies (and there is no pooling layer) the whole trunk
+        stays in NHWC: the stem in MIOpen on channels_last tensors with BatchNorm folded, ReLU fused into the split, the
+        stages on the bf16 pipe.  Returns (list of NCHW outputs of stages < last, last stage output, NHWC flag, H, W)."""
+        from .. import ops
+        stages = [getattr(self, nm) for nm in self.res_layers[:last + 1]]
+        probe = x
+        if (self.pool is None and x.is_cuda and x.dtype == torch.float32 and self.conv1.conv.out_channels % 32 == 0
+                and all(self._split_stage_ok(st, probe) for st in stages)):
+            t = self._miopen_nhwc(("stem",), self.conv1, x.contiguous(memory_format=torch.channels_last))   # (N,H,W,64)
+            N, H, W, C0 = t.shape
+            sb = self._split_buffers(("stem",), N, C0, H, W, x.device, ("s_x",))
+            ops.nhwc_to_split(t, sb["s_x"], relu=True)                # ReLU in place on t + split
+            cur = dict(split=sb["s_x"], f32=t, H=H, W=W)
+            outs = []
+            for i in range(last + 1):
+                cur = self._stage_split(i, cur)
+                outs.append(cur["f32"].permute(0, 3, 1, 2))           # channels_last NCHW view
+            return outs[:-1], cur["f32"], True, cur["H"], cur["W"]
         x = self.conv1(x)
         if self.pool is not None:
             x = self.pool(x)
         outs = []
-        cur = None
-        for i, name in enumerate(self.res_layers[:last + 1]):
-            stage = getattr(self, name)
-            probe = x if cur is None else cur["f32"]
-            if cur is not None or all(self._split_stage_ok(getattr(self, nm), probe) for nm in self.res_layers[i:last + 1]):
-                if cur is None:
-                    cur = dict(nchw=x, split=None, f32=None, H=x.shape[-2], W=x.shape[-1])
-                cur = self._stage_split(i, cur)
-                H, W = cur["H"], cur["W"]
-                outs.append(cur["f32"][:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2))     # NCHW view
-                continue
-            x = stage(x)
+        for st in stages:
+            x = st(x)
             outs.append(x)
-        if cur is not None:
-            return outs[:-1], cur["f32"], True, cur["H"], cur["W"]
         return outs[:-1], x, False, x.shape[-2], x.shape[-1]
 
     def forward(self, x, out_idx=None):
         want = tuple(out_idx) if out_idx is not None else self.out_indices
         last = max(want)                               # later stages cannot influence the outputs
-        earlier, y, padded, H, W = self._trunk(x, last)
-        if padded:
-            y = y[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2)     # NCHW view of the padded NHWC buffer
+        earlier, y, nhwc, H, W = self._trunk(x, last)
+        if nhwc:
+            y = y.permute(0, 3, 1, 2)                      # channels_last NCHW view of the dense NHWC buffer
         stage_out = earlier + [y]
         outs = [stage_out[i] for i in want]
         return outs[0] if len(outs) == 1 else tuple(outs)
 
     def forward_hwc(self, x, normalize: bool = True):
         """The tracker's fast path: features of the single requested stage as (N, H*W, C) f32 rows, L2-normalised if
-        `normalize` -- straight from the padded NHWC buffer when the stage ran on the bf16 pipe (no NCHW round trip).
+        `normalize` -- straight from the dense NHWC buffer when the stage ran on the bf16 pipe (no NCHW round trip).
         Returns (feats, H, W)."""
         from .. import ops
         assert len(self.out_indices) == 1
-        _, y, padded, H, W = self._trunk(x, self.out_indices[0])
-        if padded:
-            return ops.normalize_nhwc(y, H, W, normalize), H, W
+        _, y, nhwc, H, W = self._trunk(x, self.out_indices[0])
+        if nhwc:
+            return ops.normalize_nhwc(y, normalize), H, W
         return ops.normalize_to_hwc(y.float(), normalize, pad=True), H, W
 
 

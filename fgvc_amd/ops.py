@@ -342,15 +342,25 @@ def alloc_split_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
     return torch.zeros((N, Hp, Wp, C // 32, 64), device=device, dtype=torch.int16)
 
 
-def alloc_padded_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
+def alloc_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
+    """Dense NHWC f32 (N,H,W,C): residual / f32 output of conv_split; `.permute(0,3,1,2)` is a channels_last NCHW tensor."""
+    return torch.empty((N, H, W, C), device=device, dtype=torch.float32)
+
+
+def nhwc_to_split(x: torch.Tensor, out: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """dense NHWC f32 (N,H,W,C) -> padded split NHWC `out` (zero border); relu=True applies ReLU to x IN PLACE first."""
+    x = _chk(x, torch.float32, "x")
+    N, H, W, C = x.shape
     Hp, Wp = conv_pad_dims(H, W)
-    return torch.zeros((N, Hp, Wp, C), device=device, dtype=torch.float32)
+    assert out.shape == (N, Hp, Wp, C // 32, 64) and out.dtype == torch.int16 and out.is_contiguous()
+    _lib.call("fgvc_nhwc_to_split_f32", _ptr(x), _ptr(out), N, C, H, W, Hp, Wp, int(relu), _stream(x))
+    return out
 
 
 def nchw_to_split_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None,
                        want_split: bool = True) -> Optional[torch.Tensor]:
-    """f32 (N,C,H,W) -> padded split NHWC (N,Hp,Wp,C/32,64) int16 [and/or padded NHWC f32 `out_f32` (N,Hp,Wp,C)];
-    the destination buffers must have zero borders (alloc_split_nhwc / alloc_padded_nhwc)."""
+    """f32 (N,C,H,W) -> padded split NHWC (N,Hp,Wp,C/32,64) int16 [and/or dense NHWC f32 `out_f32` (N,H,W,C)];
+    the split destination must have a zero border (alloc_split_nhwc)."""
     x = _chk(x, torch.float32, "x")
     N, C, H, W = x.shape
     if out is None and want_split:
@@ -359,7 +369,7 @@ def nchw_to_split_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_
     if out is not None:
         assert out.shape == (N, Hp, Wp, C // 32, 64) and out.dtype == torch.int16 and out.is_contiguous()
     if out_f32 is not None:
-        assert out_f32.shape == (N, Hp, Wp, C) and out_f32.dtype == torch.float32 and out_f32.is_contiguous()
+        assert out_f32.shape == (N, H, W, C) and out_f32.dtype == torch.float32 and out_f32.is_contiguous()
     _lib.call("fgvc_nchw_to_split_nhwc_f32", _ptr(x), _ptr(out), _ptr(out_f32), N, C, H, W, Hp, Wp, _stream(x))
     return out
 
@@ -373,7 +383,7 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
     N, Hp, Wp, nch, _ = x_split.shape
     taps, nch_w, Cout, _ = w.shape
     assert nch_w == nch and taps in (1, 9) and bias.shape == (Cout,)
-    for t, dt, shape in ((residual, torch.float32, (N, Hp, Wp, Cout)), (out_f32, torch.float32, (N, Hp, Wp, Cout)),
+    for t, dt, shape in ((residual, torch.float32, (N, H, W, Cout)), (out_f32, torch.float32, (N, H, W, Cout)),
                          (out_split, torch.int16, (N, Hp, Wp, Cout // 32, 64))):
         if t is not None:
             assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv_split buffer"
@@ -381,12 +391,12 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
               N, H, W, Hp, Wp, nch * 32, Cout, 3 if taps == 9 else 1, int(relu), _stream(x_split))
 
 
-def normalize_nhwc(x: torch.Tensor, H: int, W: int, normalize: bool = True) -> torch.Tensor:
-    """padded NHWC f32 (N,Hp,Wp,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc)."""
+def normalize_nhwc(x: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    """dense NHWC f32 (N,H,W,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc)."""
     x = _chk(x, torch.float32, "x")
-    N, Hp, Wp, C = x.shape
+    N, H, W, C = x.shape
     out = torch.empty((N, H * W, C), device=x.device, dtype=torch.float32)
-    _lib.call("fgvc_normalize_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, Hp, Wp, int(normalize), _stream(x))
+    _lib.call("fgvc_normalize_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, int(normalize), _stream(x))
     return out
 
 

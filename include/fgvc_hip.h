@@ -180,19 +180,23 @@ int fgvc_bn_act_f32(const float* x, const float* residual, const float* mean, co
  *       Hp >= 8*ceil(H/8)+2, Wp >= 32*ceil(W/32)+8.
  *   weights w[KS*KS][Cin/32][Cout][hi 32 ci | lo 32 ci] bf16 with BatchNorm folded in (w * gamma / sqrt(var + eps)),
  *       tap = ky*KS + kx; bias[Cout] = beta - mean * gamma / sqrt(var + eps)   (fgvc_amd/ops.py: prepare_conv_split).
- *   residual: NULL or padded NHWC f32 [n][Hp][Wp][Cout];  outputs (either may be NULL): y_split (padded split NHWC,
- *       the next convolution's input) and y_f32 (padded NHWC f32: residual of the next block / final features).
+ *   residual: NULL or dense NHWC f32 [n][H][W][Cout] (= a channels_last NCHW tensor, what MIOpen reads/writes without a
+ *       layout conversion);  outputs (either may be NULL): y_split (padded split NHWC, the next convolution's input)
+ *       and y_f32 (dense NHWC f32: residual of the next block / final features).
  * Cin % 32 == 0, Cout % 64 == 0, KS in {1, 3}, stride 1, zero padding KS/2. */
 int fgvc_nchw_to_split_nhwc_f32(const float* in /* [N][C][H][W] */, uint16_t* out_split /* or NULL */,
-                                float* out_f32 /* padded NHWC f32, or NULL */, int N, int C, int H, int W,
+                                float* out_f32 /* dense NHWC f32, or NULL */, int N, int C, int H, int W,
                                 int Hp, int Wp, void* stream);
+/* dense NHWC f32 x[n][H][W][C] -> padded split NHWC; relu != 0 applies max(x, 0) first and writes it back to x in place
+ * (the tail of a MIOpen convolution with folded BatchNorm run on channels_last tensors) */
+int fgvc_nhwc_to_split_f32(float* x, uint16_t* out_split, int N, int C, int H, int W, int Hp, int Wp, int relu,
+                           void* stream);
 int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                         uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
                         int KS, int relu, void* stream);
-/* padded NHWC f32 -> [n][H*W][C] f32, rows L2-normalised if `normalize` (the output layout of
+/* dense NHWC f32 -> [n][H*W][C] f32, rows L2-normalised if `normalize` (the output layout of
  * fgvc_normalize_chw_to_hwc_f32) */
-int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Hp, int Wp, int normalize,
-                            void* stream);
+int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream);
 
 /* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
  * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).

@@ -488,6 +488,10 @@ def _padded_to_nchw(t, H, W):
     return t[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).contiguous()
 
 
+def _nhwc_to_nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
 def _split_to_nchw(t, H, W):
     N, Hp, Wp, nch, _ = t.shape
     v = t.view(torch.bfloat16).float().view(N, Hp, Wp, nch, 2, 32)
@@ -528,23 +532,25 @@ def test_conv_split_vs_torch(dev, case):
     xs = ops.nchw_to_split_nhwc(x.to(dev))
     assert float((_split_to_nchw(xs.cpu(), H, W) - x).abs().max()) < 1e-5 * float(x.abs().max())
     out_s = ops.alloc_split_nhwc(N, Cout, H, W, dev)
-    out_f = ops.alloc_padded_nhwc(N, Cout, H, W, dev)
-    resp = None
-    if with_res:
-        resp = ops.alloc_padded_nhwc(N, Cout, H, W, dev)
-        resp[:, 1:H + 1, 1:W + 1, :] = res.permute(0, 2, 3, 1).to(dev)
+    out_f = ops.alloc_nhwc(N, Cout, H, W, dev)
+    resp = res.permute(0, 2, 3, 1).contiguous().to(dev) if with_res else None
     ops.conv_split(xs, wp, bias, H, W, relu, residual=resp, out_split=out_s, out_f32=out_f)
-    got_f = _padded_to_nchw(out_f.cpu(), H, W).double()
+    got_f = _nhwc_to_nchw(out_f.cpu()).double()
     got_s = _split_to_nchw(out_s.cpu(), H, W).double()
     scale = float(ref.detach().abs().max())
     assert float((got_f - ref).abs().max()) < 2e-5 * scale, float((got_f - ref).abs().max()) / scale
     assert float((got_s - ref).abs().max()) < 3e-5 * scale
-    # nothing outside the interior was touched
-    assert float(out_f[:, 0].abs().max()) == 0 and float(out_f[:, H + 1:].abs().max()) == 0
-    assert float(out_f[:, :, 0].abs().max()) == 0 and float(out_f[:, :, W + 1:].abs().max()) == 0
+    # nothing outside the interior of the padded split tensor was touched
     assert int(out_s[:, :, W + 1:].abs().max()) == 0 and int(out_s[:, H + 1:].abs().max()) == 0
+    assert int(out_s[:, 0].abs().max()) == 0 and int(out_s[:, :, 0].abs().max()) == 0
+    # dense NHWC -> split with the fused in-place ReLU
+    t = torch.randn(N, H, W, Cout, generator=g).to(dev)
+    want_t = t.clamp_min(0).cpu()
+    ts = ops.nhwc_to_split(t, ops.alloc_split_nhwc(N, Cout, H, W, dev), relu=True)
+    assert torch.equal(t.cpu(), want_t)
+    assert float((_split_to_nchw(ts.cpu(), H, W) - _nhwc_to_nchw(want_t)).abs().max()) < 1e-5 * float(want_t.abs().max())
     # the normalised read-back
-    nf = ops.normalize_nhwc(out_f, H, W)
+    nf = ops.normalize_nhwc(out_f)
     want = torch.nn.functional.normalize(got_f.float().permute(0, 2, 3, 1).reshape(N, H * W, Cout), dim=2)
     assert torch.allclose(nf.cpu(), want, atol=1e-6)
 

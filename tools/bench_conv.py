@@ -30,7 +30,7 @@ for Cin, Cout, KS, H, W in [(256, 256, 3, 120, 214), (128, 256, 3, 120, 214), (1
     wp, bias = ops.prepare_conv_split(wt, bn)
     xs = ops.nchw_to_split_nhwc(x)
     out_s = ops.alloc_split_nhwc(N, Cout, H, W, dev)
-    out_f = ops.alloc_padded_nhwc(N, Cout, H, W, dev)
+    out_f = ops.alloc_nhwc(N, Cout, H, W, dev)
     t_m = timeit(lambda: F.conv2d(x, wt, padding=KS // 2))
     t_c = timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s))
     caps = {}

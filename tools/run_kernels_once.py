@@ -19,3 +19,12 @@ for _ in range(3):
     ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol)
     ops.corr_volume(feats[1], feats[0], 0.07, "f32", out=vol)
 torch.cuda.synchronize()
+# one 256 -> 256 3x3 split-bf16 convolution at the layer-3 size
+wt = torch.randn(256, 256, 3, 3, device=dev) * 0.02
+bn = torch.nn.BatchNorm2d(256).eval().to(dev)
+wp, bs = ops.prepare_conv_split(wt, bn)
+xs = ops.nchw_to_split_nhwc(torch.randn(T, 256, H, W, device=dev))
+ys = ops.alloc_split_nhwc(T, 256, H, W, dev)
+for _ in range(3):
+    ops.conv_split(xs, wp, bs, H, W, True, out_split=ys)
+torch.cuda.synchronize()
