@@ -89,6 +89,34 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
       conv_lds_dma_16(xb + gpix * pix_bytes_in + sl * 16, lds_addr(patch + (prow * CV_PW + pc0) * 128));
     }
   };
+  // The patches of chunks 1.. come through REGISTERS: global -> VGPRs is issued one stage before the chunk boundary and
+  // lands while that stage multiplies; at the boundary only ds_writes remain (an LDS-DMA there exposed the whole memory
+  // latency once per chunk, 15 % of the kernel; a second LDS patch buffer does not fit beside the weight ring).
+  constexpr int NPIECE = (8 + 2 * PADK) * (4 + PADK), MAXP = (NPIECE + 7) / 8;
+  static_assert(MAXP <= 7, "patch pieces per wave");
+  // seven named registers, not an array (as `uint4 pre[7]` touched from two lambdas hipcc left it in scratch memory), and
+  // loaded by inline assembly: for loads it knows about, hipcc's own vmcnt wait before the ds_writes is computed without
+  // the inline-assembly DMAs and comes out as vmcnt(0) -- draining the weight DMAs issued a moment before, i.e. exactly
+  // the memory latency this was meant to hide.  The explicit counted wait below leaves those DMAs in flight.
+  uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {}, pre6 = {};
+  const unsigned char* xb0 = reinterpret_cast<const unsigned char*>(p.x);
+#define CV_PIECE_GEOM(J)                                                                              \
+  const int pi_ = imin(wave + 8 * (J), NPIECE - 1);                                                   \
+  const int prow_ = pi_ / (4 + PADK), pc0_ = (pi_ - prow_ * (4 + PADK)) * 8;
+#define CV_PREFETCH(J, CHUNK)                                                                         \
+  if ((J) < MAXP) {                                                                                   \
+    CV_PIECE_GEOM(J)                                                                                  \
+    const int P_ = prow_ * CV_PW + pc0_ + d_row;                                                      \
+    const int sl_ = d_slot ^ ((P_ >> 1) & 7);                                                         \
+    const size_t g_ = ((size_t)nimg * p.Hp + (y0 + 1 - PADK + prow_)) * p.Wp + (x0 + 1 - PADK + pc0_ + d_row); \
+    const unsigned char* a_ = xb0 + (size_t)(CHUNK) * 128 + g_ * pix_bytes_in + sl_ * 16;                      \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre##J) : "v"(a_) : "memory");                       \
+  }
+#define CV_COMMIT(J)                                                                                  \
+  if ((J) < MAXP && wave + 8 * (J) < NPIECE) {                                                        \
+    CV_PIECE_GEOM(J)                                                                                  \
+    *reinterpret_cast<uint4*>(patch + (prow_ * CV_PW + pc0_) * 128 + lane * 16) = pre##J;             \
+  }
   auto stage_weights = [&](int q) {                                    // stage q = chunk * SPC + tap group
     const int chunk = q / SPC, tap0 = (q - chunk * SPC) * TG;
     unsigned char* dst = wring + (q % NSLOT) * CV_WSLOTB;
@@ -121,16 +149,20 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
     if (i < n_stage) stage_weights(i);
   for (int q = 0; q < n_stage; ++q) {
     const int chunk = q / SPC, sg = q - chunk * SPC;
-    if (sg == 0 && q > 0 && (p.debug & 1) == 0) {
-      __syncthreads();                            // everyone is done reading the previous chunk's patch
-      stage_patch(chunk);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (q + LA - 1 < n_stage) {
+    if (q + LA - 1 < n_stage) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * PPW) : "memory");   // all but the stages after q have landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
+    const bool last_of_chunk = sg == SPC - 1 && chunk + 1 < nchunk && (p.debug & 1) == 0;
+    if (last_of_chunk) {                            // next chunk's patch: lands while this stage multiplies.  Issued BEFORE
+      // this stage's weight DMAs: hipcc guards the reuse of these registers with a vmcnt wait that knows nothing of the
+      // inline-assembly DMAs and would otherwise wait for the ones issued a moment ago
+      CV_PREFETCH(0, chunk + 1) CV_PREFETCH(1, chunk + 1) CV_PREFETCH(2, chunk + 1) CV_PREFETCH(3, chunk + 1)
+      CV_PREFETCH(4, chunk + 1) CV_PREFETCH(5, chunk + 1) CV_PREFETCH(6, chunk + 1)
+      __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of this stage's MFMAs
+    }
     if (q + LA < n_stage) stage_weights(q + LA);    // its slot held stage q-1, which every wave has finished
     const unsigned char* wslot = wring + (q % NSLOT) * CV_WSLOTB;
 #pragma unroll
@@ -163,6 +195,13 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
           }
       }
+    }
+    if (last_of_chunk) {                            // chunk boundary (the registers live only inside this iteration)
+      if (q + LA < n_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // prefetch landed; this stage's
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // weight DMAs stay in flight
+      lds_barrier();                                // everyone is done reading this chunk's patch
+      CV_COMMIT(0) CV_COMMIT(1) CV_COMMIT(2) CV_COMMIT(3) CV_COMMIT(4) CV_COMMIT(5) CV_COMMIT(6)   // visible after the
+                                                                                                  // next stage's barrier
     }
   }
 
