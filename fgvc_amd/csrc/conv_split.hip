@@ -28,7 +28,7 @@ struct ConvSplitParams {
   float* y_f32;            // optional, dense NHWC f32
   int N, H, W, Hp, Wp, Cin, Cout, relu;
   int n_ty, n_tx;
-  int debug;   // profiling ablations (results WRONG): 1 = patch staged once, 2 = no epilogue, 4 = no MFMA
+  int debug;   // profiling ablations (results WRONG): 1 = patch staged once, 2 = no epilogue, 4 = no MFMA, 8 = s_memtime probe
 };
 
 __device__ __forceinline__ void conv_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
@@ -117,20 +117,22 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
     CV_PIECE_GEOM(J)                                                                                  \
     *reinterpret_cast<uint4*>(patch + (prow_ * CV_PW + pc0_) * 128 + lane * 16) = pre##J;             \
   }
-  auto stage_weights = [&](int q) {                                    // stage q = chunk * SPC + tap group
+  // one 1-KiB piece (8 output channels of one tap) of the weight slab of stage q = chunk * SPC + tap group
+  auto stage_weight_piece = [&](int q, int j) {
     const int chunk = q / SPC, tap0 = (q - chunk * SPC) * TG;
     unsigned char* dst = wring + (q % NSLOT) * CV_WSLOTB;
+    const int piece = wave * PPW + j;                                  // always PPW pieces per wave (a short last group
+    const int tg = piece / (COT / 8), c0 = (piece - tg * (COT / 8)) * 8;     // re-reads its last tap): the vmcnt
+    const int tap = imin(tap0 + tg, T - 1);                            // arithmetic stays fixed
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
+                              (((size_t)tap * nchunk + chunk) * p.Cout + co_base) * 128;
+    const int co = c0 + d_row;
+    const int sl = d_slot ^ ((co >> 1) & 7);
+    conv_lds_dma_16(wb + (size_t)co * 128 + sl * 16, lds_addr(dst + (tg * COT + c0) * 128));
+  };
+  auto stage_weights = [&](int q) {
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {                                    // always PPW pieces (a short last group re-reads
-      const int piece = wave * PPW + j;                                // its last tap): the vmcnt arithmetic stays fixed
-      const int tg = piece / (COT / 8), c0 = (piece - tg * (COT / 8)) * 8;   // 8 output channels per piece
-      const int tap = imin(tap0 + tg, T - 1);
-      const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
-                                (((size_t)tap * nchunk + chunk) * p.Cout + co_base) * 128;
-      const int co = c0 + d_row;
-      const int sl = d_slot ^ ((co >> 1) & 7);
-      conv_lds_dma_16(wb + (size_t)co * 128 + sl * 16, lds_addr(dst + (tg * COT + c0) * 128));
-    }
+    for (int j = 0; j < PPW; ++j) stage_weight_piece(q, j);
   };
 
   f32x16 acc[NA][2];
@@ -147,14 +149,20 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
 #pragma unroll
   for (int i = 0; i < LA; ++i)
     if (i < n_stage) stage_weights(i);
+  const bool timing = (p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0;   // s_memtime probe of one workgroup
+  long long t_wait = 0, t_issue = 0, t_mma = 0, t_bound = 0, t_start = 0;
+  if (timing) t_start = __builtin_amdgcn_s_memtime();
   for (int q = 0; q < n_stage; ++q) {
     const int chunk = q / SPC, sg = q - chunk * SPC;
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (timing) c0 = __builtin_amdgcn_s_memtime();
     if (q + LA - 1 < n_stage) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * PPW) : "memory");   // all but the stages after q have landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
+    if (timing) c1 = __builtin_amdgcn_s_memtime();
     const bool last_of_chunk = sg == SPC - 1 && chunk + 1 < nchunk && (p.debug & 1) == 0;
     if (last_of_chunk) {                            // next chunk's patch: lands while this stage multiplies.  Issued BEFORE
       // this stage's weight DMAs: hipcc guards the reuse of these registers with a vmcnt wait that knows nothing of the
@@ -163,7 +171,11 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
       CV_PREFETCH(4, chunk + 1) CV_PREFETCH(5, chunk + 1) CV_PREFETCH(6, chunk + 1)
       __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of this stage's MFMAs
     }
-    if (q + LA < n_stage) stage_weights(q + LA);    // its slot held stage q-1, which every wave has finished
+    // the weight DMAs of stage q+LA (its slot held stage q-1, which every wave has finished) are issued between the MFMA
+    // blocks below: issued up front they kept the matrix pipe idle for 500-900 cycles per stage (s_memtime probe)
+    const bool stage_more = q + LA < n_stage;
+    // (tried: let one wave of each SIMD issue its DMAs up front to shift it against its partner -- 10 % slower)
+    if (timing) c2 = __builtin_amdgcn_s_memtime();
     const unsigned char* wslot = wring + (q % NSLOT) * CV_WSLOTB;
 #pragma unroll
     for (int tg = 0; tg < TG; ++tg) {
@@ -185,16 +197,31 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
           bh[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 2 * s + h));
           bl[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 4 + 2 * s + h));
         }
-        if (p.debug & 4) continue;
+        if ((p.debug & 4) == 0) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
+          for (int a = 0; a < NA; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          }
+            for (int b = 0; b < 2; ++b) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (stage_more) {                           // this iteration's share of the PPW weight pieces, behind its MFMAs
+          constexpr int NIT = TG * 2;
+          const int it = tg * 2 + s;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < PPW; ++j)
+            if (j * NIT / PPW == it) stage_weight_piece(q + LA, j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+    }
+    if (timing) {
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[NA - 1][1][15]));
+      c3 = __builtin_amdgcn_s_memtime();
+      t_wait += c1 - c0; t_issue += c2 - c1; t_mma += c3 - c2;
     }
     if (last_of_chunk) {                            // chunk boundary (the registers live only inside this iteration)
       if (q + LA < n_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // prefetch landed; this stage's
@@ -202,7 +229,15 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
       lds_barrier();                                // everyone is done reading this chunk's patch
       CV_COMMIT(0) CV_COMMIT(1) CV_COMMIT(2) CV_COMMIT(3) CV_COMMIT(4) CV_COMMIT(5) CV_COMMIT(6)   // visible after the
                                                                                                   // next stage's barrier
+      if (timing) t_bound += __builtin_amdgcn_s_memtime() - c3;
     }
+  }
+  if (timing) {
+    if (lane == 0) {
+      long long* o = reinterpret_cast<long long*>(p.y_split) + wave * 8;
+      o[0] = t_wait; o[1] = t_issue; o[2] = t_mma; o[3] = t_bound; o[4] = __builtin_amdgcn_s_memtime() - t_start; o[5] = n_stage;
+    }
+    return;
   }
 
   // ---- epilogue: + bias [+ residual] [ReLU].  The C layout puts the pixel on the lane and four consecutive output
