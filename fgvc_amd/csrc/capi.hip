@@ -45,6 +45,7 @@ int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, hipStre
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
 
 void set_conv_cot_cap(int);
+void set_conv_narrow(int);
 void set_conv_debug(int);
 void set_pair_kernel(int);
 void set_pair_debug(int);
@@ -82,6 +83,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "conv_debug") == 0) {   // profiling ablations of fgvc_conv_split_f32; results are wrong when non-zero
     set_conv_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "conv_narrow") == 0) {   // fgvc_conv_split_f32 with 64 output channels per workgroup: 1 (default) = 4-row tiles,
+    set_conv_narrow(value != 0);            // two workgroups per CU;  0 = 8-row tiles, one workgroup per CU
     return FGVC_OK;
   }
   if (strcmp(name, "conv_cot_cap") == 0) {   // fgvc_conv_split_f32: at most this many output channels per workgroup (0, 64, 128)

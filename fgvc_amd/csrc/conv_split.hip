@@ -10,7 +10,7 @@
 //   weights      w[tap][Cin/32][Cout][hi 32 ci | lo 32 ci] bf16, BatchNorm folded in on the host;
 //   f32 side outputs / residuals: dense NHWC f32 [n][H][W][C] (= a channels_last NCHW tensor: MIOpen reads and writes it
 //                without any layout conversion).
-// Work split: a 512-thread workgroup owns 8 rows x 32 columns of output pixels x 256 output channels; wave (pr, ch) owns
+// Work split (widest form): a 512-thread workgroup owns 8 rows x 32 columns of output pixels x 256 output channels; wave (pr, ch) owns
 // pixel rows 2pr, 2pr+1 (two 32-pixel MFMA B operands) x channels ch*128..+128 (four 32-channel A operands): 8 accumulator
 // tiles.  K loop: for every 32-channel input chunk the (8+2) x 40 pixel patch is staged once (swizzled 128-byte pixel
 // rows: ds_read_b128 of a 3x3-shifted row segment is conflict-free for every shift), then the KS*KS taps stream their
@@ -39,8 +39,6 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 }
 
 constexpr int CV_PW = 40;                      // staged patch width in pixels (34 needed; DMA moves 8 pixels at a time)
-constexpr int CV_PH = 10;
-constexpr int CV_PATCHB = CV_PH * CV_PW * 128;  // 51200
 constexpr int CV_RINGB = 96 * 1024;             // weight ring: NSLOT slots of TG taps x COT output channels x 128 B
 
 // physical byte offset of 16-byte slot `s` (0..7) of 128-byte row `row`: slot index XOR (row >> 1) & 7
@@ -49,28 +47,34 @@ __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^
 // COT = output channels per workgroup (256 / 128 / 64: wave (pr, ch) owns COT/2 of them = NA 32-channel A operands);
 // a pipeline stage = TG taps of one 32-channel input chunk (TG = 1 at COT = 256; a whole row of three taps for the
 // narrower layers, which would otherwise synchronise every 24 MFMAs per wave); NSLOT ring slots of TG*COT*128 bytes.
-template <int KS, int COT, int TG, int NSLOT>
-__global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
+// NWR = waves along the pixel rows (4: an 8-row tile, 512 threads, one workgroup per CU; 2: a 4-row tile, 256 threads,
+// small enough in LDS and registers for TWO workgroups per CU -- for the narrow layers, whose short main loop cannot hide
+// its own prologue and epilogue, the second workgroup does).
+template <int KS, int COT, int TG, int NSLOT, int NWR>
+__global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel(ConvSplitParams p) {
   constexpr int T = KS * KS;
   constexpr int PADK = KS / 2;                  // 1 for 3x3, 0 for 1x1
+  constexpr int NW = NWR * 2;                   // waves per workgroup
+  constexpr int TROWS = NWR * 2;                // output rows per workgroup tile
+  constexpr int CV_PATCHB = (TROWS + 2) * CV_PW * 128;
   constexpr int NA = COT / 64;                  // A operands (32 output channels each) per wave
   constexpr int SPC = (T + TG - 1) / TG;        // stages per input chunk
   constexpr int CV_WSLOTB = TG * COT * 128;
-  constexpr int PPW = TG * COT / 64;            // 1-KiB DMA pieces per wave per full stage
-  static_assert(NSLOT * CV_WSLOTB <= CV_RINGB && (TG * COT) % 64 == 0, "ring");
+  constexpr int PPW = TG * COT / 8 / NW;        // 1-KiB DMA pieces per wave per full stage
+  static_assert(NSLOT * CV_WSLOTB <= CV_RINGB && (TG * COT / 8) % NW == 0, "ring");
   __shared__ __attribute__((aligned(16))) unsigned char smem[CV_PATCHB + NSLOT * CV_WSLOTB];
   unsigned char* patch = smem;
   unsigned char* wring = smem + CV_PATCHB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pr = wave & 3, ch = wave >> 2;
+  const int pr = wave % NWR, ch = wave / NWR;
   const int n = lane & 31, h = lane >> 5;
   int bid = blockIdx.x;
   const int nimg = bid / (p.n_ty * p.n_tx);
   bid -= nimg * p.n_ty * p.n_tx;
   const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
-  const int y0 = ty * 8, x0 = tx * 32;
+  const int y0 = ty * TROWS, x0 = tx * 32;
   const int co_base = blockIdx.y * COT;
   const int nchunk = p.Cin / 32;
   const size_t pix_bytes_in = (size_t)nchunk * 128;
@@ -79,9 +83,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
   const int d_row = lane >> 3, d_slot = lane & 7;
   auto stage_patch = [&](int chunk) {
     // (8 + 2 PADK) rows x (32 + 8 PADK) pixels in pieces of 8 pixels; piece i -> wave i % 8
-    constexpr int ROWS = 8 + 2 * PADK, PPR = 4 + PADK;
+    constexpr int ROWS = TROWS + 2 * PADK, PPR = 4 + PADK;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + (size_t)chunk * 128;
-    for (int i = wave; i < ROWS * PPR; i += 8) {
+    for (int i = wave; i < ROWS * PPR; i += NW) {
       const int prow = i / PPR, pc0 = (i - prow * PPR) * 8;
       const int P = prow * CV_PW + pc0 + d_row;                       // patch pixel of this lane
       const int sl = d_slot ^ ((P >> 1) & 7);                         // logical slot that lives at this physical slot
@@ -92,16 +96,16 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
   // The patches of chunks 1.. come through REGISTERS: global -> VGPRs is issued one stage before the chunk boundary and
   // lands while that stage multiplies; at the boundary only ds_writes remain (an LDS-DMA there exposed the whole memory
   // latency once per chunk, 15 % of the kernel; a second LDS patch buffer does not fit beside the weight ring).
-  constexpr int NPIECE = (8 + 2 * PADK) * (4 + PADK), MAXP = (NPIECE + 7) / 8;
-  static_assert(MAXP <= 7, "patch pieces per wave");
+  constexpr int NPIECE = (TROWS + 2 * PADK) * (4 + PADK), MAXP = (NPIECE + NW - 1) / NW;
+  static_assert(MAXP <= 8, "patch pieces per wave");
   // seven named registers, not an array (as `uint4 pre[7]` touched from two lambdas hipcc left it in scratch memory), and
   // loaded by inline assembly: for loads it knows about, hipcc's own vmcnt wait before the ds_writes is computed without
   // the inline-assembly DMAs and comes out as vmcnt(0) -- draining the weight DMAs issued a moment before, i.e. exactly
   // the memory latency this was meant to hide.  The explicit counted wait below leaves those DMAs in flight.
-  uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {}, pre6 = {};
+  uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {}, pre6 = {}, pre7 = {};
   const unsigned char* xb0 = reinterpret_cast<const unsigned char*>(p.x);
 #define CV_PIECE_GEOM(J)                                                                              \
-  const int pi_ = imin(wave + 8 * (J), NPIECE - 1);                                                   \
+  const int pi_ = imin(wave + NW * (J), NPIECE - 1);                                                   \
   const int prow_ = pi_ / (4 + PADK), pc0_ = (pi_ - prow_ * (4 + PADK)) * 8;
 #define CV_PREFETCH(J, CHUNK)                                                                         \
   if ((J) < MAXP) {                                                                                   \
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre##J) : "v"(a_) : "memory");                       \
   }
 #define CV_COMMIT(J)                                                                                  \
-  if ((J) < MAXP && wave + 8 * (J) < NPIECE) {                                                        \
+  if ((J) < MAXP && wave + NW * (J) < NPIECE) {                                                        \
     CV_PIECE_GEOM(J)                                                                                  \
     *reinterpret_cast<uint4*>(patch + (prow_ * CV_PW + pc0_) * 128 + lane * 16) = pre##J;             \
   }
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
       // this stage's weight DMAs: hipcc guards the reuse of these registers with a vmcnt wait that knows nothing of the
       // inline-assembly DMAs and would otherwise wait for the ones issued a moment ago
       CV_PREFETCH(0, chunk + 1) CV_PREFETCH(1, chunk + 1) CV_PREFETCH(2, chunk + 1) CV_PREFETCH(3, chunk + 1)
-      CV_PREFETCH(4, chunk + 1) CV_PREFETCH(5, chunk + 1) CV_PREFETCH(6, chunk + 1)
+      CV_PREFETCH(4, chunk + 1) CV_PREFETCH(5, chunk + 1) CV_PREFETCH(6, chunk + 1) CV_PREFETCH(7, chunk + 1)
       __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of this stage's MFMAs
     }
     // the weight DMAs of stage q+LA (its slot held stage q-1, which every wave has finished) are issued between the MFMA
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
       if (q + LA < n_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // prefetch landed; this stage's
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // weight DMAs stay in flight
       lds_barrier();                                // everyone is done reading this chunk's patch
-      CV_COMMIT(0) CV_COMMIT(1) CV_COMMIT(2) CV_COMMIT(3) CV_COMMIT(4) CV_COMMIT(5) CV_COMMIT(6)   // visible after the
+      CV_COMMIT(0) CV_COMMIT(1) CV_COMMIT(2) CV_COMMIT(3) CV_COMMIT(4) CV_COMMIT(5) CV_COMMIT(6) CV_COMMIT(7)   // visible after the
                                                                                                   // next stage's barrier
       if (timing) t_bound += __builtin_amdgcn_s_memtime() - c3;
     }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvSplitParams p) {
   constexpr int RS = RB + 16;                     // padded LDS row stride
   constexpr int LPR = RB / 16;                    // lanes that move one row (16 B each)
   constexpr int RPI = 64 / LPR;                   // rows per wave instruction
-  static_assert(8 * 32 * RS <= CV_PATCHB + NSLOT * CV_WSLOTB, "epilogue staging");
+  static_assert(NW * 32 * RS <= CV_PATCHB + NSLOT * CV_WSLOTB, "epilogue staging");
   __syncthreads();                                // patch and weight ring are dead: reuse them
   unsigned char* tile = smem + wave * (32 * RS);
   const int co_w = co_base + ch * CW;             // first output channel of this wave
@@ -400,6 +404,8 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
 
 static int g_conv_debug = 0;
 void set_conv_debug(int v) { g_conv_debug = v; }
+static int g_conv_narrow = 1;       // 64-channel tiling: 1 = 4-row tiles with two workgroups per CU, 0 = 8-row tiles
+void set_conv_narrow(int v) { g_conv_narrow = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
 void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 
@@ -409,19 +415,22 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   ConvSplitParams p;
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
-  p.n_ty = cdiv(H, 8); p.n_tx = cdiv(W, 32);
+  const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
+  const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap) ? g_conv_cot_cap : cot;
+  const bool narrow = cot_eff == 64 && g_conv_narrow;     // 4-row tiles, two workgroups per CU
+  p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
-  int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
-  if (g_conv_cot_cap && cot > g_conv_cot_cap) cot = g_conv_cot_cap;
-  dim3 grid(p.n_ty * p.n_tx * N, Cout / cot);
+  dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   if (KS == 3) {
-    if (cot == 256) conv_split_kernel<3, 256, 1, 3><<<grid, 512, 0, s>>>(p);
-    else if (cot == 128) conv_split_kernel<3, 128, 3, 2><<<grid, 512, 0, s>>>(p);
-    else conv_split_kernel<3, 64, 3, 3><<<grid, 512, 0, s>>>(p);
+    if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4><<<grid, 512, 0, s>>>(p);
+    else if (cot_eff == 128) conv_split_kernel<3, 128, 3, 2, 4><<<grid, 512, 0, s>>>(p);
+    else if (narrow) conv_split_kernel<3, 64, 3, 2, 2><<<grid, 256, 0, s>>>(p);
+    else conv_split_kernel<3, 64, 3, 3, 4><<<grid, 512, 0, s>>>(p);
   } else {
-    if (cot == 256) conv_split_kernel<1, 256, 1, 3><<<grid, 512, 0, s>>>(p);
-    else if (cot == 128) conv_split_kernel<1, 128, 1, 3><<<grid, 512, 0, s>>>(p);
-    else conv_split_kernel<1, 64, 1, 3><<<grid, 512, 0, s>>>(p);
+    if (cot_eff == 256) conv_split_kernel<1, 256, 1, 3, 4><<<grid, 512, 0, s>>>(p);
+    else if (cot_eff == 128) conv_split_kernel<1, 128, 1, 3, 4><<<grid, 512, 0, s>>>(p);
+    else if (narrow) conv_split_kernel<1, 64, 1, 3, 2><<<grid, 256, 0, s>>>(p);
+    else conv_split_kernel<1, 64, 1, 3, 4><<<grid, 512, 0, s>>>(p);
   }
   FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
   return FGVC_OK;
