@@ -171,3 +171,32 @@ def test_shard_frames():
     assert D.encode_range(5, 5, [0], cfg) == (5, 5)
     enc = [D.encode_range(lo, hi, [0, 20], cfg) for lo, hi in D.shard_frames(64, 8)]
     assert D.owner_of(0, enc) == 0 and D.owner_of(20, enc) == 2
+
+
+def test_prepare_conv_split_layout_reconstructs_conv_bn():
+    """Host side of fgvc_conv_split_f32 (no GPU): BatchNorm folding and the packed weight layout
+    [tap = ky*KS+kx][Cin/32][Cout][hi 32 ci | lo 32 ci].  Unpacking hi + lo and running a plain convolution must
+    reproduce conv -> BN(eval); the padded activation dims follow the documented formula."""
+    import torch.nn.functional as F
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    Cin, Cout, KS = 64, 128, 3
+    w = torch.randn(Cout, Cin, KS, KS, generator=g) * 0.1
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    bn.weight.data = torch.rand(Cout, generator=g) + 0.5
+    bn.bias.data = torch.randn(Cout, generator=g)
+    bn.running_mean = torch.randn(Cout, generator=g)
+    bn.running_var = torch.rand(Cout, generator=g) + 0.5
+    packed, bias = ops.prepare_conv_split(w, bn)
+    assert packed.shape == (KS * KS, Cin // 32, Cout, 64) and packed.dtype == torch.int16 and bias.shape == (Cout,)
+    v = packed.view(torch.bfloat16).float()
+    wrec = (v[..., :32] + v[..., 32:])                                  # [tap][chunk][co][32 ci]
+    wrec = wrec.permute(2, 1, 3, 0).reshape(Cout, Cin, KS, KS)           # tap -> (ky, kx), (chunk, ci) -> input channel
+    x = torch.randn(2, Cin, 9, 11, generator=g)
+    want = bn(F.conv2d(x, w, padding=1)).detach()
+    got = F.conv2d(x, wrec, bias, padding=1)
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    # lo really is the residue of hi (|lo| <= 2^-8 |hi|), i.e. the split is not two independent roundings of w
+    assert float((v[..., 32:].abs() - v[..., :32].abs() * 2.0 ** -7).clamp_min(0).max()) == 0.0
+    assert ops.conv_pad_dims(120, 214) == (122, 232) and ops.conv_pad_dims(8, 32) == (10, 40) and ops.conv_pad_dims(9, 33) == (18, 72)
+    assert ops.split_path_ok(256, 120, 214, 10, True) and not ops.split_path_ok(256, 120, 214, 11, True)
