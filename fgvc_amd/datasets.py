@@ -56,3 +56,35 @@ class StridedLoader:
 
     def __len__(self):
         return len(range(self.rank, len(self.dataset), self.world))
+
+
+# ---- TAP-Vid input contract (configs/eval/base_data.py:1-7: RGB2LAB + Normalize(mean=[50,0,0], std=[50,127,127])) -------
+_M_RGB2XYZ = ((0.412453, 0.357580, 0.180423), (0.212671, 0.715160, 0.072169), (0.019334, 0.119193, 0.950227))
+_WHITE_D65 = (0.950456, 1.0, 1.088754)
+
+
+def rgb_to_lab(rgb: torch.Tensor) -> torch.Tensor:
+    """sRGB in [0,1], (..., 3, h, w) float -> CIE L*a*b* (D65), L in [0,100], a/b in about [-127,127]: the conversion
+    `cv2.cvtColor(img01_float32, cv2.COLOR_RGB2Lab)` performs in the reference (augmentation.py:1372-1391), with OpenCV's
+    documented constants.  Parity with OpenCV is UNPINNED here (cv2 is not installed; its float path evaluates the
+    transfer curve and the cube root through spline tables, documented accuracy ~1e-3): the known answers in
+    tests/test_host.py are the CIE values of the sRGB primaries."""
+    x = rgb.to(torch.float32)
+    lin = torch.where(x > 0.04045, ((x + 0.055) / 1.055).clamp_min(0) ** 2.4, x / 12.92)
+    r, g, b = lin.unbind(-3)
+    xyz = [(m[0] * r + m[1] * g + m[2] * b) / w for m, w in zip(_M_RGB2XYZ, _WHITE_D65)]
+    f = [torch.where(t > 0.008856, t.clamp_min(1e-12) ** (1.0 / 3.0), 7.787 * t + 16.0 / 116.0) for t in xyz]
+    L = torch.where(xyz[1] > 0.008856, 116.0 * f[1] - 16.0, 903.3 * xyz[1])
+    return torch.stack([L, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])], -3)
+
+
+def preprocess_tapvid_frames(frames_uint8: torch.Tensor, size=(256, 256)) -> torch.Tensor:
+    """(T, h0, w0, 3) uint8 RGB -> (1, T, 3, h, w) float32 network input: bilinear resize to `size`, /255, RGB->Lab,
+    (x - [50,0,0]) / [50,127,127]  (configs/eval/base_data.py:1-7; tapvid.py:106-108 scales the points by the same size)."""
+    x = frames_uint8.permute(0, 3, 1, 2).to(torch.float32)
+    if tuple(x.shape[-2:]) != tuple(size):
+        x = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    lab = rgb_to_lab((x / 255.0).clamp(0, 1))
+    mean = torch.tensor([50.0, 0.0, 0.0], device=lab.device).view(1, 3, 1, 1)
+    std = torch.tensor([50.0, 127.0, 127.0], device=lab.device).view(1, 3, 1, 1)
+    return ((lab - mean) / std).unsqueeze(0)

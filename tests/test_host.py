@@ -200,3 +200,22 @@ def test_prepare_conv_split_layout_reconstructs_conv_bn():
     assert float((v[..., 32:].abs() - v[..., :32].abs() * 2.0 ** -7).clamp_min(0).max()) == 0.0
     assert ops.conv_pad_dims(120, 214) == (122, 232) and ops.conv_pad_dims(8, 32) == (10, 40) and ops.conv_pad_dims(9, 33) == (18, 72)
     assert ops.split_path_ok(256, 120, 214, 10, True) and not ops.split_path_ok(256, 120, 214, 11, True)
+
+
+def test_rgb_to_lab_known_answers_and_input_contract():
+    """F3 input contract: CIE L*a*b* of the sRGB primaries (published values), grey axis, and the normalisation of
+    configs/eval/base_data.py:1-7."""
+    from fgvc_amd.datasets import rgb_to_lab, preprocess_tapvid_frames
+    cols = torch.tensor([[1.0, 1, 1], [0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0.5, 0.5, 0.5]]).t().reshape(3, 1, 6)
+    lab = rgb_to_lab(cols)[:, 0].t()
+    want = torch.tensor([[100.0, 0, 0], [0, 0, 0], [53.2408, 80.0925, 67.2032], [87.7347, -86.1827, 83.1793],
+                         [32.2970, 79.1875, -107.8602], [53.3890, 0, 0]])
+    assert torch.allclose(lab, want, atol=0.02), (lab - want).abs().max()
+    frames = torch.randint(0, 256, (3, 40, 60, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    x = preprocess_tapvid_frames(frames, size=(32, 48))
+    assert x.shape == (1, 3, 3, 32, 48) and x.dtype == torch.float32
+    assert float(x[:, :, 0].min()) >= -1.0 - 1e-6 and float(x[:, :, 0].max()) <= 1.0 + 1e-6      # L in [0,100] -> [-1,1]
+    assert float(x[:, :, 1:].abs().max()) <= 1.01                                               # a,b within +-127
+    grey = torch.full((1, 8, 8, 3), 128, dtype=torch.uint8)
+    xg = preprocess_tapvid_frames(grey, size=(8, 8))
+    assert float(xg[0, 0, 1:].abs().max()) < 1e-4                                              # neutral grey: a = b = 0
