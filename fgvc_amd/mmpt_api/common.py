@@ -232,7 +232,7 @@ def masked_attention_efficient_correlation_v2(query_frame, key_frames, value, ra
     P = value.size(1)
     qf = ops.normalize_to_hwc(query.float(), normalize, pad=True)
     kf = ops.normalize_to_hwc(keys.float().contiguous(), normalize, pad=True)
-    idx, _, weight = ops.local_corr_topk(qf, kf, H, W, radius, topk, temperature)
+    idx, _, weight = ops.local_corr_topk(qf, kf, H, W, radius, topk, temperature, normalized=bool(normalize))
     labels = value[0].permute(1, 2, 3, 0).reshape(K, H * W, P).float().contiguous()
     out = ops.propagate_topk(labels, torch.arange(K, dtype=torch.int32, device=query.device), idx, weight, H, W, H, W,
                              window_L=2 * radius + 1)

@@ -181,7 +181,8 @@ class HRVanillaTracker(VanillaTracker):
         for f in range(1, T):
             ks = engine.key_slots(f, 0, pre, with_first)
             kf = feats[ks]
-            idx, _, weight = ops.local_corr_topk(feats[f:f + 1], kf, Hf, Wf, R, k, tau)
+            idx, _, weight = ops.local_corr_topk(feats[f:f + 1], kf, Hf, Wf, R, k, tau,
+                                                 normalized=bool(g("with_norm", True)))
             ops.propagate_topk(labels, torch.tensor(ks, dtype=torch.int32, device=dev), idx, weight, Hf, Wf, Hf, Wf,
                                window_L=2 * R + 1, out=labels[f])
         coords = ops.softargmax_top5(labels, Hf, Wf, h, w, gauss_points=pts)
@@ -197,7 +198,7 @@ class HRVanillaTracker(VanillaTracker):
         qf = ops.normalize_to_hwc(query_feat.float(), norm, pad=True)
         kf = ops.normalize_to_hwc(key_feats.float(), norm, pad=True)
         idx, _, weight = ops.local_corr_topk(qf, kf[:1], H, W, self.infer_radius, int(g("topk", 10)),
-                                             float(g("temperature", 1)))
+                                             float(g("temperature", 1)), normalized=norm)
         return ops.topk_coord(idx, weight, H, W, self.infer_radius, scale).t().reshape(1, 2, H, W)
 
     @torch.no_grad()

@@ -630,3 +630,20 @@ def test_sharded_tracker_hip_backend_single_rank(dev):
     assert torch.equal(order_s, order)
     diff = float((traj_s.cpu() - traj.cpu()).abs().max())
     assert diff < 1e-3, diff
+
+
+def test_local_corr_split_path_vs_oracle(dev):
+    """A7 local window on the bf16 pipe (C = 256, normalised): against the oracle and against the f32-MFMA path."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(31)
+    C, K, H, W, R, topk = 256, 3, 14, 19, 4, 10
+    q = torch.randn(C, H, W, generator=g)
+    key = torch.randn(C, K, H, W, generator=g)
+    v = torch.rand(5, K, H, W, generator=g)
+    qf = ops.normalize_to_hwc(q[None].to(dev))
+    kf = ops.normalize_to_hwc(key.permute(1, 0, 2, 3).contiguous().to(dev))
+    i1, l1, w1 = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07, normalized=True)
+    i0, l0, w0 = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07)
+    o_out, o_idx, o_logit = O.local_corr_topk(q, key.transpose(0, 1), v.transpose(0, 1), R, topk, 0.07)
+    assert torch.allclose(l1.cpu(), o_logit, atol=TOL) and torch.allclose(l1, l0, atol=1e-4)
+    assert (i1.cpu().long() == o_idx).all(1).float().mean() > 0.98 and (i1 == i0).all(1).float().mean() > 0.98

@@ -36,8 +36,8 @@ print(f"c2f (A6) per query frame, {T} key slots: coarse arg-max stage {t_coarse:
       f"({HW} queries x {cand} fine candidates x {Cf} ch = {2.0 * HW * cand * Cf / t_fine / 1e9:.1f} TFLOP/s f32 VALU)")
 R = 6
 lw = ops.normalize_to_hwc(torch.randn(T + 1, C, H, W, device=dev))
-t_local = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07))
-print(f"local window (A7) radius {R}, {T} key slots at {H}x{W}x{C}: {t_local:.3f} ms per query frame")
-R = 12
-t_local = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07))
-print(f"local window (A7) radius {R}: {t_local:.3f} ms per query frame")
+for R in (6, 12):
+    t_f32 = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07))
+    t_split = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07, normalized=True))
+    print(f"local window (A7) radius {R}, {T} key slots at {H}x{W}x{C}: f32-MFMA kernel {t_f32:.3f} ms, bf16-pipe kernel "
+          f"{t_split:.3f} ms per query frame")
