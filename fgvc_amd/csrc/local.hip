@@ -135,21 +135,60 @@ __global__ __launch_bounds__(256) void c2f_refine_kernel(const int32_t* __restri
   const float* qv = qfine + ((size_t)(qy * scale) * sW + qx * scale) * Cf;   // query_fine[:, ::scale, ::scale] (:785)
   TopK<K> top;
   top.init();
-  for (int c = lane; c < T * LL; c += 64) {
-    const int t = c / LL, tap = c - t * LL;
-    const int cell = coarse_arg[(size_t)t * HW + q];
-    const int fy = (cell / W) * scale + tap / L - Rf, fx = (cell % W) * scale + tap % L - Rf;
-    float s = 0.f;
-    if (fy >= 0 && fy < sH && fx >= 0 && fx < sW) {
-      const float* kv = kfine + (((size_t)t * sH + fy) * sW + fx) * Cf;
-      for (int ch = 0; ch < Cf; ch += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(kv + ch);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(qv + ch);
-        s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+  const int lpr = Cf >> 2;                      // lanes that read one candidate's Cf-channel row (16 B each)
+  if (lpr <= 64 && (lpr & (lpr - 1)) == 0) {
+    // Row-cooperative mapping: 64/lpr candidates per wave instruction, every row a coalesced Cf*4-byte read (with one
+    // lane per candidate every load instruction touched 64 different cache lines for 16 bytes each and the kernel was
+    // bound by the texture-address path: 2.9 ms per frame at 480p).  The group's lanes reduce by shuffles; its first
+    // lane keeps the group's running list.
+    const int grp = lane / lpr, sub = lane - grp * lpr, G = 64 / lpr;
+    const f32x4 qa = *reinterpret_cast<const f32x4*>(qv + 4 * sub);
+    constexpr int U = 4;                          // candidates in flight per lane group (8: no faster)
+    for (int c0 = grp; c0 < T * LL; c0 += G * U) {
+      f32x4 a[U];
+      bool in[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * G;
+        in[u] = false;
+        a[u] = {0.f, 0.f, 0.f, 0.f};
+        if (c < T * LL) {
+          const int t = c / LL, tap = c - t * LL;
+          const int cell = coarse_arg[(size_t)t * HW + q];
+          const int fy = (cell / W) * scale + tap / L - Rf, fx = (cell % W) * scale + tap % L - Rf;
+          if (fy >= 0 && fy < sH && fx >= 0 && fx < sW) {
+            in[u] = true;
+            a[u] = *reinterpret_cast<const f32x4*>(kfine + (((size_t)t * sH + fy) * sW + fx) * Cf + 4 * sub);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * G;
+        float sp = a[u].x * qa.x;
+        sp = fmaf(a[u].y, qa.y, sp); sp = fmaf(a[u].z, qa.z, sp); sp = fmaf(a[u].w, qa.w, sp);
+        for (int m = lpr >> 1; m >= 1; m >>= 1) sp += __shfl_xor(sp, m);
+        const float sc = (in[u] ? sp : 0.f) / temperature;            // (:847) divided BEFORE the top-k here
+        if (sub == 0 && c < T * LL && top.accepts(sc, c)) top.insert(sc, c);
       }
     }
-    s = s / temperature;  // (:847) divided BEFORE the top-k here
-    if (top.accepts(s, c)) top.insert(s, c);
+  } else {
+    for (int c = lane; c < T * LL; c += 64) {
+      const int t = c / LL, tap = c - t * LL;
+      const int cell = coarse_arg[(size_t)t * HW + q];
+      const int fy = (cell / W) * scale + tap / L - Rf, fx = (cell % W) * scale + tap % L - Rf;
+      float s = 0.f;
+      if (fy >= 0 && fy < sH && fx >= 0 && fx < sW) {
+        const float* kv = kfine + (((size_t)t * sH + fy) * sW + fx) * Cf;
+        for (int ch = 0; ch < Cf; ch += 4) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(kv + ch);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(qv + ch);
+          s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+        }
+      }
+      s = s / temperature;  // (:847) divided BEFORE the top-k here
+      if (top.accepts(s, c)) top.insert(s, c);
+    }
   }
   float win_s[K];
   int win_i[K];
