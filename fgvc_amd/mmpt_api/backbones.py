@@ -116,6 +116,7 @@ class ResNet(nn.Module):
     def init_weights(self):
         """Random init as resnet.py:587-601 when no checkpoint is given; checkpoints are loaded with
         load_state_dict / load_checkpoint (prefixes stripped like revise_keys at resnet.py:580)."""
+        self.reset_split_cache()
         if isinstance(self.pretrained, str):
             load_checkpoint(self, self.pretrained)
             return
@@ -135,9 +136,15 @@ class ResNet(nn.Module):
     # ---- stages on the bf16 matrix pipe (fgvc_conv_split_f32) ------------------------------------------------------
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
 
-    def load_state_dict(self, *args, **kwargs):
-        self.__dict__.pop("_split_cache", None)        # folded / split weights are derived from the parameters
-        return super().load_state_dict(*args, **kwargs)
+    def _load_from_state_dict(self, *args, **kwargs):
+        # called for this module by ANY load_state_dict (its own or a parent model's): folded / split weights are derived
+        # from the parameters and must be rebuilt
+        self.__dict__.pop("_split_cache", None)
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def reset_split_cache(self):
+        """Drop the cached folded / split weights and workspaces (call after changing parameters in place)."""
+        self.__dict__.pop("_split_cache", None)
 
     def _split_stage_ok(self, stage, x) -> bool:
         """A stage runs on fgvc_conv_split_f32 when it is made of BasicBlocks with dilation-1 convolutions, Cin % 32 == 0

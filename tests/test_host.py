@@ -219,3 +219,19 @@ def test_rgb_to_lab_known_answers_and_input_contract():
     grey = torch.full((1, 8, 8, 3), 128, dtype=torch.uint8)
     xg = preprocess_tapvid_frames(grey, size=(8, 8))
     assert float(xg[0, 0, 1:].abs().max()) < 1e-4                                              # neutral grey: a = b = 0
+
+
+def test_resnet_split_cache_is_dropped_when_weights_change():
+    """The folded / split convolution weights cached by the backbone must not survive a (parent) load_state_dict."""
+    import fgvc_amd.mmpt_api as api
+    model = api.build_model(dict(type="VanillaTracker",
+                                 backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                               pool_type="none")),
+                            train_cfg=None, test_cfg=api.ConfigDict(topk=10))
+    bb = model.backbone
+    bb.__dict__["_split_cache"] = {"stale": 1}
+    model.load_state_dict(model.state_dict())              # parent-level load reaches the backbone's hook
+    assert "_split_cache" not in bb.__dict__
+    bb.__dict__["_split_cache"] = {"stale": 1}
+    bb.init_weights()
+    assert "_split_cache" not in bb.__dict__
