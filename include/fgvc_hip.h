@@ -54,8 +54,14 @@ const char* fgvc_version(void);
 const char* fgvc_last_error(void);
 
 /* Process-wide tuning knobs (host only, not thread-safe against concurrent launches).
- *   "pair_kernel": 2 (default) = wave-specialised fgvc_pair_topk_f32 kernel (4 MFMA waves + 4 selection/loader
- *                  waves per workgroup), 1 = the simpler 4-wave kernel.  Results are identical. */
+ *   "pair_kernel"        fgvc_pair_topk_f32 variant: 3 (default; C = 256, 2 <= topk <= 10, analytic mask) = wave-specialised
+ *                        kernel with the sorting network in the MFMA shadow, 2 = wave-specialised, 1 = plain 4-wave kernel.
+ *                        Identical results up to the last bit of the scores.
+ *   "pair_bf16_products" fgvc_pair_topk_bf16x4: 4 (default) = hi*hi + hi*lo + lo*hi + lo*lo, 3 = without lo*lo.
+ *   "conv_cot_cap"       fgvc_conv_split_f32: at most this many output channels per workgroup (0 = widest, 64, 128).
+ *   "conv_narrow"        fgvc_conv_split_f32, 64-channel tiling: 1 (default) = 4-row tiles, two workgroups per CU.
+ *   "pair_debug", "pair_bf16_debug", "corr_debug", "conv_debug": profiling ablations (skip selection / MFMA / staging /
+ *                        epilogue, s_memtime probes); results are WRONG when non-zero -- tools/ablate_*.py, tools/time_*.py. */
 int fgvc_set_option(const char* name, int value);
 
 /* Largest integer d2 such that sqrtf((float)d2) < radius, -1 if none (host helper). */
