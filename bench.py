@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--no-autotune", action="store_true", help="MIOpen immediate mode (clean profiles)")
     ap.add_argument("--pair-precision", default="auto", choices=["auto", "f32", "split"],
                     help="pair top-k kernel: split = fgvc_pair_topk_bf16x4 (default where it applies), f32 = fgvc_pair_topk_f32")
+    ap.add_argument("--encoder-lanes", type=int, default=None,
+                    help="batch slices of the encoder run on this many HIP streams at once (default: ResNet.split_lanes)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,6 +159,9 @@ def main():
     wl = WORKLOADS[a.workload]
     T, h, w, P = wl["frames"], wl["h"], wl["w"], wl["points"]
     torch.backends.cudnn.benchmark = not a.no_autotune
+    if a.encoder_lanes is not None:
+        from fgvc_amd.mmpt_api.backbones import ResNet
+        ResNet.split_lanes = a.encoder_lanes
     model = build_tracker(wl, dev)
     if a.channels_last:
         model.test_cfg["channels_last"] = True

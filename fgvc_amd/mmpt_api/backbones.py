@@ -201,13 +201,17 @@ class ResNet(nn.Module):
         y = y.contiguous(memory_format=torch.channels_last)          # already is, for MIOpen's NHWC solvers
         return y.permute(0, 2, 3, 1)
 
+    split_lanes = 3                # batch slices run on this many HIP streams at once (1 = everything on the caller's stream)
+
     def _stage_split(self, si: int, cur):
-        """Run stage `si`.  `cur` = dict(split = padded split NHWC input, f32 = dense NHWC f32 of the same tensor or None, H,
-        W); returns the same for the stage output."""
+        """Run stage `si` for the batch slice [lo, hi) of an N-image batch.  `cur` = dict(split = padded split NHWC input,
+        f32 = dense NHWC f32 of the same tensor, H, W, lo, hi, N, need_split); returns the same for the stage output plus
+        `full` = the whole-batch dense NHWC f32 buffer the slice was written into."""
         from .. import ops
         stage = getattr(self, self.res_layers[si])
         cache = self.__dict__.setdefault("_split_cache", {})
         dev = cur["split"].device
+        lo, hi, N = cur["lo"], cur["hi"], cur["N"]
         wkey = ("w", si, dev)
         if wkey not in cache:
             cache[wkey] = [dict(c1=None if b.conv1.conv.stride != (1, 1) else
@@ -215,10 +219,11 @@ class ResNet(nn.Module):
                                 c2=ops.prepare_conv_split(b.conv2.conv.weight.detach(), b.conv2.bn),
                                 ds=None if (b.downsample is None or b.downsample.conv.stride != (1, 1)) else
                                 ops.prepare_conv_split(b.downsample.conv.weight.detach(), b.downsample.bn)) for b in stage]
+        full = None
         for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
             Cout = blk.conv2.conv.out_channels
             H, W = cur["H"], cur["W"]
-            N = cur["split"].shape[0]
+            last_conv = bi == len(stage) - 1 and not cur["need_split"]        # nobody reads the split form of the trunk output
             if blk.conv1.conv.stride != (1, 1):
                 # strided 3x3 and strided projection in MIOpen, NHWC in and out (the dense f32 tensors ARE channels_last
                 # tensors), then back onto the bf16 pipe: ReLU + split in one pass, the projection is the identity as it lies
@@ -226,40 +231,70 @@ class ResNet(nn.Module):
                 t1 = self._miopen_nhwc((si, bi, "c1"), blk.conv1, x_cl)
                 idt = self._miopen_nhwc((si, bi, "ds"), blk.downsample, x_cl)
                 _, H, W, _ = t1.shape
-                buf = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y"))
+                bufs = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y"))
+                buf = {k: v[lo:hi] for k, v in bufs.items()}
                 ops.nhwc_to_split(t1, buf["s_a"], relu=True)
             else:
-                buf = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
+                bufs = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
+                buf = {k: v[lo:hi] for k, v in bufs.items()}
                 if blk.downsample is not None:
                     ops.conv_split(cur["split"], wt["ds"][0], wt["ds"][1], H, W, relu=False, out_f32=buf["f_idt"])
                     idt = buf["f_idt"]
                 else:
                     idt = cur["f32"]
                 ops.conv_split(cur["split"], wt["c1"][0], wt["c1"][1], H, W, relu=True, out_split=buf["s_a"])
-            ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt, out_split=buf["s_y"],
-                           out_f32=buf["f_y"])
-            cur = dict(split=buf["s_y"], f32=buf["f_y"], H=H, W=W)
+            ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt,
+                           out_split=None if last_conv else buf["s_y"], out_f32=buf["f_y"])
+            full = bufs["f_y"]
+            cur = dict(cur, split=buf["s_y"], f32=buf["f_y"], H=H, W=W)
+        cur["full"] = full
         return cur
 
     def _trunk(self, x, last: int):
         """Stem and stages 0..last.  When every requested stage qualifies (and there is no pooling layer) the whole trunk
         stays in NHWC: the stem in MIOpen on channels_last tensors with BatchNorm folded, ReLU fused into the split, the
-        stages on the bf16 pipe.  Returns (list of NCHW outputs of stages < last, last stage output, NHWC flag, H, W)."""
+        stages on the bf16 pipe.  The batch is cut into `split_lanes` slices that run on separate HIP streams: a layer's
+        launch covers the 256 CUs 3.3 times at 8 frames, and the other lane's workgroups fill the tail of each launch.
+        Returns (list of NCHW outputs of stages < last, last stage output, NHWC flag, H, W)."""
         from .. import ops
         stages = [getattr(self, nm) for nm in self.res_layers[:last + 1]]
         probe = x
         if (self.pool is None and x.is_cuda and x.dtype == torch.float32 and self.conv1.conv.out_channels % 32 == 0
                 and all(self._split_stage_ok(st, probe) for st in stages)):
-            t = self._miopen_nhwc(("stem",), self.conv1, x.contiguous(memory_format=torch.channels_last))   # (N,H,W,64)
-            N, H, W, C0 = t.shape
-            sb = self._split_buffers(("stem",), N, C0, H, W, x.device, ("s_x",))
-            ops.nhwc_to_split(t, sb["s_x"], relu=True)                # ReLU in place on t + split
-            cur = dict(split=sb["s_x"], f32=t, H=H, W=W)
-            outs = []
+            N, dev = x.shape[0], x.device
+            cache = self.__dict__.setdefault("_split_cache", {})
+            n_lanes = max(1, min(int(self.split_lanes), N))
+            main = torch.cuda.current_stream(dev)
+            if n_lanes > 1:
+                skey = ("streams", dev, n_lanes)
+                if skey not in cache:
+                    cache[skey] = [torch.cuda.Stream(dev) for _ in range(n_lanes)]
+                streams = cache[skey]
+                for s in streams:
+                    s.wait_stream(main)
+            else:
+                streams = [main]
+            x_cl = x.contiguous(memory_format=torch.channels_last)
+            lanes = []
+            for li, s in enumerate(streams):
+                lo, hi = li * N // n_lanes, (li + 1) * N // n_lanes
+                with torch.cuda.stream(s):
+                    t = self._miopen_nhwc(("stem",), self.conv1, x_cl[lo:hi])   # (n,H,W,64)
+                    _, H, W, C0 = t.shape
+                    sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x",))
+                    ops.nhwc_to_split(t, sb["s_x"][lo:hi], relu=True)          # ReLU in place on t + split
+                lanes.append(dict(split=sb["s_x"][lo:hi], f32=t, H=H, W=W, lo=lo, hi=hi, N=N, need_split=True))
+            fulls = []
             for i in range(last + 1):
-                cur = self._stage_split(i, cur)
-                outs.append(cur["f32"].permute(0, 3, 1, 2))           # channels_last NCHW view
-            return outs[:-1], cur["f32"], True, cur["H"], cur["W"]
+                for li, s in enumerate(streams):                                 # lanes interleaved stage by stage
+                    with torch.cuda.stream(s):
+                        lanes[li] = self._stage_split(i, dict(lanes[li], need_split=i < last))
+                fulls.append(lanes[0]["full"])
+            if n_lanes > 1:
+                for s in streams:
+                    main.wait_stream(s)
+            outs = [f.permute(0, 3, 1, 2) for f in fulls]                        # channels_last NCHW views
+            return outs[:-1], fulls[-1], True, lanes[0]["H"], lanes[0]["W"]
         x = self.conv1(x)
         if self.pool is not None:
             x = self.pool(x)

@@ -590,10 +590,23 @@ def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev):
     assert float((a - b).abs().max()) < 2e-5 * scale and float((a - c).abs().max()) < 1e-4 * scale
     want = torch.nn.functional.normalize(c, dim=1).flatten(2).transpose(1, 2)
     assert hw.shape == (3, 19 * 33, 256) and torch.allclose(hw.cpu(), want, atol=5e-6)
-    # a second call reuses the cached workspaces (their zero borders must have stayed zero)
-    with torch.no_grad():
-        a2 = net(x.to(dev)).cpu()
-    assert torch.equal(a, a2)
+    # a second call reuses the cached workspaces (their zero borders must have stayed zero); single-stream and multi-stream
+    # trunks agree (MIOpen picks other, not bit-reproducible solvers for the stem / strided convolutions of a 1-image slice,
+    # hence a tolerance across lane counts; bit-equality on one stream)
+    lanes0 = ResNet.split_lanes
+    try:
+        with torch.no_grad():
+            ResNet.split_lanes = 1
+            s1 = net(x.to(dev)).cpu()
+            s2 = net(x.to(dev)).cpu()
+            ResNet.split_lanes = 2
+            m1 = net(x.to(dev)).cpu()
+            m2 = net(x.to(dev)).cpu()
+    finally:
+        ResNet.split_lanes = lanes0
+    assert torch.equal(s1, s2)
+    for y in (s1, m1, m2):
+        assert float((a - y).abs().max()) < 1e-5 * scale
 
 
 def test_sharded_tracker_hip_backend_single_rank(dev):
