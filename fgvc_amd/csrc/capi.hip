@@ -50,6 +50,7 @@ void set_conv_debug(int);
 void set_pair_kernel(int);
 void set_pair_debug(int);
 void set_pair_v4_debug(int);
+void set_readout_prune(int);
 void set_pair_v4_products(int);
 int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int32_t*,
                         float*, hipStream_t);
@@ -102,6 +103,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "pair_bf16_debug") == 0) {   // same for fgvc_pair_topk_bf16x4: 1 = no selection, 2 = no MFMA, 4 = no staging
     set_pair_v4_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "readout_prune") == 0) {   // fgvc_softargmax_top5_f32: 1 (default) = pruned read-out first, full scan only for
+    set_readout_prune(value != 0);            // the maps it hands back;  0 = full scan of every map (same results)
     return FGVC_OK;
   }
   set_error("fgvc_set_option: unknown option '%s'", name);
@@ -358,7 +363,7 @@ int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int str
 
 size_t fgvc_softargmax_workspace_bytes(int n_frames, int P) {
   if (n_frames < 0 || P < 0) return 0;
-  return (size_t)n_frames * P * softargmax_bands() * (2 * 5 + 1) * sizeof(float);
+  return (size_t)n_frames * P * (softargmax_bands() * (2 * 5 + 1) + 1) * sizeof(float);
 }
 
 int fgvc_softargmax_top5_f32(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,

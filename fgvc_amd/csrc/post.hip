@@ -187,6 +187,27 @@ __device__ __forceinline__ void src_index(int d, float scale, int in_size, int& 
   l1 = s - (float)i0;
 }
 
+// First-frame label at an image pixel (vanilla_tracker.py:204-221), same bits wherever it is evaluated.
+__device__ __forceinline__ float gauss_value(int x, int y, float cx, float cy, float two_sigma2) {
+  const float dx = (float)x - cx, dy = (float)y - cy;
+  return expf(-fmaf(dx, dx, dy * dy) / two_sigma2);
+}
+
+// One pixel of the upsampled map.  The contraction order is spelled out so that every kernel evaluating a pixel gets the
+// same bits (the pruned read-out and the full scan must agree on values AND ties).
+__device__ __forceinline__ float fine_value(const float* __restrict__ lab, int Hf, int Wf, int P, float sy, float sx,
+                                            int y, int x) {
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_index(y, sy, Hf, y0, y1, ly);
+  src_index(x, sx, Wf, x0, x1, lx);
+  const float v00 = lab[((size_t)y0 * Wf + x0) * P], v01 = lab[((size_t)y0 * Wf + x1) * P];
+  const float v10 = lab[((size_t)y1 * Wf + x0) * P], v11 = lab[((size_t)y1 * Wf + x1) * P];
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float top = fmaf(lx, v01, hx * v00), bot = fmaf(lx, v11, hx * v10);
+  return fmaf(ly, bot, hy * top);
+}
+
 // Stage 1: one workgroup per (label, frame, row band): top-5 candidates + partial sum of its band.
 // Stage 2: one wave per (label, frame) merges the bands and writes the coordinates.
 // (A single workgroup per map leaves half of the 256 CUs idle at 8 frames x 16 labels and runs 0.9 ms.)
@@ -196,13 +217,15 @@ __global__ __launch_bounds__(256) void softargmax_band_kernel(const float* __res
                                                                int P, int h, int w, int nbands,
                                                                const float* __restrict__ gauss_points,
                                                                float two_sigma2, float* __restrict__ part_v,
-                                                               int* __restrict__ part_i, float* __restrict__ part_sum) {
+                                                               int* __restrict__ part_i, float* __restrict__ part_sum,
+                                                               const int* __restrict__ need_scan) {
   constexpr int K = RO_K;
   __shared__ float sv[256 * K];
   __shared__ int si[256 * K];
   __shared__ float ssum[256];
   const int tid = threadIdx.x;
   const int pl = blockIdx.x, f = blockIdx.y, band = blockIdx.z;
+  if (need_scan != nullptr && need_scan[(size_t)f * P + pl] == 0) return;   // the pruned read-out finished this map
   const bool analytic = (gauss_points != nullptr) && f == 0;
   const float* lab = labels + (size_t)f * Hf * Wf * P + pl;
   const float sy = (float)Hf / (float)h, sx = (float)Wf / (float)w;
@@ -220,17 +243,9 @@ __global__ __launch_bounds__(256) void softargmax_band_kernel(const float* __res
     const int y = i / w, x = i - y * w;
     float v;
     if (analytic) {
-      const float dx = (float)x - cx, dy = (float)y - cy;
-      v = expf(-(dx * dx + dy * dy) / two_sigma2);
+      v = gauss_value(x, y, cx, cy, two_sigma2);
     } else {
-      int y0, y1, x0, x1;
-      float ly, lx;
-      src_index(y, sy, Hf, y0, y1, ly);
-      src_index(x, sx, Wf, x0, x1, lx);
-      const float v00 = lab[((size_t)y0 * Wf + x0) * P], v01 = lab[((size_t)y0 * Wf + x1) * P];
-      const float v10 = lab[((size_t)y1 * Wf + x0) * P], v11 = lab[((size_t)y1 * Wf + x1) * P];
-      const float hy = 1.f - ly, hx = 1.f - lx;
-      v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+      v = fine_value(lab, Hf, Wf, P, sy, sx, y, x);
     }
     sum += v;
     if (top.accepts(v, i)) top.insert(v, i);
@@ -267,6 +282,206 @@ __global__ __launch_bounds__(256) void softargmax_band_kernel(const float* __res
       part_i[o * K + j] = top.ix[j];
     }
     part_sum[o] = ssum[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pruned read-out (exact).  A bilinear sample is a convex combination of its four coarse corners, so no upsampled pixel of
+// interval cell (i, j) exceeds B(i, j) = max of those corners.  One workgroup per (frame, label) map:
+//   0. scan the coarse map: maximum M with its cell, minimum (negative labels -> no shortcut for the sum test -> full scan);
+//   1. evaluate the upsampled pixels of the 3 x 3 cells around the maximum; tau = their 5th largest value (a lower bound on
+//      the 5th largest of the whole map);
+//   2. every cell with B >= tau (a few ulps of slack for the rounding of the interpolation) goes on a work list;
+//   3. evaluate the pixels of the listed cells, keep those >= tau;
+//   4. rank the survivors (value desc, higher index first among equals): ranks 0-4 are the map's top 5, identical to a full
+//      scan because every pixel >= tau lies in a listed cell.
+// For non-negative maps "sum == 0" <=> M == 0.  Whatever does not fit (negative labels, flat maps whose lists overflow,
+// fewer than 5 evaluated pixels) sets need_scan[map] and is redone by softargmax_band_kernel: slower, never different.
+// The first frame's analytic Gaussians decrease with distance from the centre: their top 5 are inside a 13 x 13 window.
+// ------------------------------------------------------------------------------------------
+constexpr int RO_CELLS = 1024, RO_CAND = 2048, RO_NEIGH = 1024;
+
+// first fine coordinate whose source interval index is >= cell (lower bound over d in [0, n])
+__device__ __forceinline__ int first_fine_of_cell(int cell, float scale, int in_size, int n) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    int i0, i1;
+    float l1;
+    src_index(mid, scale, in_size, i0, i1, l1);
+    if (i0 >= cell) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __restrict__ labels, int Hf, int Wf, int P,
+                                                                 int h, int w, int nbands,
+                                                                 const float* __restrict__ gauss_points, float two_sigma2,
+                                                                 float* __restrict__ part_v, int* __restrict__ part_i,
+                                                                 float* __restrict__ part_sum, int* __restrict__ need_scan) {
+  constexpr int K = RO_K;
+  __shared__ float red_v[256];
+  __shared__ int red_i[256];
+  __shared__ float red_m[256];
+  __shared__ float neigh[RO_NEIGH];
+  __shared__ int cells[RO_CELLS];
+  __shared__ float cand_v[RO_CAND];
+  __shared__ int cand_i[RO_CAND];
+  __shared__ int n_cells, n_cand;
+  __shared__ float tau_s;
+  const int tid = threadIdx.x;
+  const int pl = blockIdx.x, f = blockIdx.y;
+  const size_t map = (size_t)f * P + pl;
+  const size_t o = map * nbands;
+  const float* lab = labels + (size_t)f * Hf * Wf * P + pl;
+  const float sy = (float)Hf / (float)h, sx = (float)Wf / (float)w;
+  const bool analytic = (gauss_points != nullptr) && f == 0;
+  if (tid == 0) { n_cells = 0; n_cand = 0; tau_s = -INFINITY; }
+  for (int j = tid; j < nbands * K; j += 256) {     // bands other than 0 stay empty unless the full scan redoes the map
+    part_v[o * K + j] = -INFINITY;
+    part_i[o * K + j] = -1;
+  }
+  for (int j = tid; j < nbands; j += 256) part_sum[o + j] = 0.f;
+  __syncthreads();
+  float map_max;
+  if (analytic) {
+    const float cx = gauss_points[2 * pl], cy = gauss_points[2 * pl + 1];
+    const int xc = (int)fminf(fmaxf(rintf(cx), 0.f), (float)(w - 1)), yc = (int)fminf(fmaxf(rintf(cy), 0.f), (float)(h - 1));
+    float mx = -INFINITY;
+    if (tid < 169) {
+      const int y = yc + tid / 13 - 6, x = xc + tid % 13 - 6;
+      if (y >= 0 && y < h && x >= 0 && x < w) {
+        const float v = gauss_value(x, y, cx, cy, two_sigma2);
+        const int slot = atomicAdd(&n_cand, 1);
+        cand_v[slot] = v;
+        cand_i[slot] = y * w + x;
+        mx = v;
+      }
+    }
+    red_v[tid] = mx;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (tid < st) red_v[tid] = fmaxf(red_v[tid], red_v[tid + st]);
+      __syncthreads();
+    }
+    map_max = red_v[0];
+    if (!(map_max >= 0.f) || n_cand < K) {            // NaN centre / degenerate window: let the full scan decide
+      if (tid == 0) need_scan[map] = 1;
+      return;
+    }
+  } else {
+    // 0. coarse scan
+    float mx = -INFINITY, mn = INFINITY;
+    int am = 0;
+    const int n_coarse = Hf * Wf;
+#pragma unroll 4
+    for (int c = tid; c < n_coarse; c += 256) {
+      const float v = lab[(size_t)c * P];
+      if (v > mx) { mx = v; am = c; }
+      mn = (v < mn || v != v) ? v : mn;               // a NaN sticks (then the comparison below fails)
+    }
+    red_v[tid] = mx; red_i[tid] = am; red_m[tid] = mn;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (tid < st) {
+        if (red_v[tid + st] > red_v[tid]) { red_v[tid] = red_v[tid + st]; red_i[tid] = red_i[tid + st]; }
+        const float a = red_m[tid], b = red_m[tid + st];
+        red_m[tid] = (a != a) ? a : ((b < a || b != b) ? b : a);
+      }
+      __syncthreads();
+    }
+    map_max = red_v[0];
+    const int cell0 = red_i[0];
+    if (!(red_m[0] >= 0.f)) {                          // negative or NaN labels: the sum test needs the full scan
+      if (tid == 0) need_scan[map] = 1;
+      return;
+    }
+    if (map_max > 0.f) {
+      // 1. the neighbourhood of the maximum gives tau
+      const int ci = cell0 / Wf, cj = cell0 - ci * Wf;
+      int y_lo = first_fine_of_cell(imax(ci - 1, 0), sy, Hf, h), y_hi = first_fine_of_cell(imin(ci + 2, Hf), sy, Hf, h);
+      int x_lo = first_fine_of_cell(imax(cj - 1, 0), sx, Wf, w), x_hi = first_fine_of_cell(imin(cj + 2, Wf), sx, Wf, w);
+      if (ci + 2 >= Hf) y_hi = h;
+      if (cj + 2 >= Wf) x_hi = w;
+      y_hi = imin(y_hi, y_lo + 32);                     // any subset of pixels gives a valid (lower) tau
+      x_hi = imin(x_hi, x_lo + 32);
+      const int nx = x_hi - x_lo, nn = nx * (y_hi - y_lo);
+      for (int t = tid; t < nn; t += 256) neigh[t] = fine_value(lab, Hf, Wf, P, sy, sx, y_lo + t / nx, x_lo + t % nx);
+      __syncthreads();
+      for (int t = tid; t < nn; t += 256) {
+        const float v = neigh[t];
+        int rank = 0;
+        for (int u = 0; u < nn; ++u) {
+          const float vu = neigh[u];
+          rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
+        }
+        if (rank == K - 1) tau_s = v;
+      }
+      __syncthreads();
+      const float tau = tau_s;
+      if (!(tau > -INFINITY)) {                         // fewer than 5 pixels evaluated
+        if (tid == 0) need_scan[map] = 1;
+        return;
+      }
+      // 2. cells that can hold a pixel >= tau
+      for (int c = tid; c < n_coarse; c += 256) {
+        const int i = c / Wf, j = c - i * Wf;
+        const int i1 = i + (i < Hf - 1 ? 1 : 0), j1 = j + (j < Wf - 1 ? 1 : 0);
+        const float b = fmaxf(fmaxf(lab[((size_t)i * Wf + j) * P], lab[((size_t)i * Wf + j1) * P]),
+                              fmaxf(lab[((size_t)i1 * Wf + j) * P], lab[((size_t)i1 * Wf + j1) * P]));
+        if (b * (1.f + 4e-6f) >= tau) {
+          const int slot = atomicAdd(&n_cells, 1);
+          if (slot < RO_CELLS) cells[slot] = c;
+        }
+      }
+      __syncthreads();
+      const int nc = n_cells;
+      if (nc > RO_CELLS) {
+        if (tid == 0) need_scan[map] = 1;
+        return;
+      }
+      // 3. pixels of the listed cells: four threads per cell, rows dealt round-robin
+      for (int k = tid >> 2; k < nc; k += 64) {
+        const int c = cells[k];
+        const int i = c / Wf, j = c - i * Wf;
+        const int ya = first_fine_of_cell(i, sy, Hf, h), yb = (i + 1 >= Hf) ? h : first_fine_of_cell(i + 1, sy, Hf, h);
+        const int xa = first_fine_of_cell(j, sx, Wf, w), xb = (j + 1 >= Wf) ? w : first_fine_of_cell(j + 1, sx, Wf, w);
+        for (int y = ya + (tid & 3); y < yb; y += 4)
+          for (int x = xa; x < xb; ++x) {
+            const float v = fine_value(lab, Hf, Wf, P, sy, sx, y, x);
+            if (v >= tau) {
+              const int slot = atomicAdd(&n_cand, 1);
+              if (slot < RO_CAND) { cand_v[slot] = v; cand_i[slot] = y * w + x; }
+            }
+          }
+      }
+      __syncthreads();
+      if (n_cand > RO_CAND || n_cand < K) {
+        if (tid == 0) need_scan[map] = 1;
+        return;
+      }
+    }
+  }
+  // 4. rank the candidates; sum flag: any positive number stands for "the map does not sum to zero"
+  if (map_max > 0.f) {
+    const int n = n_cand;
+    for (int t = tid; t < n; t += 256) {
+      const float v = cand_v[t];
+      const int id = cand_i[t];
+      int rank = 0;
+      for (int u = 0; u < n; ++u) {
+        const float vu = cand_v[u];
+        rank += (vu > v || (vu == v && cand_i[u] > id)) ? 1 : 0;
+      }
+      if (rank < K) {
+        part_v[o * K + rank] = v;
+        part_i[o * K + rank] = id;
+      }
+    }
+  }
+  if (tid == 0) {
+    part_sum[o] = map_max > 0.f ? 1.f : 0.f;
+    need_scan[map] = 0;
   }
 }
 
@@ -406,18 +621,25 @@ int gaussian_launch(const float* points, int P, int Hf, int Wf, int stride, floa
 }
 
 int softargmax_bands() { return 8; }
+static int g_readout_prune = 1;
+void set_readout_prune(int v) { g_readout_prune = v; }
 
 int softargmax_launch(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
                       const float* gauss_points, float sigma, double* coords, float* ws, hipStream_t s) {
-  // workspace layout: part_v [maps][bands][5] f32 | part_i [maps][bands][5] i32 | part_sum [maps][bands] f32
+  // workspace layout: part_v [maps][bands][5] f32 | part_i [maps][bands][5] i32 | part_sum [maps][bands] f32 | need_scan [maps] i32
   const int nb = softargmax_bands();
   const size_t maps = (size_t)n_frames * P;
   float* part_v = ws;
   int* part_i = reinterpret_cast<int*>(ws + maps * nb * RO_K);
   float* part_sum = ws + 2 * maps * nb * RO_K;
+  int* need_scan = reinterpret_cast<int*>(ws + maps * nb * (2 * RO_K + 1));
+  if (g_readout_prune) {
+    softargmax_pruned_kernel<<<dim3(P, n_frames), 256, 0, s>>>(labels, Hf, Wf, P, h, w, nb, gauss_points,
+                                                                2.f * sigma * sigma, part_v, part_i, part_sum, need_scan);
+  }
   dim3 grid(P, n_frames, nb);
   softargmax_band_kernel<<<grid, 256, 0, s>>>(labels, Hf, Wf, P, h, w, nb, gauss_points, 2.f * sigma * sigma, part_v,
-                                              part_i, part_sum);
+                                              part_i, part_sum, g_readout_prune ? need_scan : nullptr);
   softargmax_merge_kernel<<<cdiv((int)maps, 64), 64, 0, s>>>(part_v, part_i, part_sum, nb, w, (int)maps, coords);
   FGVC_CHECK_LAUNCH("fgvc_softargmax_top5_f32");
   return FGVC_OK;

@@ -178,7 +178,14 @@ class ResNet(nn.Module):
         if k not in cache:
             mk = {"s": ops.alloc_split_nhwc, "f": ops.alloc_nhwc}
             cache[k] = {nm: mk[nm[0]](N, C, H, W, device) for nm in names}
+            self._cache_filled(device)
         return cache[k]
+
+    @staticmethod
+    def _cache_filled(device):
+        """Cache entries (workspaces with zeroed borders, folded / split weights) are produced on whichever lane's stream
+        asks first and then used by every lane: make them visible to all streams once, when they are made."""
+        torch.cuda.synchronize(device)
 
     @staticmethod
     def _fold(cb: "ConvBN"):
@@ -195,6 +202,7 @@ class ResNet(nn.Module):
         k = ("m",) + key + (x_cl.device,)
         if k not in cache:
             cache[k] = self._fold(cb)
+            self._cache_filled(x_cl.device)
         w, b = cache[k]
         c = cb.conv
         y = F.conv2d(x_cl, w, b, c.stride, c.padding, c.dilation, c.groups)
@@ -203,10 +211,12 @@ class ResNet(nn.Module):
 
     split_lanes = 3                # batch slices run on this many HIP streams at once (1 = everything on the caller's stream)
 
-    def _stage_split(self, si: int, cur):
+    def _stage_split(self, si: int, cur, call):
         """Run stage `si` for the batch slice [lo, hi) of an N-image batch.  `cur` = dict(split = padded split NHWC input,
         f32 = dense NHWC f32 of the same tensor, H, W, lo, hi, N, need_split); returns the same for the stage output plus
-        `full` = the whole-batch dense NHWC f32 buffer the slice was written into."""
+        `full` = the whole-batch dense NHWC f32 buffer the slice was written into.  `call` = per-call state shared by the
+        lanes: main stream, lane streams, the stages whose output the caller receives (`fresh`: those are allocated per
+        call -- a cached workspace would be overwritten by the next forward) and the buffers allocated so far."""
         from .. import ops
         stage = getattr(self, self.res_layers[si])
         cache = self.__dict__.setdefault("_split_cache", {})
@@ -219,6 +229,7 @@ class ResNet(nn.Module):
                                 c2=ops.prepare_conv_split(b.conv2.conv.weight.detach(), b.conv2.bn),
                                 ds=None if (b.downsample is None or b.downsample.conv.stride != (1, 1)) else
                                 ops.prepare_conv_split(b.downsample.conv.weight.detach(), b.downsample.bn)) for b in stage]
+            self._cache_filled(dev)
         full = None
         for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
             Cout = blk.conv2.conv.out_channels
@@ -243,18 +254,28 @@ class ResNet(nn.Module):
                 else:
                     idt = cur["f32"]
                 ops.conv_split(cur["split"], wt["c1"][0], wt["c1"][1], H, W, relu=True, out_split=buf["s_a"])
-            ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt,
-                           out_split=None if last_conv else buf["s_y"], out_f32=buf["f_y"])
             full = bufs["f_y"]
-            cur = dict(cur, split=buf["s_y"], f32=buf["f_y"], H=H, W=W)
+            if bi == len(stage) - 1 and si in call["fresh"]:
+                if si not in call["out"]:
+                    with torch.cuda.stream(call["main"]):                # owned by the caller's stream, like any result
+                        call["out"][si] = ops.alloc_nhwc(N, Cout, H, W, dev)
+                    for st in call["streams"]:
+                        if st is not call["main"]:
+                            st.wait_stream(call["main"])                 # the block's previous life ended on that stream
+                full = call["out"][si]
+            f_y = full[lo:hi]
+            ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt,
+                           out_split=None if last_conv else buf["s_y"], out_f32=f_y)
+            cur = dict(cur, split=buf["s_y"], f32=f_y, H=H, W=W)
         cur["full"] = full
         return cur
 
-    def _trunk(self, x, last: int):
+    def _trunk(self, x, last: int, fresh=()):
         """Stem and stages 0..last.  When every requested stage qualifies (and there is no pooling layer) the whole trunk
         stays in NHWC: the stem in MIOpen on channels_last tensors with BatchNorm folded, ReLU fused into the split, the
         stages on the bf16 pipe.  The batch is cut into `split_lanes` slices that run on separate HIP streams: a layer's
         launch covers the 256 CUs 3.3 times at 8 frames, and the other lane's workgroups fill the tail of each launch.
+        Stage outputs listed in `fresh` are new tensors, the others views of cached workspaces (valid until the next call).
         Returns (list of NCHW outputs of stages < last, last stage output, NHWC flag, H, W)."""
         from .. import ops
         stages = [getattr(self, nm) for nm in self.res_layers[:last + 1]]
@@ -265,6 +286,7 @@ class ResNet(nn.Module):
             cache = self.__dict__.setdefault("_split_cache", {})
             n_lanes = max(1, min(int(self.split_lanes), N))
             main = torch.cuda.current_stream(dev)
+            x_cl = x.contiguous(memory_format=torch.channels_last)       # on the caller's stream, BEFORE the lanes wait for it
             if n_lanes > 1:
                 skey = ("streams", dev, n_lanes)
                 if skey not in cache:
@@ -274,7 +296,6 @@ class ResNet(nn.Module):
                     s.wait_stream(main)
             else:
                 streams = [main]
-            x_cl = x.contiguous(memory_format=torch.channels_last)
             lanes = []
             for li, s in enumerate(streams):
                 lo, hi = li * N // n_lanes, (li + 1) * N // n_lanes
@@ -285,10 +306,11 @@ class ResNet(nn.Module):
                     ops.nhwc_to_split(t, sb["s_x"][lo:hi], relu=True)          # ReLU in place on t + split
                 lanes.append(dict(split=sb["s_x"][lo:hi], f32=t, H=H, W=W, lo=lo, hi=hi, N=N, need_split=True))
             fulls = []
+            call = dict(main=main, streams=streams, fresh=tuple(fresh), out={})
             for i in range(last + 1):
                 for li, s in enumerate(streams):                                 # lanes interleaved stage by stage
                     with torch.cuda.stream(s):
-                        lanes[li] = self._stage_split(i, dict(lanes[li], need_split=i < last))
+                        lanes[li] = self._stage_split(i, dict(lanes[li], need_split=i < last), call)
                 fulls.append(lanes[0]["full"])
             if n_lanes > 1:
                 for s in streams:
@@ -307,7 +329,7 @@ class ResNet(nn.Module):
     def forward(self, x, out_idx=None):
         want = tuple(out_idx) if out_idx is not None else self.out_indices
         last = max(want)                               # later stages cannot influence the outputs
-        earlier, y, nhwc, H, W = self._trunk(x, last)
+        earlier, y, nhwc, H, W = self._trunk(x, last, fresh=want)
         if nhwc:
             y = y.permute(0, 3, 1, 2)                      # channels_last NCHW view of the dense NHWC buffer
         stage_out = earlier + [y]

@@ -60,6 +60,8 @@ const char* fgvc_last_error(void);
  *   "pair_bf16_products" fgvc_pair_topk_bf16x4: 4 (default) = hi*hi + hi*lo + lo*hi + lo*lo, 3 = without lo*lo.
  *   "conv_cot_cap"       fgvc_conv_split_f32: at most this many output channels per workgroup (0 = widest, 64, 128).
  *   "conv_narrow"        fgvc_conv_split_f32, 64-channel tiling: 1 (default) = 4-row tiles, two workgroups per CU.
+ *   "readout_prune"      fgvc_softargmax_top5_f32: 1 (default) = pruned read-out, full scan only for the maps it hands back;
+ *                        0 = full scan of every map.  Identical results.
  *   "pair_debug", "pair_bf16_debug", "corr_debug", "conv_debug": profiling ablations (skip selection / MFMA / staging /
  *                        epilogue, s_memtime probes); results are WRONG when non-zero -- tools/ablate_*.py, tools/time_*.py. */
 int fgvc_set_option(const char* name, int value);
@@ -221,8 +223,10 @@ int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int str
  *   labels [n_frames][Hf*Wf][P];  gauss_points: if non-NULL, frame 0 is read out from the analytic
  *   full-resolution Gaussian of these points instead (vanilla_tracker.py:329,322).
  *   coords [n_frames][P][2] f64 = (x, y); (-1,-1) where the map is all zero.
- *   workspace: caller-owned device scratch of fgvc_softargmax_workspace_bytes(n_frames, P) bytes (each map is
- *   reduced in row bands by many workgroups, then merged). */
+ *   workspace: caller-owned device scratch of fgvc_softargmax_workspace_bytes(n_frames, P) bytes.
+ *   A bilinear sample never exceeds the largest of its four coarse corners, so only the coarse cells whose corner maximum
+ *   reaches the 5th largest value found around the coarse maximum are upsampled (exactly the pixels a full scan would
+ *   select from); maps with negative labels or too flat for the work lists are scanned in full, in row bands. */
 size_t fgvc_softargmax_workspace_bytes(int n_frames, int P);
 int fgvc_softargmax_top5_f32(const float* labels, int n_frames, int Hf, int Wf, int P, int h, int w,
                              const float* gauss_points, float sigma, double* coords, void* workspace,

@@ -247,6 +247,72 @@ def test_readout_golden(dev, golden):
     assert torch.allclose(c2, oc, atol=1e-4), (c2 - oc).abs().max()
 
 
+def _readout_both(ops, labels, Hf, Wf, h, w, **kw):
+    try:
+        ops.set_option("readout_prune", 0)
+        full = ops.softargmax_top5(labels, Hf, Wf, h, w, **kw).cpu()
+    finally:
+        ops.set_option("readout_prune", 1)
+    return ops.softargmax_top5(labels, Hf, Wf, h, w, **kw).cpu(), full
+
+
+def test_readout_pruned_equals_full_scan(dev):
+    """The pruned read-out (only coarse cells whose corner maximum reaches the running 5th value are upsampled) returns the
+    bits of the full scan -- on peaked maps (its fast path) and on everything it must hand back: flat and constant maps,
+    negative labels, all-zero maps, equal twin peaks, plateaus of exact ties, up- and down-sampling, ragged scales."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(21)
+
+    def blobs(Tn, Hf, Wf, P, sigma=1.5, n_peaks=1, equal=False):
+        ys = torch.arange(Hf).view(1, Hf, 1, 1).float()
+        xs = torch.arange(Wf).view(1, 1, Wf, 1).float()
+        lab = torch.zeros(Tn, Hf, Wf, P)
+        for k in range(n_peaks):
+            cy = torch.rand(Tn, 1, 1, P, generator=g) * (Hf - 1)
+            cx = torch.rand(Tn, 1, 1, P, generator=g) * (Wf - 1)
+            amp = 1.0 if equal else float(0.5 + 0.5 * torch.rand(1, generator=g))
+            lab = lab + amp * torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / (2 * sigma ** 2))
+        return lab.reshape(Tn, Hf * Wf, P).contiguous()
+
+    cases = []
+    cases.append(("peaked x4", blobs(3, 30, 54, 16), 30, 54, 120, 214))
+    cases.append(("ragged scale", blobs(2, 30, 54, 5), 30, 54, 119, 213))
+    cases.append(("scale 8", blobs(2, 16, 20, 3, sigma=1.0), 16, 20, 128, 160))
+    cases.append(("no upsampling", blobs(2, 24, 32, 4), 24, 32, 24, 32))
+    cases.append(("downsampling", blobs(2, 24, 32, 4, sigma=3.0), 24, 32, 12, 16))
+    cases.append(("three peaks", blobs(2, 30, 54, 8, n_peaks=3), 30, 54, 120, 216))
+    twin = blobs(1, 30, 54, 4)
+    twin = torch.maximum(twin, twin.reshape(1, 30, 54, 4).flip(1, 2).reshape(1, 30 * 54, 4))    # exact mirror twins
+    cases.append(("equal twin peaks", twin, 30, 54, 120, 216))
+    cases.append(("uniform noise", torch.rand(2, 30 * 54, 6, generator=g), 30, 54, 120, 216))
+    cases.append(("constant", torch.full((1, 30 * 54, 3), 0.25), 30, 54, 120, 216))
+    z = blobs(2, 30, 54, 4)
+    z[0, :, 1] = 0.0
+    z[1, :, 2] = 0.0
+    cases.append(("all-zero maps among peaked ones", z, 30, 54, 120, 216))
+    n = blobs(2, 30, 54, 4)
+    n[0, 7, 0] = -0.5
+    n[1, :, 3] -= 0.1
+    cases.append(("negative labels", n, 30, 54, 120, 216))
+    pl = torch.zeros(1, 30 * 54, 2)
+    pl.view(1, 30, 54, 2)[0, 10:14, 20:26, :] = 1.0                           # plateau: hundreds of exactly equal pixels
+    cases.append(("plateau", pl, 30, 54, 120, 216))
+    one = torch.zeros(1, 30 * 54, 2)
+    one[0, 0, 0] = 1.0                                                        # single hot corner cell
+    one[0, 30 * 54 - 1, 1] = 1.0
+    cases.append(("hot corners", one, 30, 54, 120, 216))
+    for name, lab, Hf, Wf, h, w in cases:
+        pruned, full = _readout_both(ops, lab.to(dev), Hf, Wf, h, w)
+        assert torch.equal(pruned, full), (name, (pruned - full).abs().max())
+    # first frame read out from the analytic Gaussian: centres inside, on the border, outside, far outside (-> -1)
+    pts = torch.tensor([[50.3, 40.7], [0.0, 0.0], [215.0, 119.0], [-3.2, 60.1], [100.5, 140.0], [-400.0, 50.0],
+                        [107.5, 59.5], [300.0, -200.0]])
+    lab = blobs(2, 30, 54, pts.shape[0])
+    pruned, full = _readout_both(ops, lab.to(dev), 30, 54, 120, 216, gauss_points=pts.to(dev))
+    assert torch.equal(pruned, full), (pruned - full).abs().max()
+    assert (pruned[0, 5] == -1).all() and (pruned[0, 7] == -1).all() and (pruned[0, 0] > 0).all()
+
+
 def test_engine_vs_oracle_tracker(dev):
     """whole post-encoder path (plan -> pair top-k -> merge -> sweep -> read-out) vs the oracle driver."""
     from fgvc_amd import engine, ops
@@ -607,6 +673,13 @@ def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev):
     assert torch.equal(s1, s2)
     for y in (s1, m1, m2):
         assert float((a - y).abs().max()) < 1e-5 * scale
+    # what forward returns is the caller's: the next call must not write into it (the trunk's workspaces are cached)
+    with torch.no_grad():
+        r1 = net(x.to(dev))
+        keep = r1.clone()
+        r2 = net(torch.randn(3, 3, 76, 132, generator=g).to(dev))
+        torch.cuda.synchronize()
+    assert torch.equal(r1, keep) and not torch.equal(r1, r2)
 
 
 def test_sharded_tracker_hip_backend_single_rank(dev):
