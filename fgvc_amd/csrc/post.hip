@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void softargmax_band_kernel(const float* __res
 // fewer than 5 evaluated pixels) sets need_scan[map] and is redone by softargmax_band_kernel: slower, never different.
 // The first frame's analytic Gaussians decrease with distance from the centre: their top 5 are inside a 13 x 13 window.
 // ------------------------------------------------------------------------------------------
-constexpr int RO_CELLS = 1024, RO_CAND = 2048, RO_NEIGH = 1024;
+constexpr int RO_CELLS = 1024, RO_CAND = 2048, RO_NEIGH = 1024, RO_BLOCK = 1024;
 
 // first fine coordinate whose source interval index is >= cell (lower bound over d in [0, n])
 __device__ __forceinline__ int first_fine_of_cell(int cell, float scale, int in_size, int n) {
@@ -314,15 +314,15 @@ __device__ __forceinline__ int first_fine_of_cell(int cell, float scale, int in_
   return lo;
 }
 
-__global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __restrict__ labels, int Hf, int Wf, int P,
+__global__ __launch_bounds__(RO_BLOCK) void softargmax_pruned_kernel(const float* __restrict__ labels, int Hf, int Wf, int P,
                                                                  int h, int w, int nbands,
                                                                  const float* __restrict__ gauss_points, float two_sigma2,
                                                                  float* __restrict__ part_v, int* __restrict__ part_i,
                                                                  float* __restrict__ part_sum, int* __restrict__ need_scan) {
   constexpr int K = RO_K;
-  __shared__ float red_v[256];
-  __shared__ int red_i[256];
-  __shared__ float red_m[256];
+  __shared__ float red_v[RO_BLOCK];
+  __shared__ int red_i[RO_BLOCK];
+  __shared__ float red_m[RO_BLOCK];
   __shared__ float neigh[RO_NEIGH];
   __shared__ int cells[RO_CELLS];
   __shared__ float cand_v[RO_CAND];
@@ -337,11 +337,11 @@ __global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __r
   const float sy = (float)Hf / (float)h, sx = (float)Wf / (float)w;
   const bool analytic = (gauss_points != nullptr) && f == 0;
   if (tid == 0) { n_cells = 0; n_cand = 0; tau_s = -INFINITY; }
-  for (int j = tid; j < nbands * K; j += 256) {     // bands other than 0 stay empty unless the full scan redoes the map
+  for (int j = tid; j < nbands * K; j += RO_BLOCK) {     // bands other than 0 stay empty unless the full scan redoes the map
     part_v[o * K + j] = -INFINITY;
     part_i[o * K + j] = -1;
   }
-  for (int j = tid; j < nbands; j += 256) part_sum[o + j] = 0.f;
+  for (int j = tid; j < nbands; j += RO_BLOCK) part_sum[o + j] = 0.f;
   __syncthreads();
   float map_max;
   if (analytic) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __r
     }
     red_v[tid] = mx;
     __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
+    for (int st = RO_BLOCK / 2; st >= 1; st >>= 1) {
       if (tid < st) red_v[tid] = fmaxf(red_v[tid], red_v[tid + st]);
       __syncthreads();
     }
@@ -374,15 +374,26 @@ __global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __r
     float mx = -INFINITY, mn = INFINITY;
     int am = 0;
     const int n_coarse = Hf * Wf;
-#pragma unroll 4
-    for (int c = tid; c < n_coarse; c += 256) {
-      const float v = lab[(size_t)c * P];
-      if (v > mx) { mx = v; am = c; }
-      mn = (v < mn || v != v) ? v : mn;               // a NaN sticks (then the comparison below fails)
+    for (int c0 = tid; c0 < n_coarse; c0 += RO_BLOCK * 4) {       // four loads in flight per thread: the scan is latency-bound
+      float v4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * RO_BLOCK;
+        v4[u] = lab[(size_t)imin(c, n_coarse - 1) * P];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * RO_BLOCK;
+        const float v = v4[u];
+        if (c < n_coarse) {
+          if (v > mx) { mx = v; am = c; }
+          mn = (v < mn || v != v) ? v : mn;           // a NaN sticks (then the comparison below fails)
+        }
+      }
     }
     red_v[tid] = mx; red_i[tid] = am; red_m[tid] = mn;
     __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
+    for (int st = RO_BLOCK / 2; st >= 1; st >>= 1) {
       if (tid < st) {
         if (red_v[tid + st] > red_v[tid]) { red_v[tid] = red_v[tid + st]; red_i[tid] = red_i[tid + st]; }
         const float a = red_m[tid], b = red_m[tid + st];
@@ -406,9 +417,9 @@ __global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __r
       y_hi = imin(y_hi, y_lo + 32);                     // any subset of pixels gives a valid (lower) tau
       x_hi = imin(x_hi, x_lo + 32);
       const int nx = x_hi - x_lo, nn = nx * (y_hi - y_lo);
-      for (int t = tid; t < nn; t += 256) neigh[t] = fine_value(lab, Hf, Wf, P, sy, sx, y_lo + t / nx, x_lo + t % nx);
+      for (int t = tid; t < nn; t += RO_BLOCK) neigh[t] = fine_value(lab, Hf, Wf, P, sy, sx, y_lo + t / nx, x_lo + t % nx);
       __syncthreads();
-      for (int t = tid; t < nn; t += 256) {
+      for (int t = tid; t < nn; t += RO_BLOCK) {
         const float v = neigh[t];
         int rank = 0;
         for (int u = 0; u < nn; ++u) {
@@ -424,14 +435,23 @@ __global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __r
         return;
       }
       // 2. cells that can hold a pixel >= tau
-      for (int c = tid; c < n_coarse; c += 256) {
-        const int i = c / Wf, j = c - i * Wf;
-        const int i1 = i + (i < Hf - 1 ? 1 : 0), j1 = j + (j < Wf - 1 ? 1 : 0);
-        const float b = fmaxf(fmaxf(lab[((size_t)i * Wf + j) * P], lab[((size_t)i * Wf + j1) * P]),
-                              fmaxf(lab[((size_t)i1 * Wf + j) * P], lab[((size_t)i1 * Wf + j1) * P]));
-        if (b * (1.f + 4e-6f) >= tau) {
-          const int slot = atomicAdd(&n_cells, 1);
-          if (slot < RO_CELLS) cells[slot] = c;
+      for (int c0 = tid; c0 < n_coarse; c0 += RO_BLOCK * 4) {
+        float b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = imin(c0 + u * RO_BLOCK, n_coarse - 1);
+          const int i = c / Wf, j = c - i * Wf;
+          const int i1 = i + (i < Hf - 1 ? 1 : 0), j1 = j + (j < Wf - 1 ? 1 : 0);
+          b4[u] = fmaxf(fmaxf(lab[((size_t)i * Wf + j) * P], lab[((size_t)i * Wf + j1) * P]),
+                        fmaxf(lab[((size_t)i1 * Wf + j) * P], lab[((size_t)i1 * Wf + j1) * P]));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + u * RO_BLOCK;
+          if (c < n_coarse && b4[u] * (1.f + 4e-6f) >= tau) {
+            const int slot = atomicAdd(&n_cells, 1);
+            if (slot < RO_CELLS) cells[slot] = c;
+          }
         }
       }
       __syncthreads();
@@ -441,7 +461,7 @@ __global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __r
         return;
       }
       // 3. pixels of the listed cells: four threads per cell, rows dealt round-robin
-      for (int k = tid >> 2; k < nc; k += 64) {
+      for (int k = tid >> 2; k < nc; k += RO_BLOCK / 4) {
         const int c = cells[k];
         const int i = c / Wf, j = c - i * Wf;
         const int ya = first_fine_of_cell(i, sy, Hf, h), yb = (i + 1 >= Hf) ? h : first_fine_of_cell(i + 1, sy, Hf, h);
@@ -465,7 +485,7 @@ __global__ __launch_bounds__(256) void softargmax_pruned_kernel(const float* __r
   // 4. rank the candidates; sum flag: any positive number stands for "the map does not sum to zero"
   if (map_max > 0.f) {
     const int n = n_cand;
-    for (int t = tid; t < n; t += 256) {
+    for (int t = tid; t < n; t += RO_BLOCK) {
       const float v = cand_v[t];
       const int id = cand_i[t];
       int rank = 0;
@@ -634,7 +654,7 @@ int softargmax_launch(const float* labels, int n_frames, int Hf, int Wf, int P, 
   float* part_sum = ws + 2 * maps * nb * RO_K;
   int* need_scan = reinterpret_cast<int*>(ws + maps * nb * (2 * RO_K + 1));
   if (g_readout_prune) {
-    softargmax_pruned_kernel<<<dim3(P, n_frames), 256, 0, s>>>(labels, Hf, Wf, P, h, w, nb, gauss_points,
+    softargmax_pruned_kernel<<<dim3(P, n_frames), RO_BLOCK, 0, s>>>(labels, Hf, Wf, P, h, w, nb, gauss_points,
                                                                 2.f * sigma * sigma, part_v, part_i, part_sum, need_scan);
   }
   dim3 grid(P, n_frames, nb);
