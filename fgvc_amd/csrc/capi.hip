@@ -40,6 +40,8 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
                       int, int, int, int, hipStream_t);
+int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
+                   int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, hipStream_t);
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
@@ -51,6 +53,7 @@ void set_pair_kernel(int);
 void set_pair_debug(int);
 void set_pair_v4_debug(int);
 void set_readout_prune(int);
+void set_conv_s2_debug(int);
 void set_pair_v4_products(int);
 int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int32_t*,
                         float*, hipStream_t);
@@ -103,6 +106,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "pair_bf16_debug") == 0) {   // same for fgvc_pair_topk_bf16x4: 1 = no selection, 2 = no MFMA, 4 = no staging
     set_pair_v4_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "conv_s2_debug") == 0) {   // profiling ablations of fgvc_conv_s2_split_f32; results are wrong when non-zero
+    set_conv_s2_debug(value);
     return FGVC_OK;
   }
   if (strcmp(name, "readout_prune") == 0) {   // fgvc_softargmax_top5_f32: 1 (default) = pruned read-out first, full scan only for
@@ -333,6 +340,24 @@ int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias,
   FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
   return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, (hipStream_t)stream);
+}
+
+int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
+                           int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu, void* stream) {
+  FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: bad shape");
+  FGVC_REQUIRE(KS == 1 || KS == 3, FGVC_ERR_UNSUPPORTED, "fgvc_conv_s2_split_f32: kernel size %d (1 or 3, stride 2)", KS);
+  FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, FGVC_ERR_UNSUPPORTED,
+               "fgvc_conv_s2_split_f32: Cin=%d and Cout=%d must be multiples of 32", Cin, Cout);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;     // both forms: floor((H + 2 pad - KS) / 2) + 1 with pad = KS / 2
+  FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
+  FGVC_REQUIRE(!y_split || conv_pad_ok(Ho, Wo, Hop, Wop), FGVC_ERR_INVALID_ARG,
+               "fgvc_conv_s2_split_f32: padded output size %dx%d too small for %dx%d", Hop, Wop, Ho, Wo);
+  FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(y_split) && aligned16(y_f32),
+               FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: 16-byte alignment required");
+  FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: in-place not supported");
+  if (N == 0) return FGVC_OK;
+  return conv_s2_launch(x, w, bias, y_split, y_f32, N, Hp, Wp, Cin, Cout, KS, Ho, Wo, Hop, Wop, relu, (hipStream_t)stream);
 }
 
 int fgvc_nhwc_to_split_f32(float* x, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, int relu, void* stream) {

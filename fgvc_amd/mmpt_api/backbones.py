@@ -134,6 +134,7 @@ class ResNet(nn.Module):
                     nn.init.constant_(m.conv3.bn.weight, 0)
 
     # ---- stages on the bf16 matrix pipe (fgvc_conv_split_f32) ------------------------------------------------------
+    use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -213,7 +214,7 @@ class ResNet(nn.Module):
 
     def _stage_split(self, si: int, cur, call):
         """Run stage `si` for the batch slice [lo, hi) of an N-image batch.  `cur` = dict(split = padded split NHWC input,
-        f32 = dense NHWC f32 of the same tensor, H, W, lo, hi, N, need_split); returns the same for the stage output plus
+        f32 = dense NHWC f32 of the same tensor, H, W, lo, hi, N, need_split, need_f32); returns the same for the stage output plus
         `full` = the whole-batch dense NHWC f32 buffer the slice was written into.  `call` = per-call state shared by the
         lanes: main stream, lane streams, the stages whose output the caller receives (`fresh`: those are allocated per
         call -- a cached workspace would be overwritten by the next forward) and the buffers allocated so far."""
@@ -224,20 +225,31 @@ class ResNet(nn.Module):
         lo, hi, N = cur["lo"], cur["hi"], cur["N"]
         wkey = ("w", si, dev)
         if wkey not in cache:
-            cache[wkey] = [dict(c1=None if b.conv1.conv.stride != (1, 1) else
-                                ops.prepare_conv_split(b.conv1.conv.weight.detach(), b.conv1.bn),
+            prep = {(1, 1): ops.prepare_conv_split, (2, 2): ops.prepare_conv_s2}
+            cache[wkey] = [dict(c1=None if b.conv1.conv.stride not in prep else
+                                prep[b.conv1.conv.stride](b.conv1.conv.weight.detach(), b.conv1.bn),
                                 c2=ops.prepare_conv_split(b.conv2.conv.weight.detach(), b.conv2.bn),
-                                ds=None if (b.downsample is None or b.downsample.conv.stride != (1, 1)) else
-                                ops.prepare_conv_split(b.downsample.conv.weight.detach(), b.downsample.bn)) for b in stage]
+                                ds=None if (b.downsample is None or b.downsample.conv.stride not in prep) else
+                                prep[b.downsample.conv.stride](b.downsample.conv.weight.detach(), b.downsample.bn))
+                           for b in stage]
             self._cache_filled(dev)
         full = None
         for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
             Cout = blk.conv2.conv.out_channels
             H, W = cur["H"], cur["W"]
             last_conv = bi == len(stage) - 1 and not cur["need_split"]        # nobody reads the split form of the trunk output
-            if blk.conv1.conv.stride != (1, 1):
-                # strided 3x3 and strided projection in MIOpen, NHWC in and out (the dense f32 tensors ARE channels_last
-                # tensors), then back onto the bf16 pipe: ReLU + split in one pass, the projection is the identity as it lies
+            if blk.conv1.conv.stride == (2, 2) and self.use_s2_conv:
+                # stride-2 3x3 and stride-2 projection on the bf16 pipe as well (fgvc_conv_s2_split_f32)
+                Hi, Wi = H, W
+                H, W = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+                bufs = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
+                buf = {k: v[lo:hi] for k, v in bufs.items()}
+                ops.conv_s2_split(cur["split"], wt["ds"][0], wt["ds"][1], Hi, Wi, relu=False, out_f32=buf["f_idt"])
+                idt = buf["f_idt"]
+                ops.conv_s2_split(cur["split"], wt["c1"][0], wt["c1"][1], Hi, Wi, relu=True, out_split=buf["s_a"])
+            elif blk.conv1.conv.stride != (1, 1):
+                # other strides: strided 3x3 and strided projection in MIOpen, NHWC in and out (the dense f32 tensors ARE
+                # channels_last tensors), then back onto the bf16 pipe: ReLU + split in one pass
                 x_cl = cur["f32"].permute(0, 3, 1, 2)
                 t1 = self._miopen_nhwc((si, bi, "c1"), blk.conv1, x_cl)
                 idt = self._miopen_nhwc((si, bi, "ds"), blk.downsample, x_cl)
@@ -264,8 +276,9 @@ class ResNet(nn.Module):
                             st.wait_stream(call["main"])                 # the block's previous life ended on that stream
                 full = call["out"][si]
             f_y = full[lo:hi]
+            skip_f32 = bi == len(stage) - 1 and not cur["need_f32"]       # nobody reads the f32 form of this stage's output
             ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt,
-                           out_split=None if last_conv else buf["s_y"], out_f32=f_y)
+                           out_split=None if last_conv else buf["s_y"], out_f32=None if skip_f32 else f_y)
             cur = dict(cur, split=buf["s_y"], f32=f_y, H=H, W=W)
         cur["full"] = full
         return cur
@@ -308,9 +321,14 @@ class ResNet(nn.Module):
             fulls = []
             call = dict(main=main, streams=streams, fresh=tuple(fresh), out={})
             for i in range(last + 1):
+                need_f32 = True           # the stage output in f32: returned, or the next block's identity / MIOpen input
+                if i < last and i not in call["fresh"]:
+                    nb = stages[i + 1][0]
+                    st = nb.conv1.conv.stride
+                    need_f32 = nb.downsample is None or not (st == (1, 1) or (st == (2, 2) and self.use_s2_conv))
                 for li, s in enumerate(streams):                                 # lanes interleaved stage by stage
                     with torch.cuda.stream(s):
-                        lanes[li] = self._stage_split(i, dict(lanes[li], need_split=i < last), call)
+                        lanes[li] = self._stage_split(i, dict(lanes[li], need_split=i < last, need_f32=need_f32), call)
                 fulls.append(lanes[0]["full"])
             if n_lanes > 1:
                 for s in streams:

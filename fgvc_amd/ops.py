@@ -349,6 +349,18 @@ def prepare_conv_split(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tupl
     return packed, bias
 
 
+def prepare_conv_s2(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Folded weights for fgvc_conv_s2_split_f32: prepare_conv_split's values in MFMA-operand order
+    [KS*KS][Cin/32][Cout/32][hi k0-15 | hi k16-31 | lo k0-15 | lo k16-31][lane = 32 * (k >> 3 & 1) + cout % 32][k & 7]
+    (one contiguous KiB per operand); returns (w int16, bias f32 [Cout])."""
+    packed, bias = prepare_conv_split(weight, bn)                      # [tap][chunk][Cout][part 2 x 32 ci]
+    T, nch, Cout, _ = packed.shape
+    assert Cout % 32 == 0
+    v = packed.view(T, nch, Cout // 32, 32, 2, 2, 2, 8)                # [t][c][ct][n][part][s][h][j]
+    v = v.permute(0, 1, 2, 4, 5, 6, 3, 7).contiguous()                 # [t][c][ct][part][s][h][n][j]
+    return v.view(T, nch, Cout // 32, 4, 64, 8), bias
+
+
 def alloc_split_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
     Hp, Wp = conv_pad_dims(H, W)
     return torch.zeros((N, Hp, Wp, C // 32, 64), device=device, dtype=torch.int16)
@@ -401,6 +413,26 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
             assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv_split buffer"
     _lib.call("fgvc_conv_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
               N, H, W, Hp, Wp, nch * 32, Cout, 3 if taps == 9 else 1, int(relu), _stream(x_split))
+
+
+def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
+                  out_split: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None) -> None:
+    """3x3 / stride 2 / pad 1 or 1x1 / stride 2 convolution + bias (+ ReLU) on the bf16 pipe (fgvc_conv_s2_split_f32).
+    x_split: padded split NHWC of the (N, H, W) input; w, bias from prepare_conv_s2; outputs for the
+    ((H-1)//2+1, (W-1)//2+1) result: out_split (padded split NHWC) and / or out_f32 (dense NHWC f32)."""
+    x_split = _chk(x_split, torch.int16, "x_split")
+    N, Hp, Wp, nch, _ = x_split.shape
+    taps, nch_w, n_ct = w.shape[:3]
+    Cout = n_ct * 32
+    assert tuple(w.shape[3:]) == (4, 64, 8) and nch_w == nch and taps in (1, 9) and bias.shape == (Cout,)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hop, Wop = conv_pad_dims(Ho, Wo)
+    if out_split is not None:
+        assert out_split.dtype == torch.int16 and tuple(out_split.shape) == (N, Hop, Wop, Cout // 32, 64) and out_split.is_contiguous()
+    if out_f32 is not None:
+        assert out_f32.dtype == torch.float32 and tuple(out_f32.shape) == (N, Ho, Wo, Cout) and out_f32.is_contiguous()
+    _lib.call("fgvc_conv_s2_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(out_split), _ptr(out_f32), N, H, W, Hp, Wp,
+              nch * 32, Cout, 3 if taps == 9 else 1, Hop, Wop, int(relu), _stream(x_split))
 
 
 def normalize_nhwc(x: torch.Tensor, normalize: bool = True) -> torch.Tensor:

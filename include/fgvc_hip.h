@@ -62,7 +62,7 @@ const char* fgvc_last_error(void);
  *   "conv_narrow"        fgvc_conv_split_f32, 64-channel tiling: 1 (default) = 4-row tiles, two workgroups per CU.
  *   "readout_prune"      fgvc_softargmax_top5_f32: 1 (default) = pruned read-out, full scan only for the maps it hands back;
  *                        0 = full scan of every map.  Identical results.
- *   "pair_debug", "pair_bf16_debug", "corr_debug", "conv_debug": profiling ablations (skip selection / MFMA / staging /
+ *   "pair_debug", "pair_bf16_debug", "corr_debug", "conv_debug", "conv_s2_debug": profiling ablations (skip selection / MFMA / staging /
  *                        epilogue, s_memtime probes); results are WRONG when non-zero -- tools/ablate_*.py, tools/time_*.py. */
 int fgvc_set_option(const char* name, int value);
 
@@ -208,6 +208,17 @@ int fgvc_nhwc_to_split_f32(float* x, uint16_t* out_split, int N, int C, int H, i
 int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                         uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
                         int KS, int relu, void* stream);
+/* The stride-2 members of the same family: the 3x3 / stride 2 / zero padding 1 convolution that opens a down-sampling
+ * stage and its 1x1 / stride 2 projection (resnet.py:54-76 conv1 of the first BasicBlock, :288-296 downsample), BatchNorm
+ * folded, + bias (+ ReLU).  x: padded split NHWC of the H x W input; outputs for the Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1)
+ * result: y_split (padded split NHWC, Hop x Wop) and / or y_f32 (dense NHWC f32); bias as for fgvc_conv_split_f32;
+ * weights: the same folded (hi, lo) values in MFMA-operand order, one contiguous KiB per operand:
+ *   w[KS*KS][Cin/32][Cout/32][hi k 0-15 | hi k 16-31 | lo k 0-15 | lo k 16-31][lane = 32 * (k >> 3 & 1) + cout % 32][k & 7]
+ *   (k = input channel within the 32-channel chunk; fgvc_amd/ops.py: prepare_conv_s2).
+ * Cin % 32 == 0, Cout % 32 == 0, KS in {1, 3}. */
+int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
+                           int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu,
+                           void* stream);
 /* dense NHWC f32 -> [n][H*W][C] f32, rows L2-normalised if `normalize` (the output layout of
  * fgvc_normalize_chw_to_hwc_f32) */
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream);

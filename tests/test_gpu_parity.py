@@ -621,6 +621,52 @@ def test_conv_split_vs_torch(dev, case):
     assert torch.allclose(nf.cpu(), want, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 128, 3, 24, 43, True), (1, 64, 128, 1, 24, 43, False), (2, 128, 256, 3, 17, 66, True),
+                                  (1, 128, 256, 1, 17, 66, False), (1, 32, 96, 3, 9, 130, True), (1, 64, 64, 3, 5, 5, False),
+                                  (1, 64, 32, 1, 8, 7, False)])
+def test_conv_s2_split_vs_torch(dev, case):
+    """stride-2 3x3 (pad 1) and 1x1 (pad 0) conv -> BN(eval) [-> ReLU] against torch in float64: odd and even sizes (the last
+    input row / column is or is not read), one and several chunk groups (Cin 32 / 64 / 128), ragged output tiles, Cout
+    that does not fill the workgroup's 128 channels, inputs whose padded buffer is smaller than the tiles' reach."""
+    import torch.nn.functional as F
+    from fgvc_amd import ops
+    N, Cin, Cout, KS, H, W, relu = case
+    g = torch.Generator().manual_seed(100 + sum(int(v) for v in case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    wt = torch.randn(Cout, Cin, KS, KS, generator=g) * (2.0 / (Cin * KS * KS)) ** 0.5
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    bn.weight.data = torch.rand(Cout, generator=g) + 0.5
+    bn.bias.data = torch.randn(Cout, generator=g) * 0.1
+    bn.running_mean = torch.randn(Cout, generator=g) * 0.1
+    bn.running_var = torch.rand(Cout, generator=g) + 0.5
+    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=KS // 2)
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double().view(1, -1, 1, 1)
+    ref = (ref - bn.running_mean.double().view(1, -1, 1, 1)) * sc + bn.bias.double().view(1, -1, 1, 1)
+    if relu:
+        ref = ref.clamp_min(0)
+    ref = ref.detach()
+    Ho, Wo = ref.shape[-2:]
+    assert (Ho, Wo) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    wp, bias = ops.prepare_conv_s2(wt.to(dev), bn.to(dev))
+    xs = ops.nchw_to_split_nhwc(x.to(dev))
+    out_s = ops.alloc_split_nhwc(N, Cout, Ho, Wo, dev)
+    out_f = ops.alloc_nhwc(N, Cout, Ho, Wo, dev)
+    ops.conv_s2_split(xs, wp, bias, H, W, relu, out_split=out_s, out_f32=out_f)
+    got_f = _nhwc_to_nchw(out_f.cpu()).double()
+    got_s = _split_to_nchw(out_s.cpu(), Ho, Wo).double()
+    scale = float(ref.abs().max())
+    assert float((got_f - ref).abs().max()) < 2e-5 * scale, float((got_f - ref).abs().max()) / scale
+    assert float((got_s - ref).abs().max()) < 3e-5 * scale
+    assert int(out_s[:, :, Wo + 1:].abs().max()) == 0 and int(out_s[:, Ho + 1:].abs().max()) == 0
+    assert int(out_s[:, 0].abs().max()) == 0 and int(out_s[:, :, 0].abs().max()) == 0
+    # either output alone
+    only_f = ops.alloc_nhwc(N, Cout, Ho, Wo, dev)
+    ops.conv_s2_split(xs, wp, bias, H, W, relu, out_f32=only_f)
+    only_s = ops.alloc_split_nhwc(N, Cout, Ho, Wo, dev)
+    ops.conv_s2_split(xs, wp, bias, H, W, relu, out_split=only_s)
+    assert torch.equal(only_f, out_f) and torch.equal(only_s, out_s)
+
+
 def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev):
     """A1: layer 3 of the ResNet-18 trunk on fgvc_conv_split_f32 (the default on the GPU) against the same network with
     every convolution in MIOpen, against the CPU oracle network, and through the tracker's forward_hwc fast path."""
@@ -671,8 +717,8 @@ def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev):
     finally:
         ResNet.split_lanes = lanes0
     assert torch.equal(s1, s2)
-    for y in (s1, m1, m2):
-        assert float((a - y).abs().max()) < 1e-5 * scale
+    for y in (s1, m1, m2):                                # every lane count: as close to the all-MIOpen network as `a` is
+        assert float((y - b).abs().max()) < 2e-5 * scale and float((a - y).abs().max()) < 3e-5 * scale
     # what forward returns is the caller's: the next call must not write into it (the trunk's workspaces are cached)
     with torch.no_grad():
         r1 = net(x.to(dev))
