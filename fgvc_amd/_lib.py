@@ -31,6 +31,7 @@ SIGNATURES = {
     "fgvc_nchw_to_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_s2_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_stem7_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_nhwc_to_split_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_merge_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),

@@ -42,6 +42,7 @@ int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const floa
                       int, int, int, int, hipStream_t);
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
                    int, int, hipStream_t);
+int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, hipStream_t);
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
@@ -358,6 +359,19 @@ int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bi
   FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
   return conv_s2_launch(x, w, bias, y_split, y_f32, N, Hp, Wp, Cin, Cout, KS, Ho, Wo, Hop, Wop, relu, (hipStream_t)stream);
+}
+
+int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H,
+                         int W, int Hop, int Wop, int relu, void* stream) {
+  FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_stem7_split_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_stem7_split_f32: bad shape");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;     // floor((H + 6 - 7) / 2) + 1
+  FGVC_REQUIRE(!y_split || conv_pad_ok(Ho, Wo, Hop, Wop), FGVC_ERR_INVALID_ARG,
+               "fgvc_stem7_split_f32: padded output size %dx%d too small for %dx%d", Hop, Wop, Ho, Wo);
+  FGVC_REQUIRE(aligned16(w) && aligned16(bias) && aligned16(y_split) && aligned16(y_f32) && ((uintptr_t)x & 3) == 0,
+               FGVC_ERR_INVALID_ARG, "fgvc_stem7_split_f32: alignment (16 bytes; 4 for x)");
+  if (N == 0) return FGVC_OK;
+  return stem7_launch(x, w, bias, y_split, y_f32, N, H, W, Ho, Wo, Hop, Wop, relu, (hipStream_t)stream);
 }
 
 int fgvc_nhwc_to_split_f32(float* x, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, int relu, void* stream) {

@@ -134,6 +134,7 @@ class ResNet(nn.Module):
                     nn.init.constant_(m.conv3.bn.weight, 0)
 
     # ---- stages on the bf16 matrix pipe (fgvc_conv_split_f32) ------------------------------------------------------
+    use_stem7 = True               # 7x7 stride-2 stem on fgvc_stem7_split_f32 (False: MIOpen f32 + ReLU/split pass)
     use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
 
@@ -299,7 +300,17 @@ class ResNet(nn.Module):
             cache = self.__dict__.setdefault("_split_cache", {})
             n_lanes = max(1, min(int(self.split_lanes), N))
             main = torch.cuda.current_stream(dev)
-            x_cl = x.contiguous(memory_format=torch.channels_last)       # on the caller's stream, BEFORE the lanes wait for it
+            c1 = self.conv1.conv
+            stem7 = None
+            if (self.use_stem7 and c1.kernel_size == (7, 7) and c1.stride == (2, 2) and c1.padding == (3, 3)
+                    and c1.in_channels == 3 and c1.out_channels == 64 and c1.dilation == (1, 1) and self.conv1.relu):
+                if ("stem7", dev) not in cache:
+                    cache[("stem7", dev)] = ops.prepare_stem7(c1.weight.detach(), self.conv1.bn)
+                    self._cache_filled(dev)
+                stem7 = cache[("stem7", dev)]
+                x = x.contiguous()
+            # on the caller's stream, BEFORE the lanes wait for it
+            x_cl = None if stem7 else x.contiguous(memory_format=torch.channels_last)
             if n_lanes > 1:
                 skey = ("streams", dev, n_lanes)
                 if skey not in cache:
@@ -313,10 +324,16 @@ class ResNet(nn.Module):
             for li, s in enumerate(streams):
                 lo, hi = li * N // n_lanes, (li + 1) * N // n_lanes
                 with torch.cuda.stream(s):
-                    t = self._miopen_nhwc(("stem",), self.conv1, x_cl[lo:hi])   # (n,H,W,64)
-                    _, H, W, C0 = t.shape
-                    sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x",))
-                    ops.nhwc_to_split(t, sb["s_x"][lo:hi], relu=True)          # ReLU in place on t + split
+                    if stem7:                                                   # stem on the bf16 pipe, from the NCHW frames
+                        H, W, C0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1, 64
+                        sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x", "f_x"))
+                        t = sb["f_x"][lo:hi]
+                        ops.stem7_split(x[lo:hi], stem7[0], stem7[1], True, out_split=sb["s_x"][lo:hi], out_f32=t)
+                    else:
+                        t = self._miopen_nhwc(("stem",), self.conv1, x_cl[lo:hi])   # (n,H,W,64)
+                        _, H, W, C0 = t.shape
+                        sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x",))
+                        ops.nhwc_to_split(t, sb["s_x"][lo:hi], relu=True)          # ReLU in place on t + split
                 lanes.append(dict(split=sb["s_x"][lo:hi], f32=t, H=H, W=W, lo=lo, hi=hi, N=N, need_split=True))
             fulls = []
             call = dict(main=main, streams=streams, fresh=tuple(fresh), out={})

@@ -361,6 +361,24 @@ def prepare_conv_s2(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[t
     return v.view(T, nch, Cout // 32, 4, 64, 8), bias
 
 
+def prepare_stem7(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Folded weights (64, 3, 7, 7) for fgvc_stem7_split_f32: per kernel row ky a K block of 32 with k = 4 kx + c (c = 3
+    and kx = 7 are zero), as (hi, lo) bf16 in MFMA-operand order [7][2 k-steps][2 output tiles][hi | lo][lane][8];
+    returns (w int16, bias f32 [64])."""
+    Cout, Cin, KS, _ = weight.shape
+    assert (Cout, Cin, KS) == (64, 3, 7)
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float()
+    w = weight.float() * scale.view(-1, 1, 1, 1)
+    bias = (bn.bias - bn.running_mean * scale).float().contiguous()
+    k = torch.zeros((Cout, 7, 8, 4), device=w.device, dtype=torch.float32)        # [co][ky][kx (8)][c (4)]
+    k[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    k = k.reshape(2, 32, 7, 2, 2, 8)                                                # [ct][n][ky][s][h][j]
+    k = k.permute(2, 3, 0, 4, 1, 5).contiguous()                                    # [ky][s][ct][h][n][j]
+    hi, lo = _split_pair(k)
+    packed = torch.stack([hi, lo], dim=3).contiguous()                              # [ky][s][ct][part][h][n][j]
+    return packed.view(torch.int16).view(7, 2, 2, 2, 64, 8), bias
+
+
 def alloc_split_nhwc(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
     Hp, Wp = conv_pad_dims(H, W)
     return torch.zeros((N, Hp, Wp, C // 32, 64), device=device, dtype=torch.int16)
@@ -433,6 +451,23 @@ def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H:
         assert out_f32.dtype == torch.float32 and tuple(out_f32.shape) == (N, Ho, Wo, Cout) and out_f32.is_contiguous()
     _lib.call("fgvc_conv_s2_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(out_split), _ptr(out_f32), N, H, W, Hp, Wp,
               nch * 32, Cout, 3 if taps == 9 else 1, Hop, Wop, int(relu), _stream(x_split))
+
+
+def stem7_split(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, relu: bool = True,
+                out_split: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None) -> None:
+    """7x7 / stride 2 / pad 3 stem (3 -> 64 channels) + bias (+ ReLU) on the bf16 pipe (fgvc_stem7_split_f32): f32 NCHW
+    frames (N, 3, H, W) -> out_f32 (N, Ho, Wo, 64) dense NHWC f32 and / or out_split (padded split NHWC)."""
+    x = _chk(x, torch.float32, "x")
+    N, C, H, W = x.shape
+    assert C == 3 and x.is_contiguous() and tuple(w.shape) == (7, 2, 2, 2, 64, 8) and bias.shape == (64,)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hop, Wop = conv_pad_dims(Ho, Wo)
+    if out_split is not None:
+        assert out_split.dtype == torch.int16 and tuple(out_split.shape) == (N, Hop, Wop, 2, 64) and out_split.is_contiguous()
+    if out_f32 is not None:
+        assert out_f32.dtype == torch.float32 and tuple(out_f32.shape) == (N, Ho, Wo, 64) and out_f32.is_contiguous()
+    _lib.call("fgvc_stem7_split_f32", _ptr(x), _ptr(w), _ptr(bias), _ptr(out_split), _ptr(out_f32), N, H, W, Hop, Wop,
+              int(relu), _stream(x))
 
 
 def normalize_nhwc(x: torch.Tensor, normalize: bool = True) -> torch.Tensor:

@@ -219,6 +219,14 @@ int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias,
 int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
                            int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu,
                            void* stream);
+/* The stem: 7x7 / stride 2 / zero padding 3 convolution of 3-channel frames to 64 channels, BatchNorm folded, + bias
+ * (+ ReLU) (resnet.py:457-466 with pool_type 'none'), from the f32 NCHW frames x[N][3][H][W] to y_f32 (dense NHWC f32
+ * [N][Ho][Wo][64]) and / or y_split (padded split NHWC, Hop x Wop); Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1).
+ *   w: folded (hi, lo) bf16 weights in MFMA-operand order, K laid out per kernel row as k = 4 kx + c (c = 3 and kx = 7: zero):
+ *      w[7 ky][2 k-steps][2 output tiles][hi | lo][lane = 32 * (k >> 3 & 1) + cout % 32][k & 7]   (ops.prepare_stem7);
+ *   bias[64] = beta - mean * gamma / sqrt(var + eps). */
+int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H,
+                         int W, int Hop, int Wop, int relu, void* stream);
 /* dense NHWC f32 -> [n][H*W][C] f32, rows L2-normalised if `normalize` (the output layout of
  * fgvc_normalize_chw_to_hwc_f32) */
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream);

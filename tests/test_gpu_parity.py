@@ -667,6 +667,44 @@ def test_conv_s2_split_vs_torch(dev, case):
     assert torch.equal(only_f, out_f) and torch.equal(only_s, out_s)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 96, True), (1, 37, 131, True), (3, 9, 5, False), (1, 480, 854, True)])
+def test_stem7_split_vs_torch(dev, case):
+    """7x7 / stride 2 / pad 3 stem -> BN(eval) [-> ReLU] against torch in float64: even and odd sizes, images smaller than
+    a tile, several tiles per persistent workgroup (the 480p frame: 840 tiles on 512 workgroups)."""
+    import torch.nn.functional as F
+    from fgvc_amd import ops
+    N, H, W, relu = case
+    g = torch.Generator().manual_seed(200 + H + W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5
+    bn = torch.nn.BatchNorm2d(64).eval()
+    bn.weight.data = torch.rand(64, generator=g) + 0.5
+    bn.bias.data = torch.randn(64, generator=g) * 0.1
+    bn.running_mean = torch.randn(64, generator=g) * 0.1
+    bn.running_var = torch.rand(64, generator=g) + 0.5
+    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=3)
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double().view(1, -1, 1, 1)
+    ref = (ref - bn.running_mean.double().view(1, -1, 1, 1)) * sc + bn.bias.double().view(1, -1, 1, 1)
+    if relu:
+        ref = ref.clamp_min(0)
+    ref = ref.detach()
+    Ho, Wo = ref.shape[-2:]
+    wp, bias = ops.prepare_stem7(wt.to(dev), bn.to(dev))
+    out_s = ops.alloc_split_nhwc(N, 64, Ho, Wo, dev)
+    out_f = ops.alloc_nhwc(N, 64, Ho, Wo, dev)
+    ops.stem7_split(x.to(dev), wp, bias, relu, out_split=out_s, out_f32=out_f)
+    got_f = _nhwc_to_nchw(out_f.cpu()).double()
+    got_s = _split_to_nchw(out_s.cpu(), Ho, Wo).double()
+    scale = float(ref.abs().max())
+    assert float((got_f - ref).abs().max()) < 2e-5 * scale, float((got_f - ref).abs().max()) / scale
+    assert float((got_s - ref).abs().max()) < 3e-5 * scale
+    assert int(out_s[:, :, Wo + 1:].abs().max()) == 0 and int(out_s[:, Ho + 1:].abs().max()) == 0
+    assert int(out_s[:, 0].abs().max()) == 0 and int(out_s[:, :, 0].abs().max()) == 0
+    only_f = ops.alloc_nhwc(N, 64, Ho, Wo, dev)
+    ops.stem7_split(x.to(dev), wp, bias, relu, out_f32=only_f)
+    assert torch.equal(only_f, out_f)
+
+
 def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev):
     """A1: layer 3 of the ResNet-18 trunk on fgvc_conv_split_f32 (the default on the GPU) against the same network with
     every convolution in MIOpen, against the CPU oracle network, and through the tracker's forward_hwc fast path."""
