@@ -97,7 +97,7 @@ class VanillaTracker(BaseTracker):
                 f = f[0]
             Hf, Wf = f.shape[-2:]
             chunks.append(ops.normalize_to_hwc(f.float(), norm, pad=True))
-        return torch.cat(chunks, 0), Hf, Wf
+        return (chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)), Hf, Wf       # (cat of one tensor is a copy)
 
     def engine_config(self) -> engine.TrackerConfig:
         return engine.TrackerConfig.from_test_cfg(self.test_cfg)
@@ -171,7 +171,7 @@ class HRVanillaTracker(VanillaTracker):
             f = self.extract_feat(rgbs[0, i:i + step])
             Hf, Wf = f.shape[-2:]
             chunks.append(ops.normalize_to_hwc(f.float(), norm, pad=True))
-        feats = torch.cat(chunks, 0)
+        feats = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
         pts = query_points[0, :, 1:].to(dev, torch.float32)
         P = pts.shape[0]
         labels = torch.zeros((T, Hf * Wf, P), device=dev)
