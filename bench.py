@@ -142,6 +142,8 @@ def main():
                     help="pair top-k kernel: split = fgvc_pair_topk_bf16x4 (default where it applies), f32 = fgvc_pair_topk_f32")
     ap.add_argument("--encoder-lanes", type=int, default=None,
                     help="batch slices of the encoder run on this many HIP streams at once (default: ResNet.split_lanes)")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="fgvc_set_option knobs for A/B runs, e.g. --set-option conv_narrow=1")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +158,9 @@ def main():
 
     from fgvc_amd import _lib, engine, ops
     _lib.load()
+    for kv in a.set_option:
+        name, _, val = kv.partition("=")
+        ops.set_option(name, int(val))
     wl = WORKLOADS[a.workload]
     T, h, w, P = wl["frames"], wl["h"], wl["w"], wl["points"]
     torch.backends.cudnn.benchmark = not a.no_autotune

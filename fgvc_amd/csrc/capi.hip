@@ -91,7 +91,7 @@ int fgvc_set_option(const char* name, int value) {
     return FGVC_OK;
   }
   if (strcmp(name, "conv_narrow") == 0) {   // fgvc_conv_split_f32 with 64 output channels per workgroup: 1 (default) = 4-row tiles,
-    set_conv_narrow(value != 0);            // two workgroups per CU;  0 = 8-row tiles, one workgroup per CU
+    set_conv_narrow(value);                 // two workgroups per CU;  0 = 8-row tiles, one workgroup per CU;  +2 = the same for 128
     return FGVC_OK;
   }
   if (strcmp(name, "conv_cot_cap") == 0) {   // fgvc_conv_split_f32: at most this many output channels per workgroup (0, 64, 128)

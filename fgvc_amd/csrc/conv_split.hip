@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
 
 static int g_conv_debug = 0;
 void set_conv_debug(int v) { g_conv_debug = v; }
-static int g_conv_narrow = 1;       // 64-channel tiling: 1 = 4-row tiles with two workgroups per CU, 0 = 8-row tiles
+static int g_conv_narrow = 1;       // bit 0: 64-channel layers, bit 1: 128-channel 3x3 layers (no gain measured) -- 4-row tiles, two workgroups per CU (0: 8-row tiles)
 void set_conv_narrow(int v) { g_conv_narrow = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
 void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
@@ -417,12 +417,13 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
   const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap) ? g_conv_cot_cap : cot;
-  const bool narrow = cot_eff == 64 && g_conv_narrow;     // 4-row tiles, two workgroups per CU
+  const bool narrow = (cot_eff == 64 && (g_conv_narrow & 1)) || (cot_eff == 128 && KS == 3 && (g_conv_narrow & 2));   // 4-row tiles, two workgroups per CU
   p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   if (KS == 3) {
     if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4><<<grid, 512, 0, s>>>(p);
+    else if (cot_eff == 128 && narrow) conv_split_kernel<3, 128, 1, 3, 2><<<grid, 256, 0, s>>>(p);
     else if (cot_eff == 128) conv_split_kernel<3, 128, 3, 2, 4><<<grid, 512, 0, s>>>(p);
     else if (narrow) conv_split_kernel<3, 64, 3, 2, 2><<<grid, 256, 0, s>>>(p);
     else conv_split_kernel<3, 64, 3, 3, 4><<<grid, 512, 0, s>>>(p);

@@ -59,7 +59,8 @@ const char* fgvc_last_error(void);
  *                        Identical results up to the last bit of the scores.
  *   "pair_bf16_products" fgvc_pair_topk_bf16x4: 4 (default) = hi*hi + hi*lo + lo*hi + lo*lo, 3 = without lo*lo.
  *   "conv_cot_cap"       fgvc_conv_split_f32: at most this many output channels per workgroup (0 = widest, 64, 128).
- *   "conv_narrow"        fgvc_conv_split_f32, 64-channel tiling: 1 (default) = 4-row tiles, two workgroups per CU.
+ *   "conv_narrow"        fgvc_conv_split_f32: 4-row tiles with two workgroups per CU for the 64-channel layers (bit 0, default) /
+ *                        the 128-channel 3x3 layers (bit 1).
  *   "readout_prune"      fgvc_softargmax_top5_f32: 1 (default) = pruned read-out, full scan only for the maps it hands back;
  *                        0 = full scan of every map.  Identical results.
  *   "pair_debug", "pair_bf16_debug", "corr_debug", "conv_debug", "conv_s2_debug": profiling ablations (skip selection / MFMA / staging /

@@ -39,6 +39,11 @@ for Cin, Cout, KS, H, W in [(256, 256, 3, 120, 214), (128, 256, 3, 120, 214), (1
             ops.set_option("conv_cot_cap", cap)
             caps[cap] = round(timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s)), 3)
     ops.set_option("conv_cot_cap", 0)
+    if Cout == 128 and KS == 3:
+        ops.set_option("conv_narrow", 3)
+        caps["4-row tiles"] = round(timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s)), 3)
+        caps["4-row tiles, full epilogue"] = round(timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s, out_f32=out_f, residual=out_f)), 3)
+        ops.set_option("conv_narrow", 1)
     if Cout == 64:
         ops.set_option("conv_narrow", 0)
         caps["8-row tiles"] = round(timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=out_s)), 3)
