@@ -28,3 +28,13 @@ ys = ops.alloc_split_nhwc(T, 256, H, W, dev)
 for _ in range(3):
     ops.conv_split(xs, wp, bs, H, W, True, out_split=ys)
 torch.cuda.synchronize()
+# the stem and the stride-2 block of layer 2 at the 480p clip's sizes
+frames = torch.randn(T, 3, 480, 854, device=dev)
+sw, sb = ops.prepare_stem7(torch.randn(64, 3, 7, 7, device=dev) * 0.1, torch.nn.BatchNorm2d(64).eval().to(dev))
+st_s, st_f = ops.alloc_split_nhwc(T, 64, 240, 427, dev), ops.alloc_nhwc(T, 64, 240, 427, dev)
+w2, b2 = ops.prepare_conv_s2(torch.randn(128, 64, 3, 3, device=dev) * 0.05, torch.nn.BatchNorm2d(128).eval().to(dev))
+s2_out = ops.alloc_split_nhwc(T, 128, 120, 214, dev)
+for _ in range(3):
+    ops.stem7_split(frames, sw, sb, True, out_split=st_s, out_f32=st_f)
+    ops.conv_s2_split(st_s, w2, b2, 240, 427, True, out_split=s2_out)
+torch.cuda.synchronize()
