@@ -142,6 +142,7 @@ def main():
                     help="pair top-k kernel: split = fgvc_pair_topk_bf16x4 (default where it applies), f32 = fgvc_pair_topk_f32")
     ap.add_argument("--encoder-lanes", type=int, default=None,
                     help="batch slices of the encoder run on this many HIP streams at once (default: ResNet.split_lanes)")
+    ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="fgvc_set_option knobs for A/B runs, e.g. --set-option conv_narrow=1")
     a = ap.parse_args()
@@ -164,9 +165,11 @@ def main():
     wl = WORKLOADS[a.workload]
     T, h, w, P = wl["frames"], wl["h"], wl["w"], wl["points"]
     torch.backends.cudnn.benchmark = not a.no_autotune
+    from fgvc_amd.mmpt_api.backbones import ResNet
     if a.encoder_lanes is not None:
-        from fgvc_amd.mmpt_api.backbones import ResNet
         ResNet.split_lanes = a.encoder_lanes
+    if a.no_conv64:
+        ResNet.use_conv64 = False
     model = build_tracker(wl, dev)
     if a.channels_last:
         model.test_cfg["channels_last"] = True

@@ -42,6 +42,7 @@ int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const floa
                       int, int, int, int, hipStream_t);
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
                    int, int, hipStream_t);
+int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, hipStream_t);
@@ -341,6 +342,18 @@ int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias,
   FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
   return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, (hipStream_t)stream);
+}
+
+int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
+                          float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, void* stream) {
+  FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: bad shape");
+  FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
+  FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(y_split) && aligned16(y_f32),
+               FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: 16-byte alignment required");
+  FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: in-place not supported");
+  if (N == 0) return FGVC_OK;
+  return conv64_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, relu, (hipStream_t)stream);
 }
 
 int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,

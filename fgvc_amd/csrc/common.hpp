@@ -228,6 +228,24 @@ __device__ __forceinline__ uint16_t f2bf(float x) {
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
+// gfx950 converts in hardware: two f32 -> two bf16 (round to nearest even) in one v_cvt_pk_bf16_f32; low half = a
+typedef __bf16 fgvc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float fgvc_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf_pk(float a, float b) {
+  const fgvc_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fgvc_bf16x2));
+}
+// (hi, lo) split of four f32: hi = bf16(x), lo = bf16(x - hi), as the four-element words the split tensors store
+__device__ __forceinline__ void split_bf16_4(const f32x4& x, ushort4& hv, ushort4& lv) {
+  const uint32_t h0 = f2bf_pk(x.x, x.y), h1 = f2bf_pk(x.z, x.w);
+  const float fx = __builtin_bit_cast(float, h0 << 16), fy = __builtin_bit_cast(float, h0 & 0xFFFF0000u);
+  const float fz = __builtin_bit_cast(float, h1 << 16), fw = __builtin_bit_cast(float, h1 & 0xFFFF0000u);
+  const uint32_t l0 = f2bf_pk(x.x - fx, x.y - fy), l1 = f2bf_pk(x.z - fz, x.w - fw);
+  const uint2 hh = {h0, h1}, ll = {l0, l1};
+  hv = __builtin_bit_cast(ushort4, hh);
+  lv = __builtin_bit_cast(ushort4, ll);
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }

@@ -1,0 +1,232 @@
+// 64 -> 64 channel 3x3 stride-1 convolutions (ResNet layer 1: four per clip, on the largest activations of the trunk) with
+// the folded weights RESIDENT IN REGISTERS.  Same arithmetic and tensors as conv_split.hip (split-bf16 operands, three
+// partial products, f32 accumulate; padded split NHWC in; bias / residual / ReLU epilogue; dense NHWC f32 and / or padded
+// split NHWC out).  Why a second kernel: in conv_split's form every one of the 6720 workgroups of such a layer streams the
+// whole 147 KB weight tensor through its LDS ring -- 1 GB of L2 reads per launch, and 0.12 of the layer's 0.25-0.30 ms are
+// that skeleton (conv_debug 6).  Here 256 persistent workgroups load their weights once: a wave's 32 output channels x
+// 576 K x (hi, lo) are 72 MFMA operands = 288 VGPRs, so a wave owns a SIMD (4 waves per CU) and only pixels move:
+// the (4+2) x 40 pixel patch of the NEXT tile is LDS-DMA'd into the second buffer while the current one multiplies,
+// residuals are prefetched into registers, stores drain under the next tile.
+#include "common.hpp"
+
+namespace fgvc {
+
+struct Conv64Params {
+  const uint16_t* x;       // padded split NHWC [N][Hp][Wp][2][64]
+  const uint16_t* w;       // [2 cout tiles][9 taps][2 chunks][2 k-steps][hi | lo][64 lanes][8]: MFMA-operand order (ops.prepare_conv64)
+  const float* bias;       // [64]
+  const float* residual;   // optional, dense NHWC f32 [N][H][W][64]
+  uint16_t* y_split;       // optional, padded split NHWC
+  float* y_f32;            // optional, dense NHWC f32
+  int N, H, W, Hp, Wp, relu;
+  int n_ty, n_tx, n_tiles;
+};
+
+__device__ __forceinline__ void c64_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_uniform) : "memory");
+}
+__device__ __forceinline__ uint32_t c64_lds_addr(const void* p) {
+  return (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+__device__ __forceinline__ int c64_swz(int row, int s) { return row * 128 + ((s ^ ((row >> 1) & 7)) << 4); }
+
+constexpr int C64_TR = 4;                                  // output rows per tile
+constexpr int C64_PW = 40;                                 // staged patch width (34 needed; DMA moves 8 pixels at a time)
+constexpr int C64_CHUNKB = (C64_TR + 2) * C64_PW * 128;    // one 32-channel chunk of a patch
+constexpr int C64_PATCHB = 2 * C64_CHUNKB;
+constexpr int C64_RS = 144;                                // epilogue tile row stride (bytes)
+constexpr int C64_PIECES = 2 * (C64_TR + 2) * 5;           // 1-KiB DMA pieces per patch
+
+__global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char patches[2 * C64_PATCHB];
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[4 * 32 * C64_RS];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 1, rg = wave >> 1;
+  const int n = lane & 31, h = lane >> 5;
+  const int d_row = lane >> 3, d_slot = lane & 7;
+
+  // this wave's weights: 9 taps x 2 chunks x 2 k-steps x (hi, lo), registers for the whole kernel
+  bf16x8 wh[9][2][2], wl[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint16_t* wp = p.w + (((((size_t)ct * 9 + t) * 2 + c) * 2 + s) * 2) * 512 + lane * 8;
+        wh[t][c][s] = *reinterpret_cast<const bf16x8*>(wp);
+        wl[t][c][s] = *reinterpret_cast<const bf16x8*>(wp + 512);
+      }
+  if (tid < 64) bias_s[tid] = p.bias[tid];                 // read back per tile (registers are for the weights)
+
+  // pieces i, i + 4, ... of a patch belong to this wave; piece -> (chunk, patch row, 8-pixel column group).  Scalar base +
+  // 32-bit lane offset form of the DMA: the lane part is (row in the piece) * 256 + swizzled slot * 16, and since the first
+  // patch pixel of a piece is a multiple of 8 the swizzle key (P >> 1) & 7 is (d_row >> 1) + {0, 4} = (d_row >> 1) ^ {0, 4}:
+  // one lane constant, XORed with 64 for every other piece.
+  const uint32_t lane_off0 = (uint32_t)(d_row * 256 + ((d_slot ^ (d_row >> 1)) << 4));
+  auto stage_piece = [&](int nimg, int y0, int x0, int buf, int i) {
+    const int chunk = i / ((C64_TR + 2) * 5), r2 = i - chunk * ((C64_TR + 2) * 5);
+    const int prow = r2 / 5, pc0 = (r2 - prow * 5) * 8;
+    const int key4 = ((prow * C64_PW + pc0) >> 1) & 4;       // wave-uniform
+    const size_t gpix = ((size_t)nimg * p.Hp + (y0 + prow)) * p.Wp + (x0 + pc0);
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(p.x) + gpix * 256 + chunk * 128;
+    const uint32_t off = lane_off0 ^ (uint32_t)(key4 << 4);
+    const uint32_t dst = c64_lds_addr(patches + buf * C64_PATCHB + chunk * C64_CHUNKB + (prow * C64_PW + pc0) * 128);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
+  };
+  auto tile_origin = [&](int tile, int& nimg, int& y0, int& x0) {
+    nimg = tile / (p.n_ty * p.n_tx);
+    const int rem = tile - nimg * p.n_ty * p.n_tx;
+    const int ty = rem / p.n_tx;
+    y0 = ty * C64_TR;
+    x0 = (rem - ty * p.n_tx) * 32;
+  };
+
+  int tile = blockIdx.x, buf = 0;
+  if (tile < p.n_tiles) {
+    int ni, ya, xa;
+    tile_origin(tile, ni, ya, xa);
+    for (int i = wave; i < C64_PIECES; i += 4) stage_piece(ni, ya, xa, 0, i);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (; tile < p.n_tiles; tile += gridDim.x, buf ^= 1) {
+    const int nimg = tile / (p.n_ty * p.n_tx);
+    const int rem = tile - nimg * p.n_ty * p.n_tx;
+    const int ty = rem / p.n_tx, tx = rem - ty * p.n_tx;
+    const int y0 = ty * C64_TR, x0 = tx * 32;
+    lds_barrier();                                          // patch `buf` complete (every wave waited for its DMAs), buffer buf^1 free
+    // the next tile's patch goes into the other buffer while this one multiplies: its 15 DMA pieces per wave are issued
+    // BETWEEN the MFMA groups (a wave owns its SIMD: whatever it issues outside the MFMA stream is exposed)
+    const int next = tile + gridDim.x;
+    const bool has_next = next < p.n_tiles;
+    int nimg_n = 0, y0_n = 0, x0_n = 0;
+    if (has_next) tile_origin(next, nimg_n, y0_n, x0_n);
+
+    f32x4 res[2][4];
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const unsigned char* patch = patches + buf * C64_PATCHB;
+    // B operands of group g = (tap, chunk, k-step): [row][hi | lo], read one group ahead of the multiplies (left to itself
+    // hipcc reads each operand right before its first use: 144 exposed LDS round trips per tile, 3x the MFMA time)
+    bf16x8 bc[4], bn[4];
+    auto load_b = [&](bf16x8* d, int g) {
+      const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int P = (2 * rg + b + t / 3) * C64_PW + n + t % 3;
+        d[b * 2 + 0] = *reinterpret_cast<const bf16x8*>(patch + c * C64_CHUNKB + c64_swz(P, 2 * s + h));
+        d[b * 2 + 1] = *reinterpret_cast<const bf16x8*>(patch + c * C64_CHUNKB + c64_swz(P, 4 + 2 * s + h));
+      }
+    };
+    load_b(bc, 0);
+#pragma unroll
+    for (int g = 0; g < 36; ++g) {
+      const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
+      if (g + 1 < 36) load_b(bn, g + 1);
+      if (g >= 2 && g < 32 && (g & 1) == 0 && has_next) stage_piece(nimg_n, y0_n, x0_n, buf ^ 1, wave + 4 * ((g - 2) >> 1));
+      if (g == 24 && p.residual) {   // residual rows of this wave in accumulator layout (pixel on the lane, 4 consecutive channels per register group)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int y = imin(y0 + 2 * rg + b, p.H - 1), x = imin(x0 + n, p.W - 1);
+          const float* rp = p.residual + (((size_t)nimg * p.H + y) * p.W + x) * 64 + ct * 32 + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) res[b][q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bf16x8 xh = bc[b * 2 + 0], xl = bc[b * 2 + 1];
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t][c][s], xh, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[t][c][s], xh, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t][c][s], xl, acc[b], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bc[q] = bn[q];
+    }
+    // the next patch's DMAs (and the residual loads) are older than anything the epilogue issues: one wait covers them and
+    // leaves this tile's stores in flight across the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: bias (+ residual) (+ ReLU), transposed through a wave-private LDS tile: 128-byte rows per pixel
+    unsigned char* tw = tiles + wave * (32 * C64_RS);
+    const int mv_row = lane >> 3, mv_col = (lane & 7) * 16;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int y = y0 + 2 * rg + b;
+      if (y >= p.H) continue;                               // wave-uniform
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + ct * 32 + 8 * g + 4 * h);
+        v[g] = {acc[b][4 * g + 0] + bv.x, acc[b][4 * g + 1] + bv.y, acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w};
+        if (p.residual) v[g] += res[b][g];
+        if (p.relu) {
+          v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f);
+        }
+      }
+      if (p.y_f32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(tw + n * C64_RS + (8 * g + 4 * h) * 4) = v[g];
+        wave_sync();
+        unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_f32 + (((size_t)nimg * p.H + y) * p.W + x0) * 64 + ct * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + mv_row;
+          if (x0 + row < p.W)
+            *reinterpret_cast<uint4*>(dst + (size_t)row * 256 + mv_col) = *reinterpret_cast<const uint4*>(tw + row * C64_RS + mv_col);
+        }
+        wave_sync();
+      }
+      if (p.y_split) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 x = v[g];
+          ushort4 hv, lv;
+          split_bf16_4(x, hv, lv);
+          unsigned char* o = tw + n * C64_RS + (8 * g + 4 * h) * 2;
+          *reinterpret_cast<ushort4*>(o) = hv;
+          *reinterpret_cast<ushort4*>(o + 64) = lv;
+        }
+        wave_sync();
+        const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * 2 + ct) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + mv_row;
+          if (x0 + row < p.W)
+            *reinterpret_cast<uint4*>(dst + (size_t)row * 256 + mv_col) = *reinterpret_cast<const uint4*>(tw + row * C64_RS + mv_col);
+        }
+        wave_sync();
+      }
+    }
+  }
+}
+
+int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split, float* y_f32,
+                  int N, int H, int W, int Hp, int Wp, int relu, hipStream_t s) {
+  Conv64Params p;
+  p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
+  p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.relu = relu;
+  p.n_ty = cdiv(H, C64_TR); p.n_tx = cdiv(W, 32);
+  const long long tiles = (long long)p.n_ty * p.n_tx * N;
+  if (tiles >= (1ll << 31)) {
+    set_error("fgvc_conv64_split_f32: too many tiles");
+    return FGVC_ERR_UNSUPPORTED;
+  }
+  p.n_tiles = (int)tiles;
+  const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
+  conv64_kernel<<<grid, 256, 0, s>>>(p);
+  FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32");
+  return FGVC_OK;
+}
+
+}  // namespace fgvc

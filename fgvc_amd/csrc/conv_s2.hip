@@ -191,9 +191,7 @@ __global__ __launch_bounds__(64 * S2_NW, 2) void conv_s2_kernel(ConvS2Params p) 
       for (int g = 0; g < 4; ++g) {
         const f32x4 x = v[g];
         ushort4 hv, lv;
-        hv.x = f2bf(x.x); hv.y = f2bf(x.y); hv.z = f2bf(x.z); hv.w = f2bf(x.w);
-        lv.x = f2bf(x.x - bf2f(hv.x)); lv.y = f2bf(x.y - bf2f(hv.y));
-        lv.z = f2bf(x.z - bf2f(hv.z)); lv.w = f2bf(x.w - bf2f(hv.w));
+        split_bf16_4(x, hv, lv);
         unsigned char* o = tile + n * S2_RS + (8 * g + 4 * h) * 2;
         *reinterpret_cast<ushort4*>(o) = hv;
         *reinterpret_cast<ushort4*>(o + 64) = lv;

@@ -323,9 +323,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
         for (int g = 0; g < 4; ++g) {
           const f32x4 x = v[a][g];
           ushort4 hv, lv;
-          hv.x = f2bf(x.x); hv.y = f2bf(x.y); hv.z = f2bf(x.z); hv.w = f2bf(x.w);
-          lv.x = f2bf(x.x - bf2f(hv.x)); lv.y = f2bf(x.y - bf2f(hv.y));
-          lv.z = f2bf(x.z - bf2f(hv.z)); lv.w = f2bf(x.w - bf2f(hv.w));
+          split_bf16_4(x, hv, lv);
           unsigned char* o = tile + n * RS + a * 128 + (8 * g + 4 * h) * 2;    // [chunk a][hi 64 B | lo 64 B]
           *reinterpret_cast<ushort4*>(o) = hv;
           *reinterpret_cast<ushort4*>(o + 64) = lv;
@@ -462,9 +460,7 @@ __global__ __launch_bounds__(256) void nhwc_to_split_kernel(float* __restrict__ 
     *reinterpret_cast<f32x4*>(x + e) = v;
   }
   ushort4 hv, lv;
-  hv.x = f2bf(v.x); hv.y = f2bf(v.y); hv.z = f2bf(v.z); hv.w = f2bf(v.w);
-  lv.x = f2bf(v.x - bf2f(hv.x)); lv.y = f2bf(v.y - bf2f(hv.y));
-  lv.z = f2bf(v.z - bf2f(hv.z)); lv.w = f2bf(v.w - bf2f(hv.w));
+  split_bf16_4(v, hv, lv);
   uint16_t* o = out + ((((size_t)nimg * Hp + (y + 1)) * Wp + (xx + 1)) * (C / 32) + (c >> 5)) * 64 + (c & 31);
   *reinterpret_cast<ushort4*>(o) = hv;
   *reinterpret_cast<ushort4*>(o + 32) = lv;

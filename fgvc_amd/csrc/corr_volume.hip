@@ -112,9 +112,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   const int c = (int)(e - pix * C);
   const f32x4 x = *reinterpret_cast<const f32x4*>(feat + e);
   ushort4 h, l;
-  h.x = f2bf(x.x); h.y = f2bf(x.y); h.z = f2bf(x.z); h.w = f2bf(x.w);
-  l.x = f2bf(x.x - bf2f(h.x)); l.y = f2bf(x.y - bf2f(h.y));
-  l.z = f2bf(x.z - bf2f(h.z)); l.w = f2bf(x.w - bf2f(h.w));
+  split_bf16_4(x, h, l);
   *reinterpret_cast<ushort4*>(out + pix * 2 * C + c) = h;
   *reinterpret_cast<ushort4*>(out + pix * 2 * C + C + c) = l;
 }

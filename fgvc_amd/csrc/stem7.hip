@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(Stem7Params p) {
       const int slot = tid + 256 * j;
       if (slot < ST_NPIX) {
         ushort4 hv, lv;
-        hv.x = f2bf(pre[j][0]); hv.y = f2bf(pre[j][1]); hv.z = f2bf(pre[j][2]); hv.w = 0;
-        lv.x = f2bf(pre[j][0] - bf2f(hv.x)); lv.y = f2bf(pre[j][1] - bf2f(hv.y)); lv.z = f2bf(pre[j][2] - bf2f(hv.z)); lv.w = 0;
+        const f32x4 px = {pre[j][0], pre[j][1], pre[j][2], 0.f};
+        split_bf16_4(px, hv, lv);
         *reinterpret_cast<ushort4*>(patch + slot * 8) = hv;
         *reinterpret_cast<ushort4*>(patch + ST_PLANEB + slot * 8) = lv;
       }
@@ -157,9 +157,7 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(Stem7Params p) {
         for (int g = 0; g < 4; ++g) {
           const f32x4 x = v[g];
           ushort4 hv, lv;
-          hv.x = f2bf(x.x); hv.y = f2bf(x.y); hv.z = f2bf(x.z); hv.w = f2bf(x.w);
-          lv.x = f2bf(x.x - bf2f(hv.x)); lv.y = f2bf(x.y - bf2f(hv.y));
-          lv.z = f2bf(x.z - bf2f(hv.z)); lv.w = f2bf(x.w - bf2f(hv.w));
+          split_bf16_4(x, hv, lv);
           unsigned char* o = tw + n * ST_RS + (8 * g + 4 * h) * 2;
           *reinterpret_cast<ushort4*>(o) = hv;
           *reinterpret_cast<ushort4*>(o + 64) = lv;

@@ -134,6 +134,7 @@ class ResNet(nn.Module):
                     nn.init.constant_(m.conv3.bn.weight, 0)
 
     # ---- stages on the bf16 matrix pipe (fgvc_conv_split_f32) ------------------------------------------------------
+    use_conv64 = True              # 64 -> 64 3x3 layers on fgvc_conv64_split_f32 (register-resident weights)
     use_stem7 = True               # 7x7 stride-2 stem on fgvc_stem7_split_f32 (False: MIOpen f32 + ReLU/split pass)
     use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
@@ -226,10 +227,12 @@ class ResNet(nn.Module):
         lo, hi, N = cur["lo"], cur["hi"], cur["N"]
         wkey = ("w", si, dev)
         if wkey not in cache:
-            prep = {(1, 1): ops.prepare_conv_split, (2, 2): ops.prepare_conv_s2}
+            def prep_s1(w, bn):      # 64 -> 64 3x3: the register-resident-weights kernel (its own weight order)
+                return ops.prepare_conv64(w, bn) if (self.use_conv64 and tuple(w.shape) == (64, 64, 3, 3)) else ops.prepare_conv_split(w, bn)
+            prep = {(1, 1): prep_s1, (2, 2): ops.prepare_conv_s2}
             cache[wkey] = [dict(c1=None if b.conv1.conv.stride not in prep else
                                 prep[b.conv1.conv.stride](b.conv1.conv.weight.detach(), b.conv1.bn),
-                                c2=ops.prepare_conv_split(b.conv2.conv.weight.detach(), b.conv2.bn),
+                                c2=prep_s1(b.conv2.conv.weight.detach(), b.conv2.bn),
                                 ds=None if (b.downsample is None or b.downsample.conv.stride not in prep) else
                                 prep[b.downsample.conv.stride](b.downsample.conv.weight.detach(), b.downsample.bn))
                            for b in stage]
@@ -238,6 +241,11 @@ class ResNet(nn.Module):
         for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
             Cout = blk.conv2.conv.out_channels
             H, W = cur["H"], cur["W"]
+
+            def conv_s1(x_split, wb, **kw):       # stride-1 convolution by whichever kernel the weights were laid out for
+                fn = ops.conv64_split if wb[0].dim() == 7 else ops.conv_split
+                fn(x_split, wb[0], wb[1], H, W, **kw)
+
             last_conv = bi == len(stage) - 1 and not cur["need_split"]        # nobody reads the split form of the trunk output
             if blk.conv1.conv.stride == (2, 2) and self.use_s2_conv:
                 # stride-2 3x3 and stride-2 projection on the bf16 pipe as well (fgvc_conv_s2_split_f32)
@@ -266,7 +274,7 @@ class ResNet(nn.Module):
                     idt = buf["f_idt"]
                 else:
                     idt = cur["f32"]
-                ops.conv_split(cur["split"], wt["c1"][0], wt["c1"][1], H, W, relu=True, out_split=buf["s_a"])
+                conv_s1(cur["split"], wt["c1"], relu=True, out_split=buf["s_a"])
             full = bufs["f_y"]
             if bi == len(stage) - 1 and si in call["fresh"]:
                 if si not in call["out"]:
@@ -278,8 +286,8 @@ class ResNet(nn.Module):
                 full = call["out"][si]
             f_y = full[lo:hi]
             skip_f32 = bi == len(stage) - 1 and not cur["need_f32"]       # nobody reads the f32 form of this stage's output
-            ops.conv_split(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, relu=True, residual=idt,
-                           out_split=None if last_conv else buf["s_y"], out_f32=None if skip_f32 else f_y)
+            conv_s1(buf["s_a"], wt["c2"], relu=True, residual=idt,
+                    out_split=None if last_conv else buf["s_y"], out_f32=None if skip_f32 else f_y)
             cur = dict(cur, split=buf["s_y"], f32=f_y, H=H, W=W)
         cur["full"] = full
         return cur

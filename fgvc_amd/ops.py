@@ -349,6 +349,16 @@ def prepare_conv_split(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tupl
     return packed, bias
 
 
+def prepare_conv64(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Folded weights (64, 64, 3, 3) for fgvc_conv64_split_f32: prepare_conv_split's values in MFMA-operand order
+    [2 output tiles][9 taps][2 chunks][2 k-steps][hi | lo][lane][8]; returns (w int16, bias f32 [64])."""
+    assert tuple(weight.shape) == (64, 64, 3, 3)
+    packed, bias = prepare_conv_split(weight, bn)                      # [tap 9][chunk 2][Cout 64][part 2 x 32 ci]
+    v = packed.view(9, 2, 2, 32, 2, 2, 2, 8)                           # [t][c][ct][n][part][s][h][j]
+    v = v.permute(2, 0, 1, 5, 4, 6, 3, 7).contiguous()                 # [ct][t][c][s][part][h][n][j]
+    return v.view(2, 9, 2, 2, 2, 64, 8), bias
+
+
 def prepare_conv_s2(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor]:
     """Folded weights for fgvc_conv_s2_split_f32: prepare_conv_split's values in MFMA-operand order
     [KS*KS][Cin/32][Cout/32][hi k0-15 | hi k16-31 | lo k0-15 | lo k16-31][lane = 32 * (k >> 3 & 1) + cout % 32][k & 7]
@@ -431,6 +441,21 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
             assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv_split buffer"
     _lib.call("fgvc_conv_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
               N, H, W, Hp, Wp, nch * 32, Cout, 3 if taps == 9 else 1, int(relu), _stream(x_split))
+
+
+def conv64_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
+                 residual: Optional[torch.Tensor] = None, out_split: Optional[torch.Tensor] = None,
+                 out_f32: Optional[torch.Tensor] = None) -> None:
+    """conv_split for Cin = Cout = 64, 3x3, with register-resident weights (fgvc_conv64_split_f32; w, bias from prepare_conv64)."""
+    x_split = _chk(x_split, torch.int16, "x_split")
+    N, Hp, Wp, nch, _ = x_split.shape
+    assert nch == 2 and tuple(w.shape) == (2, 9, 2, 2, 2, 64, 8) and bias.shape == (64,)
+    for t, dt, shape in ((residual, torch.float32, (N, H, W, 64)), (out_f32, torch.float32, (N, H, W, 64)),
+                         (out_split, torch.int16, (N, Hp, Wp, 2, 64))):
+        if t is not None:
+            assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv64_split buffer"
+    _lib.call("fgvc_conv64_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
+              N, H, W, Hp, Wp, int(relu), _stream(x_split))
 
 
 def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,

@@ -209,6 +209,12 @@ int fgvc_nhwc_to_split_f32(float* x, uint16_t* out_split, int N, int C, int H, i
 int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                         uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
                         int KS, int relu, void* stream);
+/* fgvc_conv_split_f32 for Cin = Cout = 64, 3x3 (ResNet layer 1: the largest activations of the trunk), as persistent
+ * workgroups that keep the folded weights in registers instead of re-streaming them per tile.  Same tensors and epilogue;
+ * weights in MFMA-operand order:
+ *   w[2 output tiles][9 taps][2 chunks][2 k-steps][hi | lo][lane = 32 * (k >> 3 & 1) + cout % 32][k & 7]   (ops.prepare_conv64). */
+int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
+                          float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, void* stream);
 /* The stride-2 members of the same family: the 3x3 / stride 2 / zero padding 1 convolution that opens a down-sampling
  * stage and its 1x1 / stride 2 projection (resnet.py:54-76 conv1 of the first BasicBlock, :288-296 downsample), BatchNorm
  * folded, + bias (+ ReLU).  x: padded split NHWC of the H x W input; outputs for the Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1)

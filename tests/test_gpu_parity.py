@@ -667,6 +667,54 @@ def test_conv_s2_split_vs_torch(dev, case):
     assert torch.equal(only_f, out_f) and torch.equal(only_s, out_s)
 
 
+@pytest.mark.parametrize("case", [(2, 21, 50, True, True), (1, 4, 32, False, True), (1, 3, 5, True, False), (3, 61, 100, True, True),
+                                  (2, 240, 427, False, True)])
+def test_conv64_split_vs_torch(dev, case):
+    """64 -> 64 3x3 conv -> BN(eval) [-> + identity] [-> ReLU] with register-resident weights against torch in float64:
+    ragged tiles, fewer tiles than workgroups, many tiles per persistent workgroup (both LDS buffers, prefetch chain)."""
+    import torch.nn.functional as F
+    from fgvc_amd import ops
+    N, H, W, with_res, relu = case
+    g = torch.Generator().manual_seed(300 + N + H + W)
+    x = torch.randn(N, 64, H, W, generator=g)
+    wt = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    bn = torch.nn.BatchNorm2d(64).eval()
+    bn.weight.data = torch.rand(64, generator=g) + 0.5
+    bn.bias.data = torch.randn(64, generator=g) * 0.1
+    bn.running_mean = torch.randn(64, generator=g) * 0.1
+    bn.running_var = torch.rand(64, generator=g) + 0.5
+    res = torch.randn(N, 64, H, W, generator=g) if with_res else None
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double().view(1, -1, 1, 1)
+    ref = (ref - bn.running_mean.double().view(1, -1, 1, 1)) * sc + bn.bias.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    ref = ref.detach()
+    wp, bias = ops.prepare_conv64(wt.to(dev), bn.to(dev))
+    xs = ops.nchw_to_split_nhwc(x.to(dev))
+    out_s = ops.alloc_split_nhwc(N, 64, H, W, dev)
+    out_f = ops.alloc_nhwc(N, 64, H, W, dev)
+    resp = res.permute(0, 2, 3, 1).contiguous().to(dev) if with_res else None
+    ops.conv64_split(xs, wp, bias, H, W, relu, residual=resp, out_split=out_s, out_f32=out_f)
+    got_f = _nhwc_to_nchw(out_f.cpu()).double()
+    got_s = _split_to_nchw(out_s.cpu(), H, W).double()
+    scale = float(ref.abs().max())
+    assert float((got_f - ref).abs().max()) < 2e-5 * scale, float((got_f - ref).abs().max()) / scale
+    assert float((got_s - ref).abs().max()) < 3e-5 * scale
+    assert int(out_s[:, :, W + 1:].abs().max()) == 0 and int(out_s[:, H + 1:].abs().max()) == 0
+    assert int(out_s[:, 0].abs().max()) == 0 and int(out_s[:, :, 0].abs().max()) == 0
+    # same bits as the generic kernel (same products in the same order)
+    wg, bg = ops.prepare_conv_split(wt.to(dev), bn.to(dev))
+    gen_f = ops.alloc_nhwc(N, 64, H, W, dev)
+    ops.conv_split(xs, wg, bg, H, W, relu, residual=resp, out_f32=gen_f)
+    assert float((gen_f - out_f).abs().max()) < 1e-5 * scale
+    only_s = ops.alloc_split_nhwc(N, 64, H, W, dev)
+    ops.conv64_split(xs, wp, bias, H, W, relu, residual=resp, out_split=only_s)
+    assert torch.equal(only_s, out_s)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 96, True), (1, 37, 131, True), (3, 9, 5, False), (1, 480, 854, True)])
 def test_stem7_split_vs_torch(dev, case):
     """7x7 / stride 2 / pad 3 stem -> BN(eval) [-> ReLU] against torch in float64: even and odd sizes, images smaller than

@@ -43,3 +43,17 @@ for KS in (3, 1):
             ms = timeit(fn)
             ops.set_option("conv_s2_debug", 0)
             print(f"KS={KS} {name:16s} debug={dbg:2d} {ms:.4f} ms   {3 * flops / ms / 1e9:.0f} bf16 TFLOP/s-equivalent")
+
+# 64 -> 64 3x3 stride 1 at 240 x 427: generic kernel vs register-resident weights
+Hh, Ww = 240, 427
+wt = torch.randn(64, 64, 3, 3, generator=g).to(dev) * 0.05
+bn = torch.nn.BatchNorm2d(64).eval().to(dev)
+wg, bg = ops.prepare_conv_split(wt, bn)
+w6, b6 = ops.prepare_conv64(wt, bn)
+o_s, o_f = ops.alloc_split_nhwc(N, 64, Hh, Ww, dev), ops.alloc_nhwc(N, 64, Hh, Ww, dev)
+r_f = torch.randn(N, Hh, Ww, 64, device=dev)
+for name, fn in (("generic, split out", lambda: ops.conv_split(xs, wg, bg, Hh, Ww, True, out_split=o_s)),
+                 ("conv64,  split out", lambda: ops.conv64_split(xs, w6, b6, Hh, Ww, True, out_split=o_s)),
+                 ("generic, residual + f32 + split", lambda: ops.conv_split(xs, wg, bg, Hh, Ww, True, residual=r_f, out_split=o_s, out_f32=o_f)),
+                 ("conv64,  residual + f32 + split", lambda: ops.conv64_split(xs, w6, b6, Hh, Ww, True, residual=r_f, out_split=o_s, out_f32=o_f))):
+    print(f"64->64 3x3 {name:34s} {timeit(fn):.4f} ms")
