@@ -7,7 +7,7 @@
 
 A "step" = one 8-frame 480x854 synthetic clip (BASELINE.json configs[1]) through the whole path, inputs
 resident in HBM: ResNet-18 encoder (hand-written HIP end to end: fgvc_stem7_split_f32, fgvc_conv_split_f32,
-fgvc_conv_s2_split_f32 -- activations and weights as 2 x bf16, f32 accumulate, f32-grade; batch slices on 3 HIP streams)
+fgvc_conv_s2_split_f32 -- activations and weights as 2 x bf16, f32 accumulate, f32-grade; batch slices on 2 HIP streams)
 -> L2-normalise/channels-last -> windowed
 correlation + top-10 for all 27 unique (query, key) frame pairs (features split into bf16 hi + lo, four partial
 products on the bf16 matrix pipe with f32 accumulation: f32-grade scores; --pair-precision f32 selects the f32-MFMA

@@ -212,7 +212,8 @@ class ResNet(nn.Module):
         y = y.contiguous(memory_format=torch.channels_last)          # already is, for MIOpen's NHWC solvers
         return y.permute(0, 2, 3, 1)
 
-    split_lanes = 3                # batch slices run on this many HIP streams at once (1 = everything on the caller's stream)
+    split_lanes = 2                # batch slices run on this many HIP streams at once (1 = everything on the caller's stream);
+                                   # equal slices matter: 8 frames as 4+4 beat 2+3+3 once the persistent kernels came in
 
     def _stage_split(self, si: int, cur, call):
         """Run stage `si` for the batch slice [lo, hi) of an N-image batch.  `cur` = dict(split = padded split NHWC input,
