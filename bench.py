@@ -13,7 +13,9 @@ correlation + top-10 for all 27 unique (query, key) frame pairs (features split 
 products on the bf16 matrix pipe with f32 accumulation: f32-grade scores; --pair-precision f32 selects the f32-MFMA
 kernel) -> slot merge + softmax ->
 7 sequential label propagations -> fused upsample + top-5 soft-argmax read-out.  Nothing is skipped or
-cached across steps.  At N > 1 every rank runs its own clips (videos are independent units -- the
+cached across steps.  The sweep + read-out of a step (a chain of small launches) runs on a side stream, so the next step's
+encoder starts under it (--sync-tail: everything on one stream); every launch of every step completes before the closing
+barrier + synchronize.  At N > 1 every rank runs its own clips (videos are independent units -- the
 reference's own data parallelism); no collective in the data path; scaling = weak.
 
 Rank 0 prints ONE JSON line.  `roofline` = the dominant hand-written kernel of the step
@@ -142,6 +144,9 @@ def main():
                     help="pair top-k kernel: split = fgvc_pair_topk_bf16x4 (default where it applies), f32 = fgvc_pair_topk_f32")
     ap.add_argument("--encoder-lanes", type=int, default=None,
                     help="batch slices of the encoder run on this many HIP streams at once (default: ResNet.split_lanes)")
+    ap.add_argument("--sync-tail", action="store_true",
+                    help="label sweep + read-out on the main stream (default: on a side stream, so that the next step's encoder "
+                         "overlaps this step's chain of small launches; every step is complete before the closing barrier)")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="fgvc_set_option knobs for A/B runs, e.g. --set-option conv_narrow=1")
@@ -185,6 +190,8 @@ def main():
     n_pairs = len(plan.pairs)
     pair_ev = []
 
+    tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
+
     def step(timed: bool):
         feats, Hf, Wf = model.get_feats_hwc(rgbs[0])                      # encoder + normalise, all T frames
         ev = None
@@ -192,7 +199,10 @@ def main():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair_ev.append(ev)
         tk = engine.run_affinity(feats, Hf, Wf, plan, cfg, events=ev)      # pair top-k (1 launch) + merge
-        _, coords = engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)  # sequential sweep + read-out
+        if tail_stream is None:
+            _, coords = engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)  # sequential sweep + read-out
+        else:      # the same launches on a side stream: the next clip's encoder starts under this clip's sweep and read-out
+            _, coords, _ = engine.run_propagation_async(tk, 0, pts, Hf, Wf, h, w, cfg, tail_stream)
         return coords, (Hf, Wf, feats)
 
     def barrier():

@@ -256,6 +256,32 @@ def _readout_both(ops, labels, Hf, Wf, h, w, **kw):
     return ops.softargmax_top5(labels, Hf, Wf, h, w, **kw).cpu(), full
 
 
+def test_run_propagation_async_equals_sync(dev):
+    """engine.run_propagation_async (sweep + read-out on a side stream, the caller's stream free for the next clip) returns what
+    run_propagation returns, also when the caller immediately reuses its stream and drops its references."""
+    from fgvc_amd import engine, ops
+    g = torch.Generator().manual_seed(33)
+    Tn, C, Hf, Wf, h, w = 6, 64, 16, 20, 64, 80
+    feats = ops.normalize_to_hwc(torch.randn(Tn, C, Hf, Wf, generator=g).to(dev))
+    cfg = engine.TrackerConfig(neighbor_range=12)
+    plan = engine.plan_clip(Tn, [0], cfg)
+    pts = (torch.rand(5, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])).to(dev)
+    side = torch.cuda.Stream(dev)
+    want_l, want_c = engine.run_propagation(engine.run_affinity(feats, Hf, Wf, plan, cfg), 0, pts, Hf, Wf, h, w, cfg)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):
+        tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
+        labels, coords, done = engine.run_propagation_async(tk, 0, pts, Hf, Wf, h, w, cfg, side)
+        del tk                                                     # the allocator may hand these blocks out again right away
+        junk = [torch.full((1 << 20,), float(rep), device=dev) for _ in range(8)]     # ... to this, on the caller's stream
+        outs.append((labels, coords, done))
+        del junk
+    for labels, coords, done in outs:
+        done.synchronize()
+        assert torch.equal(coords, want_c) and torch.equal(labels, want_l)
+
+
 def test_readout_pruned_equals_full_scan(dev):
     """The pruned read-out (only coarse cells whose corner maximum reaches the running 5th value are upsampled) returns the
     bits of the full scan -- on peaked maps (its fast path) and on everything it must hand back: flat and constant maps,
