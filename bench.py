@@ -193,7 +193,7 @@ def main():
     tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
 
     def step(timed: bool):
-        feats, Hf, Wf = model.get_feats_hwc(rgbs[0])                      # encoder + normalise, all T frames
+        feats, Hf, Wf = model.get_feats_hwc(rgbs[0], split=True)          # encoder + normalise (+ split), all T frames
         ev = None
         if timed:                                                          # HIP events on the launch stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -291,7 +291,10 @@ def main():
         vol = torch.empty((HW, HW), device=dev, dtype=torch.float32)
         gbytes = (HW * HW * 4 + 2 * HW * C * 4) / 1e9                  # volume write + both inputs
         res = {}
-        hl = ops.split_bf16(feats[:2])
+        if feats.dtype == torch.int16:       # the bank came back split: the dense kernels' f32 operands are hi + lo of two frames
+            hl, feats = feats[:2], ops.unsplit_bf16(feats[:2])
+        else:
+            hl = ops.split_bf16(feats[:2])
         for name, fn in (("bf16x3", lambda: ops.corr_volume(hl[1], hl[0], 0.07, "bf16x3", out=vol)),
                          ("f32", lambda: ops.corr_volume(feats[1], feats[0], 0.07, "f32", out=vol)),
                          ("bf16", lambda: ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol))):

@@ -35,6 +35,7 @@ SIGNATURES = {
     "fgvc_stem7_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_nhwc_to_split_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "fgvc_normalize_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_merge_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
     "fgvc_propagate_topk_f32": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_corr_volume_f32": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),

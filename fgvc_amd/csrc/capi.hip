@@ -45,7 +45,7 @@ int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, fl
 int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
-int normalize_nhwc_launch(const float*, float*, int, int, int, int, int, hipStream_t);
+int normalize_nhwc_launch(const float*, float*, uint16_t*, int, int, int, int, int, hipStream_t);
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
 
 void set_conv_cot_cap(int);
@@ -398,12 +398,19 @@ int fgvc_nhwc_to_split_f32(float* x, uint16_t* out, int N, int C, int H, int W, 
   return nhwc_to_split_launch(x, out, N, C, H, W, Hp, Wp, relu, (hipStream_t)stream);
 }
 
+int fgvc_normalize_split_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W, int normalize,
+                                  void* stream) {
+  FGVC_REQUIRE(in && (out_f32 || out_split), FGVC_ERR_INVALID_ARG, "fgvc_normalize_split_nhwc_f32: null pointer");
+  FGVC_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_normalize_split_nhwc_f32: bad shape");
+  FGVC_REQUIRE(aligned16(in) && aligned16(out_f32) && aligned16(out_split), FGVC_ERR_INVALID_ARG,
+               "fgvc_normalize_split_nhwc_f32: 16-byte alignment required");
+  if (N == 0) return FGVC_OK;
+  return normalize_nhwc_launch(in, out_f32, out_split, N, C, H, W, normalize, (hipStream_t)stream);
+}
+
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream) {
   FGVC_REQUIRE(in && out, FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: null pointer");
-  FGVC_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: bad shape");
-  FGVC_REQUIRE(aligned16(in) && aligned16(out), FGVC_ERR_INVALID_ARG, "fgvc_normalize_nhwc_f32: 16-byte alignment required");
-  if (N == 0) return FGVC_OK;
-  return normalize_nhwc_launch(in, out, N, C, H, W, normalize, (hipStream_t)stream);
+  return fgvc_normalize_split_nhwc_f32(in, out, nullptr, N, C, H, W, normalize, stream);
 }
 
 int fgvc_gaussian_labels_f32(const float* points, int P, int Hf, int Wf, int stride, float sigma, float* out,

@@ -378,9 +378,11 @@ __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __
   }
 }
 
-// dense NHWC f32 -> L2-normalised [n][H*W][C] f32 (the layout of fgvc_normalize_chw_to_hwc_f32's output); one wave per pixel
-__global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
-                                                              int normalize, long long npix) {
+// dense NHWC f32 -> L2-normalised rows: [n][H*W][C] f32 (the layout of fgvc_normalize_chw_to_hwc_f32's output) and / or their
+// (hi, lo) bf16 split [n][H*W][hi C | lo C] (fgvc_split_bf16's output: what fgvc_pair_topk_bf16x4 reads); one wave per pixel
+__global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              uint16_t* __restrict__ out_split, int C, int normalize,
+                                                              long long npix) {
   const long long pixel = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pixel >= npix) return;
@@ -396,7 +398,13 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
   for (int c = lane * 4; c < C; c += 256) {
     f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
     v *= inv;
-    *reinterpret_cast<f32x4*>(out + pixel * C + c) = v;
+    if (out) *reinterpret_cast<f32x4*>(out + pixel * C + c) = v;
+    if (out_split) {
+      ushort4 hv, lv;
+      split_bf16_4(v, hv, lv);
+      *reinterpret_cast<ushort4*>(out_split + pixel * 2 * C + c) = hv;
+      *reinterpret_cast<ushort4*>(out_split + pixel * 2 * C + C + c) = lv;
+    }
   }
 }
 
@@ -473,9 +481,10 @@ int nhwc_to_split_launch(float* x, uint16_t* out, int N, int C, int H, int W, in
   return FGVC_OK;
 }
 
-int normalize_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int normalize, hipStream_t s) {
+int normalize_nhwc_launch(const float* in, float* out, uint16_t* out_split, int N, int C, int H, int W, int normalize,
+                          hipStream_t s) {
   const long long npix = (long long)N * H * W;
-  normalize_nhwc_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, C, normalize, npix);
+  normalize_nhwc_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
   FGVC_CHECK_LAUNCH("fgvc_normalize_nhwc_f32");
   return FGVC_OK;
 }

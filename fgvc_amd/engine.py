@@ -130,7 +130,8 @@ class DeviceTopk:
 
 def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
                  pair_chunk: int = 16384, events=None) -> DeviceTopk:
-    """Phases 1 and 2.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip.
+    """Phases 1 and 2.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip, f32 -- or their
+    split_bf16() form (T, HW, 2, C) int16 where the split pair kernel applies (VanillaTracker.get_feats_hwc(split=True)).
     `events` = (start, end) torch.cuda.Events recorded around the pair top-k launch(es)."""
     dev = feats_hwc.device
     HW = Hf * Wf
@@ -138,10 +139,13 @@ def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tra
     n = len(plan.pairs)
     pairs_dev, slot_pair, slot_frame = plan.tables(dev)
     rows = len(plan.slot_pair)
+    pre_split = feats_hwc.dtype == torch.int16            # (T, HW, 2, C): the bank already as split_bf16() of the normalised rows
     use_split = cfg.pair_precision == "split" or (
-        cfg.pair_precision == "auto" and ops.split_path_ok(feats_hwc.shape[2], Hf, Wf, k, cfg.with_norm))
+        cfg.pair_precision == "auto" and ops.split_path_ok(feats_hwc.shape[-1], Hf, Wf, k, cfg.with_norm))
+    if pre_split and not use_split:
+        raise ValueError("run_affinity: split features given, but the split pair kernel does not apply to this configuration")
     if use_split:      # bf16 matrix pipe on the hi/lo split of the (normalised) features, f32-grade scores
-        split = ops.split_bf16(feats_hwc)
+        split = feats_hwc if pre_split else ops.split_bf16(feats_hwc)
         pair_fn = lambda prs: ops.pair_topk_split(split, split, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
     else:
         pair_fn = lambda prs: ops.pair_topk(feats_hwc, feats_hwc, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)

@@ -380,16 +380,20 @@ class ResNet(nn.Module):
         outs = [stage_out[i] for i in want]
         return outs[0] if len(outs) == 1 else tuple(outs)
 
-    def forward_hwc(self, x, normalize: bool = True):
+    def forward_hwc(self, x, normalize: bool = True, split_if=None):
         """The tracker's fast path: features of the single requested stage as (N, H*W, C) f32 rows, L2-normalised if
         `normalize` -- straight from the dense NHWC buffer when the stage ran on the bf16 pipe (no NCHW round trip).
-        Returns (feats, H, W)."""
+        `split_if(C, H, W) -> bool`: when given and true for the stage's shape, the rows come back as their (hi, lo) bf16
+        split (N, H*W, 2, C) int16 instead (what the split pair kernel reads), made in the same pass.  Returns (feats, H, W)."""
         from .. import ops
         assert len(self.out_indices) == 1
         _, y, nhwc, H, W = self._trunk(x, self.out_indices[0])
+        C = y.shape[-1] if nhwc else y.shape[1]
+        as_split = bool(split_if is not None and split_if(C, H, W))
         if nhwc:
-            return ops.normalize_nhwc(y, normalize), H, W
-        return ops.normalize_to_hwc(y.float(), normalize, pad=True), H, W
+            return ops.normalize_nhwc(y, normalize, split=as_split), H, W
+        f = ops.normalize_to_hwc(y.float(), normalize, pad=True)
+        return (ops.split_bf16(f) if as_split and f.shape[-1] == C else f), H, W
 
 
 _PREFIXES = (r"^module\.", r"^backbone\.", r"^encoder\.", r"^backbone_fine\.")

@@ -75,9 +75,11 @@ class VanillaTracker(BaseTracker):
         return x
 
     @torch.no_grad()
-    def get_feats_hwc(self, frames: torch.Tensor):
+    def get_feats_hwc(self, frames: torch.Tensor, split: bool = False):
         """frames (T,3,h,w) -> normalised channels-last (T, HfWf, C'), Hf, Wf.
-        batch_step frames per encoder call (vanilla_tracker.py:135-147)."""
+        batch_step frames per encoder call (vanilla_tracker.py:135-147).  split=True: the bank comes back as its (hi, lo) bf16
+        split (T, HfWf, 2, C') int16 wherever the engine's split pair kernel applies (one pass less; engine.run_affinity takes
+        either form), f32 otherwise."""
         step = int(self.test_cfg.get("batch_step", 5))
         norm = bool(self.test_cfg.get("with_norm", True))
         chunks = []
@@ -87,9 +89,14 @@ class VanillaTracker(BaseTracker):
             frames = frames.contiguous(memory_format=torch.channels_last)
         fast = (hasattr(self.backbone, "forward_hwc") and self.head is None and not self.stride_sample
                 and len(getattr(self.backbone, "out_indices", ())) == 1)
+        split_if = None
+        if split and fast:
+            cfg = self.engine_config()
+            if cfg.pair_precision in ("auto", "split"):
+                split_if = lambda C, H, W: ops.split_path_ok(C, H, W, cfg.topk, cfg.with_norm)
         for i in range(0, frames.shape[0], step):
             if fast:       # backbone writes normalised channels-last rows itself (no NCHW round trip)
-                f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm)
+                f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm, split_if=split_if)
                 chunks.append(f)
                 continue
             f = self.extract_feat(frames[i:i + step])
@@ -116,7 +123,7 @@ class VanillaTracker(BaseTracker):
         qp = query_points[0]
         if not cfg.with_first:
             # single group that starts at frame 0 regardless of the query times (vanilla_tracker.py:302-303)
-            feats, Hf, Wf = self.get_feats_hwc(rgbs[0])
+            feats, Hf, Wf = self.get_feats_hwc(rgbs[0], split=True)
             plan = engine.plan_clip(T, [0], cfg)
             tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
             _, coords = engine.run_propagation(tk, 0, qp[:, 1:].to(dev, torch.float32), Hf, Wf, h, w, cfg)
@@ -124,7 +131,7 @@ class VanillaTracker(BaseTracker):
             return trajectories, visibilities, traj_pred, torch.zeros_like(visibilities), query_points
         t_min = int(qp[:, 0].min().item())
         # frames before the earliest query time are never used by any group
-        feats, Hf, Wf = self.get_feats_hwc(rgbs[0, t_min:])
+        feats, Hf, Wf = self.get_feats_hwc(rgbs[0, t_min:], split=True)
         qp_rel = qp.clone()
         qp_rel[:, 0] -= t_min
         traj, order = engine.track_points(feats, Hf, Wf, h, w, qp_rel, cfg)     # (T-t_min, P, 2) f64, regrouped
@@ -139,7 +146,7 @@ class VanillaTracker(BaseTracker):
         """vanilla_tracker.py:305-412: all points are propagated from frame 0 of `rgbs`."""
         cfg = self.engine_config()
         T, h, w = rgbs.shape[1], rgbs.shape[-2], rgbs.shape[-1]
-        feats, Hf, Wf = self.get_feats_hwc(rgbs[0])
+        feats, Hf, Wf = self.get_feats_hwc(rgbs[0], split=True)
         plan = engine.plan_clip(T, [0], cfg)
         tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
         pts = query_points[0, :, 1:].to(rgbs.device, torch.float32)

@@ -495,13 +495,24 @@ def stem7_split(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, relu: bool
               int(relu), _stream(x))
 
 
-def normalize_nhwc(x: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-    """dense NHWC f32 (N,H,W,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc)."""
+def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split: bool = False) -> torch.Tensor:
+    """dense NHWC f32 (N,H,W,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc); split=True returns
+    split_bf16() of those rows instead, (N, H*W, 2, C) int16, produced in the same single pass over x."""
     x = _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
+    if split:
+        out = torch.empty((N, H * W, 2, C), device=x.device, dtype=torch.int16)
+        _lib.call("fgvc_normalize_split_nhwc_f32", _ptr(x), _ptr(None), _ptr(out), N, C, H, W, int(normalize), _stream(x))
+        return out
     out = torch.empty((N, H * W, C), device=x.device, dtype=torch.float32)
     _lib.call("fgvc_normalize_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, int(normalize), _stream(x))
     return out
+
+
+def unsplit_bf16(split: torch.Tensor) -> torch.Tensor:
+    """(…, 2, C) int16 split features -> (…, C) f32 = hi + lo (2^-17-relative approximation of the rows that were split)."""
+    v = split.view(torch.bfloat16).float()
+    return v[..., 0, :] + v[..., 1, :]
 
 
 def gaussian_labels(points: torch.Tensor, Hf: int, Wf: int, stride: int, sigma: float = 6.0,

@@ -237,6 +237,10 @@ int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, u
 /* dense NHWC f32 -> [n][H*W][C] f32, rows L2-normalised if `normalize` (the output layout of
  * fgvc_normalize_chw_to_hwc_f32) */
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream);
+/* the same rows and / or their (hi, lo) bf16 split [n][H*W][hi C | lo C] (= fgvc_split_bf16 of them, what
+ * fgvc_pair_topk_bf16x4 reads) in ONE pass over the trunk output; either output may be NULL */
+int fgvc_normalize_split_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
+                                  int normalize, void* stream);
 
 /* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
  * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).

@@ -256,6 +256,38 @@ def _readout_both(ops, labels, Hf, Wf, h, w, **kw):
     return ops.softargmax_top5(labels, Hf, Wf, h, w, **kw).cpu(), full
 
 
+def test_split_feature_bank_equals_f32_bank(dev):
+    """The bank as split_bf16() rows straight from the trunk output (one pass: normalize_nhwc(split=True), and
+    VanillaTracker.get_feats_hwc(split=True)) is bit-identical to normalising first and splitting after, and engine.run_affinity
+    gives the same lists from either form."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import engine, ops
+    g = torch.Generator().manual_seed(41)
+    y = torch.randn(3, 9, 13, 256, generator=g).to(dev)
+    f = ops.normalize_nhwc(y, True)
+    assert torch.equal(ops.normalize_nhwc(y, True, split=True), ops.split_bf16(f))
+    assert torch.equal(ops.normalize_nhwc(y, False, split=True), ops.split_bf16(ops.normalize_nhwc(y, False)))
+    assert float((ops.unsplit_bf16(ops.split_bf16(f)) - f).abs().max()) < 1e-5
+    model = api.build_model(dict(type="VanillaTracker",
+                                 backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")),
+                            train_cfg=None,
+                            test_cfg=api.ConfigDict(precede_frames=3, topk=10, temperature=0.07, neighbor_range=12,
+                                                    with_first=True, with_first_neighbor=True, batch_step=2)).to(dev).eval()
+    frames = torch.randn(5, 3, 64, 96, generator=g).to(dev)
+    bank_s, Hf, Wf = model.get_feats_hwc(frames, split=True)            # 3 encoder calls (2 + 2 + 1 frames), concatenated
+    bank_f, Hf2, Wf2 = model.get_feats_hwc(frames)
+    assert bank_s.dtype == torch.int16 and bank_s.shape == (5, Hf * Wf, 2, 256) and (Hf, Wf) == (Hf2, Wf2) == (16, 24)
+    assert torch.equal(ops.split_bf16(bank_f), bank_s)                  # the hand-written trunk is deterministic call to call
+    cfg = model.engine_config()
+    plan = engine.plan_clip(5, [0], cfg)
+    a = engine.run_affinity(bank_s, Hf, Wf, plan, cfg)
+    b = engine.run_affinity(bank_f, Hf, Wf, plan, cfg)                  # f32 form: split inside
+    assert torch.equal(a.idx, b.idx) and torch.equal(a.weight, b.weight)
+    cfg32 = engine.TrackerConfig(**{**cfg.__dict__, "pair_precision": "f32"})
+    with pytest.raises(ValueError):
+        engine.run_affinity(bank_s, Hf, Wf, plan, cfg32)
+
+
 def test_run_propagation_async_equals_sync(dev):
     """engine.run_propagation_async (sweep + read-out on a side stream, the caller's stream free for the next clip) returns what
     run_propagation returns, also when the caller immediately reuses its stream and drops its references."""
