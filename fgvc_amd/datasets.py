@@ -6,6 +6,12 @@
 """
 from __future__ import annotations
 
+import glob
+import io
+import os
+import pickle
+
+import numpy as np
 import torch
 
 
@@ -88,3 +94,99 @@ def preprocess_tapvid_frames(frames_uint8: torch.Tensor, size=(256, 256)) -> tor
     mean = torch.tensor([50.0, 0.0, 0.0], device=lab.device).view(1, 3, 1, 1)
     std = torch.tensor([50.0, 127.0, 127.0], device=lab.device).view(1, 3, 1, 1)
     return ((lab - mean) / std).unsqueeze(0)
+
+
+# ---- TAP-Vid files (mmpt/datasets/tapvid.py:36-174, tapvid_evaluation_datasets.py:284-395) ---------------------------------
+def _queries_first(occluded: np.ndarray, points: np.ndarray):
+    """One query per track at its first visible frame; tracks that are never visible are dropped
+    (tapvid_evaluation_datasets.py:352-395).  occluded (P,T) bool, points (P,T,2) = (x,y).  Returns (queries (Q,3) = (t,y,x),
+    points (Q,T,2), occluded (Q,T))."""
+    keep = (~occluded).any(axis=1)
+    points, occluded = points[keep], occluded[keep]
+    t0 = np.argmax(~occluded, axis=1)
+    rows = np.arange(points.shape[0])
+    q = np.stack([t0.astype(points.dtype), points[rows, t0, 1], points[rows, t0, 0]], axis=-1)
+    return q, points, occluded
+
+
+def _queries_strided(occluded: np.ndarray, points: np.ndarray, stride: int = 5):
+    """A query at every `stride`-th frame for every track visible there; tracks are repeated per query
+    (tapvid_evaluation_datasets.py:284-349)."""
+    qs, ps, os_ = [], [], []
+    for t in range(0, occluded.shape[1], stride):
+        vis = ~occluded[:, t]
+        qs.append(np.stack([np.full(int(vis.sum()), t, dtype=points.dtype), points[vis, t, 1], points[vis, t, 0]], axis=-1))
+        ps.append(points[vis])
+        os_.append(occluded[vis])
+    return np.concatenate(qs, 0), np.concatenate(ps, 0), np.concatenate(os_, 0)
+
+
+class TapVidPickles:
+    """TAP-Vid videos from pickles in the sample format the model consumes (the reference's TAPVidDataset, tapvid.py:36-174).
+    `root`: a directory of `*.pkl` files with one video each (what the reference globs, tapvid.py:66), or ONE pickle holding
+    {name: video} or [video, ...] (the published tapvid_davis.pkl).  A video = dict(video (T,H,W,3) uint8 frames -- or an
+    array of encoded JPEG byte strings, tapvid.py:91-99 --, points (P,T,2) = (x,y) in [0,1], occluded (P,T) bool).
+    Frames go through the TAP-Vid input contract (`preprocess_tapvid_frames`: resize to `input_size`, RGB->Lab, normalise),
+    points are scaled to `input_size` pixels (tapvid.py:106-108), queries are sampled by `query_mode` 'first' | 'strided'."""
+
+    def __init__(self, root: str, query_mode: str = "first", input_size=(256, 256), device="cpu"):
+        if query_mode not in ("first", "strided"):
+            raise ValueError(f"Unknown query mode {query_mode}.")                                   # tapvid.py:115
+        self.query_mode, self.input_size, self.device = query_mode, tuple(input_size), device
+        self.videos = []                       # (path, key): key = None for one-video files
+        files = sorted(glob.glob(os.path.join(root, "*.pkl"))) if os.path.isdir(root) else [root]
+        for f in files:
+            with open(f, "rb") as fh:
+                obj = pickle.load(fh)
+            if isinstance(obj, dict) and "video" in obj:
+                self.videos.append((f, None))
+            elif isinstance(obj, dict):
+                self.videos.extend((f, k) for k in obj)
+            else:
+                self.videos.extend((f, i) for i in range(len(obj)))
+        self._open = (None, None)
+
+    def __len__(self):
+        return len(self.videos)
+
+    def _raw(self, i):
+        f, key = self.videos[i]
+        if self._open[0] != f:
+            with open(f, "rb") as fh:
+                self._open = (f, pickle.load(fh))
+        obj = self._open[1]
+        return obj if key is None else obj[key]
+
+    @staticmethod
+    def _frames(video) -> torch.Tensor:
+        if len(video) and isinstance(video[0], (bytes, bytearray)):                                  # JPEG bytes
+            from PIL import Image
+            video = np.stack([np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in video])
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(video, dtype=np.uint8)))
+
+    def __getitem__(self, i):
+        sample = self._raw(i)
+        frames = self._frames(sample["video"])                                                      # (T,H,W,3) uint8
+        h, w = self.input_size
+        points = np.asarray(sample["points"], dtype=np.float32) * np.array([w, h], dtype=np.float32)   # tapvid.py:108
+        occluded = np.asarray(sample["occluded"]).astype(bool)
+        q, points, occluded = (_queries_first if self.query_mode == "first" else _queries_strided)(occluded, points)
+        query_points = torch.from_numpy(q[:, [0, 2, 1]].astype(np.float32))                         # (t,y,x) -> (t,x,y), :132-133
+        traj = torch.from_numpy(points).permute(1, 0, 2).contiguous()                               # (T,P,2)
+        vis = ~torch.from_numpy(occluded).permute(1, 0).contiguous()                                # (T,P)
+        P = query_points.shape[0]
+        qt = query_points[:, 0].long()
+        # Kubric reports query points on the crop boundary as invisible (tapvid.py:135-150)
+        for p in range(P):
+            if not vis[qt[p], p]:
+                x, y = float(query_points[p, 1]), float(query_points[p, 2])
+                xb, yb = min(abs(x), abs(x - (w - 1))) < 1e-3, min(abs(y), abs(y - (h - 1))) < 1e-3
+                xin, yin = 0 <= x <= w - 1, 0 <= y <= h - 1
+                if (xb and yin) or (xin and yb) or (xb and yb):
+                    vis[qt[p], p] = True
+        assert bool(vis[qt, torch.arange(P)].all()), "Query points must be visible"                # tapvid.py:160-161
+        assert torch.allclose(query_points[:, 1:], traj[qt, torch.arange(P)], atol=1.0)             # tapvid.py:164-168
+        rgbs = preprocess_tapvid_frames(frames.to(self.device), self.input_size)                    # (1,T,3,h,w)
+        d = self.device
+        return dict(rgbs=rgbs, query_points=query_points.unsqueeze(0).to(d), trajectories=traj.unsqueeze(0).to(d),
+                    visibilities=vis.float().unsqueeze(0).to(d))

@@ -235,3 +235,54 @@ def test_resnet_split_cache_is_dropped_when_weights_change():
     bb.__dict__["_split_cache"] = {"stale": 1}
     bb.init_weights()
     assert "_split_cache" not in bb.__dict__
+
+
+def test_tapvid_pickles_sample_format(tmp_path):
+    """TapVidPickles on files in the TAP-Vid layout (per-video pickles, one multi-video pickle, JPEG-encoded frames): the sample
+    format and conventions of the reference's TAPVidDataset (tapvid.py:85-174) -- (t,x,y) queries in input_size pixels, 'first'
+    drops never-visible tracks and queries at the first visible frame, 'strided' repeats tracks per query frame."""
+    import io, pickle
+    import numpy as np
+    from PIL import Image
+    from fgvc_amd.datasets import TapVidPickles
+    rng = np.random.default_rng(0)
+    T, H, W, P = 7, 40, 60, 5
+    video = rng.integers(0, 255, (T, H, W, 3), dtype=np.uint8)
+    points = rng.random((P, T, 2)).astype(np.float32)
+    occ = np.zeros((P, T), dtype=bool)
+    occ[1, :3] = True            # first visible at t = 3
+    occ[2, :] = True             # never visible: dropped by 'first'
+    occ[3, 5] = True             # hidden at a strided query frame
+    sample = dict(video=video, points=points, occluded=occ)
+    d = tmp_path / "videos"
+    d.mkdir()
+    for name in ("a", "b"):
+        with open(d / f"{name}.pkl", "wb") as f:
+            pickle.dump(sample, f)
+    ds = TapVidPickles(str(d), "first", (32, 48))
+    assert len(ds) == 2
+    s0 = ds[0]
+    assert s0["rgbs"].shape == (1, T, 3, 32, 48) and s0["rgbs"].dtype == torch.float32
+    assert s0["query_points"].shape == (1, 4, 3) and s0["trajectories"].shape == (1, T, 4, 2) and s0["visibilities"].shape == (1, T, 4)
+    qp = s0["query_points"][0]
+    assert qp[:, 0].tolist() == [0.0, 3.0, 0.0, 0.0]
+    assert torch.allclose(qp[1, 1:], torch.tensor(points[1, 3] * np.array([48, 32], dtype=np.float32)))     # (x, y) in pixels
+    assert torch.allclose(s0["trajectories"][0, :, 0], torch.from_numpy(points[0] * np.array([48, 32], dtype=np.float32)))
+    assert s0["visibilities"][0, :, 1].tolist() == [0, 0, 0, 1, 1, 1, 1]
+    st = TapVidPickles(str(d), "strided", (32, 48))[1]
+    # query frames 0 and 5: visible tracks {0, 3, 4} at t = 0 and {0, 1, 4} at t = 5
+    assert st["query_points"][0][:, 0].tolist() == [0, 0, 0, 5, 5, 5]
+    assert torch.allclose(st["trajectories"][0, :, 3], torch.from_numpy(points[0] * np.array([48, 32], dtype=np.float32)))
+    # one pickle with several videos, frames stored as JPEG bytes
+    jpeg = []
+    for t in range(T):
+        b = io.BytesIO()
+        Image.fromarray(video[t]).save(b, format="JPEG")
+        jpeg.append(b.getvalue())
+    big = tmp_path / "tapvid_multi.pkl"
+    with open(big, "wb") as f:
+        pickle.dump({"v0": sample, "v1": dict(video=np.array(jpeg, dtype=object), points=points, occluded=occ)}, f)
+    dm = TapVidPickles(str(big), "first", (32, 48))
+    assert len(dm) == 2 and dm[1]["rgbs"].shape == (1, T, 3, 32, 48) and torch.equal(dm[0]["rgbs"], s0["rgbs"])
+    with pytest.raises(ValueError):
+        TapVidPickles(str(d), "random")

@@ -5,8 +5,9 @@
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/test.py CONFIG --launcher pytorch
 
 CONFIG may be the reference's own configs/eval/res18_d1_eval.py.  The TAP-Vid / JHMDB files are not available
-offline, so the dataset is `SyntheticTapVid` (same sample format); with `--data-root` pointing at real TAP-Vid
-pickles a loader can be plugged in at `build_dataset`.
+offline, so the default dataset is `SyntheticTapVid` (same sample format); `--data-root DIR_OR_PKL` reads TAP-Vid
+pickles (`fgvc_amd.datasets.TapVidPickles`: a directory of per-video pickles as the reference globs them, or the
+published tapvid_davis.pkl).
 """
 from __future__ import annotations
 
@@ -21,7 +22,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fgvc_amd.mmpt_api as api  # noqa: E402
 from fgvc_amd import apis, metrics  # noqa: E402
-from fgvc_amd.datasets import StridedLoader, SyntheticTapVid  # noqa: E402
+from fgvc_amd.datasets import StridedLoader, SyntheticTapVid, TapVidPickles  # noqa: E402
 
 DEFAULT_CFG = dict(
     model=dict(type="VanillaTracker",
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=(256, 256))
     ap.add_argument("--points", type=int, default=8)
     ap.add_argument("--query-mode", default="first")
+    ap.add_argument("--data-root", default=None, help="TAP-Vid pickles (directory of *.pkl or one .pkl); default: synthetic clips")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
 
@@ -55,7 +57,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         rank, world = dist.get_rank(), dist.get_world_size()
 
-    dataset = SyntheticTapVid(a.videos, a.frames, tuple(a.size), a.points, a.query_mode, device=dev)   # :121-122
+    if a.data_root:
+        dataset = TapVidPickles(a.data_root, a.query_mode, tuple(a.size), device=dev)                   # :121-122
+    else:
+        dataset = SyntheticTapVid(a.videos, a.frames, tuple(a.size), a.points, a.query_mode, device=dev)
     loader = StridedLoader(dataset, rank, world)                                             # :124-134
     test_cfg = cfg["test_cfg_" + a.task]                                                     # :135
     model_cfg = dict(type=cfg.get("eval_arc", "VanillaTracker"), backbone=dict(cfg.model.backbone))   # :139
