@@ -293,12 +293,14 @@ class ResNet(nn.Module):
         cur["full"] = full
         return cur
 
-    def _trunk(self, x, last: int, fresh=()):
+    def _trunk(self, x, last: int, fresh=(), post=None):
         """Stem and stages 0..last.  When every requested stage qualifies (and there is no pooling layer) the whole trunk
         stays in NHWC: the stem in MIOpen on channels_last tensors with BatchNorm folded, ReLU fused into the split, the
         stages on the bf16 pipe.  The batch is cut into `split_lanes` slices that run on separate HIP streams: a layer's
         launch covers the 256 CUs 3.3 times at 8 frames, and the other lane's workgroups fill the tail of each launch.
         Stage outputs listed in `fresh` are new tensors, the others views of cached workspaces (valid until the next call).
+        `post(y_slice, lo, hi, C, H, W)`, if given, runs at the end of every lane on that lane's stream with the lane's slice of the
+        last stage's dense NHWC output (NHWC trunk only: check the returned flag).
         Returns (list of NCHW outputs of stages < last, last stage output, NHWC flag, H, W)."""
         from .. import ops
         stages = [getattr(self, nm) for nm in self.res_layers[:last + 1]]
@@ -356,6 +358,10 @@ class ResNet(nn.Module):
                     with torch.cuda.stream(s):
                         lanes[li] = self._stage_split(i, dict(lanes[li], need_split=i < last, need_f32=need_f32), call)
                 fulls.append(lanes[0]["full"])
+            if post is not None:
+                for ln, s in zip(lanes, streams):
+                    with torch.cuda.stream(s):
+                        post(ln["f32"], ln["lo"], ln["hi"], ln["f32"].shape[-1], ln["H"], ln["W"])
             if n_lanes > 1:
                 for s in streams:
                     main.wait_stream(s)
@@ -387,11 +393,26 @@ class ResNet(nn.Module):
         split (N, H*W, 2, C) int16 instead (what the split pair kernel reads), made in the same pass.  Returns (feats, H, W)."""
         from .. import ops
         assert len(self.out_indices) == 1
-        _, y, nhwc, H, W = self._trunk(x, self.out_indices[0])
-        C = y.shape[-1] if nhwc else y.shape[1]
-        as_split = bool(split_if is not None and split_if(C, H, W))
+        box = {}
+
+        def post(y_slice, lo, hi, C, H, W):      # each lane normalises (and splits) its own frames under the other lane's tail
+            if "out" not in box:
+                as_split = bool(split_if is not None and split_if(C, H, W))
+                with torch.cuda.stream(main):                                  # the result is the caller's: its stream owns it
+                    box["out"] = torch.empty((x.shape[0], H * W, 2, C) if as_split else (x.shape[0], H * W, C), device=x.device,
+                                             dtype=torch.int16 if as_split else torch.float32)
+                torch.cuda.current_stream(x.device).wait_stream(main)          # (the block's previous life ended on that stream)
+                box["split"] = as_split
+            elif torch.cuda.current_stream(x.device) != main:
+                torch.cuda.current_stream(x.device).wait_stream(main)
+            ops.normalize_nhwc(y_slice, normalize, split=box["split"], out=box["out"][lo:hi])
+
+        main = torch.cuda.current_stream(x.device) if x.is_cuda else None
+        _, y, nhwc, H, W = self._trunk(x, self.out_indices[0], post=post)
         if nhwc:
-            return ops.normalize_nhwc(y, normalize, split=as_split), H, W
+            return box["out"], H, W
+        C = y.shape[1]
+        as_split = bool(split_if is not None and split_if(C, H, W))
         f = ops.normalize_to_hwc(y.float(), normalize, pad=True)
         return (ops.split_bf16(f) if as_split and f.shape[-1] == C else f), H, W
 

@@ -495,17 +495,18 @@ def stem7_split(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, relu: bool
               int(relu), _stream(x))
 
 
-def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split: bool = False) -> torch.Tensor:
+def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dense NHWC f32 (N,H,W,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc); split=True returns
-    split_bf16() of those rows instead, (N, H*W, 2, C) int16, produced in the same single pass over x."""
+    split_bf16() of those rows instead, (N, H*W, 2, C) int16, produced in the same single pass over x.  `out`: write there."""
     x = _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
-    if split:
-        out = torch.empty((N, H * W, 2, C), device=x.device, dtype=torch.int16)
-        _lib.call("fgvc_normalize_split_nhwc_f32", _ptr(x), _ptr(None), _ptr(out), N, C, H, W, int(normalize), _stream(x))
-        return out
-    out = torch.empty((N, H * W, C), device=x.device, dtype=torch.float32)
-    _lib.call("fgvc_normalize_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, int(normalize), _stream(x))
+    shape, dt = ((N, H * W, 2, C), torch.int16) if split else ((N, H * W, C), torch.float32)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=dt)
+    else:
+        assert tuple(out.shape) == shape and out.dtype == dt and out.is_contiguous() and out.device == x.device
+    _lib.call("fgvc_normalize_split_nhwc_f32", _ptr(x), _ptr(None if split else out), _ptr(out if split else None), N, C, H, W,
+              int(normalize), _stream(x))
     return out
 
 
