@@ -150,9 +150,9 @@ class ResNet(nn.Module):
         self.__dict__.pop("_split_cache", None)
 
     def _split_stage_ok(self, stage, x) -> bool:
-        """A stage runs on fgvc_conv_split_f32 when it is made of BasicBlocks with dilation-1 convolutions, Cin % 32 == 0
-        and Cout % 64 == 0, in eval mode on the GPU in f32.  Only the stage's first block may be strided: its strided
-        3x3 and 1x1 projection stay in MIOpen, everything after them is on the bf16 pipe."""
+        """A stage runs on the bf16 pipe when it is made of BasicBlocks with dilation-1 convolutions, Cin % 32 == 0 and
+        Cout % 64 == 0, in eval mode on the GPU in f32.  Only the stage's first block may be strided: stride 2 goes to
+        fgvc_conv_s2_split_f32 (3x3 and 1x1 projection), any other stride to MIOpen for those two convolutions only."""
         if not (self.use_split_conv and x.is_cuda and not self.training and x.dtype == torch.float32):
             return False
         for bi, blk in enumerate(stage):
@@ -295,9 +295,10 @@ class ResNet(nn.Module):
 
     def _trunk(self, x, last: int, fresh=(), post=None):
         """Stem and stages 0..last.  When every requested stage qualifies (and there is no pooling layer) the whole trunk
-        stays in NHWC: the stem in MIOpen on channels_last tensors with BatchNorm folded, ReLU fused into the split, the
-        stages on the bf16 pipe.  The batch is cut into `split_lanes` slices that run on separate HIP streams: a layer's
-        launch covers the 256 CUs 3.3 times at 8 frames, and the other lane's workgroups fill the tail of each launch.
+        stays in NHWC on the bf16 pipe: the 7x7 stride-2 stem in fgvc_stem7_split_f32 (any other stem: MIOpen on
+        channels_last tensors with BatchNorm folded, ReLU fused into the split), the stages as _stage_split runs them.
+        The batch is cut into `split_lanes` slices that run on separate HIP streams: a layer's launch covers the 256 CUs
+        3.3 times at 8 frames, and the other lane's workgroups fill the tail of each launch.
         Stage outputs listed in `fresh` are new tensors, the others views of cached workspaces (valid until the next call).
         `post(y_slice, lo, hi, C, H, W)`, if given, runs at the end of every lane on that lane's stream with the lane's slice of the
         last stage's dense NHWC output (NHWC trunk only: check the returned flag).
