@@ -134,7 +134,7 @@ template <int C, int NSEG, int NW, int SUB>
 __global__ __launch_bounds__(NW * 64, (NW == 8) ? 2 : 2) void corr_volume_bf16_kernel(const uint16_t* __restrict__ q_hl,
                                                                    const uint16_t* __restrict__ k_hl, int HWq,
                                                                    int HWk, float temperature,
-                                                                   float* __restrict__ vol, int debug) {
+                                                                   float* __restrict__ vol, int debug, int kchunk) {
   // C == 256: a key pixel's [hi|lo] row is exactly 1 KiB = one LDS-DMA wave instruction, so the whole row is
   // staged (also for NSEG == 1, which then simply ignores the lo half) with zero staging registers.
   constexpr bool DMA = (C == 256);
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 2 : 2) void corr_volume_bf16_k
     asm volatile("" ::"v"(qh[j]));
     if constexpr (NSEG == 3) asm volatile("" ::"v"(ql[j]));
   }
-  const int kb0 = blockIdx.y * KCHUNK;               // in units of 32-key blocks; a stage covers SUB of them
-  const int kb1 = imin(kb0 + KCHUNK, cdiv(HWk, 32));
+  const int kb0 = blockIdx.y * kchunk;               // in units of 32-key blocks; a stage covers SUB of them
+  const int kb1 = imin(kb0 + kchunk, cdiv(HWk, 32));
   uint4 stage[NLD];
   auto stage_load = [&](int kb, int buf) {
     if constexpr (DMA) {
@@ -224,25 +224,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 2 : 2) void corr_volume_bf16_k
       f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       f32x16 accx = acc, accy = acc;
       const unsigned char* ka = &smem[buf * BUFB + (sb * 32 + n) * LDB + 16 * hi];   // A operand: key row
-      constexpr int G = 2;                               // k16 steps per pipeline stage
+      // A operands one group of G k16-steps ahead, by inline assembly with explicit waits: for loads it knows about hipcc
+      // merges the waits of two groups into one `s_waitcnt lgkmcnt(0)` placed AFTER the next group's reads were issued, i.e.
+      // every other group waits a full LDS round trip (25 % of the 12 MFMAs between them).  Here: wait for group g (the
+      // only LDS operations outstanding), then issue group g + 1, then multiply group g.
+      constexpr int G = 4;                               // k16 steps per group: 12 MFMAs (NSEG == 3) cover the LDS latency
       constexpr int NG = KS / G;
       bf16x8 ah[2][G], al[2][(NSEG == 3) ? G : 1];
+      const uint32_t ka_lds = (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)ka;
+      auto load_group = [&](int g, int slot) {
 #pragma unroll
-      for (int i = 0; i < G; ++i) {
-        ah[0][i] = *reinterpret_cast<const bf16x8*>(ka + 32 * i);
-        if constexpr (NSEG == 3) al[0][i] = *reinterpret_cast<const bf16x8*>(ka + C * 2 + 32 * i);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < G; ++i) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[slot][i]) : "v"(ka_lds), "i"(32 * (g * G + i)) : "memory");
+          if constexpr (NSEG == 3)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[slot][i]) : "v"(ka_lds), "i"(C * 2 + 32 * (g * G + i)) : "memory");
+        }
+      };
+      load_group(0, 0);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
-#pragma unroll
-          for (int i = 0; i < G; ++i) {
-            ah[(g + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(ka + 32 * ((g + 1) * G + i));
-            if constexpr (NSEG == 3)
-              al[(g + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(ka + C * 2 + 32 * ((g + 1) * G + i));
-          }
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -325,18 +328,26 @@ int corr_volume_bf16_launch(const uint16_t* q, const uint16_t* k, int C, int HWq
   // C == 256: 8-wave workgroups (256 queries), 64-key stages through LDS-DMA; narrower features keep the
   // 4-wave / 32-key register-staged form
   if (C == 256) {
-    dim3 grid(cdiv(HWq, 256), cdiv(cdiv(HWk, 32), KCHUNK));
+    // key blocks per workgroup: one workgroup per CU (248 VGPRs), and every workgroup pays ~4 us of prologue (128 VGPRs of
+    // query fragments + the first stage) before its first MFMA -- as few, long workgroups as still fill the 256 CUs about
+    // 4 times: at 480p 81 blocks = 10 x 101 workgroups (3.95 rounds) 1.04 ms against 1.14 ms for 16 blocks (20.1 rounds)
+    const int n_q = cdiv(HWq, 256), n_kb = cdiv(HWk, 32);
+    const int chunks = imax(1, 1024 / n_q);
+    int kchunk = imax(16, cdiv(n_kb, chunks));
+    kchunk += kchunk & 1;                                 // whole 64-key stages
+    if (g_corr_debug >> 8) kchunk = g_corr_debug >> 8;    // tools/ablate_corr.py sweeps it
+    dim3 grid(n_q, cdiv(n_kb, kchunk));
     if (nseg == 3)
-      corr_volume_bf16_kernel<256, 3, 8, 2><<<grid, 512, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug);
+      corr_volume_bf16_kernel<256, 3, 8, 2><<<grid, 512, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug & 255, kchunk);
     else
-      corr_volume_bf16_kernel<256, 1, 8, 2><<<grid, 512, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug);
+      corr_volume_bf16_kernel<256, 1, 8, 2><<<grid, 512, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug & 255, kchunk);
   } else {
     dim3 grid(cdiv(HWq, 128), cdiv(cdiv(HWk, 32), KCHUNK));
 #define FGVC_BF(CC)                                                                                       \
   if (nseg == 3)                                                                                          \
-    corr_volume_bf16_kernel<CC, 3, 4, 1><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug);         \
+    corr_volume_bf16_kernel<CC, 3, 4, 1><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug & 255, KCHUNK);         \
   else                                                                                                    \
-    corr_volume_bf16_kernel<CC, 1, 4, 1><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug)
+    corr_volume_bf16_kernel<CC, 1, 4, 1><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug & 255, KCHUNK)
     switch (C) {
       case 64: FGVC_BF(64); break;
       case 128: FGVC_BF(128); break;
