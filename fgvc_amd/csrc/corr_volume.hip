@@ -23,7 +23,7 @@ template <int C>
 __global__ __launch_bounds__(256, 2) void corr_volume_f32_kernel(const float* __restrict__ qfeat,
                                                                   const float* __restrict__ kfeat, int HWq,
                                                                   int HWk, float temperature,
-                                                                  float* __restrict__ vol) {
+                                                                  float* __restrict__ vol, int kchunk) {
   constexpr int LDK = C + 4;
   constexpr int BUF = 32 * LDK;
   constexpr int NLD = C / 32;
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256, 2) void corr_volume_f32_kernel(const float* __
   // wait for the freshly issued key loads and the previous tile's stores -- a memory round trip per tile.
 #pragma unroll
   for (int j = 0; j < C / 2; ++j) asm volatile("" ::"v"(qreg[j]));
-  const int kb0 = blockIdx.y * KCHUNK;
-  const int kb1 = imin(kb0 + KCHUNK, cdiv(HWk, 32));
+  const int kb0 = blockIdx.y * kchunk;
+  const int kb1 = imin(kb0 + kchunk, cdiv(HWk, 32));
   f32x4 stage[NLD];
   auto stage_load = [&](int kb) {
 #pragma unroll
@@ -299,12 +299,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 2 : 2) void corr_volume_bf16_k
 // ------------------------------------------------------------------------------------------
 int corr_volume_f32_launch(const float* q, const float* k, int C, int HWq, int HWk, float temperature, float* vol,
                            hipStream_t s) {
-  dim3 grid(cdiv(HWq, 128), cdiv(cdiv(HWk, 32), KCHUNK));
+  // key blocks per workgroup: long workgroups amortise the query-fragment prologue (see corr_volume_bf16_launch); two
+  // workgroups share a CU here, so the grid should cover 512 slots about 4 times
+  const int n_q = cdiv(HWq, 128), n_kb = cdiv(HWk, 32);
+  const int kchunk = imax(KCHUNK, cdiv(n_kb, imax(1, 2048 / n_q)));
+  dim3 grid(n_q, cdiv(n_kb, kchunk));
   switch (C) {
-    case 32: corr_volume_f32_kernel<32><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol); break;
-    case 64: corr_volume_f32_kernel<64><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol); break;
-    case 128: corr_volume_f32_kernel<128><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol); break;
-    case 256: corr_volume_f32_kernel<256><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol); break;
+    case 32: corr_volume_f32_kernel<32><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, kchunk); break;
+    case 64: corr_volume_f32_kernel<64><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, kchunk); break;
+    case 128: corr_volume_f32_kernel<128><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, kchunk); break;
+    case 256: corr_volume_f32_kernel<256><<<grid, 256, 0, s>>>(q, k, HWq, HWk, temperature, vol, kchunk); break;
     default:
       set_error("fgvc_corr_volume_f32: C=%d unsupported (32, 64, 128 or 256)", C);
       return FGVC_ERR_UNSUPPORTED;
