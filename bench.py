@@ -198,11 +198,12 @@ def main():
         if timed:                                                          # HIP events on the launch stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair_ev.append(ev)
-        tk = engine.run_affinity(feats, Hf, Wf, plan, cfg, events=ev)      # pair top-k (1 launch) + merge
+        pl = engine.run_pairs(feats, Hf, Wf, plan, cfg, events=ev)         # pair top-k (1 launch)
         if tail_stream is None:
+            tk = engine.merge_pairs(pl, cfg)                                   # slot merge + softmax
             _, coords = engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)  # sequential sweep + read-out
-        else:      # the same launches on a side stream: the next clip's encoder starts under this clip's sweep and read-out
-            _, coords, _ = engine.run_propagation_async(tk, 0, pts, Hf, Wf, h, w, cfg, tail_stream)
+        else:      # the same launches on a side stream: the next clip's encoder starts under this clip's merge, sweep and read-out
+            _, coords, _ = engine.run_propagation_async(pl, 0, pts, Hf, Wf, h, w, cfg, tail_stream)
         return coords, (Hf, Wf, feats)
 
     def barrier():

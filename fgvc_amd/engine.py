@@ -128,9 +128,35 @@ class DeviceTopk:
     slot_frame: torch.Tensor  # (rows, t_max) int32
 
 
+@dataclass
+class PairLists:
+    """phase 1 results on the device: per (query frame, key frame) pair the top-k list of every query pixel."""
+    plan: Plan
+    idx: torch.Tensor        # (pairs, HW, k) int32   pixel index in the key frame
+    score: torch.Tensor      # (pairs, HW, k)
+    HW: int
+
+
 def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
                  pair_chunk: int = 16384, events=None) -> DeviceTopk:
-    """Phases 1 and 2.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip, f32 -- or their
+    """Phases 1 and 2 (= merge_pairs(run_pairs(...)))."""
+    return merge_pairs(run_pairs(feats_hwc, Hf, Wf, plan, cfg, pair_chunk, events), cfg)
+
+
+def merge_pairs(pl: PairLists, cfg: TrackerConfig) -> DeviceTopk:
+    """Phase 2: per query frame, merge the lists of its key slots and softmax the k survivors."""
+    plan = pl.plan
+    _, slot_pair, slot_frame = plan.tables(pl.idx.device)
+    if len(plan.slot_pair) == 0:
+        e = torch.empty((0, pl.HW, cfg.topk), device=pl.idx.device)
+        return DeviceTopk(plan, e.int(), e, e, slot_frame)
+    idx, logit, weight = ops.merge_topk(pl.idx, pl.score, slot_pair, pl.HW, cfg.topk, cfg.temperature, cfg.mode, validate=False)
+    return DeviceTopk(plan, idx, logit, weight, slot_frame)
+
+
+def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
+              pair_chunk: int = 16384, events=None) -> PairLists:
+    """Phase 1.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip, f32 -- or their
     split_bf16() form (T, HW, 2, C) int16 where the split pair kernel applies (VanillaTracker.get_feats_hwc(split=True)).
     `events` = (start, end) torch.cuda.Events recorded around the pair top-k launch(es)."""
     dev = feats_hwc.device
@@ -162,11 +188,7 @@ def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tra
             pidx[c0:c1], pscore[c0:c1] = i, s
     if events is not None:
         events[1].record()
-    if rows == 0:
-        e = torch.empty((0, HW, k), device=dev)
-        return DeviceTopk(plan, e.int(), e, e, slot_frame)
-    idx, logit, weight = ops.merge_topk(pidx, pscore, slot_pair, HW, k, cfg.temperature, cfg.mode, validate=False)
-    return DeviceTopk(plan, idx, logit, weight, slot_frame)
+    return PairLists(plan, pidx, pscore, HW)
 
 
 def run_propagation(topk: DeviceTopk, start: int, points_xy: torch.Tensor, Hf: int, Wf: int, h: int, w: int,
@@ -192,15 +214,20 @@ def run_propagation(topk: DeviceTopk, start: int, points_xy: torch.Tensor, Hf: i
     return labels, coords
 
 
-def run_propagation_async(topk: DeviceTopk, start: int, points_xy: torch.Tensor, Hf: int, Wf: int, h: int, w: int,
+def run_propagation_async(topk, start: int, points_xy: torch.Tensor, Hf: int, Wf: int, h: int, w: int,
                           cfg: TrackerConfig, stream: "torch.cuda.Stream"):
     """run_propagation on a side stream: the sweep and the read-out are a chain of small launches that leave most of the GPU
-    idle (0.27 ms per 480p clip); on their own stream the NEXT clip's encoder runs under them.  The caller's stream does not
-    wait: returns (labels, coords, event) -- wait for the event (or synchronise) before reading them.  The inputs are kept
-    from the caching allocator until the side stream is done with them (record_stream)."""
+    idle (0.27 ms per 480p clip); on their own stream the NEXT clip's encoder runs under them.  `topk`: a DeviceTopk, or the
+    PairLists of run_pairs() -- then the merge runs on the side stream as well.  The caller's stream does not wait: returns
+    (labels, coords, event) -- wait for the event (or synchronise) before reading them.  The inputs are kept from the caching
+    allocator until the side stream is done with them (record_stream)."""
     cur = torch.cuda.current_stream(points_xy.device)
     stream.wait_stream(cur)
     with torch.cuda.stream(stream):
+        if isinstance(topk, PairLists):
+            for t in (topk.idx, topk.score):
+                t.record_stream(stream)
+            topk = merge_pairs(topk, cfg)
         for t in (topk.idx, topk.logit, topk.weight, topk.slot_frame, points_xy):
             t.record_stream(stream)
         labels, coords = run_propagation(topk, start, points_xy, Hf, Wf, h, w, cfg)

@@ -303,8 +303,8 @@ def test_run_propagation_async_equals_sync(dev):
     torch.cuda.synchronize()
     outs = []
     for rep in range(4):
-        tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
-        labels, coords, done = engine.run_propagation_async(tk, 0, pts, Hf, Wf, h, w, cfg, side)
+        tk = engine.run_affinity(feats, Hf, Wf, plan, cfg) if rep % 2 else engine.run_pairs(feats, Hf, Wf, plan, cfg)
+        labels, coords, done = engine.run_propagation_async(tk, 0, pts, Hf, Wf, h, w, cfg, side)    # merged lists | pair lists
         del tk                                                     # the allocator may hand these blocks out again right away
         junk = [torch.full((1 << 20,), float(rep), device=dev) for _ in range(8)]     # ... to this, on the caller's stream
         outs.append((labels, coords, done))
