@@ -318,7 +318,7 @@ def main():
             "variants": res,
         }
         del vol
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:          # reported at N = 1 only (the other ranks would sit at the barrier)
         out["cpu_baseline"] = cpu_baseline(wl)
     if rank == 0:
         print(json.dumps(out), flush=True)
