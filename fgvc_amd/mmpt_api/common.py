@@ -191,7 +191,7 @@ def compute_affinity(src_img, dst_img, temperature=1.0, normalize=True, softmax_
 def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask, temperature=1, topk=None,
                                    normalize=True, step=32, non_mask_len=0, mode="softmax",
                                    sim_mode="dot_product", radius_fine=12):
-    """local_attention.py:721-880.  Coarse stage = fgvc_pair_topk_f32 with topk=1 per key slot (arg-max of
+    """local_attention.py:721-880.  Coarse stage = fgvc_pair_topk_bf16x4 / fgvc_pair_topk_f32 with topk=1 per key slot (arg-max of
     the per-frame softmax, :835-837); fine stage = fgvc_c2f_refine_f32."""
     _check_common(query, key, value, mode, sim_mode, topk)
     if mode != "softmax":
@@ -211,7 +211,8 @@ def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask
     qf = ops.normalize_to_hwc(query.float(), normalize, pad=True)
     kf = ops.normalize_to_hwc(key[0].transpose(0, 1).float().contiguous(), normalize, pad=True)
     pairs = ops.make_pairs([(0, t, any_mask and t >= non_mask_len) for t in range(T)], dev)
-    cidx, _ = ops.pair_topk(qf, kf, pairs, H, W, H, W, spec, 1, validate=False, dense_mask=dense)
+    cidx, _ = ops.pair_topk_auto(qf, kf, pairs, H, W, H, W, spec, 1, normalized=bool(normalize), validate=False,
+                                 dense_mask=dense)          # C = 256, normalised: the bf16-pipe kernel; else fgvc_pair_topk_f32
     coarse = cidx[:, :, 0].clamp_min(0).contiguous()
     qfine = ops.normalize_to_hwc(query_fine.float(), normalize)[0]
     kfine = ops.normalize_to_hwc(key_fine[0].transpose(0, 1).float().contiguous(), normalize)
