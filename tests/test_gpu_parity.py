@@ -288,6 +288,27 @@ def test_split_feature_bank_equals_f32_bank(dev):
         engine.run_affinity(bank_s, Hf, Wf, plan, cfg32)
 
 
+def test_c2f_operator_256_channels_vs_oracle(dev):
+    """masked_attention_efficient_c2f at the API level with 256 coarse channels: its coarse arg-max stage then runs on the
+    bf16-pipe pair kernel (top-1); against the oracle's c2f_attention (local_attention.py:721-880)."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd.mmpt_api.common import masked_attention_efficient_c2f, spatial_neighbor
+    g = torch.Generator().manual_seed(52)
+    C, Cf, H, W, Tn, P, scale, topk, Rf, nr = 256, 32, 12, 16, 3, 3, 2, 5, 3, 8
+    q = torch.randn(1, C, H, W, generator=g)
+    key = torch.randn(1, C, Tn, H, W, generator=g)
+    qfine = torch.randn(1, Cf, H * scale, W * scale, generator=g)
+    kfine = torch.randn(1, Cf, Tn, H * scale, W * scale, generator=g)
+    v = torch.rand(1, P, Tn, H * scale, W * scale, generator=g)
+    mask = spatial_neighbor(1, H, W, neighbor_range=nr, device=dev, dtype=torch.bool, dim=1, mode="circle")
+    out = masked_attention_efficient_c2f(q.to(dev), key.to(dev), qfine.to(dev), kfine.to(dev), v.to(dev), mask,
+                                         temperature=0.07, topk=topk, normalize=True, radius_fine=Rf).cpu()
+    o_out, o_arg, _, _ = O.c2f_attention(q[0], key[0], qfine[0], kfine[0], v[0], topk, 0.07, neighbor_range=nr, radius_fine=Rf)
+    assert out.shape == (1, P, H, W)
+    close = (out[0] - o_out).abs().amax(0) < 1e-4                 # per query pixel (a flipped arg-max changes the whole window)
+    assert float(close.float().mean()) > 0.99, float(close.float().mean())
+
+
 def test_run_propagation_async_equals_sync(dev):
     """engine.run_propagation_async (sweep + read-out on a side stream, the caller's stream free for the next clip) returns what
     run_propagation returns, also when the caller immediately reuses its stream and drops its references."""
