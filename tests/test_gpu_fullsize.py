@@ -8,7 +8,9 @@ size-independent properties, where the CPU oracle would take minutes per frame:
     bf16x3 within the 1e-3 score bar of f32;
   * merge: weights sum to one, merged list = best k of the slot lists;
   * propagation: linear in the labels, constant labels are reproduced (weights sum to 1);
-  * read-out: a Gaussian bump is read back at its centre.
+  * read-out: a Gaussian bump is read back at its centre;
+  * encoder kernels (stem, 64-channel, stride-2, 256-channel convolutions on the clip's tensors): exact homogeneity
+    (2x in -> 2x out, bit for bit), batch independence, sampled outputs against float64 receptive-field sums.
 """
 import pytest
 import torch
@@ -227,3 +229,119 @@ def test_track_points_full_size(dev, clip):
     assert traj.shape == (T_CLIP, 12, 2)
     drift = (traj.float() - xy[order].to(dev).unsqueeze(0)).abs().max()
     assert float(drift) < 3.0, float(drift)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# encoder kernels at the 480p clip's sizes: properties that need no oracle
+# ---------------------------------------------------------------------------------------------------------------
+def _bn_identity_bias0(C, dev, g):
+    """eval-mode BatchNorm whose folded bias is exactly zero (so that the layer is homogeneous of degree one)."""
+    bn = torch.nn.BatchNorm2d(C).eval()
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data.zero_()
+    bn.running_mean.zero_()
+    bn.running_var = torch.rand(C, generator=g) + 0.5
+    return bn.to(dev)
+
+
+def _sample_check(out_nhwc, x_nchw, wt, bn, stride, pad, relu, n=48, seed=0):
+    """`n` random output positions against a float64 convolution of the receptive field alone."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    N, Ho, Wo, Co = out_nhwc.shape
+    KS = wt.shape[-1]
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().double().cpu()
+    bias = (bn.bias - bn.running_mean * (bn.weight / torch.sqrt(bn.running_var + bn.eps))).detach().double().cpu()
+    xp = F.pad(x_nchw.double().cpu(), (pad, pad, pad, pad))
+    worst = 0.0
+    for _ in range(n):
+        i, y, x = int(torch.randint(N, (1,), generator=g)), int(torch.randint(Ho, (1,), generator=g)), int(torch.randint(Wo, (1,), generator=g))
+        if _ % 4 == 0:
+            y, x = (0, Ho - 1)[_ % 8 == 0], (0, Wo - 1)[_ % 3 == 0]               # corners and edges
+        patch = xp[i, :, y * stride: y * stride + KS, x * stride: x * stride + KS]
+        ref = (wt.double().cpu() * patch[None]).sum((1, 2, 3)) * sc + bias
+        if relu:
+            ref = ref.clamp_min(0)
+        got = out_nhwc[i, y, x].double().cpu()
+        worst = max(worst, float((got - ref).abs().max()) / max(1.0, float(ref.abs().max())))
+    return worst
+
+
+def test_encoder_kernels_full_size_properties(dev):
+    """fgvc_stem7_split_f32, fgvc_conv64_split_f32, fgvc_conv_s2_split_f32 and fgvc_conv_split_f32 on the 8 x 480 x 854 clip's
+    tensors: (i) exact homogeneity -- doubling the input doubles every output bit for bit (power-of-two scaling commutes with the
+    bf16 split, the products and the f32 accumulation; bias folded to zero); (ii) batch independence -- an image alone gives the
+    bits it gives inside the batch (persistent tile loops, lanes of tiles); (iii) sampled outputs, borders included, against a
+    float64 convolution of their receptive fields; (iv) the register-resident 64-channel kernel against the generic one."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(77)
+    N, h, w = 8, 480, 854
+    frames = torch.randn(N, 3, h, w, generator=g).to(dev)
+    # stem
+    w0 = (torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5).to(dev)
+    bn0 = _bn_identity_bias0(64, dev, g)
+    sw, sb = ops.prepare_stem7(w0, bn0)
+    H1, W1 = 240, 427
+
+    def stem(x):
+        s, f = ops.alloc_split_nhwc(x.shape[0], 64, H1, W1, dev), ops.alloc_nhwc(x.shape[0], 64, H1, W1, dev)
+        ops.stem7_split(x, sw, sb, True, out_split=s, out_f32=f)
+        return s, f
+
+    s1, f1 = stem(frames)
+    s1d, f1d = stem(frames * 2)
+    assert torch.equal(f1d, f1 * 2)
+    assert torch.equal(stem(frames[5:6])[1][0], f1[5])
+    assert _sample_check(f1, frames, w0, bn0, 2, 3, True) < 2e-5
+    # layer 1: 64 -> 64 3x3 with residual, register-resident weights vs the generic kernel
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).to(dev)
+    bn1 = _bn_identity_bias0(64, dev, g)
+    c6, b6 = ops.prepare_conv64(w1, bn1)
+    cg, bg = ops.prepare_conv_split(w1, bn1)
+
+    def layer1(s_in, res, fn, wb):
+        s, f = ops.alloc_split_nhwc(s_in.shape[0], 64, H1, W1, dev), ops.alloc_nhwc(s_in.shape[0], 64, H1, W1, dev)
+        fn(s_in, wb[0], wb[1], H1, W1, True, residual=res, out_split=s, out_f32=f)
+        return s, f
+
+    s2, f2 = layer1(s1, f1, ops.conv64_split, (c6, b6))
+    _, f2d = layer1(s1d, f1d, ops.conv64_split, (c6, b6))
+    assert torch.equal(f2d, f2 * 2)
+    assert torch.equal(layer1(s1[2:3].contiguous(), f1[2:3].contiguous(), ops.conv64_split, (c6, b6))[1][0], f2[2])
+    _, f2g = layer1(s1, f1, ops.conv_split, (cg, bg))
+    assert float((f2g - f2).abs().max()) < 1e-5 * float(f2.abs().max())
+    x1_nchw = f1.permute(0, 3, 1, 2)
+    no_res = ops.alloc_nhwc(N, 64, H1, W1, dev)
+    ops.conv64_split(s1, c6, b6, H1, W1, False, out_f32=no_res)
+    assert _sample_check(no_res, x1_nchw, w1, bn1, 1, 1, False, seed=1) < 2e-5
+    # layer 2 entry: stride-2 3x3 (64 -> 128) and its 1x1 projection
+    H2, W2 = 120, 214
+    for KS in (3, 1):
+        w2 = (torch.randn(128, 64, KS, KS, generator=g) * (2.0 / (64 * KS * KS)) ** 0.5).to(dev)
+        bn2 = _bn_identity_bias0(128, dev, g)
+        c2, b2 = ops.prepare_conv_s2(w2, bn2)
+
+        def s2conv(s_in):
+            f = ops.alloc_nhwc(s_in.shape[0], 128, H2, W2, dev)
+            ops.conv_s2_split(s_in, c2, b2, H1, W1, KS == 3, out_f32=f)
+            return f
+
+        f3 = s2conv(s2)
+        assert torch.equal(s2conv(layer1(s1d, f1d, ops.conv64_split, (c6, b6))[0]), f3 * 2)
+        assert torch.equal(s2conv(s2[7:8].contiguous())[0], f3[7])
+        assert _sample_check(f3, f2.permute(0, 3, 1, 2), w2, bn2, 2, KS // 2, KS == 3, seed=2 + KS) < 2e-5
+    # layer 3: 256 -> 256 3x3 on the 120 x 214 grid
+    x3 = torch.randn(N, 256, H2, W2, generator=g).to(dev)
+    w3 = (torch.randn(256, 256, 3, 3, generator=g) * (2.0 / 2304) ** 0.5).to(dev)
+    bn3 = _bn_identity_bias0(256, dev, g)
+    c3, b3 = ops.prepare_conv_split(w3, bn3)
+
+    def layer3(x):
+        f = ops.alloc_nhwc(x.shape[0], 256, H2, W2, dev)
+        ops.conv_split(ops.nchw_to_split_nhwc(x), c3, b3, H2, W2, True, out_f32=f)
+        return f
+
+    f4 = layer3(x3)
+    assert torch.equal(layer3(x3 * 2), f4 * 2)
+    assert torch.equal(layer3(x3[3:4].contiguous())[0], f4[3])
+    assert _sample_check(f4, x3, w3, bn3, 1, 1, True, seed=9) < 2e-5
