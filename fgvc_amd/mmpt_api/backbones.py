@@ -1,8 +1,10 @@
 """ResNet trunk behind the reference's registry name and constructor keys
-(mmpt/models/backbones/resnet.py:329-638).  On the GPU in eval mode the stride-1 convolutions of the residual
-stages run in fgvc_conv_split_f32 (hi/lo bf16 split, f32-grade, BatchNorm folded, identity and ReLU in the epilogue);
-the stem and strided convolutions run in MIOpen with the BN(eval) [+ residual] [+ ReLU] tail as one hand-written
-launch (fgvc_bn_act_f32).  `ResNet.use_split_conv = False` sends every convolution through MIOpen.
+(mmpt/models/backbones/resnet.py:329-638).  On the GPU in eval mode the whole ResNet-18 trunk of the shipped configs
+runs as hand-written HIP on the bf16 pipe (hi/lo bf16 split, f32-grade, BatchNorm folded, identity and ReLU in the
+epilogues): fgvc_stem7_split_f32 (7x7 stride-2 stem), fgvc_conv64_split_f32 / fgvc_conv_split_f32 (stride-1 3x3),
+fgvc_conv_s2_split_f32 (stride-2 3x3 and 1x1 projection).  Everything outside that path (pooling stems, other block
+types, `ResNet.use_split_conv = False`) runs in MIOpen with the BN(eval) [+ residual] [+ ReLU] tail as one hand-written
+launch (fgvc_bn_act_f32).
 
 What must match the reference: the state_dict key names (mmcv ConvModule nesting:
 `conv1.conv.weight`, `layer2.0.downsample.bn.running_var`, ...), the strides/out_indices/pool_type

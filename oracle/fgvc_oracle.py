@@ -10,8 +10,8 @@ Pinning: the reference ships no tests or golden vectors for this path
 ITSELF: `tests/golden/gen_golden.py` imports the genuine reference operators from
 /root/reference in the build container (via oracle/ref_import.py) and commits
 their inputs/outputs as fixtures under tests/golden/; `tests/test_oracle.py`
-checks every function below against those fixtures, and
-`tests/test_oracle_vs_reference.py` re-checks live when /root/reference exists.
+checks every function below against those fixtures (re-running gen_golden.py in
+the build container reproduces them bit for bit).
 Third-party arithmetic that is NOT under /root/reference and therefore stays
 "parity unpinned": mmcv-full==1.5.2 `ConvModule` (restated as Conv2d+BatchNorm2d+
 ReLU, exact given identical weights) and `mmcv.ops.Correlation` (restated from the

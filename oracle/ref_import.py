@@ -2,9 +2,8 @@
 
 TEST INFRASTRUCTURE, BUILD CONTAINER ONLY.  Nothing here is shipped to the GPU
 box as reference code: this module reads the reference *in place* (read-only)
-so that `tests/golden/gen_golden.py` can record input/output vectors and
-`tests/test_oracle_vs_reference.py` can validate the CPU restatement in
-`oracle/fgvc_oracle.py`.  It is never imported by the product package.
+so that `tests/golden/gen_golden.py` can record the input/output vectors that pin the CPU
+restatement in `oracle/fgvc_oracle.py` (`tests/test_oracle.py`).  It is never imported by the product package.
 
 The reference package (`import mmpt`) needs mmcv-full==1.5.2, cv2, av, ... which
 are absent here.  The hot-path *files* however only touch a

@@ -196,9 +196,6 @@ def main():
     print(f"total fixture bytes: {tot}")
 
 
-if __name__ == "__main__":
-    main()
-
 
 def gen_tapvid_metrics():
     """tests/golden/tapvid_metrics.npz: the reference's compute_tapvid_metrics (numpy only) is lifted out of its
@@ -227,3 +224,8 @@ def gen_tapvid_metrics():
         outs.update({f"{mode}__{k}": np.asarray(v) for k, v in m.items()})
     save("tapvid_metrics", query_points=qp, gt_occluded=gt_occ, gt_tracks=gt, pred_occluded=pred_occ,
          pred_tracks=pred, **outs)
+
+
+if __name__ == "__main__":
+    main()
+    gen_tapvid_metrics()
