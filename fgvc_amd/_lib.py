@@ -27,7 +27,7 @@ SIGNATURES = {
     "fgvc_r2max_for_radius": (_i, [_f]),
     "fgvc_normalize_chw_to_hwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_pair_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
-    "fgvc_pair_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "fgvc_pair_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "fgvc_nchw_to_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv64_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -42,6 +42,9 @@ SIGNATURES = {
     "fgvc_split_bf16": (_i, [_p, _p, C.c_int64, _i, _p]),
     "fgvc_corr_volume_bf16x3": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
     "fgvc_corr_volume_bf16": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
+    "fgvc_dense_attend_splits": (_i, [_i, _i]),
+    "fgvc_dense_attend_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "fgvc_dense_attend_finish_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "fgvc_local_corr_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "fgvc_local_corr_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "fgvc_topk_coord_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),

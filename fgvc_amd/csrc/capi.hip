@@ -57,9 +57,12 @@ void set_pair_v4_debug(int);
 void set_readout_prune(int);
 void set_conv_s2_debug(int);
 void set_pair_v4_products(int);
-int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int32_t*,
+int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, int32_t*,
                         float*, hipStream_t);
 void set_corr_debug(int);
+int dense_attend_splits(int, int);
+int dense_attend_launch(const float*, const float*, int, int, int, int, int, int, int, int, int, int, int, float*, int, hipStream_t);
+int dense_attend_finish_launch(const float*, int, int, int, int, float*, hipStream_t);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -165,7 +168,7 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
 }
 
 int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq,
-                          int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int32_t* idx_out,
+                          int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
                           float* score_out, void* stream) {
   FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_bf16x4: null pointer");
   FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
@@ -183,8 +186,8 @@ int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const 
                    (long long)Hq * Wq < (1ll << 30),
                FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: grid too large");
   if (n_pairs == 0) return FGVC_OK;
-  return pair_topk_v4_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, idx_out, score_out,
-                             (hipStream_t)stream);
+  return pair_topk_v4_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked != 0 && any_limit,
+                             idx_out, score_out, (hipStream_t)stream);
 }
 
 int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, int n_out, int T,
@@ -251,6 +254,31 @@ int fgvc_corr_volume_bf16(const uint16_t* q, const uint16_t* k, int C, int HWq, 
   return corr_bf16_common("fgvc_corr_volume_bf16", q, k, C, HWq, HWk, temperature, vol, 1, stream);
 }
 
+int fgvc_dense_attend_splits(int HWq, int HWk) { return (HWq > 0 && HWk > 0) ? dense_attend_splits(HWq, HWk) : 1; }
+
+int fgvc_dense_attend_f32(const float* vol, const float* labels, int Hq, int Wq, int Hk, int Wk, int P, int masked, int r2max,
+                          int ry, int rx, int weight_mode, int first, float* state, int nsplit, void* stream) {
+  FGVC_REQUIRE(vol && labels && state, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_f32: null pointer");
+  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_f32: bad shape");
+  FGVC_REQUIRE((long long)Hk * Wk < (1ll << 30) && (long long)Hq * Wq < (1ll << 30), FGVC_ERR_UNSUPPORTED,
+               "fgvc_dense_attend_f32: grid too large");
+  FGVC_REQUIRE(P >= 1 && P <= 32, FGVC_ERR_UNSUPPORTED, "fgvc_dense_attend_f32: P=%d outside 1..32", P);
+  FGVC_REQUIRE(nsplit >= 1 && nsplit <= 65535, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_f32: nsplit=%d", nsplit);
+  FGVC_REQUIRE(weight_mode == FGVC_WEIGHT_SOFTMAX || weight_mode == FGVC_WEIGHT_COSINE, FGVC_ERR_INVALID_ARG,
+               "fgvc_dense_attend_f32: unknown weight mode %d", weight_mode);
+  FGVC_REQUIRE(!masked || (r2max >= 0 && ry >= 0 && rx >= 0), FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_f32: negative mask parameter");
+  FGVC_REQUIRE(!masked || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
+               "fgvc_dense_attend_f32: a spatial mask needs equal query/key grids (local_attention.py:331)");
+  return dense_attend_launch(vol, labels, Hq, Wq, Hk, Wk, P, masked != 0, r2max, ry, rx, weight_mode == FGVC_WEIGHT_COSINE,
+                             first != 0, state, nsplit, (hipStream_t)stream);
+}
+
+int fgvc_dense_attend_finish_f32(const float* state, int nsplit, int HWq, int P, int weight_mode, float* out, void* stream) {
+  FGVC_REQUIRE(state && out, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_finish_f32: null pointer");
+  FGVC_REQUIRE(HWq > 0 && P >= 1 && P <= 32 && nsplit >= 1, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_finish_f32: bad shape");
+  return dense_attend_finish_launch(state, nsplit, HWq, P, weight_mode == FGVC_WEIGHT_COSINE, out, (hipStream_t)stream);
+}
+
 int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_slots, int C, int H,
                              int W, int R, int topk, float temperature, int32_t* pair_idx_ws, float* pair_score_ws,
                              int32_t* idx_out, float* logit_out, float* weight_out, void* stream) {
@@ -275,7 +303,8 @@ int fgvc_local_corr_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, 
   FGVC_REQUIRE(R >= 0 && n_slots >= 1 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_local_corr_topk_bf16x4: bad R/n_slots/temperature");
   FGVC_REQUIRE((long long)n_slots * (2 * R + 1) * (2 * R + 1) < (1ll << 31), FGVC_ERR_UNSUPPORTED,
                "fgvc_local_corr_topk_bf16x4: index overflow");
-  int rc = fgvc_pair_topk_bf16x4(qsplit, ksplit, pairs, n_slots, C, H, W, H, W, FGVC_NO_LIMIT, R, R, topk, pair_idx_ws,
+  // every slot of a local window is a masked pair (the window IS the mask): all_masked = 1
+  int rc = fgvc_pair_topk_bf16x4(qsplit, ksplit, pairs, n_slots, C, H, W, H, W, FGVC_NO_LIMIT, R, R, topk, 1, pair_idx_ws,
                                  pair_score_ws, stream);
   if (rc != FGVC_OK) return rc;
   return local_merge_launch(pair_idx_ws, pair_score_ws, n_slots, H, W, R, topk, temperature, idx_out, logit_out,

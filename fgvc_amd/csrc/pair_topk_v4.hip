@@ -124,7 +124,10 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v4(PairParamsB p) {
     const int bxl = imax(0, TX0 - imin(reach_x, TX0)) / QBW;
     const int bxh = imin(p.Wk - 1, TX0 + 2 * QBW - 1 + imin(reach_x, p.Wk)) / QBW;
     const int nbx = bxh - bxl + 1;
-    const int ncand = imin((by_hi - by_lo + 1) * nbx, V4_LIST_CAP);
+    // the host has checked that a MASKED pair's reach fits the list; an unmasked pair on a larger key grid than the list holds
+    // (the caller promised there was none: `all_masked`) gets EMPTY lists (-1 / -inf), never truncated ones
+    const int nall = (by_hi - by_lo + 1) * nbx;
+    const int ncand = nall > V4_LIST_CAP ? 0 : nall;
     int count = 0;
     for (int base = 0; base < ncand; base += 64) {
       const int c = base + lane;
@@ -443,8 +446,8 @@ void set_pair_v4_debug(int v) { g_pair_v4_debug = v; }
 void set_pair_v4_products(int v) { g_pair_v4_products = v; }
 
 int pair_topk_v4_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_t* pairs, int n_pairs, int Hq, int Wq,
-                        int Hk, int Wk, int r2max, int ry, int rx, int topk, int32_t* idx_out, float* score_out,
-                        hipStream_t s) {
+                        int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
+                        float* score_out, hipStream_t s) {
   PairParamsB p;
   p.q_hl = q_hl; p.k_hl = k_hl; p.pairs = reinterpret_cast<const int4*>(pairs);
   p.Hq = Hq; p.Wq = Wq; p.Hk = Hk; p.Wk = Wk;
@@ -456,13 +459,15 @@ int pair_topk_v4_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_
   p.n_ty = cdiv(Hq, 2 * QBH); p.n_tx = cdiv(Wq, 2 * QBW);
   p.idx_out = idx_out; p.score_out = score_out;
   p.debug = g_pair_v4_debug;
-  {  // the per-workgroup block list must hold every key block a super-tile can reach (worst case: unmasked pair)
+  {  // the per-workgroup block list must hold every key block a super-tile can reach: the mask's reach for a masked pair,
+     // the whole key grid for a pair without FGVC_PAIR_MASKED (the caller says whether there is one: pairs live on the device)
     const long long nby = imin(cdiv(Hk, QBH), (2 * QBH - 1 + 2 * (long long)imin(p.reach_y, Hk)) / QBH + 2);
     const long long nbx = imin(cdiv(Wk, QBW), (2 * QBW - 1 + 2 * (long long)imin(p.reach_x, Wk)) / QBW + 2);
-    const long long worst = (long long)cdiv(Hk, QBH) * cdiv(Wk, QBW);   // pairs without FGVC_PAIR_MASKED scan the frame
-    if (imax((int)imin(nby * nbx, 1 << 30), (int)imin(worst, 1 << 30)) > V4_LIST_CAP || Hk >= 4096 * QBH || Wk >= 4096 * QBW) {
-      set_error("fgvc_pair_topk_bf16x4: key grid %dx%d needs more than %d key blocks per query tile; use fgvc_pair_topk_f32",
-                Hk, Wk, V4_LIST_CAP);
+    const long long whole = (long long)cdiv(Hk, QBH) * cdiv(Wk, QBW);
+    const long long need = all_masked ? nby * nbx : whole;
+    if (need > V4_LIST_CAP || Hk >= 4096 * QBH || Wk >= 4096 * QBW) {
+      set_error("fgvc_pair_topk_bf16x4: key grid %dx%d needs %lld > %d key blocks per query tile (%s); use fgvc_pair_topk_f32",
+                Hk, Wk, need, V4_LIST_CAP, all_masked ? "mask reach" : "a pair without FGVC_PAIR_MASKED scans the frame");
       return FGVC_ERR_UNSUPPORTED;
     }
   }

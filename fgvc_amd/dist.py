@@ -90,7 +90,7 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
     dev = device if device is not None else rgbs.device
     qp = query_points.detach().cpu()
     times = qp[:, 0].to(torch.int64)
-    starts = sorted(set(times.tolist())) if cfg.with_first else [0]
+    starts = sorted(set(times.tolist())) if cfg.regroup else [0]
     s_min = min(starts)
 
     ranges = shard_frames(T, world, first=s_min + 1)
@@ -173,7 +173,7 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
     traj = torch.zeros((T, qp.shape[0], 2), device=dev, dtype=torch.float64)
     order, col = [], 0
     for s in starts:
-        sel = (times == s).nonzero().flatten() if cfg.with_first else torch.arange(qp.shape[0])
+        sel = (times == s).nonzero().flatten() if cfg.regroup else torch.arange(qp.shape[0])
         pts = qp[sel, 1:].to(dev, torch.float32)
         coords = backend.sweep(idx, weight, slot_frame_dev, gplan, s, pts, Hf, Wf, h, w, cfg)
         traj[s:, col:col + sel.numel()] = coords

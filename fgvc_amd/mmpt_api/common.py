@@ -93,18 +93,25 @@ def images2video(imgs, clip_len):
 
 
 # ----------------------------------------------------------------------------------------------
-def _check_common(query, key, value, mode, sim_mode, topk):
+def _check_common(query, key, value, mode, sim_mode, normalize=True):
     assert mode in ["softmax", "cosine"]
     assert query.size(0) == key.size(0) == value.size(0)
     if query.size(0) != 1:
         # the reference's index_select is only correct for N == 1 (local_attention.py:360-362,
         # enforced upstream by vanilla_tracker.py:134)
         raise NotImplementedError("fgvc_amd: batch size must be 1 (as in the reference's tracker)")
-    if sim_mode != "dot_product":
-        raise NotImplementedError(f"fgvc_amd: sim_mode={sim_mode!r} is not on the accelerated path")
-    if topk is None:
-        raise NotImplementedError("fgvc_amd: topk=None (dense softmax) is not on the accelerated path; "
-                                  "every shipped config uses topk=10")
+    if sim_mode not in ("dot_product", "l2-distance"):
+        raise NotImplementedError(f"fgvc_amd: sim_mode={sim_mode!r} (the reference knows 'dot_product' and 'l2-distance')")
+    if sim_mode == "l2-distance" and (not normalize or mode != "softmax"):
+        # (2 k.q - |k|^2) / sqrt(C): with |k| = 1 the -|k|^2 term shifts every logit alike -- same ranking as the dot product, and
+        # the softmax does not see the shift.  Un-normalised keys or the (shift-sensitive) cosine weights need another kernel.
+        raise NotImplementedError("fgvc_amd: sim_mode='l2-distance' is on the accelerated path for normalize=True, mode='softmax'")
+
+
+def _temperature(sim_mode, temperature, channels):
+    """Divisor of the raw dot product: `temperature` (local_attention.py:321-323), or sqrt(C)/2 for 'l2-distance' (:324-327:
+    (2 k.q - 1) / sqrt(C), `temperature` is not read on that branch)."""
+    return (channels ** 0.5) / 2.0 if sim_mode == "l2-distance" else temperature
 
 
 def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk, normalize, non_mask_len, mode):
@@ -123,12 +130,16 @@ def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk,
     any_mask = dense_mask is not None or not spec.is_none
     if any_mask:
         assert same or dense_mask is not None
+    labels = value[0].permute(1, 2, 3, 0).reshape(T, Hk * Wk, P).float().contiguous()
+    if topk is None:        # weights over every unmasked key (local_attention.py:376-383)
+        out = ops.dense_attend(qf[0], kf, labels, Hq, Wq, Hk, Wk, spec, temperature, mode, non_mask_len if any_mask else T,
+                               dense_mask)
+        return out.t().reshape(1, P, Hq, Wq).to(query.dtype)
     pairs = ops.make_pairs([(0, t, any_mask and t >= non_mask_len) for t in range(T)], query.device)
     pidx, pscore = ops.pair_topk_auto(qf, kf, pairs, Hq, Wq, Hk, Wk, spec, topk, normalized=bool(normalize),
-                                      validate=False, dense_mask=dense_mask)
+                                      validate=False, dense_mask=dense_mask, all_masked=any_mask and non_mask_len == 0)
     slot_pair = torch.arange(T, dtype=torch.int32, device=query.device).view(1, T)
     idx, _, weight = ops.merge_topk(pidx, pscore, slot_pair, Hk * Wk, topk, temperature, mode, validate=False)
-    labels = value[0].permute(1, 2, 3, 0).reshape(T, Hk * Wk, P).float().contiguous()
     out = ops.propagate_topk(labels, torch.arange(T, dtype=torch.int32, device=query.device), idx[0], weight[0],
                              Hq, Wq, Hk, Wk)
     return out.t().reshape(1, P, Hq, Wq).to(query.dtype)
@@ -139,7 +150,7 @@ def masked_attention_efficient(query, key, value, mask, temperature=1, topk=None
     """local_attention.py:267-389.  `step` is accepted and ignored: nothing is chunked because the
     (T*HW x step) slab never exists.  `mask`: None, a NeighborMask from spatial_neighbor(), or any
     (HkWk, HqWq) tensor."""
-    _check_common(query, key, value, mode, sim_mode, topk)
+    _check_common(query, key, value, mode, sim_mode, normalize)
     spec, dense = MaskSpec.none(), None
     if isinstance(mask, NeighborMask):
         spec = mask.spec
@@ -147,14 +158,15 @@ def masked_attention_efficient(query, key, value, mask, temperature=1, topk=None
         hk, wk = key.shape[-2:]
         assert tuple(mask.shape[-2:]) == (hk * wk, query.shape[2] * query.shape[3])
         dense = mask.reshape(hk * wk, -1).bool()
-    return _attention(query, key, value, spec, dense, temperature, topk, normalize, non_mask_len, mode)
+    return _attention(query, key, value, spec, dense, _temperature(sim_mode, temperature, query.shape[1]), topk, normalize,
+                      non_mask_len, mode)
 
 
 def masked_attention_efficient_v2(query, key, value, radius, temperature=1, topk=None, normalize=True, step=32,
                                   non_mask_len=0, mode="softmax", sim_mode="dot_product"):
     """local_attention.py:392-508: the disc `dist < radius` rebuilt per chunk there, analytic here.
-    (The reference ignores non_mask_len in this variant, :467-470; so do we.)"""
-    _check_common(query, key, value, mode, sim_mode, topk)
+    (The reference ignores non_mask_len and sim_mode in this variant, :453-470; so do we.)"""
+    _check_common(query, key, value, mode, "dot_product", normalize)    # `sim_mode` is accepted and never read there (:453-455)
     return _attention(query, key, value, MaskSpec.circle(radius), None, temperature, topk, normalize, 0, mode)
 
 
@@ -193,9 +205,9 @@ def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask
                                    sim_mode="dot_product", radius_fine=12):
     """local_attention.py:721-880.  Coarse stage = fgvc_pair_topk_bf16x4 / fgvc_pair_topk_f32 with topk=1 per key slot (arg-max of
     the per-frame softmax, :835-837); fine stage = fgvc_c2f_refine_f32."""
-    _check_common(query, key, value, mode, sim_mode, topk)
-    if mode != "softmax":
-        raise NotImplementedError("c2f: softmax mode only")
+    _check_common(query, key, value, mode, sim_mode, normalize)
+    if mode != "softmax" or sim_mode != "dot_product" or topk is None:
+        raise NotImplementedError("fgvc_amd c2f: mode='softmax', sim_mode='dot_product' and an integer topk only")
     if key.ndim == 4:
         key, value = key.unsqueeze(2), value.unsqueeze(2)
         key_fine = key_fine.unsqueeze(2) if key_fine.ndim == 4 else key_fine
@@ -212,7 +224,7 @@ def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask
     kf = ops.normalize_to_hwc(key[0].transpose(0, 1).float().contiguous(), normalize, pad=True)
     pairs = ops.make_pairs([(0, t, any_mask and t >= non_mask_len) for t in range(T)], dev)
     cidx, _ = ops.pair_topk_auto(qf, kf, pairs, H, W, H, W, spec, 1, normalized=bool(normalize), validate=False,
-                                 dense_mask=dense)          # C = 256, normalised: the bf16-pipe kernel; else fgvc_pair_topk_f32
+                                 dense_mask=dense, all_masked=any_mask and non_mask_len == 0)          # C = 256, normalised: the bf16-pipe kernel; else fgvc_pair_topk_f32
     coarse = cidx[:, :, 0].clamp_min(0).contiguous()
     qfine = ops.normalize_to_hwc(query_fine.float(), normalize)[0]
     kfine = ops.normalize_to_hwc(key_fine[0].transpose(0, 1).float().contiguous(), normalize)

@@ -93,7 +93,8 @@ class VanillaTracker(BaseTracker):
         if split and fast:
             cfg = self.engine_config()
             if cfg.pair_precision in ("auto", "split"):
-                split_if = lambda C, H, W: ops.split_path_ok(C, H, W, cfg.topk, cfg.with_norm)
+                split_if = lambda C, H, W: ops.split_path_ok(C, H, W, cfg.topk, cfg.with_norm, None, cfg.mask,
+                                                             cfg.with_first_neighbor or not cfg.with_first)
         for i in range(0, frames.shape[0], step):
             if fast:       # backbone writes normalised channels-last rows itself (no NCHW round trip)
                 f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm, split_if=split_if)
@@ -121,7 +122,7 @@ class VanillaTracker(BaseTracker):
         T, h, w = rgbs.shape[1], rgbs.shape[-2], rgbs.shape[-1]
         dev = rgbs.device
         qp = query_points[0]
-        if not cfg.with_first:
+        if not cfg.regroup:
             # single group that starts at frame 0 regardless of the query times (vanilla_tracker.py:302-303)
             feats, Hf, Wf = self.get_feats_hwc(rgbs[0], split=True)
             plan = engine.plan_clip(T, [0], cfg)
@@ -156,93 +157,120 @@ class VanillaTracker(BaseTracker):
 
 @MODELS.register_module()
 class HRVanillaTracker(VanillaTracker):
-    """Single-scale local-window variant (vanilla_tracker.py:417-585): mmcv.ops.Correlation(max_displacement=R)
-    + F.unfold + top-k is one call to fgvc_local_corr_topk_f32 per frame."""
+    """Single-scale local-window variant (vanilla_tracker.py:417-660): mmcv.ops.Correlation(max_displacement=R)
+    + F.unfold + top-k is one call to fgvc_local_corr_topk_{bf16x4,f32} per frame.
+
+    Keys read here exactly as the reference reads them: `neighbor_range` (default 24, -> R), `withnorm` (sic, :437; NOT
+    `with_norm`), `topk` (10), `temperature` (default 1, :563), `precede_frames`, `with_first` (slot 0, default True, :534;
+    regrouping, default False, :246), `batch_step`.  `dilations` is passed by the reference as the dilation of the
+    Correlation KERNEL (:426-428), which has a single tap (kernel_size=1): any value gives the same result, so it is accepted
+    and has no effect (mmcv arithmetic: "parity unpinned").  `save_mem=True` is refused (the reference's branch pairs one key
+    frame with several label maps, :538-545, and cannot run)."""
 
     def __init__(self, stride=2, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.stride = stride
-        self.infer_radius = self.test_cfg.get("neighbor_range", 24) // 2
-        if self.test_cfg.get("dilations", 1) != 1:
-            raise NotImplementedError("fgvc_amd: Correlation dilation != 1 is not on the accelerated path")
-
-    @torch.no_grad()
-    def forward_test_main(self, rgbs, query_points, trajectories, visibilities):
         g = self.test_cfg.get
-        T, h, w = rgbs.shape[1], rgbs.shape[-2], rgbs.shape[-1]
-        dev = rgbs.device
-        step = int(g("batch_step", 5))
-        norm = bool(g("withnorm", True))                                       # sic (vanilla_tracker.py:437)
+        self.infer_radius = g("neighbor_range", 24) // 2
+        self.infer_dilations = g("dilations", 1)
+        self.grid_size_hr = 2 * self.infer_radius + 1
+        if g("save_mem", False):
+            raise NotImplementedError("fgvc_amd: HRVanillaTracker save_mem=True (unrunnable in the reference, vanilla_tracker.py:538-545)")
+
+    def _feats_hwc(self, frames: torch.Tensor):
+        """frames (T,3,h,w) -> channels-last rows (T, HfWf, C'), L2-normalised iff `withnorm` (:437-439), Hf, Wf."""
+        step = int(self.test_cfg.get("batch_step", 5))
+        norm = bool(self.test_cfg.get("withnorm", True))
         chunks = []
-        for i in range(0, T, step):
-            f = self.extract_feat(rgbs[0, i:i + step])
+        for i in range(0, frames.shape[0], step):
+            f = self.extract_feat(frames[i:i + step])
+            if isinstance(f, (tuple, list)):
+                f = f[0]
             Hf, Wf = f.shape[-2:]
             chunks.append(ops.normalize_to_hwc(f.float(), norm, pad=True))
-        feats = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
-        pts = query_points[0, :, 1:].to(dev, torch.float32)
-        P = pts.shape[0]
+        return (chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)), Hf, Wf, norm
+
+    def _sweep(self, feats, Hf, Wf, norm, h, w, pts):
+        """Labels + read-out for the points `pts` (P,2)=(x,y) given at the first frame of the bank `feats` (T,HW,C')."""
+        g = self.test_cfg.get
+        T, dev, P = feats.shape[0], feats.device, pts.shape[0]
         labels = torch.zeros((T, Hf * Wf, P), device=dev)
         ops.gaussian_labels(pts, Hf, Wf, h // Hf, 6.0, out=labels[0])
         R, k, tau = self.infer_radius, int(g("topk", 10)), float(g("temperature", 1))
         pre, with_first = int(g("precede_frames", 5)), bool(g("with_first", True))
         for f in range(1, T):
             ks = engine.key_slots(f, 0, pre, with_first)
-            kf = feats[ks]
-            idx, _, weight = ops.local_corr_topk(feats[f:f + 1], kf, Hf, Wf, R, k, tau,
-                                                 normalized=bool(g("with_norm", True)))
+            # `normalized` must be the flag that controlled the normalisation of the bank: the bf16-pipe kernel's fixed-point
+            # keys assume |q.k| <= 1 and raw ResNet dot products are not (they go through fgvc_local_corr_topk_f32)
+            idx, _, weight = ops.local_corr_topk(feats[f:f + 1], feats[ks], Hf, Wf, R, k, tau, normalized=norm)
             ops.propagate_topk(labels, torch.tensor(ks, dtype=torch.int32, device=dev), idx, weight, Hf, Wf, Hf, Wf,
                                window_L=2 * R + 1, out=labels[f])
-        coords = ops.softargmax_top5(labels, Hf, Wf, h, w, gauss_points=pts)
-        return trajectories, visibilities, coords.unsqueeze(0), torch.zeros_like(visibilities), query_points
+        return ops.softargmax_top5(labels, Hf, Wf, h, w, gauss_points=pts)
+
+    @torch.no_grad()
+    def forward_test_main(self, rgbs, query_points, trajectories, visibilities):
+        """"backward warping" (:492-585): labels of frame f = top-k softmax over the (2R+1)^2 windows of its key slots."""
+        h, w = rgbs.shape[-2], rgbs.shape[-1]
+        feats, Hf, Wf, norm = self._feats_hwc(rgbs[0])
+        coords = self._sweep(feats, Hf, Wf, norm, h, w, query_points[0, :, 1:].to(rgbs.device, torch.float32))
+        vis = torch.zeros_like(visibilities) if visibilities is not None else None
+        return trajectories, visibilities, coords.unsqueeze(0), vis, query_points
+
+    def _coord_field(self, qrow, krow, H, W, scale, norm):
+        idx, _, weight = ops.local_corr_topk(qrow, krow, H, W, self.infer_radius, int(self.test_cfg.get("topk", 10)),
+                                             float(self.test_cfg.get("temperature", 1)), normalized=norm)
+        return ops.topk_coord(idx, weight, H, W, self.infer_radius, scale).t().reshape(1, 2, H, W)
 
     @torch.no_grad()
     def get_coord(self, query_feat, key_feats, shape, scale):
         """vanilla_tracker.py:445-488: dense forward-warping field.  query_feat (1,C,H,W), key_feats (1,C,H,W) ->
         (1,2,H,W) expected (x,y) image coordinate of each query pixel's match in the key frame."""
-        g = self.test_cfg.get
-        norm = bool(g("withnorm", True))
+        norm = bool(self.test_cfg.get("withnorm", True))
         H, W = query_feat.shape[-2:]
         qf = ops.normalize_to_hwc(query_feat.float(), norm, pad=True)
         kf = ops.normalize_to_hwc(key_feats.float(), norm, pad=True)
-        idx, _, weight = ops.local_corr_topk(qf, kf[:1], H, W, self.infer_radius, int(g("topk", 10)),
-                                             float(g("temperature", 1)), normalized=norm)
-        return ops.topk_coord(idx, weight, H, W, self.infer_radius, scale).t().reshape(1, 2, H, W)
+        return self._coord_field(qf, kf[:1], H, W, scale, norm)
 
     @torch.no_grad()
-    def forward_test_forward(self, imgs, ref, **kw):
-        """vanilla_tracker.py:591-645 ("forward warpping"): push the points `ref` (1,P,2)=(y,x) through the chain of
-        frame-to-frame coordinate fields.  imgs (1,3,T,h,w).  Returns coords (1,P,2,T) as (x,y)."""
+    def forward_test_forward(self, imgs, ref_seg_map=None, img_meta=None, ref=None, save_image=False, save_path=None,
+                             iteration=None):
+        """"forward warping" (vanilla_tracker.py:591-660): push the points `ref` (B,2,P) = rows (y,x) through the chain of
+        frame-to-frame coordinate fields (query = frame max(0, f - precede_frames), key = frame f).  imgs (B,1,3,T,h,w).
+        Returns what the reference returns: a list over the batch of float64 numpy arrays (2,P,T), rows (x,y)."""
         from .common import bilinear_sample
         h, w = imgs.shape[-2:]
+        imgs = imgs.reshape((-1,) + imgs.shape[2:])                                    # :599
+        assert imgs.shape[0] == 1, "batch size must be 1 (get_feats, vanilla_tracker.py:134)"
         T = imgs.shape[2]
-        feats = [self.extract_feat(imgs[:, :, t]) for t in range(T)]
-        scale = w // feats[0].shape[-1]
-        coord = torch.flip(ref, (2,)).float()                                        # (1,P,2) -> (x,y)
+        feats, Hf, Wf, norm = self._feats_hwc(imgs[0].transpose(0, 1))
+        scale = w // Wf                                                                # :609
+        coord = torch.flip(ref, (1,)).float()                                          # :611 (B,2,P) -> rows (x,y)
         coords = [coord]
         pre = int(self.test_cfg.get("precede_frames", 5))
         for f in range(1, T):
             start = max(0, f - pre)
-            field = self.get_coord(feats[start], feats[f], (h, w), scale)            # query = frame `start`
-            pts = (coord.clone() / scale).unsqueeze(2)                               # (1,P,1,2) feature coordinates
-            coord = bilinear_sample(field, pts, align_corners=True).squeeze(-1).transpose(1, 2)
+            field = self._coord_field(feats[start:start + 1], feats[f:f + 1], Hf, Wf, scale, norm)
+            coord = bilinear_sample(field, coord.clone().unsqueeze(-1) / scale, align_corners=True).squeeze(-1)   # :639
             coords.append(coord)
-        return torch.stack(coords, -1)
+        return list(torch.stack(coords, -1).cpu().numpy().astype(float))              # :642-660
 
     @torch.no_grad()
     def forward_test(self, rgbs, query_points, trajectories, visibilities, **kw):
         if not self.test_cfg.get("with_first", False):
             return self.forward_test_main(rgbs, query_points, trajectories, visibilities)
-        # inherited regrouping (vanilla_tracker.py:246-299), one main pass per distinct query time
-        B, T, P = trajectories.shape[:3]
+        # inherited regrouping (vanilla_tracker.py:246-299): one sweep per distinct query time over the tail of the clip; the
+        # frames are encoded ONCE (the reference re-encodes rgbs[:, t:] per group, :284 -- same features)
+        h, w = rgbs.shape[-2], rgbs.shape[-1]
         times = query_points[0, :, 0].to(torch.int64)
+        t_min = int(times.min())
+        feats, Hf, Wf, norm = self._feats_hwc(rgbs[0, t_min:])
         order, col = [], 0
         traj_pred = torch.zeros_like(trajectories)
         for t in sorted(set(times.tolist())):
             sel = (times == t).nonzero().flatten()
-            qp = query_points[:, sel].clone()
-            qp[:, :, 0] -= t
-            out = self.forward_test_main(rgbs[:, t:], qp, None, torch.zeros(1, T - t, sel.numel(), device=rgbs.device))
-            traj_pred[0, t:, col:col + sel.numel()] = out[2][0].to(traj_pred.dtype)
+            pts = query_points[0, sel, 1:].to(rgbs.device, torch.float32)
+            coords = self._sweep(feats[t - t_min:], Hf, Wf, norm, h, w, pts)
+            traj_pred[0, t:, col:col + sel.numel()] = coords.to(traj_pred.dtype)
             order.extend(sel.tolist())
             col += sel.numel()
         order = torch.tensor(order, device=rgbs.device)

@@ -9,6 +9,7 @@ top-k lists (…, HW, k) in canonical order (score desc, index asc).
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -133,9 +134,11 @@ def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq:
 
 
 def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int,
-                    Wk: int, mask: MaskSpec, topk: int, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                    Wk: int, mask: MaskSpec, topk: int, validate: bool = True,
+                    all_masked: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """pair_topk() on the bf16 matrix pipe (fgvc_pair_topk_bf16x4): qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256)
-    int16 = split_bf16() of L2-NORMALISED features.  Same outputs as pair_topk()."""
+    int16 = split_bf16() of L2-NORMALISED features.  Same outputs as pair_topk().  all_masked=True: the caller built `pairs`
+    with PAIR_MASKED on every row (then only the mask's reach, not the whole key grid, must fit the kernel's block list)."""
     qsplit, ksplit = _chk(qsplit, torch.int16, "qsplit"), _chk(ksplit, torch.int16, "ksplit")
     pairs = _chk(pairs, torch.int32, "pairs")
     assert qsplit.dim() == 4 and ksplit.dim() == 4 and qsplit.shape[2] == 2 and ksplit.shape[2] == 2
@@ -144,26 +147,39 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
     if n and validate:
         lim = pairs[:, :2].amax(0).tolist()
         assert lim[0] < qsplit.shape[0] and lim[1] < ksplit.shape[0] and int(pairs[:, :2].min()) >= 0, "pair out of range"
+        assert not all_masked or bool((pairs[:, 2] & PAIR_MASKED).all()), "all_masked=True but a pair is not masked"
     idx = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.int32)
     score = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.float32)
     _lib.call("fgvc_pair_topk_bf16x4", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n, qsplit.shape[3], Hq, Wq, Hk, Wk,
-              mask.r2max, mask.ry, mask.rx, topk, _ptr(idx), _ptr(score), _stream(qsplit))
+              mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(idx), _ptr(score), _stream(qsplit))
     return idx, score
 
 
 V4_LIST_CAP = 4096   # key blocks (4x8 pixels) one query tile may visit in fgvc_pair_topk_bf16x4 (csrc/pair_topk_v4.hip)
 
 
-def split_path_ok(C: int, Hk: int, Wk: int, topk: int, normalized: bool, dense_mask=None) -> bool:
+def v4_blocks_needed(Hk: int, Wk: int, mask: Optional[MaskSpec] = None, all_masked: bool = False) -> int:
+    """Key blocks a 8x16-pixel query tile of fgvc_pair_topk_bf16x4 may have to list (pair_topk_v4_launch's own check):
+    the blocks within the mask's reach when every pair is masked, the whole key grid otherwise."""
+    whole = -(-Hk // 4) * -(-Wk // 8)
+    if not all_masked or mask is None or mask.is_none:
+        return whole
+    rr = math.isqrt(mask.r2max) if mask.r2max < NO_LIMIT else NO_LIMIT
+    reach_y, reach_x = min(mask.ry, rr, Hk), min(mask.rx, rr, Wk)
+    return min(-(-Hk // 4), (7 + 2 * reach_y) // 4 + 2) * min(-(-Wk // 8), (15 + 2 * reach_x) // 8 + 2)
+
+
+def split_path_ok(C: int, Hk: int, Wk: int, topk: int, normalized: bool, dense_mask=None, mask: Optional[MaskSpec] = None,
+                  all_masked: bool = False) -> bool:
     """Whether fgvc_pair_topk_bf16x4 applies: 256 channels, top-k <= 10, analytic mask, L2-normalised rows (its
-    fixed-point keys assume |q.k| <= 1) and a key grid of at most 4096 4x8-pixel blocks."""
+    fixed-point keys assume |q.k| <= 1) and at most 4096 key blocks per query tile (v4_blocks_needed)."""
     return (normalized and C == 256 and 1 <= topk <= 10 and dense_mask is None
-            and -(-Hk // 4) * -(-Wk // 8) <= V4_LIST_CAP and Hk < 16384 and Wk < 32768)
+            and v4_blocks_needed(Hk, Wk, mask, all_masked) <= V4_LIST_CAP and Hk < 16384 and Wk < 32768)
 
 
 def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
                    mask: MaskSpec, topk: int, normalized: bool, precision: str = "auto", validate: bool = True,
-                   dense_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   dense_mask: Optional[torch.Tensor] = None, all_masked: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """pair_topk() with the kernel chosen by `precision`:
       "f32"   fgvc_pair_topk_f32 (f32 MFMA);
       "split" fgvc_pair_topk_bf16x4 on split_bf16() of the features (raises when it does not apply);
@@ -171,15 +187,16 @@ def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor
     qfeat/kfeat are the f32 channels-last features either way (the split costs one extra pass over them)."""
     if precision not in ("auto", "f32", "split"):
         raise ValueError(f"precision={precision!r}")
-    use_split = precision == "split" or (precision == "auto" and split_path_ok(qfeat.shape[2], Hk, Wk, topk, normalized,
-                                                                                dense_mask))
+    ok = split_path_ok(qfeat.shape[2], Hk, Wk, topk, normalized, dense_mask, mask, all_masked)
+    use_split = precision == "split" or (precision == "auto" and ok)
     if not use_split:
         return pair_topk(qfeat, kfeat, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, dense_mask)
-    if not split_path_ok(qfeat.shape[2], Hk, Wk, topk, normalized, dense_mask):
-        raise ValueError("fgvc_pair_topk_bf16x4 needs C == 256, topk <= 10, an analytic mask and normalised features")
+    if not ok:
+        raise ValueError("fgvc_pair_topk_bf16x4 needs C == 256, topk <= 10, an analytic mask, normalised features and "
+                         f"<= {V4_LIST_CAP} key blocks per query tile")
     ks = split_bf16(kfeat)
     qs = ks if qfeat is kfeat else split_bf16(qfeat)
-    return pair_topk_split(qs, ks, pairs, Hq, Wq, Hk, Wk, mask, topk, validate)
+    return pair_topk_split(qs, ks, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, all_masked)
 
 
 def merge_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pair: torch.Tensor, HWk: int, topk: int,
@@ -253,6 +270,43 @@ def corr_volume(qfeat: torch.Tensor, kfeat: torch.Tensor, temperature: float = 1
     return out
 
 
+def dense_attend(qfeat: torch.Tensor, kfeat: torch.Tensor, labels: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
+                 mask: MaskSpec, temperature: float, mode: str = "softmax", non_mask_len: int = 0,
+                 dense_mask: Optional[torch.Tensor] = None, precision: str = "f32") -> torch.Tensor:
+    """topk=None branch (local_attention.py:376-383): weights over every unmasked key of every key slot.
+    qfeat (HWq, C) f32 rows, kfeat (T, HWk, C), labels (T, HWk, P) -> (HWq, P).  One HWk x HWq volume slab lives at a time
+    (fgvc_corr_volume_f32, or _bf16x3 with precision='bf16x3' for C % 64 == 0), streamed once by fgvc_dense_attend_f32."""
+    qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
+    labels = _chk(labels, torch.float32, "labels")
+    T, HWk, P = labels.shape
+    HWq = qfeat.shape[0]
+    assert HWq == Hq * Wq and HWk == Hk * Wk and kfeat.shape[:2] == (T, HWk) and 0 <= non_mask_len <= T
+    dev = qfeat.device
+    wm = {"softmax": WEIGHT_SOFTMAX, "cosine": WEIGHT_COSINE}[mode]
+    ns = _lib.load().fgvc_dense_attend_splits(HWq, HWk)
+    state = torch.empty((ns, HWq, P + 2), device=dev, dtype=torch.float32)
+    vol = torch.empty((HWk, HWq), device=dev, dtype=torch.float32)
+    if precision == "bf16x3":
+        qs, ks = split_bf16(qfeat), split_bf16(kfeat)
+    if dense_mask is not None:
+        dense_mask = _chk(dense_mask.to(torch.bool), torch.bool, "dense_mask")
+        assert dense_mask.shape == (HWk, HWq) and mask.is_none
+    for t in range(T):
+        if precision == "bf16x3":
+            corr_volume(qs, ks[t], temperature, "bf16x3", out=vol)
+        else:
+            corr_volume(qfeat, kfeat[t], temperature, "f32", out=vol)
+        masked = t >= non_mask_len
+        if dense_mask is not None and masked:
+            vol.masked_fill_(~dense_mask, float("-inf"))             # a user's arbitrary mask tensor: applied to the slab as given
+        _lib.call("fgvc_dense_attend_f32", _ptr(vol), _ptr(labels[t]), Hq, Wq, Hk, Wk, P, int(masked and not mask.is_none),
+                  min(mask.r2max, NO_LIMIT), min(mask.ry, NO_LIMIT), min(mask.rx, NO_LIMIT), wm, int(t == 0), _ptr(state), ns,
+                  _stream(qfeat))
+    out = torch.empty((HWq, P), device=dev, dtype=torch.float32)
+    _lib.call("fgvc_dense_attend_finish_f32", _ptr(state), ns, HWq, P, wm, _ptr(out), _stream(qfeat))
+    return out
+
+
 def local_corr_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, H: int, W: int, R: int, topk: int,
                     temperature: float, normalized: bool = False):
     """A7: qfeat (1, HW, C), kfeat (K, HW, C) -> idx (HW,k) int32 = slot*(2R+1)^2 + tap, logit, weight.
@@ -260,7 +314,7 @@ def local_corr_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, H: int, W: int, R:
     qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
     K = kfeat.shape[0]
     dev = qfeat.device
-    if split_path_ok(qfeat.shape[-1], H, W, topk, normalized):
+    if split_path_ok(qfeat.shape[-1], H, W, topk, normalized, None, MaskSpec(ry=R, rx=R), True):
         qs, ks = split_bf16(qfeat), split_bf16(kfeat)
         pairs = make_pairs([(0, t) for t in range(K)], dev)
         ws_i = torch.empty((K, H * W, topk), device=dev, dtype=torch.int32)

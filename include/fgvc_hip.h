@@ -104,9 +104,14 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
  * (scores closer than 6e-8 tie and are ordered by pixel index, like equal f32 scores).
  * The default pair kernel of the engine for C == 256.
  *   Precondition: feature rows L2-normalised (|q.k| <= 1), as fgvc_normalize_chw_to_hwc_f32(normalize=1) makes them.
- *   C == 256; 1 <= topk <= 10; analytic mask only (a dense mask tensor needs fgvc_pair_topk_f32). */
+ *   C == 256; 1 <= topk <= 10; analytic mask only (a dense mask tensor needs fgvc_pair_topk_f32).
+ *   A query tile walks a list of at most 4096 key blocks (4x8 pixels): the key blocks within the mask's reach for a pair with
+ *   FGVC_PAIR_MASKED, the whole key grid for a pair without.  `pairs` lives on the device, so the caller states with
+ *   all_masked != 0 that EVERY pair carries FGVC_PAIR_MASKED; then only the reach is checked against the list (a 480x854 grid
+ *   with a radius-6 window is fine), otherwise the whole grid must fit (FGVC_ERR_UNSUPPORTED beyond 4096 blocks).  A pair
+ *   that breaks the promise on such a grid gets empty lists (-1 / -inf), never truncated ones. */
 int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs,
-                          int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk,
+                          int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked,
                           int32_t* idx_out, float* score_out, void* stream);
 
 /* ---- A5 step 2: merge the per-pair lists of the T key slots of each query frame, divide by the
@@ -144,6 +149,21 @@ int fgvc_corr_volume_bf16x3(const uint16_t* q_hi_lo, const uint16_t* k_hi_lo, in
                             float temperature, float* vol, void* stream);
 int fgvc_corr_volume_bf16(const uint16_t* q_hi_lo, const uint16_t* k_hi_lo, int C, int HWq, int HWk,
                           float temperature, float* vol, void* stream);
+
+/* ---- A5, topk=None branch: weights over EVERY unmasked key instead of the k best
+ * replaces local_attention.py:376-383 (`cur_affinity.softmax(dim=1)` / `.clamp(min=0)**2` over the (T*HWk x step) slab and the
+ * einsum with value_vec).  Called once per key slot t with that slot's dense volume vol[HWk][HWq] (fgvc_corr_volume_*, already
+ * divided by the temperature; -inf entries are skipped) and labels[HWk][P]:
+ *   softmax mode: per query an online softmax state {running max, denominator, P weighted label sums} in
+ *     state[nsplit][HWq][P+2] f32, `first` != 0 starts it, later calls merge into it;
+ *   cosine mode (weight_mode = FGVC_WEIGHT_COSINE): plain sums of max(a,0)^2 * label.
+ * masked != 0 applies the predicate (r2max, ry, rx) on key - query offsets (equal grids required) and visits only the key
+ * rows a band of queries can reach.  nsplit = fgvc_dense_attend_splits(HWq, HWk) (host helper) workgroups share a band's key rows.
+ * fgvc_dense_attend_finish_f32 merges the splits and normalises: out[HWq][P]. P <= 32. */
+int fgvc_dense_attend_splits(int HWq, int HWk);
+int fgvc_dense_attend_f32(const float* vol, const float* labels, int Hq, int Wq, int Hk, int Wk, int P, int masked,
+                          int r2max, int ry, int rx, int weight_mode, int first, float* state, int nsplit, void* stream);
+int fgvc_dense_attend_finish_f32(const float* state, int nsplit, int HWq, int P, int weight_mode, float* out, void* stream);
 
 /* ---- A7: single-scale local-window correlation + top-k (mmcv.ops.Correlation semantics as used at
  * vanilla_tracker.py:435-443,547-566; torch twin local_attention.py:1190-1240).

@@ -224,21 +224,57 @@ def propagate_topk(value: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor)
     return (g * weight.unsqueeze(0)).sum(-1)
 
 
+def dense_affinity(query, key, temperature=1.0, normalize=True, sim_mode="dot_product", neighbor_range=None,
+                   mask_mode="circle", mask=None, non_mask_len=0) -> torch.Tensor:
+    """The whole masked affinity slab (T*HWk, HWq) of local_attention.py:308-353, for either `sim_mode`:
+    'dot_product' = <k,q>/temperature (:321-323); 'l2-distance' = (2<k,q> - |k|^2)/sqrt(C), no temperature (:324-327)."""
+    C, Hq, Wq = query.shape
+    _, T, Hk, Wk = key.shape
+    if normalize:
+        query, key = l2_normalize(query, 0), l2_normalize(key, 0)
+    qv, kv = query.reshape(C, -1), key.reshape(C, -1)
+    if sim_mode == "dot_product":
+        aff = torch.einsum("ci,cj->ij", kv, qv) / temperature
+    elif sim_mode == "l2-distance":
+        aff = (2 * (kv.t() @ qv) - kv.pow(2).sum(0).unsqueeze(1)) / math.sqrt(C)
+    else:
+        raise ValueError(sim_mode)
+    if mask is not None:
+        m = mask.unsqueeze(0).expand(T, -1, -1).clone()
+        m[:non_mask_len] = True
+        aff = aff.masked_fill(~m.reshape(T * Hk * Wk, -1), NEG_INF)
+    elif neighbor_range is not None:
+        aff = aff.masked_fill(~mask_slab(Hq, Wq, Hk, Wk, T, torch.arange(Hq * Wq), neighbor_range, mask_mode, non_mask_len),
+                              NEG_INF)
+    return aff
+
+
 def masked_attention_efficient(query, key, value, mask=None, temperature=1, topk=None, normalize=True,
                                step=32, non_mask_len=0, mode="softmax", neighbor_range=None,
-                               mask_mode="circle"):
-    """Same contract as local_attention.py:267-389 for N=1, sim_mode='dot_product', topk given.
+                               mask_mode="circle", sim_mode="dot_product"):
+    """Same contract as local_attention.py:267-389 for N=1.
 
     query (1,C,Hq,Wq), key (1,C,T,Hk,Wk), value (1,P,T,Hk,Wk) -> (1,P,Hq,Wq).
+    topk=None: weights over EVERY key (softmax, or clamp(min=0)**2) instead of the k best (:376-383).
     """
-    assert query.shape[0] == 1 and topk is not None
+    assert query.shape[0] == 1
     if key.dim() == 4:
         key, value = key.unsqueeze(2), value.unsqueeze(2)
+    P = value.shape[1]
+    if topk is None or sim_mode != "dot_product":
+        aff = dense_affinity(query[0], key[0], temperature, normalize, sim_mode, neighbor_range, mask_mode, mask, non_mask_len)
+        if topk is None:
+            w = aff.softmax(0) if mode == "softmax" else aff.clamp(min=0) ** 2                   # :377-380
+            out = value[0].reshape(P, -1) @ w                                                    # :383
+        else:
+            v, i = topk_canonical(aff, topk)
+            out = propagate_topk(value[0].reshape(P, -1), i.t(), topk_weights(v.t(), mode))
+        return out.reshape(1, P, query.shape[2], query.shape[3])
     idx, logit = affinity_topk(query[0], key[0], topk, temperature, neighbor_range, mask_mode, mask,
                                normalize, non_mask_len, step)
     w = topk_weights(logit, mode)
-    out = propagate_topk(value[0].reshape(value.shape[1], -1), idx, w)
-    return out.reshape(1, value.shape[1], query.shape[2], query.shape[3])
+    out = propagate_topk(value[0].reshape(P, -1), idx, w)
+    return out.reshape(1, P, query.shape[2], query.shape[3])
 
 
 # ----------------------------------------------------------------------------
@@ -384,6 +420,15 @@ def img2coord(maps: np.ndarray, topk: int = 5) -> np.ndarray:
     return coords
 
 
+def readout_ties(maps: np.ndarray, topk: int = 5) -> np.ndarray:
+    """(P,T) bool: the `topk`-th and (`topk`+1)-th largest values of a map are EQUAL, i.e. which pixel img2coord's argsort
+    keeps is unspecified (np.argsort, vanilla_tracker.py:181) and a comparison with the reference must skip that read-out.
+    Typical source: the bilinear upsample replicates border rows/columns, so a maximum at the border is a run of equal values."""
+    T, P, h, w = maps.shape
+    srt = np.sort(maps.reshape(T, P, -1), axis=-1)
+    return (srt[..., -topk] == srt[..., -topk - 1]).T
+
+
 # ----------------------------------------------------------------------------
 # A1  ResNet-18 trunk (mmcv ConvModule naming)
 # ----------------------------------------------------------------------------
@@ -498,14 +543,17 @@ def forward_test_main(feats: torch.Tensor, query_xy: torch.Tensor, h: int, w: in
     return traj
 
 
-def forward_test(encode, rgbs: torch.Tensor, query_points: torch.Tensor, trajectories, visibilities, **cfg):
+def forward_test(encode, rgbs: torch.Tensor, query_points: torch.Tensor, trajectories, visibilities, main=None, **cfg):
     """VanillaTracker.forward_test regrouping by query time (vanilla_tracker.py:246-303).
 
     encode(frames (T,3,h,w)) -> feats (T,C,Hf,Wf).  rgbs (1,T,3,h,w), query_points (1,P,3)=(t,x,y).
+    `main` = the per-group driver (default forward_test_main; hr_forward_test_main for HRVanillaTracker, which inherits
+    this regrouping).
     """
+    forward_test_main = main if main is not None else globals()["forward_test_main"]
     B, T, P = trajectories.shape[:3]
     h, w = rgbs.shape[-2:]
-    if not cfg.get("with_first", True):
+    if not cfg.get("with_first", False):                               # :246 (default False; the slot list's default is True, :353)
         traj = forward_test_main(encode(rgbs[0]), query_points[0, :, 1:], h, w, **cfg)
         return trajectories, visibilities, traj, torch.zeros_like(visibilities), query_points
     ts = torch.unique(query_points[:, :, 0])
@@ -524,6 +572,54 @@ def forward_test(encode, rgbs: torch.Tensor, query_points: torch.Tensor, traject
         vi_r[:, :, K:K + n] = visibilities[:, :, sel]
         K += n
     return tr_r, vi_r, tp_r, torch.zeros_like(visibilities), qp_r
+
+
+def hr_forward_test_main(feats: torch.Tensor, query_xy: torch.Tensor, h: int, w: int, *, radius: int, precede_frames=5,
+                         topk=10, temperature=1.0, with_first=True, normalize=True, return_all=False):
+    """HRVanillaTracker.forward_test_main ("backward warping") after feature extraction (vanilla_tracker.py:492-585):
+    per frame a local (2R+1)^2 window over every key slot (mmcv Correlation, :547), top-k over K*(2R+1)^2 of the RAW
+    correlation (:558), temperature then softmax (:563-564), labels gathered from the unfolded label maps (:550-561).
+    `normalize` is the reference's `withnorm` key (:437).  feats (T,C,Hf,Wf), query_xy (P,2)=(x,y) at frame 0.
+    Returns trajectories_pred (1,T,P,2) float64 [+ internals]."""
+    T, C, Hf, Wf = feats.shape
+    stride = h // Hf
+    full0, lab0 = gaussian_labels(query_xy, h, w, stride)
+    labels, preds, idxs, logits = [lab0], [full0], [], []
+    for f in range(1, T):
+        ks = key_slots(f, precede_frames, with_first)                                   # :521-536
+        out, idx, logit = local_corr_topk(feats[f], feats[ks], torch.stack([labels[k] for k in ks], 0), radius, topk,
+                                          temperature, normalize)
+        labels.append(out)
+        preds.append(upsample_bilinear(out, h, w))                                      # :569-573
+        idxs.append(idx); logits.append(logit)
+    seg = torch.stack(preds, 0).numpy()
+    coords = img2coord(seg)                                                             # :577-579
+    traj = torch.from_numpy(coords).permute(2, 1, 0).unsqueeze(0)                       # :580
+    if return_all:
+        return traj, dict(labels=torch.stack(labels, 0), idx=idxs, logit=logits, ties=readout_ties(seg).T)
+    return traj
+
+
+def hr_forward_test_forward(feats: torch.Tensor, ref_yx: torch.Tensor, h: int, w: int, *, radius: int, precede_frames=5,
+                            topk=10, temperature=1.0, normalize=True) -> torch.Tensor:
+    """HRVanillaTracker.forward_test_forward ("forward warping", vanilla_tracker.py:591-645): the points are pushed through
+    a chain of coordinate fields; the field of step f has QUERY = frame max(0, f - precede_frames) and KEY = frame f (:622-637)
+    and is sampled bilinearly (align_corners=True) at the current coordinates / scale (:639).
+    feats (T,C,Hf,Wf), ref_yx (2,P) = (y,x) rows -> (2,P,T) float64, rows (x,y)."""
+    T, C, Hf, Wf = feats.shape
+    scale = w // Wf                                                                     # :609
+    coord = torch.flip(ref_yx, (0,)).float()                                            # :611
+    coords = [coord]
+    for f in range(1, T):
+        start = max(0, f - precede_frames)                                              # :617
+        field = get_coord(feats[start], feats[f], radius, topk, temperature, scale, normalize)     # :636 (2,Hf,Wf)
+        g = (coord.clone() / scale).t()                                                 # (P,2) = (x,y) feature coordinates
+        gx = g[:, 0] * 2.0 / max(Wf - 1, 1) - 1.0                                       # corr_lookup.py:61-63
+        gy = g[:, 1] * 2.0 / max(Hf - 1, 1) - 1.0
+        grid = torch.stack([gx, gy], -1).view(1, -1, 1, 2)
+        coord = F.grid_sample(field.unsqueeze(0), grid, "bilinear", "zeros", True)[0, :, :, 0]     # (2,P)
+        coords.append(coord)
+    return torch.stack(coords, -1).double()                                             # :642-644
 
 
 # ----------------------------------------------------------------------------

@@ -132,6 +132,27 @@ def _constant_init(module, val, bias=0):
         nn.init.constant_(module.bias, bias)
 
 
+class _Correlation(nn.Module):
+    """Stand-in for mmcv.ops.Correlation (mmcv-full==1.5.2, CUDA only, absent here) with the arguments
+    HRVanillaTracker passes (vanilla_tracker.py:426-428): kernel_size=1, stride=1, padding=0, dilation_patch=1.
+    out[b, ph, pw, y, x] = sum_c in1[b,c,y,x] * in2[b,c,y+ph-R,x+pw-R], zero outside the map -- restated from mmcv's
+    published semantics and from the reference's own torch-only twin (local_attention.py:1190-1198); `dilation` is the
+    dilation of the correlation KERNEL, which has one tap here, so it changes nothing.  The arithmetic of this class is
+    "parity unpinned"; what the HR golden pins is the reference's DRIVER LOOP around it."""
+
+    def __init__(self, kernel_size=1, max_displacement=1, stride=1, padding=0, dilation=1, dilation_patch=1):
+        super().__init__()
+        assert kernel_size == 1 and stride == 1 and padding == 0 and dilation_patch == 1
+        self.R = max_displacement
+
+    def forward(self, input1, input2):
+        import torch.nn.functional as F
+        B, C, H, W = input1.shape
+        L = 2 * self.R + 1
+        unf = F.unfold(input2, kernel_size=L, padding=self.R).reshape(B, C, L * L, H, W)
+        return (unf * input1.unsqueeze(2)).sum(1).reshape(B, L, L, H, W)
+
+
 def _auto_fp16(*a, **k):
     def deco(fn):
         return fn
@@ -158,8 +179,10 @@ def _install_mmcv_stub():
     utils.Registry = _Registry
     utils._BatchNorm = nn.modules.batchnorm._BatchNorm
     utils.ConfigDict = _ConfigDict
-    mmcv.cnn, mmcv.runner, mmcv.utils = cnn, runner, utils
-    sys.modules.update({"mmcv": mmcv, "mmcv.cnn": cnn, "mmcv.runner": runner, "mmcv.utils": utils})
+    mops = types.ModuleType("mmcv.ops")
+    mops.Correlation = _Correlation
+    mmcv.cnn, mmcv.runner, mmcv.utils, mmcv.ops = cnn, runner, utils, mops
+    sys.modules.update({"mmcv": mmcv, "mmcv.cnn": cnn, "mmcv.runner": runner, "mmcv.utils": utils, "mmcv.ops": mops})
     if "tqdm" not in sys.modules:
         try:
             import tqdm  # noqa: F401
@@ -233,7 +256,7 @@ def load():
         if not hasattr(common, missing):
             setattr(common, missing, None)
     _exec("mmpt.models.trackers.base", "mmpt/models/trackers/base.py")
-    # HRVanillaTracker imports mmcv.ops lazily in __init__; VanillaTracker does not need it.
+    # HRVanillaTracker imports mmcv.ops lazily in __init__ (the _Correlation stand-in above); VanillaTracker does not need it.
     vt = _exec("mmpt.models.trackers.vanilla_tracker", "mmpt/models/trackers/vanilla_tracker.py")
 
     ns = types.SimpleNamespace(
@@ -251,6 +274,7 @@ def load():
         coords_grid=mods['local_attention'].coords_grid,
         ResNet=resnet.ResNet,
         VanillaTracker=vt.VanillaTracker,
+        HRVanillaTracker=vt.HRVanillaTracker,
         builder=sys.modules["mmpt.models.builder"],
         registry=sys.modules["mmpt.models.registry"],
         ConfigDict=_ConfigDict,

@@ -226,6 +226,77 @@ def gen_tapvid_metrics():
          pred_tracks=pred, **outs)
 
 
+def gen_hr_tracker():
+    """tests/golden/hr_tracker_5x48x64.npz: the genuine HRVanillaTracker driver loops (vanilla_tracker.py:417-660: backward
+    warping forward_test_main, the query-time regrouping it inherits, forward warping forward_test_forward) run around the
+    mmcv.ops.Correlation stand-in of oracle/ref_import.py (its arithmetic stays "parity unpinned")."""
+    ref = ref_import.load()
+    g = torch.Generator().manual_seed(800)
+    T, h, w = 5, 48, 64
+    rgbs = torch.randn(1, T, 3, h, w, generator=g)
+    sd = O.seeded_resnet_state(seed=11, strides=(1, 2, 1, 1), pool_type="none")
+    out = {}
+    for tag, extra in (("norm", {}), ("raw", dict(withnorm=False, temperature=4.0)), ("nofirst", dict(with_first=False))):
+        cfg = ref.ConfigDict(dict(precede_frames=2, topk=6, temperature=0.07, neighbor_range=8, with_first=True,
+                                  batch_step=2), **extra)
+        model = ref.builder.build_model(
+            dict(type="HRVanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                                        pool_type="none")), train_cfg=None, test_cfg=cfg)
+        model.backbone.load_state_dict(sd, strict=True)
+        model.eval()
+        qp0 = torch.tensor([[[0., 10., 20.], [0., 33.5, 12.25], [0., 50., 40.]]])
+        with ref_import.cuda_as_cpu(), torch.no_grad():
+            main = model.forward_test_main(rgbs, qp0, torch.zeros(1, T, 3, 2), torch.zeros(1, T, 3))
+        out[f"main_{tag}"] = main[2]
+        if tag == "norm":
+            qp = torch.tensor([[[0., 10., 20.], [2., 33.5, 12.25], [0., 50., 40.], [1., 5., 30.]]])
+            traj_gt = torch.rand(1, T, 4, 2, generator=g) * 48
+            vis_gt = (torch.rand(1, T, 4, generator=g) > 0.3).float()
+            ref_yx = torch.tensor([[[20., 12.25, 40.], [10., 33.5, 50.]]])                  # (1, 2, P) = (y, x)
+            with ref_import.cuda_as_cpu(), torch.no_grad():
+                outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj_gt, visibilities=vis_gt)
+                fwd = model.forward_test_forward(rgbs.transpose(1, 2).unsqueeze(1), None, None, ref_yx)
+                q, k = model.backbone(rgbs[0, :1]), model.backbone(rgbs[0, 1:2])
+                coord = model.get_coord(q, k, (h, w), w // q.shape[-1])
+            out.update(query_points=qp, trajectories=traj_gt, visibilities=vis_gt, out_trajectories=outs[0],
+                       out_visibilities=outs[1], out_traj_pred=outs[2], out_vis_pred=outs[3], out_query_points=outs[4],
+                       ref_yx=ref_yx, forward_coords=np.stack(fwd, 0), coord_field=coord)
+    save("hr_tracker_5x48x64", rgbs=rgbs, seed=11, query_points0=qp0, **out)
+
+
+def gen_extra_modes():
+    """tests/golden/mae_l2_12x16.npz, mae_dense_softmax_10x12.npz: the branches of masked_attention_efficient the shipped
+    configs do not take -- sim_mode='l2-distance' (local_attention.py:324-327) and topk=None (dense softmax / cosine weights
+    over every unmasked key, :376-383)."""
+    ref = ref_import.load()
+    g = torch.Generator().manual_seed(900)
+    C, T, H, W, P, nr, k = 48, 3, 12, 16, 4, 10, 8
+    q, key, v = rnd(g, 1, C, H, W), rnd(g, 1, C, T, H, W), torch.rand(1, P, T, H, W, generator=g)
+    mask = ref.spatial_neighbor(1, H, W, neighbor_range=nr, device="cpu", dtype=torch.float32)
+    with TopkSpy() as spy:
+        out = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=k, step=64, sim_mode="l2-distance")
+    save("mae_l2_12x16", query=q, key=key, value=v, nr=nr, topk=k, temperature=0.07, out=out,
+         ref_topk_val=torch.cat([c[0][0] for c in spy.calls], 1).t().contiguous(),
+         ref_topk_idx=torch.cat([c[1][0] for c in spy.calls], 1).t().contiguous().to(torch.int32))
+    g = torch.Generator().manual_seed(901)
+    C, T, H, W, P, nr = 32, 2, 10, 12, 3, 8
+    q, key, v = rnd(g, 1, C, H, W), rnd(g, 1, C, T, H, W), torch.rand(1, P, T, H, W, generator=g)
+    mask = ref.spatial_neighbor(1, H, W, neighbor_range=nr, device="cpu", dtype=torch.float32)
+    kw = dict(temperature=0.07, topk=None, step=50)
+    save("mae_dense_softmax_10x12", query=q, key=key, value=v, nr=nr, temperature=0.07,
+         out=ref.masked_attention_efficient(q, key, v, mask, **kw),
+         out_nml1=ref.masked_attention_efficient(q, key, v, mask, non_mask_len=1, **kw),
+         out_nomask=ref.masked_attention_efficient(q, key, v, None, **kw),
+         out_cos=ref.masked_attention_efficient(q, key, v, mask, mode="cosine", **kw),
+         out_l2=ref.masked_attention_efficient(q, key, v, mask, sim_mode="l2-distance", **kw))
+
+
 if __name__ == "__main__":
-    main()
-    gen_tapvid_metrics()
+    if len(sys.argv) > 1:          # regenerate single fixtures: python gen_golden.py gen_hr_tracker ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        main()
+        gen_tapvid_metrics()
+        gen_hr_tracker()
+        gen_extra_modes()

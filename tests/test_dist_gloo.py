@@ -69,7 +69,7 @@ def _worker(rank, world, port, feats, qp, q):
     torch.set_num_threads(2)
     from fgvc_amd import dist as D
     from fgvc_amd.engine import TrackerConfig
-    cfg = TrackerConfig(neighbor_range=8)
+    cfg = TrackerConfig(neighbor_range=8, regroup=True)
     h, w = feats.shape[-2] * 2, feats.shape[-1] * 2
     try:
         traj, order = _run(D, OracleBackend(), feats, qp, cfg, h, w)
@@ -139,7 +139,7 @@ def test_single_process_path_equals_engine_semantics():
     T, C, Hf, Wf = 6, 8, 8, 8
     feats = torch.randn(T, C, Hf, Wf, generator=g)
     qp = torch.tensor([[0., 3., 4.], [2., 10., 9.]])
-    cfg = TrackerConfig(neighbor_range=6)
+    cfg = TrackerConfig(neighbor_range=6, regroup=True)
     traj, order = _run(D, OracleBackend(), feats, qp, cfg, 16, 16)
     e0 = O.forward_test_main(feats, qp[:1, 1:], 16, 16, neighbor_range=6)[0]
     e2 = O.forward_test_main(feats[2:], qp[1:, 1:], 16, 16, neighbor_range=6)[0]

@@ -399,7 +399,7 @@ def test_engine_vs_oracle_tracker(dev):
     Tn, C, Hf, Wf, h, w = 9, 64, 16, 20, 32, 40
     feats = torch.randn(Tn, C, Hf, Wf, generator=g)
     qp = torch.tensor([[0., 10., 20.], [0., 30.2, 5.7], [3., 12.3, 9.1], [3., 25.0, 25.0], [6., 3.3, 30.1]])
-    cfg = engine.TrackerConfig(neighbor_range=12)
+    cfg = engine.TrackerConfig(neighbor_range=12, regroup=True)
     fh = ops.normalize_to_hwc(feats.to(dev))
     traj, order = engine.track_points(fh, Hf, Wf, h, w, qp, cfg)
     traj = traj.cpu()
@@ -620,7 +620,7 @@ def test_engine_split_and_f32_paths_agree(dev):
     qp = torch.tensor([[0, 40.0, 30.0], [0, 100.0, 60.0], [2, 80.0, 20.0]])
     outs = {}
     for prec in ("f32", "split", "auto"):
-        cfg = engine.TrackerConfig(pair_precision=prec)
+        cfg = engine.TrackerConfig(pair_precision=prec, regroup=True)
         outs[prec] = engine.track_points(feats, H, W, H * 4, W * 4, qp, cfg)[0]
     assert torch.equal(outs["split"], outs["auto"])
     assert float((outs["split"] - outs["f32"]).abs().max()) < 1e-3

@@ -138,7 +138,7 @@ def test_tracker(golden):
         assert torch.allclose(feats[:, ::16, ::4, ::4], T(g["feats_sub"]), atol=1e-4, rtol=1e-4)
         main = O.forward_test_main(feats, qp[0, [0, 2], 1:], 64, 64)
         assert torch.allclose(main, T(g["main_traj_pred"]).double(), atol=2e-3)
-        outs = O.forward_test(lambda x: net(x), rgbs, qp, T(g["trajectories"]), T(g["visibilities"]))
+        outs = O.forward_test(lambda x: net(x), rgbs, qp, T(g["trajectories"]), T(g["visibilities"]), with_first=True)
     assert torch.equal(outs[0], T(g["out_trajectories"]))
     assert torch.equal(outs[1], T(g["out_visibilities"]))
     assert torch.equal(outs[4], T(g["out_query_points"]))
@@ -149,3 +149,45 @@ def test_tracker(golden):
     d[0, 1, 2, 0] = 0
     assert float(d.max()) < 2e-3
     assert torch.equal(outs[3], T(g["out_vis_pred"]))
+
+
+def test_hr_tracker(golden):
+    """The HR driver twins against the genuine HRVanillaTracker loops (run around the Correlation stand-in)."""
+    g = golden("hr_tracker_5x48x64")
+    sd = O.seeded_resnet_state(int(g["seed"]), (1, 2, 1, 1), "none")
+    net = O.ResNet18((1, 2, 1, 1), 2, "none")
+    net.load_state_dict(sd)
+    net.eval()
+    rgbs = T(g["rgbs"])
+    h, w = rgbs.shape[-2:]
+    base = dict(radius=4, precede_frames=2, topk=6, temperature=0.07)
+    with torch.no_grad():
+        feats = net(rgbs[0])
+        q0 = T(g["query_points0"])[0, :, 1:]
+        for tag, extra in (("norm", {}), ("raw", dict(normalize=False, temperature=4.0)), ("nofirst", dict(with_first=False))):
+            main, al = O.hr_forward_test_main(feats, q0, h, w, return_all=True, **{**base, **extra})
+            d = (main - T(g[f"main_{tag}"]).double()).abs()[0]
+            d[torch.from_numpy(al["ties"])] = 0          # read-outs whose 5th/6th values tie: argsort order unspecified
+            assert float(d.max()) < 2e-3, tag
+            assert al["ties"].mean() < 0.5
+        outs = O.forward_test(lambda x: net(x), rgbs, T(g["query_points"]), T(g["trajectories"]), T(g["visibilities"]),
+                              main=O.hr_forward_test_main, with_first=True, **base)
+        fwd = O.hr_forward_test_forward(feats, T(g["ref_yx"])[0], h, w, **base)
+        field = O.get_coord(feats[0], feats[1], 4, 6, 0.07, w // feats.shape[-1])
+    assert torch.equal(outs[0], T(g["out_trajectories"])) and torch.equal(outs[4], T(g["out_query_points"]))
+    assert float((outs[2].double() - T(g["out_traj_pred"]).double()).abs().max()) < 2e-3
+    assert float((fwd - T(g["forward_coords"])[0].double()).abs().max()) < 2e-3
+    assert float((field - T(g["coord_field"])[0]).abs().max()) < 2e-3
+
+
+def test_l2_distance_and_dense_softmax_branches(golden):
+    g = golden("mae_l2_12x16")
+    out = O.masked_attention_efficient(T(g["query"]), T(g["key"]), T(g["value"]), temperature=0.07, topk=int(g["topk"]),
+                                       neighbor_range=int(g["nr"]), sim_mode="l2-distance")
+    assert torch.allclose(out, T(g["out"]), atol=1e-5)
+    g = golden("mae_dense_softmax_10x12")
+    q, k, v, nr = T(g["query"]), T(g["key"]), T(g["value"]), int(g["nr"])
+    for name, kw in (("out", dict(neighbor_range=nr)), ("out_nml1", dict(neighbor_range=nr, non_mask_len=1)), ("out_nomask", {}),
+                     ("out_cos", dict(neighbor_range=nr, mode="cosine")), ("out_l2", dict(neighbor_range=nr, sim_mode="l2-distance"))):
+        out = O.masked_attention_efficient(q, k, v, temperature=0.07, topk=None, **kw)
+        assert torch.allclose(out, T(g[name]), atol=1e-5, rtol=1e-5), name
