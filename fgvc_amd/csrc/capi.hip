@@ -60,6 +60,9 @@ void set_pair_v4_products(int);
 int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, int32_t*,
                         float*, hipStream_t);
 void set_corr_debug(int);
+int split_f16f8_launch(const float*, unsigned char*, long long, int, hipStream_t);
+int corr_volume_f16f8_launch(const unsigned char*, const unsigned char*, int, int, float, float*, hipStream_t);
+void set_corr8_debug(int);
 int dense_attend_splits(int, int);
 int dense_attend_launch(const float*, const float*, int, int, int, int, int, int, int, int, int, int, int, float*, int, hipStream_t);
 int dense_attend_finish_launch(const float*, int, int, int, int, float*, hipStream_t);
@@ -84,6 +87,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "corr_debug") == 0) {   // profiling ablation: 1 = bf16 volume kernels skip their stores
     set_corr_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "corr8_debug") == 0) {   // fgvc_corr_volume_f16f8 ablations: 1 = no stores, 2 = no MFMA (results wrong); 4 = no row
+    set_corr8_debug(value);                 // classes (results right); value >> 8 = key blocks per workgroup
     return FGVC_OK;
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
@@ -252,6 +259,24 @@ int fgvc_corr_volume_bf16x3(const uint16_t* q, const uint16_t* k, int C, int HWq
 int fgvc_corr_volume_bf16(const uint16_t* q, const uint16_t* k, int C, int HWq, int HWk, float temperature,
                           float* vol, void* stream) {
   return corr_bf16_common("fgvc_corr_volume_bf16", q, k, C, HWq, HWk, temperature, vol, 1, stream);
+}
+
+int fgvc_split_f16f8(const float* feat, uint8_t* out, int64_t n_pixels, int C, void* stream) {
+  FGVC_REQUIRE(feat && out, FGVC_ERR_INVALID_ARG, "fgvc_split_f16f8: null pointer");
+  FGVC_REQUIRE(n_pixels >= 0 && C > 0 && C % 4 == 0, FGVC_ERR_INVALID_ARG, "fgvc_split_f16f8: C must be a multiple of 4");
+  FGVC_REQUIRE(aligned16(feat) && aligned16(out), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f8: 16-byte alignment required");
+  if (n_pixels == 0) return FGVC_OK;
+  return split_f16f8_launch(feat, out, n_pixels, C, (hipStream_t)stream);
+}
+
+int fgvc_corr_volume_f16f8(const uint8_t* q, const uint8_t* k, int C, int HWq, int HWk, float temperature, float* vol,
+                           void* stream) {
+  FGVC_REQUIRE(q && k && vol, FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f16f8: null pointer");
+  FGVC_REQUIRE(aligned16(q) && aligned16(k) && aligned16(vol), FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f16f8: 16-byte alignment required");
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_corr_volume_f16f8: C=%d unsupported (256 only; use fgvc_corr_volume_bf16x3)", C);
+  FGVC_REQUIRE(HWq > 0 && HWk > 0 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f16f8: bad shape");
+  FGVC_REQUIRE((long long)HWq < (1ll << 30) && (long long)HWk < (1ll << 30), FGVC_ERR_UNSUPPORTED, "fgvc_corr_volume_f16f8: grid too large");
+  return corr_volume_f16f8_launch(q, k, HWq, HWk, temperature, vol, (hipStream_t)stream);
 }
 
 int fgvc_dense_attend_splits(int HWq, int HWk) { return (HWq > 0 && HWk > 0) ? dense_attend_splits(HWq, HWk) : 1; }

@@ -247,10 +247,22 @@ def split_bf16(feat: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_f16f8(feat: torch.Tensor) -> torch.Tensor:
+    """(…, C) f32 L2-normalised rows -> (…, 4 C) uint8: per pixel [h = f16(256 x) | h8 = e4m3(h) | l8 = e4m3(256 (256 x - h))],
+    the operand format of fgvc_corr_volume_f16f8."""
+    feat = _chk(feat, torch.float32, "feat")
+    Cc = feat.shape[-1]
+    n = feat.numel() // Cc
+    out = torch.empty((*feat.shape[:-1], 4 * Cc), device=feat.device, dtype=torch.uint8)
+    _lib.call("fgvc_split_f16f8", _ptr(feat), _ptr(out), n, Cc, _stream(feat))
+    return out
+
+
 def corr_volume(qfeat: torch.Tensor, kfeat: torch.Tensor, temperature: float = 1.0, precision: str = "f32",
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Dense volume vol[key j][query i] = <k_j, q_i>/temperature, (HWk, HWq) f32.
-    precision 'f32': qfeat (HWq,C), kfeat (HWk,C) f32.  'bf16x3' / 'bf16': the split_bf16() forms (HW,2,C)."""
+    precision 'f32': qfeat (HWq,C), kfeat (HWk,C) f32.  'bf16x3' / 'bf16': the split_bf16() forms (HW,2,C).
+    'f16f8': the split_f16f8() forms (HW, 4C) uint8 of L2-normalised rows, C == 256 (parity-grade, the fastest)."""
     HWq, HWk, Cc = qfeat.shape[0], kfeat.shape[0], qfeat.shape[-1]
     if out is None:
         out = torch.empty((HWk, HWq), device=qfeat.device, dtype=torch.float32)
@@ -259,6 +271,11 @@ def corr_volume(qfeat: torch.Tensor, kfeat: torch.Tensor, temperature: float = 1
     if precision == "f32":
         qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
         _lib.call("fgvc_corr_volume_f32", _ptr(qfeat), _ptr(kfeat), Cc, HWq, HWk, float(temperature), _ptr(out),
+                  _stream(qfeat))
+    elif precision == "f16f8":
+        qfeat, kfeat = _chk(qfeat, torch.uint8, "qfeat"), _chk(kfeat, torch.uint8, "kfeat")
+        assert qfeat.dim() == 2 and qfeat.shape[1] % 4 == 0 and kfeat.shape[1] == qfeat.shape[1]
+        _lib.call("fgvc_corr_volume_f16f8", _ptr(qfeat), _ptr(kfeat), qfeat.shape[1] // 4, HWq, HWk, float(temperature), _ptr(out),
                   _stream(qfeat))
     elif precision in ("bf16x3", "bf16"):
         qfeat, kfeat = _chk(qfeat, torch.int16, "qfeat"), _chk(kfeat, torch.int16, "kfeat")

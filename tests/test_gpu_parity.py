@@ -161,8 +161,40 @@ def test_corr_volume(dev):
         assert ex3 < TOL, ex3
         vb = ops.corr_volume(qs, ks, 0.07, "bf16").cpu()
         eb = float((vb.double() - ref64).abs().max())
-        assert eb < 0.2, eb        # plain bf16 is NOT within the 1e-3 bar (reported, reduced precision)
-        print(f"C={C}: max |err| logits  f32 {e32:.2e}  bf16x3 {ex3:.2e}  bf16 {eb:.2e}")
+        assert eb < 3e-2, eb        # plain bf16 is NOT within the 1e-3 bar (reported, reduced precision; bound ~ 5 sigma of its rounding)
+        e8 = -1.0
+        if C == 256:               # f16 + block-scaled fp8 cross terms: parity-grade at two bf16-MFMA times per tile
+            v8 = ops.corr_volume(ops.split_f16f8(qf), ops.split_f16f8(kf), 0.07, "f16f8").cpu()
+            e8 = float((v8.double() - ref64).abs().max())
+            assert e8 < TOL / 2, e8
+        print(f"C={C}: max |err| logits  f32 {e32:.2e}  bf16x3 {ex3:.2e}  f16f8 {e8:.2e}  bf16 {eb:.2e}")
+
+
+def test_corr_volume_f16f8_ragged_shapes_and_adversarial_rows(dev):
+    """fgvc_corr_volume_f16f8 on grids whose HW is not a multiple of 32 (row classes of equal line phase: periods 1, 2, 4 and the
+    unshifted fallback), non-square query/key grids, and on rows built to stress the split (one-hot, heavy-tailed, tiny and
+    negative-zero components): every entry within 1e-3 of the float64 product."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(19)
+    for (HWq, HWk, kind) in [(48 * 37 + 16, 1000, "gauss"), (2056, 777, "gauss"), (33 * 31, 33 * 31, "gauss"), (25 * 52, 64, "gauss"),
+                             (4096, 4096, "onehot"), (1500, 1300, "heavy"), (31, 5, "gauss"), (300, 300, "relu")]:
+        def rows(n):
+            x = torch.randn(n, 256, generator=g)
+            if kind == "onehot":
+                x = x * (torch.rand(n, 256, generator=g) < 0.02) + 1e-4 * torch.randn(n, 256, generator=g)
+                x[0] = 0.0
+                x[0, 5] = -1.0
+                x[1, 7] = -0.0
+            elif kind == "heavy":
+                x = x ** 3
+            elif kind == "relu":
+                x = torch.relu(torch.randn(1, 256, generator=g) + 0.3 * x)
+            return torch.nn.functional.normalize(x, dim=1)
+        q, k = rows(HWq), rows(HWk)
+        vol = ops.corr_volume(ops.split_f16f8(q.to(dev)), ops.split_f16f8(k.to(dev)), 0.07, "f16f8").cpu()
+        assert vol.shape == (HWk, HWq)
+        err = float((vol.double() - (k.double() @ q.double().t()) / 0.07).abs().max())
+        assert err < TOL, (HWq, HWk, kind, err)
 
 
 def test_dense_golden(dev, golden):
