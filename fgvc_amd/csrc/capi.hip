@@ -90,7 +90,7 @@ int fgvc_set_option(const char* name, int value) {
     return FGVC_OK;
   }
   if (strcmp(name, "corr8_debug") == 0) {   // fgvc_corr_volume_f16f8 ablations: 1 = no stores, 2 = no MFMA (results wrong); 4 = no row
-    set_corr8_debug(value);                 // classes (results right); value >> 8 = key blocks per workgroup
+    set_corr8_debug(value);                 // classes, 8 = wave stagger, 16 = the 32x32-shape kernel (results right); >> 8 = key blocks per workgroup
     return FGVC_OK;
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -19,10 +20,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C = 256, KS = C / 16, LDB = 1024 + 16;
 
-template <int PROD, int QT, int NW, int ST, int BAR = 0, int STAG = 0>
+template <int PROD, int QT, int NW, int ST, int BAR = 0, int STAG = 0, int DMA = 0>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void kern(const uint4* __restrict__ qsrc, float* __restrict__ vol, int HW,
                                                                  int pitch, int kchunk) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[64 * LDB];
+  __shared__ __attribute__((aligned(16))) unsigned char lds2[DMA ? 64 * LDB : 16];
   for (int i = threadIdx.x; i < 64 * LDB / 4; i += NW * 64) reinterpret_cast<uint32_t*>(lds)[i] = (i * 2654435761u) & 0x3bff3bffu;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -179,12 +181,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void kern(const uint4* __
         }
       }
     }
-    if (BAR && ((kb - kb0) & 1)) asm volatile("s_barrier" ::: "memory");
+    if (DMA && !((kb - kb0) & 1)) {   // stage start: LDS-DMA of the next 64 key rows (8 x 1 KiB per wave)
+#pragma unroll
+      for (int i = 0; i < 64 / NW; ++i) {
+        const int row = wave * (64 / NW) + i;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(qsrc) + ((size_t)((kb * 32 + row) % 4096)) * 1024 + 16 * lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)&lds2[row * LDB], 16, 0, 0);
+      }
+    }
+    if (BAR && ((kb - kb0) & 1)) {
+      if (DMA == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
   }
 }
 
-template <int PROD, int QT, int NW, int ST, int BAR = 0, int STAG = 0>
-void run(const char* name, const uint4* q, float* vol, int HW, int pitch) {
+template <int PROD, int QT, int NW, int ST, int BAR = 0, int STAG = 0, int DMA = 0>
+float run(const char* name, const uint4* q, float* vol, int HW, int pitch) {
   const int n_q = (HW + 32 * QT * NW - 1) / (32 * QT * NW), n_kb = (HW + 31) / 32;
   const int chunks = std::max(1, 1024 / n_q);
   int kchunk = (n_kb + chunks - 1) / chunks;
@@ -192,18 +206,16 @@ void run(const char* name, const uint4* q, float* vol, int HW, int pitch) {
   dim3 grid(n_q, (n_kb + kchunk - 1) / kchunk);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) kern<PROD, QT, NW, ST, BAR, STAG><<<grid, NW * 64>>>(q, vol, HW, pitch, kchunk);
+  for (int i = 0; i < 3; ++i) kern<PROD, QT, NW, ST, BAR, STAG, DMA><<<grid, NW * 64>>>(q, vol, HW, pitch, kchunk);
   (void)hipEventRecord(e0);
-  const int reps = 5;
-  for (int i = 0; i < reps; ++i) kern<PROD, QT, NW, ST, BAR, STAG><<<grid, NW * 64>>>(q, vol, HW, pitch, kchunk);
+  const int reps = 10;
+  for (int i = 0; i < reps; ++i) kern<PROD, QT, NW, ST, BAR, STAG, DMA><<<grid, NW * 64>>>(q, vol, HW, pitch, kchunk);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  ms /= reps;
-  hipError_t e = hipGetLastError();
-  printf("%-34s PROD=%d QT=%d NW=%d ST=%d pitch=%d grid=%dx%d kchunk=%d : %.3f ms  (%.2f TB/s of volume)%s\n", name, PROD, QT, NW, ST, pitch,
-         grid.x, grid.y, kchunk, ms, (double)HW * HW * 4 / ms / 1e9, e == hipSuccess ? "" : hipGetErrorString(e));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return ms / reps;
 }
 
 int main(int argc, char** argv) {
@@ -219,13 +231,25 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(q, h, 4096 * 64 * 16, hipMemcpyHostToDevice);
     free(h);
   }
-  run<2, 1, 8, 0>("f16+fp8x2 compute 32x32", q, vol, HW, pitchA);
-  run<4, 1, 8, 0>("f16+fp8x2 compute 16x16", q, vol, HW, pitchA);
-  run<2, 1, 4, 0>("f16+fp8x2 compute 32x32 NW=4", q, vol, HW, pitchA);
-  run<4, 1, 4, 0>("f16+fp8x2 compute 16x16 NW=4", q, vol, HW, pitchA);
-  run<2, 1, 8, 1, 1>("32x32 nt aligned + barrier", q, vol, HW, pitchA);
-  run<4, 1, 8, 1, 1>("16x16 nt aligned + barrier (store shape of 32x32)", q, vol, HW, pitchA);
-  run<2, 1, 8, 1, 1, 1>("32x32 nt aligned + barrier + stagger", q, vol, HW, pitchA);
-  run<4, 1, 8, 1, 1, 1>("16x16 nt aligned + barrier + stagger", q, vol, HW, pitchA);
+  struct Cfg { const char* name; float (*fn)(const char*, const uint4*, float*, int, int); int pitch; float best; };
+  Cfg cfgs[] = {
+    {"16x16 nt aligned + barrier + DMA", run<4, 1, 8, 1, 1, 0, 1>, pitchA, 1e9f},
+    {"16x16 nt aligned + barrier + DMA + stagger", run<4, 1, 8, 1, 1, 1, 1>, pitchA, 1e9f},
+    {"16x16 PLAIN aligned + barrier + DMA", run<4, 1, 8, 2, 1, 0, 1>, pitchA, 1e9f},
+    {"16x16 nt aligned + barrier + DMA not waited for", run<4, 1, 8, 1, 1, 0, 2>, pitchA, 1e9f},
+    {"16x16 nt aligned + barrier + DMA not waited + stagger", run<4, 1, 8, 1, 1, 1, 2>, pitchA, 1e9f},
+    {"16x16 nt aligned + barrier, no DMA", run<4, 1, 8, 1, 1, 0, 0>, pitchA, 1e9f},
+  };
+  const int n = sizeof(cfgs) / sizeof(cfgs[0]);
+  float first[16], last[16];
+  for (int round = 0; round < 4; ++round)
+    for (int c = 0; c < n; ++c) {
+      const float ms = cfgs[c].fn(cfgs[c].name, q, vol, HW, cfgs[c].pitch);
+      if (round == 0) first[c] = ms;
+      last[c] = ms;
+      cfgs[c].best = std::min(cfgs[c].best, ms);
+    }
+  for (int c = 0; c < n; ++c)
+    printf("%-46s min %.3f ms (%.2f TB/s)  first round %.3f  last round %.3f\n", cfgs[c].name, cfgs[c].best, (double)HW * HW * 4 / cfgs[c].best / 1e9, first[c], last[c]);
   return 0;
 }
