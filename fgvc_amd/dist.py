@@ -5,23 +5,30 @@ Why it is legal: top-k indices/weights of query frame f depend only on the featu
 
 Per rank r (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on the GPUs,
 "gloo" in the CPU tests):
-  1. owns a contiguous range of query frames [lo, hi); encodes frames [lo - p, hi) itself
-     (p-frame halo recompute: cheaper and simpler than shipping 5 x 26 MB of features);
-  2. EXCHANGE STEP 1 -- `broadcast` of each group's first-frame ("query") features from the rank
-     that encoded it: C*HW*4 B = 26 MB at 480p/stride 4, fan-out over the 7 xGMI links;
-  3. correlation + top-k + merge for its own frames (no communication);
-  4. EXCHANGE STEP 2 -- `all_gather` of the merged per-frame lists (idx int32 + weight f32 =
+  1. owns a contiguous clip of query frames [lo, hi) and encodes exactly those (the first rank also the
+     video's first frame);
+  2. EXCHANGE STEP 1 -- `broadcast` of each group's first-frame ("query") features from the rank that
+     encoded it: 26 MB at 480p / stride 4 in either bank format, fan-out over the 7 xGMI links;
+  3. HALO -- the p = precede_frames frames in front of a clip belong to the previous rank(s):
+       halo="exchange" (default): one point-to-point message per (source, destination) pair, all posted
+         together (`batch_isend_irecv`): p x 26 MB = 131 MB over one xGMI link (~153 GB/s) = 0.9 ms, against
+         ~2.5 ms for encoding five more 480p frames;
+       halo="recompute": every rank encodes its own halo (no message, 5 more encoder frames per rank);
+  4. correlation + top-k + merge for its own frames (no communication);
+  5. EXCHANGE STEP 2 -- `all_gather` of the merged per-frame lists (idx int32 + weight f32 =
      HW*k*8 B = 2 MB per frame);
-  5. every rank runs the (cheap, deterministic) sequential label sweep + read-out, so no final
+  6. every rank runs the (cheap, deterministic) sequential label sweep + read-out, so no final
      broadcast of the coordinates is needed.
 There is no all-reduce anywhere; the ring-bound per-link limit of xGMI is irrelevant at these sizes.
 
 The compute is injected through a small backend object so that the choreography (halo ranges,
-ownership, gather order) is exercised on CPU with gloo and an oracle-backed backend in
-tests/test_dist_gloo.py, and by HipBackend on the GPUs.
+ownership, message plan, gather order) is exercised on CPU with gloo and an oracle-backed backend in
+tests/test_dist_gloo.py, and by HipBackend on the GPUs.  The feature bank travels in whatever form the
+backend's encoder returns: f32 rows (HW, C) or the (hi, lo) bf16 split (HW, 2, C) int16 the pair kernel reads.
 """
 from __future__ import annotations
 
+import time
 from dataclasses import replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -46,7 +53,7 @@ def shard_frames(n_frames: int, world: int, first: int = 1) -> List[Tuple[int, i
 
 
 def encode_range(lo: int, hi: int, starts: Sequence[int], cfg: TrackerConfig) -> Tuple[int, int]:
-    """Frames rank must encode itself: its query frames plus the preceding-frame halo, clipped at the
+    """halo="recompute": frames a rank encodes itself = its query frames plus the preceding-frame halo, clipped at the
     earliest start (frames before every start are never used)."""
     if hi <= lo:
         return (lo, lo)
@@ -61,6 +68,66 @@ def owner_of(frame: int, enc_ranges: List[Tuple[int, int]]) -> int:
     return 0
 
 
+def own_ranges(ranges: List[Tuple[int, int]], s_min: int) -> List[Tuple[int, int]]:
+    """halo="exchange": every frame from s_min on is encoded by exactly one rank -- its query range, and frame s_min (a query
+    frame of nobody) goes to the first rank that has any."""
+    out, given = [], False
+    for lo, hi in ranges:
+        if hi > lo and not given:
+            out.append((s_min, hi))
+            given = True
+        else:
+            out.append((lo, hi))
+    return out
+
+
+def halo_messages(ranges: List[Tuple[int, int]], own: List[Tuple[int, int]], s_min: int, p: int) -> List[Tuple[int, int, int, int]]:
+    """halo="exchange": the message plan, identical on every rank: (src, dst, frame_lo, frame_hi) = rank `src` sends its
+    frames [frame_lo, frame_hi) to `dst`, whose clip starts within p frames behind them."""
+    msgs = []
+    for dst, (lo, hi) in enumerate(ranges):
+        if hi <= lo:
+            continue
+        need_lo, need_hi = max(s_min, lo - p), own[dst][0]          # frames in front of what dst encodes itself
+        for src, (a, b) in enumerate(own):
+            x, y = max(need_lo, a), min(need_hi, b)
+            if src != dst and y > x:
+                msgs.append((src, dst, x, y))
+    return msgs
+
+
+class Timing:
+    """Optional per-phase timing of track_points_sharded: CUDA events on the current stream when the work is on a GPU (read
+    with .report() after a synchronize), wall clock otherwise."""
+
+    def __init__(self, device=None):
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.spans: Dict[str, list] = {}
+
+    def start(self, name):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+        else:
+            e = time.perf_counter()
+        self.spans.setdefault(name, []).append([e, None])
+
+    def stop(self, name):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+        else:
+            e = time.perf_counter()
+        self.spans[name][-1][1] = e
+
+    def report(self) -> Dict[str, float]:
+        """Total milliseconds per phase over everything recorded so far."""
+        out = {}
+        for name, sp in self.spans.items():
+            out[name] = sum((a.elapsed_time(b) if self.cuda else (b - a) * 1e3) for a, b in sp if b is not None)
+        return out
+
+
 class HipBackend:
     """The product backend: encoder through the tracker model, kernels through fgvc_amd.engine."""
 
@@ -68,7 +135,8 @@ class HipBackend:
         self.model = model
 
     def encode(self, frames: torch.Tensor):
-        return self.model.get_feats_hwc(frames)
+        # the bank in the form the pair kernel reads ((hi, lo) bf16 split where it applies): no second pass, same bytes to ship
+        return self.model.get_feats_hwc(frames, split=True)
 
     def affinity(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig):
         tk = engine.run_affinity(bank, Hf, Wf, plan, cfg)
@@ -79,11 +147,27 @@ class HipBackend:
         return engine.run_propagation(tk, start, pts, Hf, Wf, h, w, cfg)[1]
 
 
+def _span(timing: Optional[Timing], name: str):
+    class _Ctx:
+        def __enter__(self_):
+            if timing is not None:
+                timing.start(name)
+
+        def __exit__(self_, *exc):
+            if timing is not None:
+                timing.stop(name)
+            return False
+    return _Ctx()
+
+
 def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor, cfg: TrackerConfig,
-                         group=None, device: Optional[torch.device] = None):
-    """One video, all ranks.  rgbs (T,3,h,w) (every rank may hold the whole clip on the host; only
+                         group=None, device: Optional[torch.device] = None, halo: str = "exchange",
+                         timing: Optional[Timing] = None):
+    """One video, all ranks.  rgbs (T,3,h,w) (every rank may hold the whole clip on the host or the device; only
     its own frames are moved/encoded), query_points (P,3)=(t,x,y).
     Returns (traj (T,P',2) f64 regrouped by query time, order (P',)) on every rank."""
+    if halo not in ("exchange", "recompute"):
+        raise ValueError(f"halo={halo!r}")
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     T, h, w = rgbs.shape[0], rgbs.shape[-2], rgbs.shape[-1]
@@ -92,91 +176,126 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
     times = qp[:, 0].to(torch.int64)
     starts = sorted(set(times.tolist())) if cfg.regroup else [0]
     s_min = min(starts)
+    p = cfg.precede_frames
 
     ranges = shard_frames(T, world, first=s_min + 1)
-    enc = [encode_range(lo, hi, starts, cfg) for lo, hi in ranges]
+    if halo == "exchange" and world > 1:
+        enc = own_ranges(ranges, s_min)
+        msgs = halo_messages(ranges, enc, s_min, p)
+    else:
+        enc = [encode_range(lo, hi, starts, cfg) for lo, hi in ranges]
+        msgs = []
     lo, hi = ranges[rank]
     e_lo, e_hi = enc[rank]
 
-    # ---- 1. local encode (own frames + halo)
+    # ---- 1. local encode
     feats: Dict[int, torch.Tensor] = {}
-    Hf = Wf = C = None
-    if e_hi > e_lo:
-        f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev))
-        C = f.shape[-1]
-        for i in range(e_hi - e_lo):
-            feats[e_lo + i] = f[i]
-    for s in starts:                       # a start frame nobody's range covers is encoded by its owner
-        if owner_of(s, enc) == rank and s not in feats:
-            f, Hf, Wf = backend.encode(rgbs[s:s + 1].to(dev))
-            C = f.shape[-1]
-            feats[s] = f[0]
-    # ranks with an empty range still take part in the collectives: learn the shapes from rank 0
-    shape = torch.tensor([Hf or 0, Wf or 0, C or 0], dtype=torch.int64, device=dev)
+    Hf = Wf = None
+    frame_shape = None
+    with _span(timing, "encode"):
+        if e_hi > e_lo:
+            f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev))
+            frame_shape, frame_dtype = tuple(f.shape[1:]), f.dtype
+            for i in range(e_hi - e_lo):
+                feats[e_lo + i] = f[i]
+        for s in starts:                       # a start frame nobody's range covers is encoded by its owner
+            if owner_of(s, enc) == rank and s not in feats:
+                f, Hf, Wf = backend.encode(rgbs[s:s + 1].to(dev))
+                frame_shape, frame_dtype = tuple(f.shape[1:]), f.dtype
+                feats[s] = f[0]
+    # ranks with an empty range still take part in the collectives: learn the bank's geometry from rank 0
     if world > 1:
-        shape0 = shape.clone()
-        dist.broadcast(shape0, src=0, group=group)
-        Hf, Wf, C = (int(v) for v in shape0.tolist())
+        meta = torch.zeros(8, dtype=torch.int64, device=dev)
+        if rank == 0:
+            vals = [Hf, Wf, 1 if frame_dtype == torch.int16 else 0, len(frame_shape)] + list(frame_shape)
+            meta[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
+        dist.broadcast(meta, src=0, group=group)
+        m = meta.tolist()
+        Hf, Wf = int(m[0]), int(m[1])
+        frame_dtype = torch.int16 if m[2] else torch.float32
+        frame_shape = tuple(int(v) for v in m[4:4 + int(m[3])])
     HW = Hf * Wf
 
     # ---- 2. exchange step 1: broadcast every group's first-frame features from its owner
-    for s in starts:
-        src = owner_of(s, enc)
-        buf = feats[s].contiguous() if s in feats and rank == src else torch.empty((HW, C), device=dev,
-                                                                                   dtype=torch.float32)
-        if world > 1:
-            dist.broadcast(buf, src=src, group=group)
-        if s not in feats:
-            feats[s] = buf
+    with _span(timing, "broadcast_first_frames"):
+        for s in starts:
+            src = owner_of(s, enc)
+            buf = feats[s].contiguous() if (s in feats and rank == src) else torch.empty(frame_shape, device=dev, dtype=frame_dtype)
+            if world > 1:
+                dist.broadcast(buf, src=src, group=group)
+            if s not in feats:
+                feats[s] = buf
 
-    # ---- 3. local affinity on a compact local bank
+    # ---- 3. halo: the p frames in front of this rank's clip, from the rank(s) that encoded them
+    with _span(timing, "halo_exchange"):
+        if msgs:
+            ops_, recvs = [], []
+            for (src, dst, a, b) in msgs:
+                if src == rank:
+                    t = torch.stack([feats[f] for f in range(a, b)], 0) if b - a > 1 else feats[a].unsqueeze(0).contiguous()
+                    ops_.append(dist.P2POp(dist.isend, t, dst, group))
+                elif dst == rank:
+                    t = torch.empty((b - a,) + frame_shape, device=dev, dtype=frame_dtype)
+                    ops_.append(dist.P2POp(dist.irecv, t, src, group))
+                    recvs.append((a, b, t))
+            if ops_:
+                for req in dist.batch_isend_irecv(ops_):
+                    req.wait()
+            for a, b, t in recvs:
+                for i in range(b - a):
+                    feats.setdefault(a + i, t[i])
+
+    # ---- 4. local affinity on a compact local bank
     plan = engine.plan_clip(T, starts, cfg, frame_range=(lo, hi))
     local_ids = sorted(feats)
     remap = {f: i for i, f in enumerate(local_ids)}
     needed = {f for (q, k, _) in plan.pairs for f in (q, k)}
     assert needed <= set(local_ids), f"rank {rank}: frames {sorted(needed - set(local_ids))} missing"
     k = cfg.topk
-    if plan.pairs:
-        bank = torch.stack([feats[f] for f in local_ids], 0)
-        lplan = replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={})
-        idx, weight = backend.affinity(bank, Hf, Wf, lplan, cfg)
-    else:
-        idx = torch.empty((0, HW, k), device=dev, dtype=torch.int32)
-        weight = torch.empty((0, HW, k), device=dev, dtype=torch.float32)
+    with _span(timing, "affinity"):
+        if plan.pairs:
+            bank = torch.stack([feats[f] for f in local_ids], 0)
+            lplan = replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={})
+            idx, weight = backend.affinity(bank, Hf, Wf, lplan, cfg)
+        else:
+            idx = torch.empty((0, HW, k), device=dev, dtype=torch.int32)
+            weight = torch.empty((0, HW, k), device=dev, dtype=torch.float32)
 
-    # ---- 4. exchange step 2: all_gather of the merged lists (padded to the largest shard)
+    # ---- 5. exchange step 2: all_gather of the merged lists (padded to the largest shard)
     plans = [engine.plan_clip(T, starts, cfg, frame_range=r) for r in ranges]   # deterministic on every rank
-    rows = [len(p.slot_pair) for p in plans]
-    if world > 1:
-        mx = max(rows)
-        pad_i = torch.zeros((mx, HW, k), device=dev, dtype=torch.int32)
-        pad_w = torch.zeros((mx, HW, k), device=dev, dtype=torch.float32)
-        pad_i[: idx.shape[0]] = idx
-        pad_w[: weight.shape[0]] = weight
-        all_i = [torch.empty_like(pad_i) for _ in range(world)]
-        all_w = [torch.empty_like(pad_w) for _ in range(world)]
-        dist.all_gather(all_i, pad_i, group=group)
-        dist.all_gather(all_w, pad_w, group=group)
-        idx = torch.cat([all_i[r][: rows[r]] for r in range(world)], 0)
-        weight = torch.cat([all_w[r][: rows[r]] for r in range(world)], 0)
+    rows = [len(pp.slot_pair) for pp in plans]
+    with _span(timing, "all_gather_lists"):
+        if world > 1:
+            mx = max(rows)
+            pad_i = torch.zeros((mx, HW, k), device=dev, dtype=torch.int32)
+            pad_w = torch.zeros((mx, HW, k), device=dev, dtype=torch.float32)
+            pad_i[: idx.shape[0]] = idx
+            pad_w[: weight.shape[0]] = weight
+            all_i = [torch.empty_like(pad_i) for _ in range(world)]
+            all_w = [torch.empty_like(pad_w) for _ in range(world)]
+            dist.all_gather(all_i, pad_i, group=group)
+            dist.all_gather(all_w, pad_w, group=group)
+            idx = torch.cat([all_i[r][: rows[r]] for r in range(world)], 0)
+            weight = torch.cat([all_w[r][: rows[r]] for r in range(world)], 0)
     # global plan = concatenation of the per-rank plans, rows renumbered in rank order
     out_rows, slot_frame, base = {}, [], 0
-    for p in plans:
-        for key, r in p.out_rows.items():
+    for pp in plans:
+        for key, r in pp.out_rows.items():
             out_rows[key] = base + r
-        slot_frame.extend(p.slot_frame)
-        base += len(p.slot_pair)
+        slot_frame.extend(pp.slot_frame)
+        base += len(pp.slot_pair)
     gplan = Plan(T, starts, [], out_rows, [], slot_frame, plan.t_max)
     slot_frame_dev = torch.tensor(slot_frame, dtype=torch.int32, device=dev).reshape(len(slot_frame), plan.t_max)
 
-    # ---- 5. sequential sweep + read-out, replicated on every rank
+    # ---- 6. sequential sweep + read-out, replicated on every rank
     traj = torch.zeros((T, qp.shape[0], 2), device=dev, dtype=torch.float64)
     order, col = [], 0
-    for s in starts:
-        sel = (times == s).nonzero().flatten() if cfg.regroup else torch.arange(qp.shape[0])
-        pts = qp[sel, 1:].to(dev, torch.float32)
-        coords = backend.sweep(idx, weight, slot_frame_dev, gplan, s, pts, Hf, Wf, h, w, cfg)
-        traj[s:, col:col + sel.numel()] = coords
-        order.extend(sel.tolist())
-        col += sel.numel()
+    with _span(timing, "sweep_readout"):
+        for s in starts:
+            sel = (times == s).nonzero().flatten() if cfg.regroup else torch.arange(qp.shape[0])
+            pts = qp[sel, 1:].to(dev, torch.float32)
+            coords = backend.sweep(idx, weight, slot_frame_dev, gplan, s, pts, Hf, Wf, h, w, cfg)
+            traj[s:, col:col + sel.numel()] = coords
+            order.extend(sel.tolist())
+            col += sel.numel()
     return traj, torch.tensor(order, dtype=torch.int64)

@@ -162,6 +162,10 @@ class DeviceTopk:
     logit: torch.Tensor      # (rows, HW, k)
     weight: torch.Tensor     # (rows, HW, k)
     slot_frame: torch.Tensor  # (rows, t_max) int32
+    row_map: Optional[Dict[int, int]] = None    # plan row -> row of idx / weight / slot_frame when only some rows were merged
+
+    def row(self, plan_row: int) -> int:
+        return plan_row if self.row_map is None else self.row_map[plan_row]
 
 
 @dataclass
@@ -180,16 +184,25 @@ def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tra
     return merge_pairs(run_pairs(feats_hwc, Hf, Wf, plan, cfg, pair_chunk, events), cfg)
 
 
-def merge_pairs(pl: PairLists, cfg: TrackerConfig) -> DeviceTopk:
-    """Phase 2: per query frame, merge the lists of its key slots and softmax the k survivors."""
+def merge_pairs(pl: PairLists, cfg: TrackerConfig, rows: Optional[Sequence[int]] = None) -> DeviceTopk:
+    """Phase 2: per query frame, merge the lists of its key slots and softmax the k survivors.
+    `rows` = plan rows to merge (default all).  track_points merges one query-time group at a time: with strided TAP-Vid queries
+    a clip has one group per distinct query time and merging every (group, frame) row at once costs rows * HW * k * 12 bytes
+    (T = 250 at 128 x 128: ~6k rows, 12 GB)."""
     plan = pl.plan
     _, slot_pair, slot_frame = plan.tables(pl.idx.device)
-    if len(plan.slot_pair) == 0:
+    row_map = None
+    if rows is not None:
+        rows = list(rows)
+        sel = torch.tensor(rows, dtype=torch.int64, device=pl.idx.device)
+        slot_pair, slot_frame = slot_pair[sel].contiguous(), slot_frame[sel].contiguous()
+        row_map = {r: i for i, r in enumerate(rows)}
+    if slot_pair.shape[0] == 0:
         e = torch.empty((0, pl.HW, cfg.topk), device=pl.idx.device)
-        return DeviceTopk(plan, e.int(), e, e, slot_frame)
+        return DeviceTopk(plan, e.int(), e, e, slot_frame, row_map)
     idx, logit, weight = ops.merge_topk(pl.idx, pl.score, slot_pair, pl.HW, cfg.topk, cfg.softmax_temperature(pl.channels),
                                         cfg.mode, validate=False)
-    return DeviceTopk(plan, idx, logit, weight, slot_frame)
+    return DeviceTopk(plan, idx, logit, weight, slot_frame, row_map)
 
 
 def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
@@ -247,7 +260,7 @@ def run_propagation(topk: DeviceTopk, start: int, points_xy: torch.Tensor, Hf: i
     if lo <= start + 1:
         ops.gaussian_labels(points_xy, Hf, Wf, stride, cfg.sigma, out=labels[start])
     for f in range(max(lo, start + 1), hi):
-        row = plan.out_rows[(start, f)]
+        row = topk.row(plan.out_rows[(start, f)])
         ops.propagate_topk(labels, topk.slot_frame[row], topk.idx[row], topk.weight[row], Hf, Wf, Hf, Wf,
                            out=labels[f])
     coords = ops.softargmax_top5(labels[start:], Hf, Wf, h, w, gauss_points=points_xy, sigma=cfg.sigma)
@@ -287,13 +300,14 @@ def track_points(feats_hwc: torch.Tensor, Hf: int, Wf: int, h: int, w: int, quer
     times = qp[:, 0].to(torch.int64)
     starts = sorted(set(times.tolist())) if cfg.regroup else [0]
     plan = plan_clip(T, starts, cfg)
-    topk = run_affinity(feats_hwc, Hf, Wf, plan, cfg)
+    pl = run_pairs(feats_hwc, Hf, Wf, plan, cfg)
     traj = torch.zeros((T, qp.shape[0], 2), device=dev, dtype=torch.float64)
     order = []
     K = 0
     for s in starts:
         sel = (times == s).nonzero().flatten() if cfg.regroup else torch.arange(qp.shape[0])
         pts = qp[sel, 1:].to(dev, torch.float32)
+        topk = merge_pairs(pl, cfg, [plan.out_rows[(s, f)] for f in range(s + 1, T)])     # this group's rows only
         _, coords = run_propagation(topk, s, pts, Hf, Wf, h, w, cfg)
         traj[s:, K:K + sel.numel()] = coords
         order.extend(sel.tolist())

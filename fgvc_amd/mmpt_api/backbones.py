@@ -116,11 +116,17 @@ class ResNet(nn.Module):
         self.feat_dim = cin
 
     def init_weights(self):
-        """Random init as resnet.py:587-601 when no checkpoint is given; checkpoints are loaded with
-        load_state_dict / load_checkpoint (prefixes stripped like revise_keys at resnet.py:580)."""
+        """resnet.py:566-601: `pretrained` (a path or a state dict) is a TORCHVISION checkpoint when `torchvision_pretrain` (the
+        constructor default) -- its keys are remapped onto the ConvModule nesting (:525-563) -- else one of the reference's own
+        (prefixes stripped like revise_keys at :580; a dict there raises, :590); random init (:592-601) when `pretrained` is None."""
         self.reset_split_cache()
-        if isinstance(self.pretrained, str):
-            load_checkpoint(self, self.pretrained)
+        if isinstance(self.pretrained, (str, dict)):
+            if self.torchvision_pretrain:
+                load_torchvision_checkpoint(self, self.pretrained)
+            elif isinstance(self.pretrained, str):
+                load_checkpoint(self, self.pretrained)
+            else:
+                raise Exception("a state dict is only accepted as a torchvision checkpoint (resnet.py:590)")
             return
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -179,12 +185,30 @@ class ResNet(nn.Module):
         split NHWC, "f_*" = dense NHWC f32."""
         from .. import ops
         cache = self.__dict__.setdefault("_split_cache", {})
-        k = ("b",) + key + (N, C, H, W, device)
+        k = ("b", self.__dict__.get("_ws_sig")) + key + (N, C, H, W, device)
         if k not in cache:
             mk = {"s": ops.alloc_split_nhwc, "f": ops.alloc_nhwc}
             cache[k] = {nm: mk[nm[0]](N, C, H, W, device) for nm in names}
             self._cache_filled(device)
         return cache[k]
+
+    max_workspace_shapes = 2       # padded activation workspaces are kept for this many distinct input shapes (N, h, w); older
+                                   # ones are dropped (a variable-resolution dataset would otherwise grow HBM use without bound)
+
+    def _touch_workspace_shape(self, sig):
+        """LRU over input shapes: the workspaces of `_split_buffers` are keyed by the input shape that made them."""
+        cache = self.__dict__.setdefault("_split_cache", {})
+        order = cache.setdefault("_ws_order", [])
+        if sig in order:
+            order.remove(sig)
+        order.append(sig)
+        while len(order) > max(1, int(self.max_workspace_shapes)):
+            old = order.pop(0)
+            if isinstance(sig[-1], torch.device) and sig[-1].type == "cuda":
+                torch.cuda.synchronize(sig[-1])                      # nothing in flight may still read the evicted buffers
+            for k in [k for k in cache if isinstance(k, tuple) and len(k) > 1 and k[0] == "b" and k[1] == old]:
+                del cache[k]
+        self.__dict__["_ws_sig"] = sig
 
     @staticmethod
     def _cache_filled(device):
@@ -312,6 +336,7 @@ class ResNet(nn.Module):
                 and all(self._split_stage_ok(st, probe) for st in stages)):
             N, dev = x.shape[0], x.device
             cache = self.__dict__.setdefault("_split_cache", {})
+            self._touch_workspace_shape((N, x.shape[2], x.shape[3], dev))
             n_lanes = max(1, min(int(self.split_lanes), N))
             main = torch.cuda.current_stream(dev)
             c1 = self.conv1.conv
@@ -418,6 +443,40 @@ class ResNet(nn.Module):
         as_split = bool(split_if is not None and split_if(C, H, W))
         f = ops.normalize_to_hwc(y.float(), normalize, pad=True)
         return (ops.split_bf16(f) if as_split and f.shape[-1] == C else f), H, W
+
+
+def torchvision_key(name: str) -> str:
+    """Own state_dict key -> the torchvision ResNet key it is filled from (resnet.py:540-556): a ConvModule `X` holds `X.conv.*`
+    and `X.bn.*`; torchvision has `layerN.M.convK.weight` / `layerN.M.bnK.*` and `layerN.M.downsample.0.* / .1.*`."""
+    mod, _, leaf = name.rpartition(".")               # e.g. "layer2.0.downsample.bn", "running_var"
+    owner, _, part = mod.rpartition(".")              # "layer2.0.downsample", "bn"
+    if part not in ("conv", "bn"):
+        return name
+    if "downsample" in owner:
+        return f"{owner}.{0 if part == 'conv' else 1}.{leaf}"
+    return f"{owner if part == 'conv' else owner.replace('conv', 'bn')}.{leaf}"
+
+
+def load_torchvision_checkpoint(module: nn.Module, filename_or_state):
+    """resnet.py:525-563: copy a torchvision ResNet checkpoint into the ConvModule-nested parameters; keys of the checkpoint that
+    have no counterpart (fc.*, stages that were not built) are ignored, buffers absent from it (num_batches_tracked) keep their
+    values.  Returns the checkpoint keys that were not used."""
+    sd = torch.load(filename_or_state, map_location="cpu") if isinstance(filename_or_state, str) else filename_or_state
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    own = module.state_dict()
+    used = set()
+    with torch.no_grad():
+        for k, v in own.items():
+            tv = torchvision_key(k)
+            if tv in sd:
+                v.copy_(sd[tv])
+                used.add(tv)
+            elif not k.endswith("num_batches_tracked"):
+                raise KeyError(f"torchvision checkpoint has no '{tv}' (for '{k}')")     # the reference indexes it unguarded
+    if hasattr(module, "reset_split_cache"):
+        module.reset_split_cache()
+    return sorted(set(sd) - used)
 
 
 _PREFIXES = (r"^module\.", r"^backbone\.", r"^encoder\.", r"^backbone_fine\.")

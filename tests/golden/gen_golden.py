@@ -291,6 +291,45 @@ def gen_extra_modes():
          out_l2=ref.masked_attention_efficient(q, key, v, mask, sim_mode="l2-distance", **kw))
 
 
+def gen_tv_keymap():
+    """tests/golden/tv_keymap.json: which torchvision ResNet-18 key the genuine ResNet._load_torchvision_checkpoint
+    (resnet.py:525-563) copies into each of its own parameters / buffers.  Every tensor of a torchvision-shaped state dict is
+    filled with its own index; the loaded model's tensors then name their sources."""
+    ref = ref_import.load()
+    net = ref.ResNet(depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")
+    own = net.state_dict()
+    tv = {}
+    def add(name, shape):
+        tv[name] = torch.full(shape, float(len(tv) + 1))
+    add("conv1.weight", own["conv1.conv.weight"].shape)
+    for b in ("weight", "bias", "running_mean", "running_var"):
+        add(f"bn1.{b}", (64,))
+    tv["bn1.num_batches_tracked"] = torch.tensor(len(tv) + 1)
+    for L in range(1, 5):
+        for blk in range(2):
+            for c in (1, 2):
+                add(f"layer{L}.{blk}.conv{c}.weight", own[f"layer{L}.{blk}.conv{c}.conv.weight"].shape)
+                n = own[f"layer{L}.{blk}.conv{c}.bn.weight"].shape
+                for b in ("weight", "bias", "running_mean", "running_var"):
+                    add(f"layer{L}.{blk}.bn{c}.{b}", n)
+            if f"layer{L}.{blk}.downsample.conv.weight" in own:
+                add(f"layer{L}.{blk}.downsample.0.weight", own[f"layer{L}.{blk}.downsample.conv.weight"].shape)
+                n = own[f"layer{L}.{blk}.downsample.bn.weight"].shape
+                for b in ("weight", "bias", "running_mean", "running_var"):
+                    add(f"layer{L}.{blk}.downsample.1.{b}", n)
+    add("fc.weight", (1000, 512)); add("fc.bias", (1000,))
+    ids = {float(v.flatten()[0]): k for k, v in tv.items()}
+    import logging
+    net._load_torchvision_checkpoint(tv, strict=False, logger=logging.getLogger("gen"))
+    keymap = {}
+    for k, v in net.state_dict().items():
+        src = ids.get(float(v.flatten()[0].item())) if v.numel() else None
+        keymap[k] = src if (src is not None and bool((v == v.flatten()[0]).all())) else None
+    with open(os.path.join(HERE, "tv_keymap.json"), "w") as f:
+        json.dump(keymap, f, indent=0, sort_keys=True)
+    print(f"  tv_keymap.json  {sum(v is not None for v in keymap.values())} of {len(keymap)} own tensors filled from the checkpoint")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate single fixtures: python gen_golden.py gen_hr_tracker ...
         for name in sys.argv[1:]:
@@ -300,3 +339,4 @@ if __name__ == "__main__":
         gen_tapvid_metrics()
         gen_hr_tracker()
         gen_extra_modes()
+        gen_tv_keymap()

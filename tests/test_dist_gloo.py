@@ -63,16 +63,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, feats, qp, q):
+def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from fgvc_amd import dist as D
     from fgvc_amd.engine import TrackerConfig
-    cfg = TrackerConfig(neighbor_range=8, regroup=True)
+    cfg = TrackerConfig(neighbor_range=8, regroup=True, precede_frames=precede)
     h, w = feats.shape[-2] * 2, feats.shape[-1] * 2
     try:
-        traj, order = _run(D, OracleBackend(), feats, qp, cfg, h, w)
+        timing = D.Timing()
+        traj, order = _run(D, OracleBackend(), feats, qp, cfg, h, w, halo=halo, timing=timing)
+        rep = timing.report()
+        assert set(rep) == {"encode", "broadcast_first_frames", "halo_exchange", "affinity", "all_gather_lists", "sweep_readout"}
         q.put((rank, traj, order))
     except Exception as e:  # surface the failure instead of letting the parent time out
         q.put((rank, repr(e), None))
@@ -81,7 +84,7 @@ def _worker(rank, world, port, feats, qp, q):
     dist.destroy_process_group()
 
 
-def _run(D, backend, feats, qp, cfg, h, w):
+def _run(D, backend, feats, qp, cfg, h, w, **kw):
     """track_points_sharded takes h,w from rgbs; wrap the feature clip so the last two dims read as the image."""
     class Wrapped:
         def __init__(self, f):
@@ -97,11 +100,13 @@ def _run(D, backend, feats, qp, cfg, h, w):
                 def to(s2, dev):
                     return s2.t
             return _S(self.f[s])
-    return D.track_points_sharded(backend, Wrapped(feats), qp, cfg)
+    return D.track_points_sharded(backend, Wrapped(feats), qp, cfg, **kw)
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_sharding_matches_unsharded_oracle():
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,halo,precede", [(2, "exchange", 5), (2, "recompute", 5), (3, "exchange", 5)])
+def test_multi_rank_sharding_matches_unsharded_oracle(world, halo, precede):
+    """2 ranks in both halo modes; 3 ranks with clips SHORTER than the halo (a rank then needs frames of two other ranks)."""
     g = torch.Generator().manual_seed(21)
     T, C, Hf, Wf = 11, 16, 10, 12
     feats = torch.randn(T, C, Hf, Wf, generator=g)
@@ -112,15 +117,15 @@ def test_two_rank_sharding_matches_unsharded_oracle():
     col = 0
     for s in (0, 4, 7):
         sel = (qp[:, 0] == s).nonzero().flatten()
-        exp[s:, col:col + sel.numel()] = O.forward_test_main(feats[s:], qp[sel, 1:], h, w, neighbor_range=8)[0]
+        exp[s:, col:col + sel.numel()] = O.forward_test_main(feats[s:], qp[sel, 1:], h, w, neighbor_range=8, precede_frames=precede)[0]
         col += sel.numel()
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, feats, qp, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, feats, qp, q, halo, precede)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([q.get(timeout=400) for _ in range(world)], key=lambda r: r[0])
     assert all(r[2] is not None for r in res), res
     for p in procs:
         p.join(60)
@@ -128,7 +133,50 @@ def test_two_rank_sharding_matches_unsharded_oracle():
     for rank, traj, order in res:
         assert order.tolist() == [0, 1, 2, 3, 4]
         assert torch.allclose(traj, exp, atol=1e-6), (rank, float((traj - exp).abs().max()))
-    assert torch.equal(res[0][1], res[1][1])          # replicated sweep is deterministic across ranks
+    assert all(torch.equal(res[0][1], r[1]) for r in res[1:])          # replicated sweep is deterministic across ranks
+
+
+def test_halo_message_plan():
+    from fgvc_amd import dist as D
+    ranges = D.shard_frames(17, 4, first=1)                              # [(1,5),(5,9),(9,13),(13,17)]
+    own = D.own_ranges(ranges, 0)
+    assert own == [(0, 5), (5, 9), (9, 13), (13, 17)]
+    msgs = D.halo_messages(ranges, own, 0, 5)
+    # a 4-frame clip is shorter than the 5-frame halo: rank 2 needs frames 4..8 = one frame of rank 0 and all of rank 1's
+    assert msgs == [(0, 1, 0, 5), (0, 2, 4, 5), (1, 2, 5, 9), (1, 3, 8, 9), (2, 3, 9, 13)]
+    # every needed frame arrives exactly once
+    for dst, (lo, hi) in enumerate(ranges):
+        got = sorted(f for (s, d, a, b) in msgs if d == dst for f in range(a, b))
+        assert got == list(range(max(0, lo - 5), own[dst][0]))
+    assert D.halo_messages(D.shard_frames(9, 8, first=1), D.own_ranges(D.shard_frames(9, 8, first=1), 0), 0, 5)[:2] == [(0, 1, 0, 2), (0, 2, 0, 2)]
+
+
+def _collect_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fgvc_amd import apis
+    # rank r ran videos r, r + world, ... (mmpt/datasets/samplers/distributed_sampler.py:53); video i's result carries i
+    mine = [tuple(torch.full((1, 2, 3), float(i)) for _ in range(5)) for i in range(rank, 7, world)]
+    out = apis.collect_results(mine, size=7)
+    q.put((rank, None if out is None else [float(r[2].flatten()[0]) for r in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_collect_results_two_ranks():
+    """apis.collect_results (mmpt/apis/test.py:131-236): rank 0 gets every video's 5-tuple back in dataset order."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_collect_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=200) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0] and res[1] is None
 
 
 def test_single_process_path_equals_engine_semantics():

@@ -286,3 +286,63 @@ def test_tapvid_pickles_sample_format(tmp_path):
     assert len(dm) == 2 and dm[1]["rgbs"].shape == (1, T, 3, 32, 48) and torch.equal(dm[0]["rgbs"], s0["rgbs"])
     with pytest.raises(ValueError):
         TapVidPickles(str(d), "random")
+
+
+def test_torchvision_checkpoint_key_map_matches_reference():
+    """ResNet.init_weights with a torchvision checkpoint (the constructor default, resnet.py:566-585): every own tensor is filled
+    from the checkpoint key the genuine loader used (tests/golden/tv_keymap.json, recorded from the reference)."""
+    import json
+    from fgvc_amd.mmpt_api import backbones
+    keymap = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tv_keymap.json")))
+    net = backbones.ResNet(depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")
+    assert set(net.state_dict()) == set(keymap)
+    tv = {}
+    for k, src in keymap.items():
+        assert src is None or backbones.torchvision_key(k) == src, (k, src, backbones.torchvision_key(k))
+        if src is not None:
+            tv[src] = torch.full_like(net.state_dict()[k], float(len(tv) + 1))
+    tv["fc.weight"] = torch.zeros(1000, 512)
+    net.pretrained = tv                                   # a state dict, torchvision_pretrain=True (:586-590)
+    net.init_weights()
+    sd = net.state_dict()
+    for k, src in keymap.items():
+        if src is not None:
+            assert torch.equal(sd[k], tv[src].to(sd[k].dtype)), k
+    net2 = backbones.ResNet(depth=18, pretrained=dict(tv), torchvision_pretrain=False)
+    with pytest.raises(Exception):
+        net2.init_weights()                               # a dict is only accepted as a torchvision checkpoint (:590)
+
+
+def test_test_cfg_keys_are_honoured_or_refused():
+    """engine.TrackerConfig.from_test_cfg reads the keys as the reference's driver does (vanilla_tracker.py:246, :330-392)."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import engine
+    c = engine.TrackerConfig.from_test_cfg(api.ConfigDict(precede_frames=3, topk=7, temperature=0.05, neighbor_range=20))
+    assert (c.regroup, c.with_first) == (False, True)                      # no key: one group from frame 0, first frame in slot 0
+    c = engine.TrackerConfig.from_test_cfg(api.ConfigDict(with_first=True, neighbor_range=20))
+    assert (c.regroup, c.with_first) == (True, True)
+    c = engine.TrackerConfig.from_test_cfg(api.ConfigDict(with_first=False, neighbor_range=20))
+    assert (c.regroup, c.with_first) == (False, False)
+    c = engine.TrackerConfig.from_test_cfg(api.ConfigDict(test_mode="v2", neighbor_range=20, mask_mode="square", with_first_neighbor=False,
+                                                          sim_mode="l2-distance"))
+    assert (c.mask_mode, c.with_first_neighbor, c.sim_mode) == ("circle", True, "dot_product")   # _v2 reads none of the three
+    c = engine.TrackerConfig.from_test_cfg(api.ConfigDict(sim_mode="l2-distance", neighbor_range=20))
+    assert c.softmax_temperature(256) == 8.0 and engine.TrackerConfig().softmax_temperature(256) == 0.07
+    for bad, exc in ((dict(sim_mode="cosine-distance"), NotImplementedError), (dict(sim_mode="l2-distance", with_norm=False), NotImplementedError),
+                     (dict(test_mode="v2"), ValueError)):
+        with pytest.raises(exc):
+            engine.TrackerConfig.from_test_cfg(api.ConfigDict(**bad))
+
+
+def test_workspace_cache_is_bounded():
+    """ResNet keeps the padded activation workspaces of at most `max_workspace_shapes` input shapes (LRU)."""
+    from fgvc_amd.mmpt_api import backbones
+    net = backbones.ResNet(depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")
+    cache = net.__dict__.setdefault("_split_cache", {})
+    sigs = [(8, 480, 854, "cpu"), (8, 256, 256, "cpu"), (5, 480, 854, "cpu"), (8, 256, 256, "cpu"), (2, 64, 64, "cpu")]
+    for i, sig in enumerate(sigs):
+        net._touch_workspace_shape(sig)
+        cache[("b", sig, "stage", i)] = object()          # what _split_buffers would add for this shape
+        live = {k[1] for k in cache if isinstance(k, tuple) and k[0] == "b"}
+        assert len(live) <= net.max_workspace_shapes and sig in live
+    assert {k[1] for k in cache if isinstance(k, tuple) and k[0] == "b"} == {(8, 256, 256, "cpu"), (2, 64, 64, "cpu")}
