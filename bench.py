@@ -5,22 +5,24 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" = one 8-frame 480x854 synthetic clip (BASELINE.json configs[1]) through the whole path, inputs
-resident in HBM: ResNet-18 encoder (hand-written HIP end to end: fgvc_stem7_split_f32, fgvc_conv_split_f32,
-fgvc_conv_s2_split_f32 -- activations and weights as 2 x bf16, f32 accumulate, f32-grade; batch slices on 2 HIP streams)
--> L2-normalise/channels-last -> windowed
-correlation + top-10 for all 27 unique (query, key) frame pairs (features split into bf16 hi + lo, four partial
-products on the bf16 matrix pipe with f32 accumulation: f32-grade scores; --pair-precision f32 selects the f32-MFMA
-kernel) -> slot merge + softmax ->
-7 sequential label propagations -> fused upsample + top-5 soft-argmax read-out.  Nothing is skipped or
-cached across steps.  The sweep + read-out of a step (a chain of small launches) runs on a side stream, so the next step's
-encoder starts under it (--sync-tail: everything on one stream); every launch of every step completes before the closing
-barrier + synchronize.  At N > 1 every rank runs its own clips (videos are independent units -- the
-reference's own data parallelism); no collective in the data path; scaling = weak.
+A "step" = one synthetic 480x854 video of N x 8 frames (BASELINE.json configs[1]: an 8-frame 480p clip per GPU) through the
+whole path, inputs resident in HBM, SHARDED BY CLIP over the N ranks exactly as BASELINE.json's north_star describes
+(fgvc_amd.dist.track_points_sharded with the product backend): every rank encodes its own 8-frame clip (hand-written HIP ResNet-18
+trunk on the bf16 pipe, f32-grade), rank 0 broadcasts the first-frame ("query") features over RCCL/xGMI, the 5-frame halo in front
+of a clip comes from the previous rank by a point-to-point message, windowed correlation + top-10 for the clip's (query, key) frame
+pairs (features as bf16 hi + lo, four partial products on the bf16 matrix pipe: f32-grade scores), slot merge + softmax,
+all_gather of the merged lists, then the sequential label sweep + fused upsample / top-5 soft-argmax read-out over the whole video
+(replicated; on a side stream so that the next step's encoder starts under it).  Nothing is skipped or cached across steps.
+At N = 1 the same function runs without any collective (27 pairs, 7 propagations: the single-GPU figure of configs[1]).
+Per-GPU work is fixed as N grows (one 8-frame clip each): scaling = "weak"; value = all frames of the video / time.
+`--mode clips` times the reference's own data parallelism instead (independent 8-frame clips per rank, no data-path collective).
 
-Rank 0 prints ONE JSON line.  `roofline` = the dominant hand-written kernel of the step
-(fgvc_pair_topk_bf16x4, or fgvc_pair_topk_f32 with --pair-precision f32; MFMA-bound); `corr_volume` = the dense materialised volume kernel that
-BASELINE.json's "ms/corr-volume" and HBM-roofline target refer to, timed right after the steps;
+Rank 0 prints ONE JSON line.  `roofline` = the time-dominant kernel of the step (fgvc_conv_split_f32 256 -> 256 3x3, four
+launches per clip and lane), priced both as algorithmic f32 FLOPs and as executed bf16 partial products; `kernels` = the other
+hand-written kernels of the step, each with its own roofline object (launch durations from HIP events inside the timed region, on
+the launch stream); `corr_volume` = the dense materialised volume kernel that BASELINE.json's "ms/corr-volume" and the
+>= 50 % HBM-roofline target refer to, timed right after the steps; `mfma_util` / `traffic` come from the committed rocprofv3 PMC
+passes of the same kernels at the same shapes (profiles/r02_pmc.json: counters cannot be read from inside this process);
 `cpu_baseline` = the oracle (CPU restatement of the reference) timed on this box's host cores.
 """
 from __future__ import annotations
@@ -38,8 +40,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, no sparsity)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak (no sparsity)
 SPLIT_PRODUCTS = 4                # partial products per f32-grade product in fgvc_pair_topk_bf16x4 (hi*hi, hi*lo, lo*hi, lo*lo)
+CONV_PRODUCTS = 3                 # fgvc_conv_split_f32: hi*hi + hi*lo + lo*hi
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 
 WORKLOADS = {
@@ -54,15 +57,18 @@ WORKLOADS = {
 }
 
 
-def measured_traffic(kernel: str):
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json): PMC counters
-    cannot be read from inside this process, so the figure is the offline measurement of the same kernel
-    at the same workload, corrected as MI355X_MICROARCH.md prescribes.  None if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return float(json.load(f)[kernel]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+def pmc(kernel: str):
+    """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r02_pmc.json, written by tools/pmc_report.py from
+    separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes); {} if absent."""
+    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if kernel in d:
+                return d[kernel]
+        except Exception:
+            pass
+    return {}
 
 
 def build_tracker(wl, dev):
@@ -79,9 +85,32 @@ def build_tracker(wl, dev):
     return model.to(dev).eval()
 
 
+def host_cpu():
+    """(model name, physical cores, logical cpus) of this box, from /proc/cpuinfo."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+                phys.add((pid, cid))
+    except Exception:
+        pass
+    return model, (len(phys) or None), (logical or os.cpu_count())
+
+
 def cpu_baseline(wl, budget_s=25.0):
     """The oracle on the host cores, bounded sample of the same workload -> frames/s estimate."""
     from oracle import fgvc_oracle as O
+    model, phys, logical = host_cpu()
     # torch CPU ops stop scaling (and then regress) long before 256 threads on these hosts: use up to 32
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
@@ -122,7 +151,9 @@ def cpu_baseline(wl, budget_s=25.0):
     t_mask_video = t_mask / n_chunks * chunks_per_frame / 6.0                              # one (HW x HW) mask per video
     clip_s = T * t_enc + chunks_per_frame * t_chunk * slots / 6.0 + T * t_read + t_mask_video
     return dict(value=T / clip_s, unit="frames/s", cores=cores, kind="port",
-                sample=(f"oracle/fgvc_oracle.py on {cores} host threads: 1 frame through ResNet-18 ({t_enc:.2f}s), "
+                host_cpu=dict(model=model, physical_cores=phys, logical_cpus=logical, threads_used=cores),
+                sample=(f"oracle/fgvc_oracle.py on {cores} threads of {model} ({phys} physical cores, {logical} logical): "
+                        f"1 frame through ResNet-18 ({t_enc:.2f}s), "
                         f"{n_chunks} of {chunks_per_frame} 512-query chunks of affinity_topk+propagate at T=6 "
                         f"({t_chunk:.3f}s each, plain torch.topk like the reference), mask build "
                         f"{t_mask_video:.1f}s per video, 1 frame read-out ({t_read:.2f}s); extrapolated to the "
@@ -130,15 +161,43 @@ def cpu_baseline(wl, budget_s=25.0):
                 clip_seconds_est=clip_s)
 
 
+class KernelProbe:
+    """HIP events around chosen launches, recorded on the launch's own stream (the encoder's lanes run on side streams)."""
+
+    def __init__(self):
+        self.on = False
+        self.ev = {}
+
+    def wrap(self, fn, tag_of):
+        def wrapped(*a, **k):
+            tag = tag_of(*a, **k) if self.on else None
+            if tag is None:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.ev.setdefault(tag, []).append((e0, e1))
+            return r
+        return wrapped
+
+    def mean_ms(self, tag):
+        ev = self.ev.get(tag, [])
+        return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (None, 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2_480p_8f", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="video", choices=["video", "clips"],
+                    help="video = one N x T-frame video per step, sharded by clip over the ranks (broadcast + halo message + "
+                         "all_gather in the data path); clips = an independent T-frame clip per rank per step (no collective)")
+    ap.add_argument("--halo", default="exchange", choices=["exchange", "recompute"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr-volume", action="store_true")
-    ap.add_argument("--channels-last", type=int, default=0, help="run the MIOpen encoder in NHWC (experiment)")
     ap.add_argument("--no-autotune", action="store_true", help="MIOpen immediate mode (clean profiles)")
     ap.add_argument("--pair-precision", default="auto", choices=["auto", "f32", "split"],
                     help="pair top-k kernel: split = fgvc_pair_topk_bf16x4 (default where it applies), f32 = fgvc_pair_topk_f32")
@@ -148,6 +207,7 @@ def main():
                     help="label sweep + read-out on the main stream (default: on a side stream, so that the next step's encoder "
                          "overlaps this step's chain of small launches; every step is complete before the closing barrier)")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
+    ap.add_argument("--repeats", type=int, default=5, help="extra blocks of 20 steps after the timed region, for the spread")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="fgvc_set_option knobs for A/B runs, e.g. --set-option conv_narrow=1")
     a = ap.parse_args()
@@ -155,6 +215,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -162,13 +225,14 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
 
-    from fgvc_amd import _lib, engine, ops
+    from fgvc_amd import _lib, dist as fdist, engine, ops
     _lib.load()
     for kv in a.set_option:
         name, _, val = kv.partition("=")
         ops.set_option(name, int(val))
     wl = WORKLOADS[a.workload]
-    T, h, w, P = wl["frames"], wl["h"], wl["w"], wl["points"]
+    Tc, h, w, P = wl["frames"], wl["h"], wl["w"], wl["points"]
+    T = Tc * world if a.mode == "video" else Tc                    # frames of the video of one step (per rank in `clips` mode)
     torch.backends.cudnn.benchmark = not a.no_autotune
     from fgvc_amd.mmpt_api.backbones import ResNet
     if a.encoder_lanes is not None:
@@ -176,35 +240,51 @@ def main():
     if a.no_conv64:
         ResNet.use_conv64 = False
     model = build_tracker(wl, dev)
-    if a.channels_last:
-        model.test_cfg["channels_last"] = True
-        model = model.to(memory_format=torch.channels_last)
     cfg = model.engine_config()
     cfg.pair_precision = a.pair_precision
+    cfg.regroup = False                                              # all points are given at frame 0 of the video
 
-    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    rgbs = torch.randn(1, T, 3, h, w, generator=g).to(dev)           # stands for Lab-normalised frames
-    qp = torch.cat([torch.zeros(P, 1), torch.rand(P, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])], 1)
+    # the same video on every rank (seeded): a rank only ever touches its own frames of it
+    g = torch.Generator(device="cpu").manual_seed(1000 if a.mode == "video" else 1000 + rank)
+    lo, hi = (fdist.shard_frames(T, world, first=1)[rank] if a.mode == "video" else (1, T))
+    e_lo = 0 if (rank == 0 or a.mode == "clips") else lo
+    frames_all = None
+    rgbs = torch.empty((T, 3, h, w), dtype=torch.float32, device=dev) if a.mode == "video" else None
+    if a.mode == "video":
+        for f in range(T):                                           # generate frame by frame: identical stream on every rank
+            fr = torch.randn(3, h, w, generator=g)
+            if e_lo <= f < hi or (a.halo == "recompute" and lo - cfg.precede_frames <= f < hi):
+                rgbs[f] = fr.to(dev)
+    else:
+        rgbs = torch.randn(T, 3, h, w, generator=g).to(dev)
+    qp = torch.cat([torch.zeros(P, 1), torch.rand(P, 2, generator=torch.Generator().manual_seed(7)) * torch.tensor([w - 1.0, h - 1.0])], 1)
     pts = qp[:, 1:].to(dev)
-    plan = engine.plan_clip(T, [0], cfg)
-    n_pairs = len(plan.pairs)
-    pair_ev = []
+
+    probe = KernelProbe()
+    # launch probes: the 256 -> 256 3x3 convolutions of encoder layer 3 and the pair top-k, timed where they run
+    ops.conv_split = probe.wrap(ops.conv_split, lambda x, wt, *r, **k: ("conv256", x.shape[0]) if (wt.shape[0] == 9 and wt.shape[2] == 256 and x.shape[3] * 32 == 256) else None)
+    ops.pair_topk_split = probe.wrap(ops.pair_topk_split, lambda q, k_, prs, *r, **kw: ("pair_split", prs.shape[0]))
+    ops.pair_topk = probe.wrap(ops.pair_topk, lambda q, k_, prs, *r, **kw: ("pair_f32", prs.shape[0]))
 
     tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
+    backend = fdist.HipBackend(model, tail_stream=tail_stream)
+    timing = fdist.Timing(dev)
+    plan1 = engine.plan_clip(Tc, [0], cfg)
+    state = {}
+    sched_cache = {}
 
     def step(timed: bool):
-        feats, Hf, Wf = model.get_feats_hwc(rgbs[0], split=True)          # encoder + normalise (+ split), all T frames
-        ev = None
-        if timed:                                                          # HIP events on the launch stream
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            pair_ev.append(ev)
-        pl = engine.run_pairs(feats, Hf, Wf, plan, cfg, events=ev)         # pair top-k (1 launch)
+        if a.mode == "video":
+            traj, _ = fdist.track_points_sharded(backend, rgbs, qp, cfg, device=dev, halo=a.halo, timing=timing if timed else None,
+                                                  cache=sched_cache)
+            return traj
+        feats, Hf, Wf = model.get_feats_hwc(rgbs, split=True)          # encoder + normalise (+ split), all T frames
+        state["geom"] = (Hf, Wf, feats)
+        pl = engine.run_pairs(feats, Hf, Wf, plan1, cfg)
         if tail_stream is None:
-            tk = engine.merge_pairs(pl, cfg)                                   # slot merge + softmax
-            _, coords = engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)  # sequential sweep + read-out
-        else:      # the same launches on a side stream: the next clip's encoder starts under this clip's merge, sweep and read-out
-            _, coords, _ = engine.run_propagation_async(pl, 0, pts, Hf, Wf, h, w, cfg, tail_stream)
-        return coords, (Hf, Wf, feats)
+            tk = engine.merge_pairs(pl, cfg)
+            return engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)[1]
+        return engine.run_propagation_async(pl, 0, pts, Hf, Wf, h, w, cfg, tail_stream)[1]
 
     def barrier():
         if world > 1:
@@ -214,108 +294,145 @@ def main():
     for _ in range(a.warmup):
         step(False)
     barrier()
+    probe.on = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        coords, (Hf, Wf, feats) = step(True)
+        out_coords = step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    probe.on = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert bool(torch.isfinite(coords).all())
+    assert bool(torch.isfinite(out_coords).all())
+    n_frames_total = T * a.steps if a.mode == "video" else world * T * a.steps
 
-    HW, C = Hf * Wf, feats.shape[-1]
-    pair_ms = sum(e0.elapsed_time(e1) for e0, e1 in pair_ev) / len(pair_ev)
-    n_disc = sum(1 for dy in range(-40, 41) for dx in range(-40, 41) if dy * dy + dx * dx <= cfg.mask.r2max)
-    flops_per_pair = 2.0 * HW * n_disc * C                            # windowed FLOPs per (q,k) pair
-    use_split = cfg.pair_precision == "split" or (cfg.pair_precision == "auto"
-                                                   and ops.split_path_ok(C, Hf, Wf, cfg.topk, cfg.with_norm))
-    f32_eq_tf = flops_per_pair * n_pairs / (pair_ms * 1e-3) / 1e12   # the operator's f32 FLOPs (what the reference computes)
-    if use_split:
-        # priced on the pipe it runs on: every f32-grade product is SPLIT_PRODUCTS bf16 MFMA products
-        pair_roof = {"kernel": "fgvc_pair_topk_bf16x4", "bound": "mfma", "achieved": SPLIT_PRODUCTS * f32_eq_tf,
-                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": SPLIT_PRODUCTS * f32_eq_tf / BF16_MFMA_PEAK_TFLOPS,
-                     "note": f"bf16 MFMA FLOPs executed for the in-window candidates = {SPLIT_PRODUCTS} partial products x "
-                             f"the operator's f32 FLOPs; f32-equivalent rate {f32_eq_tf:.1f} TFLOP/s "
-                             f"(the f32-MFMA peak a v_mfma_f32_32x32x2_f32 kernel is bound by: {F32_MFMA_PEAK_TFLOPS})",
-                     "f32_equivalent_tflops": f32_eq_tf}
-    else:
-        pair_roof = {"kernel": "fgvc_pair_topk_f32", "bound": "mfma", "achieved": f32_eq_tf,
-                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f32_eq_tf / F32_MFMA_PEAK_TFLOPS}
-    pair_roof.update({"traffic": measured_traffic(pair_roof["kernel"]) if a.workload == "cfg2_480p_8f" else None,
-                      "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
-                      "ms_per_launch": pair_ms, "pairs_per_launch": n_pairs,
-                      "flops_per_pair": flops_per_pair, "ms_per_pair": pair_ms / n_pairs})
+    # spread: a few more short blocks (not part of `value`)
+    rep = []
+    for _ in range(max(0, a.repeats)):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            step(False)
+        barrier()
+        rep.append((time.perf_counter() - t1) / 20 * 1e3)
+
+    Hf, Wf = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    for s_ in wl["strides"][:wl["out_indices"][0] + 1]:
+        Hf, Wf = (Hf - 1) // s_ + 1, (Wf - 1) // s_ + 1
+    HW, C = Hf * Wf, 256
+    n_pairs_clip = len(plan1.pairs)
+
+    # ---- roofline objects ---------------------------------------------------------------------------------------------------
+    kernels = {}
+    conv_tags = [t for t in probe.ev if t[0] == "conv256"]
+    if conv_tags:
+        # per launch: the lane's batch slice (N frames) of one 256 -> 256 3x3 convolution
+        tot_ms = sum(sum(e0.elapsed_time(e1) for e0, e1 in probe.ev[t]) for t in conv_tags)
+        tot_fl = sum(len(probe.ev[t]) * 2.0 * t[1] * HW * 256 * 256 * 9 for t in conv_tags)
+        n_l = sum(len(probe.ev[t]) for t in conv_tags)
+        f32_tf = tot_fl / (tot_ms * 1e-3) / 1e12
+        pm = pmc("fgvc_conv_split_f32")
+        kernels["encoder_conv"] = {
+            "kernel": "fgvc_conv_split_f32 (256 -> 256, 3x3: the time-dominant kernel, 4 launches per clip and encoder lane)",
+            "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f32_tf / BF16_MFMA_PEAK_TFLOPS,
+            "what": "ALGORITHMIC f32 FLOPs of the convolution (2 N H W Cin Cout 9) / mean launch duration, against the dense peak of "
+                    "the bf16 pipe it runs on",
+            "executed_tflops": CONV_PRODUCTS * f32_tf, "frac_executed": CONV_PRODUCTS * f32_tf / BF16_MFMA_PEAK_TFLOPS,
+            "executed_note": f"{CONV_PRODUCTS} bf16 partial products per f32-grade product (hi*hi + hi*lo + lo*hi)",
+            "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
+            "ms_per_launch": tot_ms / n_l, "launches_timed": n_l,
+            "launch_note": "HIP events on the lane's stream inside the timed region; the encoder's lanes run concurrently, so a launch "
+                           "shares the GPU with the other lane's kernels",
+            "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch"),
+            "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone on the GPU (profiles/r02_pmc.json)"}
+    pair_tag = next((t for t in probe.ev if t[0] in ("pair_split", "pair_f32")), None)
+    if pair_tag:
+        pair_ms, n_l = probe.mean_ms(pair_tag)
+        n_disc = sum(1 for dy in range(-40, 41) for dx in range(-40, 41) if dy * dy + dx * dx <= cfg.mask.r2max)
+        fl = 2.0 * HW * n_disc * C * pair_tag[1]                       # windowed FLOPs of the launch's pairs
+        f32_tf = fl / (pair_ms * 1e-3) / 1e12
+        split = pair_tag[0] == "pair_split"
+        name = "fgvc_pair_topk_bf16x4" if split else "fgvc_pair_topk_f32"
+        pm = pmc(name)
+        kernels["pair_topk"] = {
+            "kernel": name, "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": f32_tf / (BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS),
+            "what": "ALGORITHMIC windowed f32 FLOPs (2 HW N_disc C per pair, N_disc = 697) / mean launch duration",
+            "executed_tflops": (SPLIT_PRODUCTS if split else 1) * f32_tf,
+            "frac_executed": (SPLIT_PRODUCTS * f32_tf / BF16_MFMA_PEAK_TFLOPS) if split else f32_tf / F32_MFMA_PEAK_TFLOPS,
+            "executed_note": "4 bf16 partial products per f32-grade product, in-window candidates only (the 4x8-block tiling "
+                             "multiplies 1312 candidates per query for 697 in the disc)" if split else "exact f32 MFMA",
+            "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
+            "ms_per_launch": pair_ms, "pairs_per_launch": pair_tag[1], "launches_timed": n_l,
+            "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch")}
+    head = kernels.get("encoder_conv") or kernels.get("pair_topk")
+    roofline = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "what", "executed_tflops",
+                                     "frac_executed", "frac_of_f32_mfma_peak", "ms_per_launch", "mfma_util")} if head else None
+
     out = {
         "metric": "frames/sec + ms/corr-volume, 480p 8-frame clip, 1/2/4/8 MI355X",
-        "value": world * a.steps * T / elapsed, "unit": "frames/s",
+        "value": n_frames_total / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (encoder stages and correlation: every f32 value as 2 x bf16, partial products on the bf16 MFMA pipe, "
-                 "f32 accumulate)" if use_split else "f32 (encoder stages: 2 x bf16 split, f32 accumulate)",
+        "dtype": "f32 (encoder stages and correlation: every f32 value as 2 x bf16, partial products on the bf16 MFMA pipe, f32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"{a.workload}: {T}x{h}x{w} clip -> {Hf}x{Wf}x{C} features, {n_pairs} unique "
-                               f"(query,key) pairs, top-10, radius 15, tau 0.07, P={P}, one clip per rank per step",
-                   "parallelism": f"dp{world} (independent clips per rank, no data-path collective)"},
-        "roofline": pair_roof,
+        "config": {"workload": (f"{a.workload}: one {T}x{h}x{w} video per step = {world} clip(s) of {Tc} frames, one per rank -> {Hf}x{Wf}x{C} "
+                                f"features, top-10, radius 15, tau 0.07, P={P}" if a.mode == "video" else
+                                f"{a.workload}: {Tc}x{h}x{w} clip -> {Hf}x{Wf}x{C} features, {n_pairs_clip} unique (query,key) pairs, top-10, "
+                                f"radius 15, tau 0.07, P={P}, one independent clip per rank per step"),
+                   "parallelism": (f"clip-sharded video over {world} rank(s): RCCL broadcast of first-frame features, point-to-point "
+                                   f"{cfg.precede_frames}-frame halo ({a.halo}), all_gather of merged top-k lists, replicated sweep"
+                                   if a.mode == "video" else f"dp{world} (independent clips per rank, no data-path collective)")},
+        "timed_seconds": elapsed,
+        "repeat_ms_per_step": rep,
+        "roofline": roofline,
+        "kernels": kernels,
     }
-
-    if rank == 0 and C == 256 and getattr(type(model.backbone), "use_split_conv", False):
-        # the other big hand-written kernel of the step: one 256 -> 256 3x3 convolution of encoder layer 3 on this clip
-        # (4 such launches + 9 narrower ones per step), timed alone with HIP events
-        blk = model.backbone.layer3[-1]
-        wp, bs = ops.prepare_conv_split(blk.conv2.conv.weight.detach(), blk.conv2.bn)
-        xs_in = ops.nchw_to_split_nhwc(torch.relu(torch.randn(T, 256, Hf, Wf, device=dev)))     # post-ReLU-like activations
-        ys_out = ops.alloc_split_nhwc(T, 256, Hf, Wf, dev)
-        fn = lambda: ops.conv_split(xs_in, wp, bs, Hf, Wf, True, out_split=ys_out)
-        for _ in range(3):
-            fn()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-        for e0, e1 in evs:
-            e0.record(); fn(); e1.record()
+    if a.mode == "video":
         torch.cuda.synchronize()
-        cms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
-        cfl = 2.0 * T * Hf * Wf * 256 * 256 * 9
-        out["encoder_conv"] = {
-            "what": f"fgvc_conv_split_f32, 256->256 3x3 on {T}x{Hf}x{Wf} (one of 13 split-bf16 convolutions per clip)",
-            "ms_per_launch": cms,
-            "roofline": {"kernel": "fgvc_conv_split_f32", "bound": "mfma", "achieved": 3 * cfl / (cms * 1e-3) / 1e12,
-                         "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": 3 * cfl / (cms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                         "note": "bf16 MFMA FLOPs = 3 partial products x the convolution's f32 FLOPs",
-                         "f32_equivalent_tflops": cfl / (cms * 1e-3) / 1e12,
-                         "traffic": measured_traffic("fgvc_conv_split_f32") if a.workload == "cfg2_480p_8f" else None}}
-        del xs_in, ys_out
+        ph = timing.report()
+        out["sharding_ms_per_step"] = {k: v / a.steps for k, v in ph.items()}
+        out["sharding_note"] = ("HIP-event time per phase on rank 0's main stream (the sweep runs on a side stream and overlaps the next "
+                                "step's encoder; at N = 1 broadcast / halo / all_gather are skipped)")
+
     if rank == 0 and not a.no_corr_volume:
+        gq = torch.Generator(device=dev).manual_seed(5)
+        feats2 = torch.nn.functional.normalize(torch.randn(2, HW, C, generator=gq, device=dev), dim=2)
         vol = torch.empty((HW, HW), device=dev, dtype=torch.float32)
-        gbytes = (HW * HW * 4 + 2 * HW * C * 4) / 1e9                  # volume write + both inputs
-        res = {}
-        if feats.dtype == torch.int16:       # the bank came back split: the dense kernels' f32 operands are hi + lo of two frames
-            hl, feats = feats[:2], ops.unsplit_bf16(feats[:2])
-        else:
-            hl = ops.split_bf16(feats[:2])
-        for name, fn in (("bf16x3", lambda: ops.corr_volume(hl[1], hl[0], 0.07, "bf16x3", out=vol)),
-                         ("f32", lambda: ops.corr_volume(feats[1], feats[0], 0.07, "f32", out=vol)),
-                         ("bf16", lambda: ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol))):
-            for _ in range(2):
+        gbytes = (HW * HW * 4 + 2 * HW * C * 4) / 1e9                  # volume write + both inputs (f32-sized)
+        hl, sp = ops.split_bf16(feats2), ops.split_f16f8(feats2)
+        fns = {"f16f8": lambda: ops.corr_volume(sp[1], sp[0], 0.07, "f16f8", out=vol),
+               "bf16x3": lambda: ops.corr_volume(hl[1], hl[0], 0.07, "bf16x3", out=vol),
+               "f32": lambda: ops.corr_volume(feats2[1], feats2[0], 0.07, "f32", out=vol),
+               "bf16": lambda: ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol)}
+        res = {k: [] for k in fns}
+        for rnd in range(4):                                           # round-robin: the first kernel timed in a process runs slow
+            for name, fn in fns.items():
                 fn()
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-            for e0, e1 in evs:
-                e0.record(); fn(); e1.record()
-            torch.cuda.synchronize()
-            ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
-            res[name] = {"ms": ms, "achieved": gbytes / (ms * 1e-3), "frac": gbytes / (ms * 1e-3) / HBM_PEAK_GBPS}
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for e0, e1 in evs:
+                    e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    res[name].append(sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs))
+        var = {k: {"ms": sum(v) / len(v), "ms_min": min(v), "achieved": gbytes / (sum(v) / len(v) * 1e-3),
+                   "frac": gbytes / (sum(v) / len(v) * 1e-3) / HBM_PEAK_GBPS} for k, v in res.items()}
+        var["f16f8"]["max_abs_err_bound"] = "1e-3 logit (tests); measured 4e-5 on Gaussian rows, 8e-5 against bf16x3 at 720p"
+        var["bf16x3"]["max_abs_err_bound"] = "1e-3 logit (tests); measured 2e-5"
+        var["bf16"]["max_abs_err_bound"] = "3e-2 logit (reduced precision: reported, not parity-grade)"
+        pm = pmc("fgvc_corr_volume_f16f8")
         out["corr_volume"] = {
-            "what": f"dense materialised ({HW}x{HW}) f32 volume for one (query,key) frame pair; bf16x3 meets the 1e-3 "
-                    "score bar, f32 is exact, bf16 is reduced precision (reported, not parity-grade)",
-            "ms_per_corr_volume": res["bf16x3"]["ms"],
-            "roofline": {"kernel": "fgvc_corr_volume_bf16x3", "bound": "hbm", "achieved": res["bf16x3"]["achieved"],
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": res["bf16x3"]["frac"],
-                         "traffic": measured_traffic("fgvc_corr_volume_bf16x3") if a.workload == "cfg2_480p_8f" else None,
-                         "bytes_per_launch": gbytes * 1e9},
-            "variants": res,
+            "what": f"dense materialised ({HW}x{HW}) f32 volume for one (query,key) frame pair.  f16f8 (f16 main product + block-scaled "
+                    "fp8 cross terms) and bf16x3 meet the 1e-3 score bar, f32 is exact, plain bf16 is reduced precision",
+            "ms_per_corr_volume": var["f16f8"]["ms"],
+            "roofline": {"kernel": "fgvc_corr_volume_f16f8", "bound": "hbm", "achieved": var["f16f8"]["achieved"],
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": var["f16f8"]["frac"],
+                         "traffic": pm.get("hbm_bytes_per_launch"), "mfma_util": pm.get("mfma_util"),
+                         "bytes_per_launch": gbytes * 1e9,
+                         "note": "mean of 3 rounds x 10 launches (HIP events), round-robin with the other variants"},
+            "variants": var,
         }
         del vol
     if rank == 0 and world == 1 and not a.no_cpu_baseline:          # reported at N = 1 only (the other ranks would sit at the barrier)

@@ -129,10 +129,15 @@ class Timing:
 
 
 class HipBackend:
-    """The product backend: encoder through the tracker model, kernels through fgvc_amd.engine."""
+    """The product backend: encoder through the tracker model, kernels through fgvc_amd.engine.
+    `tail_stream`: run the replicated sweep + read-out (a chain of small launches that leaves most CUs idle) on this side stream,
+    so that whatever the caller enqueues next -- the next video's encoder -- starts under it.  The returned trajectories are then
+    produced on that stream: wait for `backend.tail_event` (or synchronise) before reading them."""
 
-    def __init__(self, model):
+    def __init__(self, model, tail_stream: Optional["torch.cuda.Stream"] = None):
         self.model = model
+        self.tail_stream = tail_stream
+        self.tail_event = None
 
     def encode(self, frames: torch.Tensor):
         # the bank in the form the pair kernel reads ((hi, lo) bf16 split where it applies): no second pass, same bytes to ship
@@ -162,29 +167,53 @@ def _span(timing: Optional[Timing], name: str):
 
 def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor, cfg: TrackerConfig,
                          group=None, device: Optional[torch.device] = None, halo: str = "exchange",
-                         timing: Optional[Timing] = None):
+                         timing: Optional[Timing] = None, cache: Optional[dict] = None):
     """One video, all ranks.  rgbs (T,3,h,w) (every rank may hold the whole clip on the host or the device; only
     its own frames are moved/encoded), query_points (P,3)=(t,x,y).
-    Returns (traj (T,P',2) f64 regrouped by query time, order (P',)) on every rank."""
+    Returns (traj (T,P',2) f64 regrouped by query time, order (P',)) on every rank.
+    `cache`: a dict the caller keeps between calls with the SAME video shape, query points, cfg and process group; the schedule
+    (frame ranges, message plan, slot tables on the device, query points on the device, bank geometry) is then built once --
+    per call that is a dozen small blocking host-to-device copies and, at more than one rank, one tiny broadcast + host read."""
     if halo not in ("exchange", "recompute"):
         raise ValueError(f"halo={halo!r}")
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     T, h, w = rgbs.shape[0], rgbs.shape[-2], rgbs.shape[-1]
     dev = device if device is not None else rgbs.device
-    qp = query_points.detach().cpu()
-    times = qp[:, 0].to(torch.int64)
-    starts = sorted(set(times.tolist())) if cfg.regroup else [0]
-    s_min = min(starts)
-    p = cfg.precede_frames
-
-    ranges = shard_frames(T, world, first=s_min + 1)
-    if halo == "exchange" and world > 1:
-        enc = own_ranges(ranges, s_min)
-        msgs = halo_messages(ranges, enc, s_min, p)
-    else:
-        enc = [encode_range(lo, hi, starts, cfg) for lo, hi in ranges]
-        msgs = []
+    sc = cache.get("schedule") if cache is not None else None
+    if sc is None:
+        qp = query_points.detach().cpu()
+        times = qp[:, 0].to(torch.int64)
+        starts = sorted(set(times.tolist())) if cfg.regroup else [0]
+        s_min = min(starts)
+        ranges = shard_frames(T, world, first=s_min + 1)
+        if halo == "exchange" and world > 1:
+            enc = own_ranges(ranges, s_min)
+            msgs = halo_messages(ranges, enc, s_min, cfg.precede_frames)
+        else:
+            enc = [encode_range(lo, hi, starts, cfg) for lo, hi in ranges]
+            msgs = []
+        plan = engine.plan_clip(T, starts, cfg, frame_range=ranges[rank])
+        plans = [engine.plan_clip(T, starts, cfg, frame_range=r) for r in ranges]   # deterministic on every rank
+        # global plan = concatenation of the per-rank plans, rows renumbered in rank order
+        out_rows, slot_frame, base = {}, [], 0
+        for pp in plans:
+            for key, r in pp.out_rows.items():
+                out_rows[key] = base + r
+            slot_frame.extend(pp.slot_frame)
+            base += len(pp.slot_pair)
+        groups, order = [], []
+        for s in starts:
+            sel = (times == s).nonzero().flatten() if cfg.regroup else torch.arange(qp.shape[0])
+            groups.append((s, sel.numel(), qp[sel, 1:].to(dev, torch.float32)))
+            order.extend(sel.tolist())
+        sc = dict(starts=starts, s_min=s_min, ranges=ranges, enc=enc, msgs=msgs, plan=plan, rows=[len(pp.slot_pair) for pp in plans],
+                  gplan=Plan(T, starts, [], out_rows, [], slot_frame, plan.t_max),
+                  slot_frame_dev=torch.tensor(slot_frame, dtype=torch.int32, device=dev).reshape(len(slot_frame), plan.t_max),
+                  groups=groups, order=torch.tensor(order, dtype=torch.int64), n_points=qp.shape[0], lplan=None, geom=None)
+        if cache is not None:
+            cache["schedule"] = sc
+    starts, ranges, enc, msgs, plan = sc["starts"], sc["ranges"], sc["enc"], sc["msgs"], sc["plan"]
     lo, hi = ranges[rank]
     e_lo, e_hi = enc[rank]
 
@@ -192,9 +221,11 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
     feats: Dict[int, torch.Tensor] = {}
     Hf = Wf = None
     frame_shape = None
+    enc_bank = None
     with _span(timing, "encode"):
         if e_hi > e_lo:
             f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev))
+            enc_bank = f
             frame_shape, frame_dtype = tuple(f.shape[1:]), f.dtype
             for i in range(e_hi - e_lo):
                 feats[e_lo + i] = f[i]
@@ -205,15 +236,15 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                 feats[s] = f[0]
     # ranks with an empty range still take part in the collectives: learn the bank's geometry from rank 0
     if world > 1:
-        meta = torch.zeros(8, dtype=torch.int64, device=dev)
-        if rank == 0:
-            vals = [Hf, Wf, 1 if frame_dtype == torch.int16 else 0, len(frame_shape)] + list(frame_shape)
-            meta[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
-        dist.broadcast(meta, src=0, group=group)
-        m = meta.tolist()
-        Hf, Wf = int(m[0]), int(m[1])
-        frame_dtype = torch.int16 if m[2] else torch.float32
-        frame_shape = tuple(int(v) for v in m[4:4 + int(m[3])])
+        if sc["geom"] is None:
+            meta = torch.zeros(8, dtype=torch.int64, device=dev)
+            if rank == 0:
+                vals = [Hf, Wf, 1 if frame_dtype == torch.int16 else 0, len(frame_shape)] + list(frame_shape)
+                meta[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
+            dist.broadcast(meta, src=0, group=group)
+            m = meta.tolist()
+            sc["geom"] = (int(m[0]), int(m[1]), torch.int16 if m[2] else torch.float32, tuple(int(v) for v in m[4:4 + int(m[3])]))
+        Hf, Wf, frame_dtype, frame_shape = sc["geom"]
     HW = Hf * Wf
 
     # ---- 2. exchange step 1: broadcast every group's first-frame features from its owner
@@ -246,24 +277,26 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                     feats.setdefault(a + i, t[i])
 
     # ---- 4. local affinity on a compact local bank
-    plan = engine.plan_clip(T, starts, cfg, frame_range=(lo, hi))
     local_ids = sorted(feats)
-    remap = {f: i for i, f in enumerate(local_ids)}
-    needed = {f for (q, k, _) in plan.pairs for f in (q, k)}
-    assert needed <= set(local_ids), f"rank {rank}: frames {sorted(needed - set(local_ids))} missing"
     k = cfg.topk
     with _span(timing, "affinity"):
         if plan.pairs:
-            bank = torch.stack([feats[f] for f in local_ids], 0)
-            lplan = replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={})
-            idx, weight = backend.affinity(bank, Hf, Wf, lplan, cfg)
+            if sc["lplan"] is None or sc["lplan"][0] != local_ids:
+                remap = {f: i for i, f in enumerate(local_ids)}
+                needed = {f for (q, kk, _) in plan.pairs for f in (q, kk)}
+                assert needed <= set(local_ids), f"rank {rank}: frames {sorted(needed - set(local_ids))} missing"
+                sc["lplan"] = (local_ids, replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={}))
+            if enc_bank is not None and local_ids == list(range(e_lo, e_hi)):
+                bank = enc_bank                                        # nothing came from elsewhere: the encoder's own tensor, no copy
+            else:
+                bank = torch.stack([feats[f] for f in local_ids], 0)
+            idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg)
         else:
             idx = torch.empty((0, HW, k), device=dev, dtype=torch.int32)
             weight = torch.empty((0, HW, k), device=dev, dtype=torch.float32)
 
     # ---- 5. exchange step 2: all_gather of the merged lists (padded to the largest shard)
-    plans = [engine.plan_clip(T, starts, cfg, frame_range=r) for r in ranges]   # deterministic on every rank
-    rows = [len(pp.slot_pair) for pp in plans]
+    rows = sc["rows"]
     with _span(timing, "all_gather_lists"):
         if world > 1:
             mx = max(rows)
@@ -277,25 +310,31 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
             dist.all_gather(all_w, pad_w, group=group)
             idx = torch.cat([all_i[r][: rows[r]] for r in range(world)], 0)
             weight = torch.cat([all_w[r][: rows[r]] for r in range(world)], 0)
-    # global plan = concatenation of the per-rank plans, rows renumbered in rank order
-    out_rows, slot_frame, base = {}, [], 0
-    for pp in plans:
-        for key, r in pp.out_rows.items():
-            out_rows[key] = base + r
-        slot_frame.extend(pp.slot_frame)
-        base += len(pp.slot_pair)
-    gplan = Plan(T, starts, [], out_rows, [], slot_frame, plan.t_max)
-    slot_frame_dev = torch.tensor(slot_frame, dtype=torch.int32, device=dev).reshape(len(slot_frame), plan.t_max)
+    gplan, slot_frame_dev = sc["gplan"], sc["slot_frame_dev"]
 
     # ---- 6. sequential sweep + read-out, replicated on every rank
-    traj = torch.zeros((T, qp.shape[0], 2), device=dev, dtype=torch.float64)
-    order, col = [], 0
+    tail = getattr(backend, "tail_stream", None)
+    if tail is not None:
+        tail.wait_stream(torch.cuda.current_stream(dev))
+        for t in (idx, weight, slot_frame_dev):
+            t.record_stream(tail)                      # keep them from the caching allocator until the side stream is done
+    col = 0
     with _span(timing, "sweep_readout"):
-        for s in starts:
-            sel = (times == s).nonzero().flatten() if cfg.regroup else torch.arange(qp.shape[0])
-            pts = qp[sel, 1:].to(dev, torch.float32)
-            coords = backend.sweep(idx, weight, slot_frame_dev, gplan, s, pts, Hf, Wf, h, w, cfg)
-            traj[s:, col:col + sel.numel()] = coords
-            order.extend(sel.tolist())
-            col += sel.numel()
-    return traj, torch.tensor(order, dtype=torch.int64)
+        with (torch.cuda.stream(tail) if tail is not None else _Null()):
+            traj = torch.zeros((T, sc["n_points"], 2), device=dev, dtype=torch.float64)
+            for s, n_sel, pts in sc["groups"]:
+                coords = backend.sweep(idx, weight, slot_frame_dev, gplan, s, pts, Hf, Wf, h, w, cfg)
+                traj[s:, col:col + n_sel] = coords
+                col += n_sel
+            if tail is not None:
+                backend.tail_event = torch.cuda.Event()
+                backend.tail_event.record(tail)
+    return traj, sc["order"]
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
