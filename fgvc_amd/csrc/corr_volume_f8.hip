@@ -244,15 +244,15 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_kernel(const uns
 //     at the start of the P part: every read has 256 pipe cycles to land, and each set is re-read only after its last reader issued.
 //   * stores: v_permlane16_swap of the two query halves turns a register pair into two row pieces of 128 B each (rows 16 kt + i and
 //     16 kt + 8 + i | 16 kt + 4 + i and 16 kt + 12 + i): the same 2 x 128-byte store shape as the 32 x 32 accumulator.
-//   * stagger (OFF by default, corr8_debug bit 8): waves 4-7 (the SIMD partners of waves 0-3) hold a finished tile in its accumulators
-//     and store it at the start of their NEXT tile (across the stage barrier too), so that a stage opens with one wave of each SIMD
-//     multiplying and the other in the store queue.  -4 % in the stand-alone model of this loop (tools/micro/corr_bounds.hip), but
-//     +12 % here: the deferred tile of waves 4-7 and the last tile of waves 0-3 now enter the store queue together at the barrier.
+//   * stagger (corr8_debug bit 8 switches it off): waves 4-7 (the SIMD partners of waves 0-3) hold a finished tile in its
+//     accumulators and store it at the start of their NEXT tile (across the stage barrier too), so that a stage opens with one wave
+//     of each SIMD multiplying and the other in the store queue: -1.5 % (round-robin timing, tools/try_f16f8.py).
 //   * the natural fp8 element order (bytes [32 g, 32 g + 32) of a K-128 block) costs a 2-way bank conflict on the P reads; the
 //     conflict-free order (two 16-byte pieces 64 bytes apart) needs a shufflevector of two reads, which makes hipcc wait for
 //     BOTH reads at once (s_waitcnt lgkmcnt(0) right behind them) instead of counting: measured slower.
 // ------------------------------------------------------------------------------------------
-template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong), 8 = wave stagger on (results right)
+template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong), 8 = no wave stagger (results right),
+                               // 32 = s_memtime probe of one workgroup, written over the first floats of vol (tools/time_corr8.py)
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const unsigned char* __restrict__ q_sp,
                                                                          const unsigned char* __restrict__ k_sp, int HWq, int HWk,
                                                                          float out_scale, float* __restrict__ vol, int kchunk,
@@ -267,6 +267,10 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
   const int qw0 = blockIdx.x * (NW * 32) + wave * 32 - shift;   // wave-uniform: first query of this wave's tile
   const int n_v = (HWk - cls + period - 1) / period;            // virtual rows of this class
 
+  const bool probe = (DEBUG & 32) && blockIdx.x == 50 && blockIdx.y == 1 && blockIdx.z == 0;
+  long long p_start = 0, p_pro = 0, p_comp = 0, p_store = 0, p_sync = 0, c0 = 0;
+  int p_stages = 0;
+  if (probe) p_start = __builtin_amdgcn_s_memtime();
   // query fragments (B operands) of the two query halves
   f16x8 bq16[2][8];
   i32x8 bq8h[2][2], bq8l[2][2];
@@ -303,14 +307,28 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
                                        (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
     }
   };
+  // Staging the NEXT stage costs the issuing wave ~125 cycles per LDS-DMA instruction (64 of them per stage).  The older wave of a
+  // SIMD wins the issue arbitration, finishes its multiplies first and then sits ~2000 cycles at the stage barrier (s_memtime
+  // probe: tools/time_corr8.py), while its partner is the critical path.  So waves 0-3 stage ALL 64 rows, two per multiply
+  // part, and waves 4-7 none (as a burst behind the barrier, or spread over every wave, the matrix pipe idled ~1000 cycles per stage).
+  const bool stager = wave < NW / 2;
+  auto stage_row = [&](int kb, int buf, int i) {
+    const int row = wave * (2 * ROWS / NW) + i;
+    const int pix = imin((kb * 32 + row) * period + cls, HWk - 1);
+    const unsigned char* src = k_sp + (size_t)pix * ROWB + 16 * lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
+  };
+  static_assert(2 * ROWS / NW == 16, "two DMA rows per multiply part of a staging wave: 2 tiles x 4 parts");
   stage_load(kb0, 0);
   __syncthreads();
+  if (probe) p_pro = __builtin_amdgcn_s_memtime() - p_start;
 
   const size_t row_pitch = (size_t)period * HWq;
   const int scol = qw0 + (lane & 31);                                // the column this lane STORES (after the lane swap)
   const int lane_off = 8 * (lane >> 5) * period * HWq + scol;        // + row 8 (lane >> 5) of the row pair a store covers
   const bool wave_full = qw0 >= 0 && qw0 + 31 < HWq;
-  const bool defer = (DEBUG & 8) ? wave >= NW / 2 : false;
+  const bool defer = (DEBUG & 8) ? false : wave >= NW / 2;
   f32x4 acc[2][2];
   int pend_v = -1, n_counted = 0;
 
@@ -328,33 +346,36 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
     if (!full) n_counted = -1;
     else if (n_counted >= 0) n_counted += 16;
     // x = rows 16 kt + 4 g + i of query half 0, y = the same rows of query half 1  ->  after the swap x = rows 16 kt + i (+ 8)
-    // x 32 queries, y = rows 16 kt + 4 + i (+ 8).  (Inline assembly: with the builtin hipcc 7.2 stored the FIRST result twice
-    // in this kernel; hipcc pads no hazard wait states inside asm, so the VALU results are given their distance by hand.)
+    // x 32 queries, y = rows 16 kt + 4 + i (+ 8).  Inline assembly: with the builtin hipcc 7.2 stored the FIRST result twice
+    // in this kernel, and it pads no hazard wait states inside asm -- so all 16 products first, ONE s_nop, the 8 swaps back to
+    // back (each reads registers written at least 8 instructions earlier), one s_nop, then the stores.
+    float x[8], y[8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[4 * kt + i] = acc[kt][0][i] * out_scale;
+        y[4 * kt + i] = acc[kt][1][i] * out_scale;
+      }
+    asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x[e]), "+v"(y[e]));
+    asm volatile("s_nop 1" ::: "memory");
     if (full) {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int e = 0; e < 8; ++e) {
+        float* p0 = tile + (size_t)(16 * (e >> 2) + (e & 3)) * row_pitch;
+        __builtin_nontemporal_store(x[e], p0 + lane_off);
+        __builtin_nontemporal_store(y[e], p0 + 4 * row_pitch + lane_off);
+      }
+    } else if (scol >= 0 && scol < HWq) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float x = acc[kt][0][i] * out_scale, y = acc[kt][1][i] * out_scale;
-          asm volatile("s_nop 4\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-          float* p0 = tile + (size_t)(16 * kt + i) * row_pitch;
-          __builtin_nontemporal_store(x, p0 + lane_off);
-          __builtin_nontemporal_store(y, p0 + 4 * row_pitch + lane_off);
-        }
-    } else {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float x = acc[kt][0][i] * out_scale, y = acc[kt][1][i] * out_scale;
-          asm volatile("s_nop 4\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-          const int r0 = 16 * kt + i, r1 = r0 + 4;
-          float* p0 = tile + (size_t)r0 * row_pitch;
-          if (scol >= 0 && scol < HWq) {
-            if (8 * (lane >> 5) < n_v - vrow0 - r0) __builtin_nontemporal_store(x, p0 + lane_off);
-            if (8 * (lane >> 5) < n_v - vrow0 - r1) __builtin_nontemporal_store(y, p0 + 4 * row_pitch + lane_off);
-          }
-        }
+      for (int e = 0; e < 8; ++e) {
+        const int r0 = 16 * (e >> 2) + (e & 3), r1 = r0 + 4;
+        float* p0 = tile + (size_t)r0 * row_pitch;
+        if (8 * (lane >> 5) < n_v - vrow0 - r0) __builtin_nontemporal_store(x[e], p0 + lane_off);
+        if (8 * (lane >> 5) < n_v - vrow0 - r1) __builtin_nontemporal_store(y[e], p0 + 4 * row_pitch + lane_off);
+      }
     }
   };
 
@@ -379,9 +400,9 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
   int buf = 0;
   for (int kb = kb0; kb < kb1; kb += SUB) {
     const bool more = kb + SUB < kb1;
-    if (more) stage_load(kb + SUB, buf ^ 1);
     n_counted = 0;
     load_F(&smem[buf * BUFB + r * LDB + 16 * g], 0);
+    if (probe) c0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int sb = 0; sb < SUB; ++sb) {
       if (kb + sb >= kb1) break;                       // wave-uniform (ragged tail of the chunk)
@@ -397,6 +418,10 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         load_P(ka, u);                                 // lands during the F part
+        if (more && stager) {
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u);
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(DEBUG & 2)) {
 #pragma unroll
@@ -415,6 +440,10 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
         __builtin_amdgcn_sched_barrier(0);
         if (u == 0) load_F(ka, 1);                     // lands during the P part
         else if (next_here) load_F(ka + 32 * LDB, 0);
+        if (more && stager) {
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 2);
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 3);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(DEBUG & 2)) {
 #pragma unroll
@@ -435,18 +464,26 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
         __builtin_amdgcn_sched_barrier(0);
       }
       const int vrow0 = (kb + sb) * 32;
+      if (probe) { const long long c1 = __builtin_amdgcn_s_memtime(); p_comp += c1 - c0; c0 = c1; }
       if (defer) pend_v = vrow0;
       else store_tile(vrow0);
+      if (probe) { const long long c1 = __builtin_amdgcn_s_memtime(); p_store += c1 - c0; c0 = c1; }
     }
-    if (more) {
-      if (n_counted == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      else if (n_counted == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (more && stager) {
+      // the last DMA of the stage was issued inside the second tile: only that tile's own store burst (16, if it was a whole
+      // tile stored right away) is younger and may stay in flight across the barrier.  Waves 4-7 issued no load: no wait.
+      if (!defer && n_counted == 32 && kb + 1 < kb1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
+    if (probe) { p_sync += __builtin_amdgcn_s_memtime() - c0; ++p_stages; }
     buf ^= 1;
   }
   if (defer && pend_v >= 0) store_tile(pend_v);
+  if (probe && lane == 0) {
+    long long* o = reinterpret_cast<long long*>(vol) + 8 * wave;
+    o[0] = p_pro; o[1] = p_comp; o[2] = p_store; o[3] = p_sync; o[4] = __builtin_amdgcn_s_memtime() - p_start; o[5] = p_stages;
+  }
 }
 
 static int g_corr8_debug = 0;
@@ -461,9 +498,25 @@ int corr_volume_f16f8_launch(const unsigned char* q, const unsigned char* k, int
   if (period > 4 || (g_corr8_debug & 4)) period = 1;       // too many classes (or ablation): unshifted, straddling stores
   const int n_q = cdiv(HWq + (period > 1 ? 31 : 0), 256);  // shifted classes start up to 31 queries early
   const int n_vb = cdiv(cdiv(HWk, period), 32);            // 32-row blocks of virtual rows per class
-  const int chunks = imax(1, 1024 / (n_q * period));
-  int kchunk = imax(16, cdiv(n_vb, chunks));
-  kchunk += kchunk & 1;                                    // whole 64-key stages
+  // key blocks per workgroup.  One workgroup per CU (135 KB of LDS), ~20 000 cycles of prologue each (query fragments + first
+  // stage) and ~5 800 per 64-key stage (s_memtime probe, tools/time_corr8.py): take the number of key chunks that minimises
+  //   rounds over the 256 CUs x (prologue + stages per chunk)
+  // (480p: 5 chunks = 1020 workgroups = 3.98 rounds; 720p: 9 chunks = 2025 workgroups = 7.9 rounds -- 4 chunks would leave half of
+  // the fourth round empty).
+  int kchunk = n_vb + (n_vb & 1);
+  {
+    long long best = -1;
+    for (int c = 1; c <= 32; ++c) {
+      int kc = cdiv(n_vb, c);
+      kc += kc & 1;                                         // whole 64-key stages
+      const long long wgs = (long long)n_q * period * cdiv(n_vb, kc);
+      const long long cost = ((wgs + 255) / 256) * (20000ll + 5800ll * (kc / 2));
+      if (best < 0 || cost < best) {
+        best = cost;
+        kchunk = kc;
+      }
+    }
+  }
   if (g_corr8_debug >> 8) kchunk = g_corr8_debug >> 8;
   dim3 grid(n_q, cdiv(n_vb, kchunk), period);
   const float out_scale = 1.0f / (temperature * F8_S * F8_S);
@@ -478,7 +531,9 @@ int corr_volume_f16f8_launch(const unsigned char* q, const unsigned char* k, int
       default: FGVC_C8(3); break;
     }
   } else {
-    switch (g_corr8_debug & 11) {
+    switch (g_corr8_debug & 43) {
+      case 32: FGVC_C8V2(32); break;
+      case 33: FGVC_C8V2(33); break;
       case 0: FGVC_C8V2(0); break;
       case 1: FGVC_C8V2(1); break;
       case 2: FGVC_C8V2(2); break;

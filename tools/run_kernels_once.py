@@ -1,4 +1,5 @@
-"""One launch each of the roofline kernels at the bench size (for rocprofv3 --pmc passes)."""
+"""A few launches each of the roofline kernels at the bench shapes (cfg2: 8 x 480x854 -> 120x214x256), for rocprofv3 --pmc passes
+(tools/pmc_report.py turns the result directories into profiles/r02_pmc.json).  Run the interpreter directly after `--`."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,10 +12,12 @@ plan = engine.plan_clip(T, [0], cfg)
 pairs = ops.make_pairs(plan.pairs, dev)
 hl_all = ops.split_bf16(feats)
 hl = hl_all[:2]
+sp = ops.split_f16f8(feats[:2])
 vol = torch.empty((HW, HW), device=dev)
 for _ in range(3):
-    ops.pair_topk_split(hl_all, hl_all, pairs, H, W, H, W, cfg.mask, 10, validate=False)
+    ops.pair_topk_split(hl_all, hl_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True)
     ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False)
+    ops.corr_volume(sp[1], sp[0], 0.07, "f16f8", out=vol)
     ops.corr_volume(hl[1], hl[0], 0.07, "bf16x3", out=vol)
     ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol)
     ops.corr_volume(feats[1], feats[0], 0.07, "f32", out=vol)
@@ -23,18 +26,21 @@ torch.cuda.synchronize()
 wt = torch.randn(256, 256, 3, 3, device=dev) * 0.02
 bn = torch.nn.BatchNorm2d(256).eval().to(dev)
 wp, bs = ops.prepare_conv_split(wt, bn)
-xs = ops.nchw_to_split_nhwc(torch.randn(T, 256, H, W, device=dev))
+xs = ops.nchw_to_split_nhwc(torch.relu(torch.randn(T, 256, H, W, device=dev)))
 ys = ops.alloc_split_nhwc(T, 256, H, W, dev)
 for _ in range(3):
     ops.conv_split(xs, wp, bs, H, W, True, out_split=ys)
 torch.cuda.synchronize()
-# the stem and the stride-2 block of layer 2 at the 480p clip's sizes
+# layer 1 (64 -> 64, register-resident weights), the stem and the stride-2 block of layer 2 at the 480p clip's sizes
 frames = torch.randn(T, 3, 480, 854, device=dev)
 sw, sb = ops.prepare_stem7(torch.randn(64, 3, 7, 7, device=dev) * 0.1, torch.nn.BatchNorm2d(64).eval().to(dev))
 st_s, st_f = ops.alloc_split_nhwc(T, 64, 240, 427, dev), ops.alloc_nhwc(T, 64, 240, 427, dev)
+w64, b64 = ops.prepare_conv64(torch.randn(64, 64, 3, 3, device=dev) * 0.05, torch.nn.BatchNorm2d(64).eval().to(dev))
+y64 = ops.alloc_split_nhwc(T, 64, 240, 427, dev)
 w2, b2 = ops.prepare_conv_s2(torch.randn(128, 64, 3, 3, device=dev) * 0.05, torch.nn.BatchNorm2d(128).eval().to(dev))
 s2_out = ops.alloc_split_nhwc(T, 128, 120, 214, dev)
 for _ in range(3):
     ops.stem7_split(frames, sw, sb, True, out_split=st_s, out_f32=st_f)
+    ops.conv64_split(st_s, w64, b64, 240, 427, True, out_split=y64)
     ops.conv_s2_split(st_s, w2, b2, 240, 427, True, out_split=s2_out)
 torch.cuda.synchronize()

@@ -24,7 +24,7 @@ for (H, W) in sizes:
     ref = (f[0][kk].double() * f[1][qq].double()).sum(1) / tau
     v3 = ops.corr_volume(hl[1], hl[0], tau, "bf16x3")
     errs = {}
-    for dbg, label in ((0, "default"), (8, "stagger"), (16, "v1")):
+    for dbg, label in ((0, "default"), (8, "no stagger"), (16, "v1")):
         ops.set_option("corr8_debug", dbg)
         v8 = ops.corr_volume(sp[1], sp[0], tau, "f16f8")
         errs[label] = (float((v8[kk, qq].double() - ref).abs().max()), float((v8 - v3).abs().max()))
@@ -33,7 +33,7 @@ for (H, W) in sizes:
     print(f"{H}x{W}: max err vs f64 sample / vs bf16x3 whole volume: " + "  ".join(f"{k} {a:.1e}/{b:.1e}" for k, (a, b) in errs.items()))
     out = torch.empty_like(v3)
     del v3
-    cfgs = [("f16f8", 0), ("stagger", 8), ("no classes", 4), ("stagger no classes", 12), ("v1 (32x32)", 16), ("no stores", 1), ("stagger no stores", 9),
+    cfgs = [("f16f8", 0), ("no stagger", 8), ("no classes", 4), ("no stagger no classes", 12), ("v1 (32x32)", 16), ("no stores", 1), ("no stagger no stores", 9),
             ("kchunk 40", 40 << 8), ("kchunk 120", 120 << 8), ("kchunk 200", 200 << 8)]
     best, last = {}, {}
     def run_all():
