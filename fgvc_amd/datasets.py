@@ -190,3 +190,72 @@ class TapVidPickles:
         d = self.device
         return dict(rgbs=rgbs, query_points=query_points.unsqueeze(0).to(d), trajectories=traj.unsqueeze(0).to(d),
                     visibilities=vis.float().unsqueeze(0).to(d))
+
+
+# ---- JHMDB (mmpt/datasets/jhmdb_dataset.py:72-141) -> the tracker's sample format -------------------------------------------------
+class JhmdbPoses:
+    """JHMDB pose videos in the sample format VanillaTracker.forward_test consumes.  The reference's JHMDB dataset yields
+    `imgs` / `ref_seg_map` (jhmdb_dataset.py:112-141), which the released tracker does not accept (SURVEY.md section 8b);
+    this is the adaptation the release lacks: the 15 joints of the FIRST frame become query points at t = 0.
+
+    Files as the reference reads them (:72-96): `<list_path>/<split>_list.txt` with lines "<anno.mat> <frames dir>", both relative
+    to `root`; frames `*.png`; the .mat holds `pos_img` (2, 15, T) = (x; y), 1-based (:125 "magic -1").  Frames are resized to
+    `input_size` (test_pipeline_jhmdb: 320 x 320, keep_ratio=False) and go through the RGB->Lab contract; joints are scaled
+    the same way.  `pose_prediction(sample, traj_pred)` maps a prediction back to the (2, 15, T) original-resolution array that
+    `metrics.jhmdb_pck` (jhmdb_dataset.py:174-256) scores against `sample["gt_poses"]`."""
+    NUM_KEYPOINTS = 15
+
+    def __init__(self, root: str, list_path: str = None, split: str = "val", input_size=(320, 320), device="cpu"):
+        self.root, self.input_size, self.device = root, tuple(input_size), device
+        self.samples = []
+        with open(os.path.join(list_path or root, f"{split}_list.txt")) as f:
+            for line in f:
+                if not line.strip():
+                    continue
+                anno, vname = line.strip("\n").split()
+                frames = sorted(glob.glob(os.path.join(root, vname, "*.png")))
+                if frames:
+                    self.samples.append(dict(frames_path=frames, anno_path=os.path.join(root, anno), video_path=os.path.join(root, vname)))
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        import scipy.io as sio
+        from PIL import Image
+        s = self.samples[i]
+        frames = torch.from_numpy(np.stack([np.array(Image.open(p).convert("RGB")) for p in s["frames_path"]]))   # (T,h0,w0,3)
+        T, h0, w0 = frames.shape[:3]
+        gt = np.asarray(sio.loadmat(s["anno_path"])["pos_img"], dtype=np.float64) - 1.0                          # (2,15,Tg)
+        Tg = gt.shape[-1]
+        h, w = self.input_size
+        scale = np.array([w / w0, h / h0]).reshape(2, 1, 1)
+        gts = gt * scale
+        n = min(T, Tg)                                                                                           # :205
+        traj = torch.from_numpy(gts[:, :, :n]).permute(2, 1, 0).float().contiguous()                             # (T,15,2)
+        qp = torch.cat([torch.zeros(self.NUM_KEYPOINTS, 1), traj[0]], 1)                                        # (15,3) = (0,x,y)
+        rgbs = preprocess_tapvid_frames(frames[:n].to(self.device), self.input_size)
+        d = self.device
+        return dict(rgbs=rgbs, query_points=qp.unsqueeze(0).to(d), trajectories=traj.unsqueeze(0).to(d),
+                    visibilities=torch.ones(1, n, self.NUM_KEYPOINTS, device=d)), dict(gt_poses=gt[:, :, :n], original_shape=(h0, w0))
+
+    def pose_prediction(self, meta, traj_pred) -> np.ndarray:
+        """traj_pred (1,T,15,2) at the network input size -> (2,15,T) at the video's own resolution."""
+        h0, w0 = meta["original_shape"]
+        h, w = self.input_size
+        p = np.asarray(traj_pred.cpu() if hasattr(traj_pred, "cpu") else traj_pred, dtype=np.float64)[0]            # (T,15,2)
+        return p.transpose(2, 1, 0) * np.array([w0 / w, h0 / h]).reshape(2, 1, 1)
+
+
+def jhmdb_evaluate(model, dataset: "JhmdbPoses"):
+    """Run the tracker over a JhmdbPoses dataset and score PCK@0.1..0.5 as the reference's pck_evaluate does."""
+    from . import metrics
+    preds, gts = [], []
+    for i in range(len(dataset)):
+        sample, meta = dataset[i]
+        out = model(test_mode=True, **sample)
+        assert torch.equal(out[4], sample["query_points"])              # every query is at t = 0: one group, order kept
+        pred = out[2]
+        preds.append(dataset.pose_prediction(meta, pred))
+        gts.append(meta["gt_poses"])
+    return metrics.jhmdb_pck(preds, gts)

@@ -6,6 +6,8 @@
                         (mmpt/datasets/flyingthingsplus/utils/figures.py:179-296; docstring known answers :225-246)
 * jhmdb_pck           : PCK@alpha with the 0.6 * ||bbox of visible GT joints|| normaliser
                         (mmpt/datasets/jhmdb_dataset.py:144-152, :174-256)
+* tapvid_summaries / save_results : the per-point records and the on-disk files of TAPVidDataset.tapvid_evaluate
+                        (mmpt/datasets/tapvid.py:198-350): summaries<dataset>.json, results_df<dataset>.csv, results_list<dataset>.pkl
 """
 from __future__ import annotations
 
@@ -60,15 +62,37 @@ def _ade(a: np.ndarray, b: np.ndarray) -> float:
     return float(np.linalg.norm(a - b, axis=-1).mean()) if len(a) else float("nan")
 
 
-def trajectory_summary(traj_gt, traj_pred, vis_gt, vis_pred, query_point, query_mode: str = "first") -> Dict[str, float]:
-    """One point: traj (T,2), vis (T,) bool, query_point (3,)=(t,x,y).  TAP-Vid numbers are x100 like the reference's
-    compute_summary (figures.py:289); ADEs in pixels."""
+SUMMARY_EXTRA_THRESHOLDS = (0.01, 0.05, *[0.1 * (i + 1) for i in range(10)], *[(i + 1) for i in range(10)])   # figures.py:281-285
+
+
+def _visible_chain(vis: np.ndarray, t: int):
+    """Slice of the frames around query time t that are visible without interruption (figures.py:112-176)."""
+    assert vis[t], "Query point must be visible"
+    occ = np.nonzero(~vis)[0]
+    after, before = occ[occ > t], occ[occ < t]
+    return slice(int(before[-1]) + 1 if len(before) else 0, int(after[0]) if len(after) else len(vis))
+
+
+def trajectory_summary(traj_gt, traj_pred, vis_gt, vis_pred, query_point, query_mode: str = "first", idx: str = None,
+                       extra_thresholds: Iterable[float] = ()) -> Dict[str, float]:
+    """One point: traj (T,2), vis (T,) bool, query_point (3,)=(t,x,y).  The record of the reference's compute_summary
+    (figures.py:179-296): TAP-Vid numbers x100 (:289), ADEs in pixels, `idx` = "<iter>--<video_idx>--<point_idx_in_video>"."""
     traj_gt, traj_pred = np.asarray(traj_gt, np.float64), np.asarray(traj_pred, np.float64)
     vis_gt, vis_pred = np.asarray(vis_gt).astype(bool), np.asarray(vis_pred).astype(bool)
-    s = {"ade": _ade(traj_gt, traj_pred), "ade_visible": _ade(traj_gt[vis_gt], traj_pred[vis_gt]),
-         "n_timesteps": len(traj_gt), "n_timesteps_visible": int(vis_gt.sum())}
+    s = {}
+    if idx is not None:
+        s["idx"] = idx
+    s.update({"ade": _ade(traj_gt, traj_pred), "ade_visible": _ade(traj_gt[vis_gt], traj_pred[vis_gt])})
+    t = int(query_point[0])
+    if 0 <= t < len(vis_gt) and vis_gt[t]:
+        ch = _visible_chain(vis_gt, t)
+        s["ade_visible_chain"] = _ade(traj_gt[ch], traj_pred[ch])
+        n_chain = ch.stop - ch.start
+    else:
+        s["ade_visible_chain"], n_chain = float("nan"), 0
+    s.update({"n_timesteps": len(traj_gt), "n_timesteps_visible": int(vis_gt.sum()), "n_timesteps_visible_chain": n_chain})
     m = tapvid_metrics(np.asarray(query_point, np.float64)[None, None], ~vis_gt[None, None], traj_gt[None, None],
-                       ~vis_pred[None, None], traj_pred[None, None], query_mode)
+                       ~vis_pred[None, None], traj_pred[None, None], query_mode, extra_thresholds)
     s.update({k: float(v[0]) * 100 for k, v in m.items()})
     return s
 
@@ -85,6 +109,49 @@ def tapvid_evaluate(results: Sequence, query_mode: str = "first") -> Dict[str, f
                                            qp[0, p], query_mode))
     keys = rows[0].keys() if rows else []
     return {k: float(np.nanmean([r[k] for r in rows])) for k in keys}
+
+
+def tapvid_summaries(results: Sequence, query_mode: str = "first", input_size=(256, 256), size=(256, 256)):
+    """The per-point records TAPVidDataset.tapvid_evaluate builds (tapvid.py:235-268): one per point of every video, coordinates
+    scaled from the network input size back to the evaluation size (`size` = (h, w); :241-245), idx "<video>_<point>" fields
+    iter / video_idx / point_idx_in_video as there.  Returns (summaries, results_list)."""
+    summaries, results_list = [], []
+    sx, sy = size[1] / input_size[1], size[0] / input_size[0]
+    for vid, (traj, vis, tp, vp, qp) in enumerate(results):
+        traj, vis, tp, vp, qp = (np.asarray(x.cpu() if hasattr(x, "cpu") else x, dtype=np.float64) for x in (traj, vis, tp, vp, qp))
+        scale = np.array([sx, sy])
+        for n in range(traj.shape[2]):
+            rec = {"idx": f"{vid}_{n}", "iter": vid, "video_idx": 0, "point_idx_in_video": n,
+                   "trajectory_gt": traj[0, :, n] * scale, "trajectory_pred": tp[0, :, n] * scale,
+                   "visibility_gt": vis[0, :, n] > 0.5, "visibility_pred": vp[0, :, n] > 0.5, "query_point": qp[0, n]}
+            results_list.append(rec)
+            summaries.append(trajectory_summary(rec["trajectory_gt"], rec["trajectory_pred"], rec["visibility_gt"], rec["visibility_pred"],
+                                                rec["query_point"], query_mode, idx=f"{vid}--0--{n}",
+                                                extra_thresholds=SUMMARY_EXTRA_THRESHOLDS))
+    return summaries, results_list
+
+
+def save_results(summaries, results_list, output_dir: str, metadata: Dict) -> Dict[str, str]:
+    """The files of the reference's save_results (tapvid.py:316-350), same names and formats: summaries<dataset>.json (list of
+    records), results_df<dataset>.csv (pandas DataFrame.from_records(summaries).to_csv) and, when `results_list` is non-empty,
+    results_list<dataset>.pkl.  (The figures the reference draws from the data frame are not produced.)  Returns the paths."""
+    import json
+    import os
+    import pickle
+
+    import pandas as pd
+    dataset = metadata["dataset"]
+    os.makedirs(output_dir, exist_ok=True)
+    paths = {"summaries": os.path.join(output_dir, f"summaries{dataset}.json"),
+             "results_df": os.path.join(output_dir, f"results_df{dataset}.csv")}
+    with open(paths["summaries"], "w", encoding="utf8") as f:
+        json.dump(summaries, f)
+    pd.DataFrame.from_records(summaries).to_csv(paths["results_df"])
+    if len(results_list) > 0:
+        paths["results_list"] = os.path.join(output_dir, f"results_list{dataset}.pkl")
+        with open(paths["results_list"], "wb") as f:
+            pickle.dump(results_list, f)
+    return paths
 
 
 def jhmdb_pck(pred_poses: Sequence[np.ndarray], gt_poses: Sequence[np.ndarray],

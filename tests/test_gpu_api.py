@@ -232,3 +232,24 @@ def test_hr_tracker_vs_reference_driver_golden(dev, golden):
     assert float(np.abs(fwd[0] - g["forward_coords"][0]).max()) < 5e-3
     with pytest.raises(NotImplementedError):
         _tracker(dev, "HRVanillaTracker", (1, 2, 1, 1), dict(base, save_mem=True), 1)
+
+
+def test_jhmdb_adapter_end_to_end(dev, tmp_path):
+    """F3: JHMDB-format files -> JhmdbPoses -> VanillaTracker -> PCK as the reference's pck_evaluate computes it.  The fixture's
+    frames are rigidly translating textures with joints that move along, so even a random-init encoder must follow them
+    (a check of the adapter + metric plumbing, not an accuracy claim)."""
+    from fgvc_amd import datasets
+    from tests.test_metrics import _write_fake_jhmdb
+    _write_fake_jhmdb(str(tmp_path), n_videos=2, T=6, size=(96, 128))
+    ds = datasets.JhmdbPoses(str(tmp_path), split="val", input_size=(128, 160), device=dev)
+    import fgvc_amd.mmpt_api as api
+    model = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4), out_indices=(2,),
+                                                                       pool_type="none", zero_init_residual=False)),
+                            train_cfg=None, test_cfg=api.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30,
+                                                                    with_first=True, with_first_neighbor=True))
+    torch.manual_seed(0)
+    model.init_weights()
+    model = model.to(dev).eval()
+    pck = datasets.jhmdb_evaluate(model, ds)
+    assert set(pck) == {"PCK@0.1", "PCK@0.2", "PCK@0.3", "PCK@0.4", "PCK@0.5"}
+    assert pck["PCK@0.2"] > 80.0 and pck["PCK@0.1"] <= pck["PCK@0.2"] <= pck["PCK@0.5"], pck

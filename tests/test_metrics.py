@@ -1,6 +1,9 @@
 """CPU: evaluation arithmetic against the reference's function output (golden) and the
 reference's docstring known answers (figures.py:225-246)."""
+import os
+
 import numpy as np
+import torch
 
 from fgvc_amd import metrics as M
 
@@ -45,3 +48,90 @@ def test_jhmdb_pck():
     p3 = g3.copy()
     p3[:, 2, 0] = -1
     assert abs(M.jhmdb_pck([p3], [g3])["PCK@0.1"] - 100.0) < 1e-9
+
+
+def _write_fake_jhmdb(root, n_videos=2, T=6, size=(96, 128), seed=0):
+    """A JHMDB-format tree (list file, PNG frames, pos_img .mat, 1-based) holding rigidly translating textures whose 15 'joints'
+    move with the texture: the tracker must follow them."""
+    import numpy as np
+    import scipy.io as sio
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    h, w = size
+    lines = []
+    for v in range(n_videos):
+        pad = 3 * T
+        base = rng.integers(0, 255, (h + 2 * pad, w + 2 * pad, 3)).astype(np.uint8)
+        base = np.asarray(Image.fromarray(base).resize((w + 2 * pad, h + 2 * pad), Image.BILINEAR))       # keep it an image
+        small = Image.fromarray(base).resize(((w + 2 * pad) // 6, (h + 2 * pad) // 6), Image.BILINEAR)
+        base = np.asarray(small.resize((w + 2 * pad, h + 2 * pad), Image.BICUBIC))                         # smooth texture
+        vx, vy = int(rng.integers(-2, 3)), int(rng.integers(-2, 3))
+        vdir = os.path.join(root, "JHMDB", "Rename_Images", f"vid{v}")
+        os.makedirs(vdir, exist_ok=True)
+        for t in range(T):
+            Image.fromarray(base[pad - vy * t: pad - vy * t + h, pad - vx * t: pad - vx * t + w]).save(os.path.join(vdir, f"{t + 1:05d}.png"))
+        x0 = rng.uniform(20, w - 20, 15)
+        y0 = rng.uniform(20, h - 20, 15)
+        ts = np.arange(T)
+        pos = np.stack([x0[:, None] + vx * ts[None], y0[:, None] + vy * ts[None]], 0) + 1.0               # (2,15,T), 1-based
+        adir = os.path.join(root, "JHMDB", "joint_positions", f"vid{v}")
+        os.makedirs(adir, exist_ok=True)
+        sio.savemat(os.path.join(adir, "joint_positions.mat"), {"pos_img": pos})
+        lines.append(f"JHMDB/joint_positions/vid{v}/joint_positions.mat JHMDB/Rename_Images/vid{v}")
+    with open(os.path.join(root, "val_list.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def test_jhmdb_adapter_sample_format_and_pck(tmp_path):
+    """F3: JHMDB files -> (rgbs, query_points, trajectories, visibilities); predictions map back to (2,15,T) at the video's
+    own resolution; a perfect prediction scores PCK 100, one shifted by 0.2 x the normaliser scores 0 at 0.1 and 100 at 0.3."""
+    from fgvc_amd import datasets, metrics
+    _write_fake_jhmdb(str(tmp_path))
+    ds = datasets.JhmdbPoses(str(tmp_path), split="val", input_size=(64, 80))
+    assert len(ds) == 2
+    sample, meta = ds[0]
+    assert sample["rgbs"].shape == (1, 6, 3, 64, 80) and sample["query_points"].shape == (1, 15, 3)
+    assert sample["trajectories"].shape == (1, 6, 15, 2) and sample["visibilities"].shape == (1, 6, 15)
+    assert float(sample["query_points"][0, :, 0].abs().max()) == 0.0
+    assert torch.allclose(sample["query_points"][0, :, 1:], sample["trajectories"][0, 0])
+    assert meta["original_shape"] == (96, 128) and meta["gt_poses"].shape == (2, 15, 6)
+    # joints were written 1-based at (x0, y0): back at the original resolution they are 0-based pixel coordinates
+    back = ds.pose_prediction(meta, sample["trajectories"])
+    assert np.allclose(back, meta["gt_poses"], atol=1e-4)
+    assert metrics.jhmdb_pck([back], [meta["gt_poses"]])["PCK@0.1"] == 100.0
+    gt = meta["gt_poses"]
+    box = 0.6 * np.linalg.norm(gt.max(axis=1) - gt.min(axis=1), axis=0)                                  # (T,)
+    shifted = gt + np.stack([0.2 * box, np.zeros_like(box)], 0)[:, None, :]
+    r = metrics.jhmdb_pck([shifted], [gt])
+    assert r["PCK@0.1"] == 0.0 and r["PCK@0.3"] == 100.0
+
+
+def test_summaries_and_result_files(tmp_path):
+    """F4: the per-point records and files of TAPVidDataset.tapvid_evaluate / save_results (tapvid.py:235-350)."""
+    import json
+    import pickle
+    import pandas as pd
+    from fgvc_amd import metrics
+    s = metrics.trajectory_summary([[0, 0], [1, 1], [2, 2]], [[0, 0], [2, 2], [3, 3]], [1, 1, 0], [1, 1, 1], [0, 0, 0], idx="123--2--31")
+    # docstring known answers of the reference's compute_summary (figures.py:225-246); TAP-Vid numbers are x100 (:289)
+    want = {"idx": "123--2--31", "ade": 0.9428090453147888, "ade_visible": 0.7071067690849304, "ade_visible_chain": 0.7071067690849304,
+            "n_timesteps": 3, "n_timesteps_visible": 2, "n_timesteps_visible_chain": 2, "occlusion_accuracy": 50.0, "jaccard_1": 0.0,
+            "jaccard_2": 50.0, "jaccard_16": 50.0, "average_jaccard": 40.0, "pts_within_1": 0.0, "pts_within_2": 100.0,
+            "average_pts_within_thresh": 80.0}
+    for k, v in want.items():
+        assert s[k] == v if not isinstance(v, float) else abs(s[k] - v) < 1e-5, (k, s[k], v)
+    g = torch.Generator().manual_seed(3)
+    results = []
+    for _ in range(2):
+        traj = torch.rand(1, 5, 3, 2, generator=g) * 256
+        vis = torch.ones(1, 5, 3)
+        results.append((traj, vis, traj + 1.5, torch.zeros(1, 5, 3), torch.cat([torch.zeros(1, 3, 1), traj[:, 0]], -1)))
+    summaries, results_list = metrics.tapvid_summaries(results, "first", input_size=(256, 256), size=(256, 256))
+    assert len(summaries) == 6 and summaries[4]["idx"] == "1--0--1" and results_list[4]["idx"] == "1_1"
+    assert "pts_within_0.01" in summaries[0] and "pts_within_10" in summaries[0]
+    paths = metrics.save_results(summaries, results_list, str(tmp_path / "out"), {"dataset": "davis", "query_mode": "first"})
+    assert sorted(os.path.basename(p) for p in paths.values()) == ["results_dfdavis.csv", "results_listdavis.pkl", "summariesdavis.json"]
+    assert json.load(open(paths["summaries"])) == json.loads(json.dumps(summaries))
+    df = pd.read_csv(paths["results_df"], index_col=0)
+    assert list(df.columns) == list(summaries[0].keys()) and len(df) == 6
+    assert len(pickle.load(open(paths["results_list"], "rb"))) == 6

@@ -22,7 +22,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fgvc_amd.mmpt_api as api  # noqa: E402
 from fgvc_amd import apis, metrics  # noqa: E402
-from fgvc_amd.datasets import StridedLoader, SyntheticTapVid, TapVidPickles  # noqa: E402
+from fgvc_amd.datasets import JhmdbPoses, StridedLoader, SyntheticTapVid, TapVidPickles, jhmdb_evaluate  # noqa: E402
 
 DEFAULT_CFG = dict(
     model=dict(type="VanillaTracker",
@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--query-mode", default="first")
     ap.add_argument("--data-root", default=None, help="TAP-Vid pickles (directory of *.pkl or one .pkl); default: synthetic clips")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--out-dir", default=None, help="write summaries<task>.json / results_df<task>.csv / results_list<task>.pkl there "
+                                                    "(the files of the reference's save_results, tapvid.py:316-350)")
     a = ap.parse_args()
 
     cfg = api.Config.fromfile(a.config) if a.config else api.Config(DEFAULT_CFG)           # tools/test.py:75
@@ -57,11 +59,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         rank, world = dist.get_rank(), dist.get_world_size()
 
-    if a.data_root:
+    if a.task == "jhmdb":
+        if not a.data_root:
+            raise SystemExit("--task jhmdb needs --data-root (JHMDB frames + joint_positions + val_list.txt)")
+        dataset = None
+    elif a.data_root:
         dataset = TapVidPickles(a.data_root, a.query_mode, tuple(a.size), device=dev)                   # :121-122
     else:
         dataset = SyntheticTapVid(a.videos, a.frames, tuple(a.size), a.points, a.query_mode, device=dev)
-    loader = StridedLoader(dataset, rank, world)                                             # :124-134
+    loader = StridedLoader(dataset, rank, world) if dataset is not None else None          # :124-134
     test_cfg = cfg["test_cfg_" + a.task]                                                     # :135
     model_cfg = dict(type=cfg.get("eval_arc", "VanillaTracker"), backbone=dict(cfg.model.backbone))   # :139
     for k in ("out_indices", "strides", "dilations"):                                        # :141-145
@@ -73,6 +79,10 @@ def main():
         api.load_checkpoint(model, a.checkpoint)                                             # :158-159
     model = model.to(dev).eval()
 
+    if a.task == "jhmdb":      # pose tracking: the 15 joints of frame 0 are the query points (fgvc_amd.datasets.JhmdbPoses)
+        pck = jhmdb_evaluate(model, JhmdbPoses(a.data_root, split="val", input_size=(320, 320), device=dev))
+        print(json.dumps({k: round(v, 2) for k, v in pck.items()}))
+        return
     outputs = apis.multi_gpu_test(model, loader) if distributed else apis.single_gpu_test(model, loader)   # :160-190
     if rank == 0:
         summary = metrics.tapvid_evaluate(outputs, a.query_mode)                             # :192-198
@@ -81,6 +91,9 @@ def main():
         if a.out:
             with open(a.out, "w") as f:
                 json.dump(summary, f, indent=1)
+        if a.out_dir:
+            summaries, results_list = metrics.tapvid_summaries(outputs, a.query_mode, tuple(a.size), tuple(a.size))
+            print(json.dumps(metrics.save_results(summaries, results_list, a.out_dir, {"dataset": a.task, "query_mode": a.query_mode})))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
