@@ -63,6 +63,9 @@ void set_corr_debug(int);
 int split_f16f8_launch(const float*, unsigned char*, long long, int, hipStream_t);
 int corr_volume_f16f8_launch(const unsigned char*, const unsigned char*, int, int, float, float*, hipStream_t);
 void set_corr8_debug(int);
+int split_f16f6_launch(const float*, unsigned char*, long long, hipStream_t);
+int corr_volume_f16f6_launch(const unsigned char*, const unsigned char*, int, int, float, float*, hipStream_t);
+void set_corr6_debug(int);
 int dense_attend_splits(int, int);
 int dense_attend_launch(const float*, const float*, int, int, int, int, int, int, int, int, int, int, int, float*, int, hipStream_t);
 int dense_attend_finish_launch(const float*, int, int, int, int, float*, hipStream_t);
@@ -91,6 +94,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "corr8_debug") == 0) {   // fgvc_corr_volume_f16f8 ablations: 1 = no stores, 2 = no MFMA (results wrong); 4 = no row
     set_corr8_debug(value);                 // classes, 8 = wave stagger, 16 = the 32x32-shape kernel (results right); >> 8 = key blocks per workgroup
+    return FGVC_OK;
+  }
+  if (strcmp(name, "corr6_debug") == 0) {   // fgvc_corr_volume_f16f6 ablations: the bits of corr8_debug (1, 2, 4, 8; >> 8 = key blocks per workgroup)
+    set_corr6_debug(value);
     return FGVC_OK;
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
@@ -277,6 +284,25 @@ int fgvc_corr_volume_f16f8(const uint8_t* q, const uint8_t* k, int C, int HWq, i
   FGVC_REQUIRE(HWq > 0 && HWk > 0 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f16f8: bad shape");
   FGVC_REQUIRE((long long)HWq < (1ll << 30) && (long long)HWk < (1ll << 30), FGVC_ERR_UNSUPPORTED, "fgvc_corr_volume_f16f8: grid too large");
   return corr_volume_f16f8_launch(q, k, HWq, HWk, temperature, vol, (hipStream_t)stream);
+}
+
+int fgvc_split_f16f6(const float* feat, uint8_t* out, int64_t n_pixels, int C, void* stream) {
+  FGVC_REQUIRE(feat && out, FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6: null pointer");
+  FGVC_REQUIRE(n_pixels >= 0, FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6: negative pixel count");
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_split_f16f6: C=%d unsupported (256 only)", C);
+  FGVC_REQUIRE(aligned16(feat) && aligned16(out), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6: 16-byte alignment required");
+  if (n_pixels == 0) return FGVC_OK;
+  return split_f16f6_launch(feat, out, n_pixels, (hipStream_t)stream);
+}
+
+int fgvc_corr_volume_f16f6(const uint8_t* q, const uint8_t* k, int C, int HWq, int HWk, float temperature, float* vol,
+                           void* stream) {
+  FGVC_REQUIRE(q && k && vol, FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f16f6: null pointer");
+  FGVC_REQUIRE(aligned16(q) && aligned16(k) && aligned16(vol), FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f16f6: 16-byte alignment required");
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_corr_volume_f16f6: C=%d unsupported (256 only; use fgvc_corr_volume_bf16x3)", C);
+  FGVC_REQUIRE(HWq > 0 && HWk > 0 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_corr_volume_f16f6: bad shape");
+  FGVC_REQUIRE((long long)HWq < (1ll << 30) && (long long)HWk < (1ll << 30), FGVC_ERR_UNSUPPORTED, "fgvc_corr_volume_f16f6: grid too large");
+  return corr_volume_f16f6_launch(q, k, HWq, HWk, temperature, vol, (hipStream_t)stream);
 }
 
 int fgvc_dense_attend_splits(int HWq, int HWk) { return (HWq > 0 && HWk > 0) ? dense_attend_splits(HWq, HWk) : 1; }

@@ -1,0 +1,425 @@
+// Dense correlation volume, parity-grade, at 1.5 bf16-MFMA times per tile (f16f8: 2, bf16x3: 3).
+//
+// Arithmetic.  As fgvc_corr_volume_f16f8 (corr_volume_f8.hip), with the cross terms in block-scaled FP6 instead of FP8:
+//     h  = f16(256 x)               11 significand bits, exact products h_k * h_q in f32
+//     h6 = e2m3(h / 2^sh)           h again: 4 significand bits, E8M0 scale 2^sh per 32 consecutive channels
+//     l6 = e2m3(l / 2^sl)           l = 256 (256 x - h), the residual of h, same format
+//     2^16 <k, q>  =  sum h_k h_q  +  2^-8 (sum h6_k l6_q  +  sum l6_k h6_q)          (sum l l = 2^-22, dropped)
+// The cross sums are 2^-11 of the first sum, so their 4 significand bits carry them to ~2^-15 of the result; e2m3 has only
+// three binades (values 0 .. 7.5), the per-block scale puts the block maximum into the top one, and an element 8x below its
+// block's maximum still has 3 bits.  Simulated against float64 before it was built (tools/sim_split_formats.py): the error is the
+// same as fp8's (6e-5 logit on Gaussian rows, 3.4e-4 on adversarially sparse / one-hot / heavy-tailed rows; bound asserted: 1e-3);
+// FP4 (e2m1) would miss the bar (1.3e-3).  v_mfma_scale_f32_16x16x128_f8f6f4 retires a K-128 block of FP6 operands in the 16
+// cycles the f16 form needs for K 32, so per 32 x 32 tile and C = 256: 32 f16 MFMAs + 16 scaled FP6 MFMAs = 512 + 256 = 768
+// matrix-pipe cycles (f16f8: 1024, bf16x3: 1536).
+// Operand layout of the FP6 form (probed with exact integers, tools/micro/probe_fp6_scaled.hip): lane (r = l & 15, g = l >> 4)
+// holds row / column r, k = 32 g + i, element i in bits [6 i, 6 i + 6) of its SIX operand registers; the scale byte that opsel picks
+// from lane (r, g)'s scale register applies to exactly those 32 elements -- one scale block per lane.
+//
+// Row format (fgvc_split_f16f6), 1 KiB per pixel, C = 256:
+//     [0, 512)    h, 256 f16
+//     [512, 704)  h6: K-128 block u at 512 + 96 u = [lane piece 0: 4 x 16 B (g = 0..3)][lane piece 1: 4 x 8 B]; lane g's 24 bytes
+//                 (16 + 8) are channels 128 u + 32 g + i, i = 0..31, 6 bits each, little-endian
+//     [704, 896)  l6, the same layout
+//     [896, 912)  scales: dword g = {sh(u=0,g), sh(u=1,g), sl(u=0,g), sl(u=1,g)} as E8M0 bytes of 2^(s-4): the two scales of a
+//                 product carry the 2^-8 between them
+//     [912, 1024) zero
+// Structure: corr_volume_f16f8_v2_kernel (query fragments resident as B operands, 64-key stages through LDS by LDS-DMA issued by
+// the older waves, 16 x 16 MFMA shapes, lane-swapped 128-byte row pieces, row classes for whole-line stores, wave stagger).
+#include "common.hpp"
+
+namespace fgvc {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float F6_S = 256.f;
+constexpr int F6_ROWB = 1024, F6_H6 = 512, F6_L6 = 704, F6_SC = 896, F6_END = 912;
+
+// E8M0 exponent s with max / 2^s <= 7.5 (the largest e2m3 value); an all-zero block gets a small harmless scale
+__device__ __forceinline__ int f6_scale_exp(float m) {
+  if (!(m > 0.f)) return -40;
+  int e;
+  const float f = frexpf(m * (1.0f / 7.5f), &e);       // m / 7.5 = f 2^e, f in [0.5, 1)
+  int s = (f > 0.5f) ? e : e - 1;                       // ceil(log2(m / 7.5))
+  if (m * exp2f((float)-s) > 7.5f) ++s;                 // guards the rounding of the division above
+  return imax(s, -40);
+}
+
+// |y| <= 7.5 -> e2m3 code, round to nearest even
+__device__ __forceinline__ unsigned f6_code(float y) {
+  const float a = fabsf(y);
+  const float inv_step = a < 2.f ? 8.f : (a < 4.f ? 4.f : 2.f);
+  const float r = fminf(__builtin_rintf(a * inv_step) / inv_step, 7.5f);
+  const float c = r < 2.f ? 8.f * r : (r < 4.f ? 8.f + 4.f * r : 16.f + 2.f * r);
+  return (unsigned)c | (y < 0.f ? 32u : 0u);
+}
+
+// 32 codes -> 192 bits
+__device__ __forceinline__ void f6_pack(const unsigned (&c)[32], unsigned (&w)[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) w[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int bit = 6 * i, word = bit >> 5, sh = bit & 31;
+    w[word] |= c[i] << sh;
+    if (sh > 26) w[word + 1] |= c[i] >> (32 - sh);
+  }
+}
+
+// one thread per (pixel, 32-channel block)
+__global__ __launch_bounds__(256) void split_f16f6_kernel(const float* __restrict__ feat, unsigned char* __restrict__ out,
+                                                           long long n_blocks) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_blocks) return;
+  const long long pix = t >> 3;
+  const int blk = (int)(t & 7), u = blk >> 2, g = blk & 3;
+  const float* src = feat + pix * 256 + 32 * blk;
+  float hf[32], lf[32];
+  unsigned char* row = out + pix * F6_ROWB;
+  float mh = 0.f, ml = 0.f;
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * v);
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4 hv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xs = x[j] * F6_S;
+      const _Float16 h = (_Float16)xs;
+      hv[j] = h;
+      hf[4 * v + j] = (float)h;
+      lf[4 * v + j] = (xs - (float)h) * F6_S;
+      mh = fmaxf(mh, fabsf(hf[4 * v + j]));
+      ml = fmaxf(ml, fabsf(lf[4 * v + j]));
+    }
+    *reinterpret_cast<f16x4*>(row + 64 * blk + 8 * v) = hv;
+  }
+  const int sh = f6_scale_exp(mh), sl = f6_scale_exp(ml);
+  const float ih = exp2f((float)-sh), il = exp2f((float)-sl);
+  unsigned ch[32], cl[32], wh[6], wl[6];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    ch[i] = f6_code(hf[i] * ih);
+    cl[i] = f6_code(lf[i] * il);
+  }
+  f6_pack(ch, wh);
+  f6_pack(cl, wl);
+  const i32x4 h4 = {(int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]}, l4 = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]};
+  const i32x2 h2 = {(int)wh[4], (int)wh[5]}, l2 = {(int)wl[4], (int)wl[5]};
+  *reinterpret_cast<i32x4*>(row + F6_H6 + 96 * u + 16 * g) = h4;
+  *reinterpret_cast<i32x2*>(row + F6_H6 + 96 * u + 64 + 8 * g) = h2;
+  *reinterpret_cast<i32x4*>(row + F6_L6 + 96 * u + 16 * g) = l4;
+  *reinterpret_cast<i32x2*>(row + F6_L6 + 96 * u + 64 + 8 * g) = l2;
+  row[F6_SC + 4 * g + u] = (unsigned char)(sh + 127 - 4);
+  row[F6_SC + 4 * g + 2 + u] = (unsigned char)(sl + 127 - 4);
+  if (blk < 7) *reinterpret_cast<i32x4*>(row + F6_END + 16 * blk) = i32x4{0, 0, 0, 0};
+}
+
+int split_f16f6_launch(const float* feat, unsigned char* out, long long n_pixels, hipStream_t s) {
+  const long long nb = n_pixels * 8;
+  split_f16f6_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(feat, out, nb);
+  FGVC_CHECK_LAUNCH("fgvc_split_f16f6");
+  return FGVC_OK;
+}
+
+// six-register FP6 operand from its 16-byte and 8-byte pieces (registers 6 and 7 of the builtin's type stay undefined: the
+// instruction reads six)
+__device__ __forceinline__ i32x8 f6_operand(const i32x4& a, const i32x2& b) {
+  const i32x8 a8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, -1, -1, -1, -1);
+  const i32x8 b8 = __builtin_shufflevector(b, b, 0, 1, -1, -1, -1, -1, -1, -1);
+  return __builtin_shufflevector(a8, b8, 0, 1, 2, 3, 8, 9, -1, -1);
+}
+
+template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong), 8 = no wave stagger (results right)
+__global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const unsigned char* __restrict__ q_sp,
+                                                                      const unsigned char* __restrict__ k_sp, int HWq, int HWk,
+                                                                      float out_scale, float* __restrict__ vol, int kchunk,
+                                                                      int period, int m32) {
+  constexpr int SUB = 2, ROWB = F6_ROWB, LDB = ROWB + 32, ROWS = 32 * SUB, BUFB = ROWS * LDB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int cls = blockIdx.z;                                   // row class: key rows j = period * v + cls
+  const int shift = (cls * m32) & 31;                           // its query tiles start `shift` queries early
+  const int qw0 = blockIdx.x * (NW * 32) + wave * 32 - shift;   // wave-uniform: first query of this wave's tile
+  const int n_v = (HWk - cls + period - 1) / period;            // virtual rows of this class
+
+  // query fragments (B operands) of the two query halves
+  f16x8 bq16[2][8];
+  i32x8 bq6h[2][2], bq6l[2][2];
+  int sq[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const unsigned char* qp = q_sp + (size_t)imin(imax(qw0 + 16 * qt + r, 0), HWq - 1) * ROWB;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bq16[qt][t] = *reinterpret_cast<const f16x8*>(qp + 16 * g + 64 * t);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bq6h[qt][u] = f6_operand(*reinterpret_cast<const i32x4*>(qp + F6_H6 + 96 * u + 16 * g),
+                               *reinterpret_cast<const i32x2*>(qp + F6_H6 + 96 * u + 64 + 8 * g));
+      bq6l[qt][u] = f6_operand(*reinterpret_cast<const i32x4*>(qp + F6_L6 + 96 * u + 16 * g),
+                               *reinterpret_cast<const i32x2*>(qp + F6_L6 + 96 * u + 64 + 8 * g));
+    }
+    sq[qt] = *reinterpret_cast<const int*>(qp + F6_SC + 4 * g);
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(bq16[qt][t]));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile("" ::"v"(bq6h[qt][u]));
+      asm volatile("" ::"v"(bq6l[qt][u]));
+    }
+    asm volatile("" ::"v"(sq[qt]));
+  }
+  const int kb0 = blockIdx.y * kchunk;                // in units of 32 virtual rows
+  const int kb1 = imin(kb0 + kchunk, cdiv(n_v, 32));
+  auto stage_load = [&](int kb, int buf) {
+#pragma unroll
+    for (int i = 0; i < ROWS / NW; ++i) {
+      const int row = wave * (ROWS / NW) + i;
+      const int pix = imin((kb * 32 + row) * period + cls, HWk - 1);
+      const unsigned char* src = k_sp + (size_t)pix * ROWB + 16 * lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
+    }
+  };
+  // waves 0-3 (the older wave of each SIMD: it wins the issue arbitration and would otherwise wait at the stage barrier) stage
+  // all 64 rows of the next stage, two per multiply part; waves 4-7 none (corr_volume_f8.hip, s_memtime probe)
+  const bool stager = wave < NW / 2;
+  auto stage_row = [&](int kb, int buf, int i) {
+    const int row = wave * (2 * ROWS / NW) + i;
+    const int pix = imin((kb * 32 + row) * period + cls, HWk - 1);
+    const unsigned char* src = k_sp + (size_t)pix * ROWB + 16 * lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
+  };
+  static_assert(2 * ROWS / NW == 16, "two DMA rows per multiply part of a staging wave: 2 tiles x 4 parts");
+  stage_load(kb0, 0);
+  __syncthreads();
+
+  const size_t row_pitch = (size_t)period * HWq;
+  const int scol = qw0 + (lane & 31);                                // the column this lane STORES (after the lane swap)
+  const int lane_off = 8 * (lane >> 5) * period * HWq + scol;        // + row 8 (lane >> 5) of the row pair a store covers
+  const bool wave_full = qw0 >= 0 && qw0 + 31 < HWq;
+  const bool defer = (DEBUG & 8) ? false : wave >= NW / 2;
+  f32x4 acc[2][2];
+  int pend_v = -1, n_counted = 0;
+
+  auto store_tile = [&](int vrow0) {
+    if constexpr (DEBUG & 1) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) asm volatile("" ::"v"(acc[kt][qt]));
+      n_counted = -1;
+      return;
+    }
+    float* tile = vol + (size_t)(vrow0 * period + cls) * HWq;
+    const bool full = wave_full && vrow0 + 32 <= n_v;                 // wave-uniform
+    if (!full) n_counted = -1;
+    else if (n_counted >= 0) n_counted += 16;
+    // x = rows 16 kt + 4 g + i of query half 0, y = the same rows of query half 1  ->  after the swap x = rows 16 kt + i (+ 8)
+    // x 32 queries, y = rows 16 kt + 4 + i (+ 8).  Inline assembly with hand-placed wait states (see corr_volume_f8.hip).
+    float x[8], y[8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[4 * kt + i] = acc[kt][0][i] * out_scale;
+        y[4 * kt + i] = acc[kt][1][i] * out_scale;
+      }
+    asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x[e]), "+v"(y[e]));
+    asm volatile("s_nop 1" ::: "memory");
+    if (full) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float* p0 = tile + (size_t)(16 * (e >> 2) + (e & 3)) * row_pitch;
+        __builtin_nontemporal_store(x[e], p0 + lane_off);
+        __builtin_nontemporal_store(y[e], p0 + 4 * row_pitch + lane_off);
+      }
+    } else if (scol >= 0 && scol < HWq) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r0 = 16 * (e >> 2) + (e & 3), r1 = r0 + 4;
+        float* p0 = tile + (size_t)r0 * row_pitch;
+        if (8 * (lane >> 5) < n_v - vrow0 - r0) __builtin_nontemporal_store(x[e], p0 + lane_off);
+        if (8 * (lane >> 5) < n_v - vrow0 - r1) __builtin_nontemporal_store(y[e], p0 + 4 * row_pitch + lane_off);
+      }
+    }
+  };
+
+  // A operand register sets: F = the 8 f16 fragments of a K-128 block (2 key halves x 4 K-32 steps), P = its FP6 operands
+  // (2 key halves x {h6, l6}); S = the scale dwords of a tile's two key halves.  P of a block is read at the start of its F
+  // part, F of the next block at the start of the P part.
+  f16x8 F[2][4];
+  i32x8 Ph[2], Pl[2];
+  int S[2];
+  auto load_F = [&](const unsigned char* ka, int u) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) F[kt][tt] = *reinterpret_cast<const f16x8*>(ka + 16 * kt * LDB + 16 * g + 64 * (4 * u + tt));
+  };
+  auto load_P = [&](const unsigned char* ka, int u) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const unsigned char* p = ka + 16 * kt * LDB + F6_H6 + 96 * u;
+      Ph[kt] = f6_operand(*reinterpret_cast<const i32x4*>(p + 16 * g), *reinterpret_cast<const i32x2*>(p + 64 + 8 * g));
+      Pl[kt] = f6_operand(*reinterpret_cast<const i32x4*>(p + 192 + 16 * g), *reinterpret_cast<const i32x2*>(p + 192 + 64 + 8 * g));
+    }
+  };
+  auto load_S = [&](const unsigned char* ka) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) S[kt] = *reinterpret_cast<const int*>(ka + 16 * kt * LDB + F6_SC + 4 * g);
+  };
+
+  int buf = 0;
+  for (int kb = kb0; kb < kb1; kb += SUB) {
+    const bool more = kb + SUB < kb1;
+    n_counted = 0;
+    load_F(&smem[buf * BUFB + r * LDB], 0);
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) {
+      if (kb + sb >= kb1) break;                       // wave-uniform (ragged tail of the chunk)
+      const unsigned char* ka = &smem[buf * BUFB + (sb * 32 + r) * LDB];
+      const bool next_here = sb + 1 < SUB && kb + sb + 1 < kb1;
+      __builtin_amdgcn_sched_barrier(0);
+      if (defer && pend_v >= 0) store_tile(pend_v);    // waves 4-7: the previous tile leaves under the partner's multiplies
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      load_S(ka);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        load_P(ka, u);                                 // lands during the F part
+        if (more && stager) {
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u);
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(DEBUG & 2)) {
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int qt = 0; qt < 2; ++qt)
+                acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F[kt][tt], bq16[qt][4 * u + tt], acc[kt][qt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) asm volatile("" ::"v"(F[kt][tt]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u == 0) load_F(ka, 1);                     // lands during the P part
+        else if (next_here) load_F(ka + 32 * LDB, 0);
+        if (more && stager) {
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 2);
+          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(DEBUG & 2)) {
+          // scale bytes (opsel): 0 / 1 = h6 of block u = 0 / 1, 2 / 3 = l6; each is 2^(s - 4), so a product enters at 2^-8
+#define FGVC_F6_MFMA(A, B, OA, OB) \
+  acc[kt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc[kt][qt], 2, 2, OA, S[kt], OB, sq[qt])
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+              if (u == 0) FGVC_F6_MFMA(Ph[kt], bq6l[qt][0], 0, 2);
+              else FGVC_F6_MFMA(Ph[kt], bq6l[qt][1], 1, 3);
+            }
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+              if (u == 0) FGVC_F6_MFMA(Pl[kt], bq6h[qt][0], 2, 0);
+              else FGVC_F6_MFMA(Pl[kt], bq6h[qt][1], 3, 1);
+            }
+#undef FGVC_F6_MFMA
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            asm volatile("" ::"v"(Ph[kt]));
+            asm volatile("" ::"v"(Pl[kt]));
+            asm volatile("" ::"v"(S[kt]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int vrow0 = (kb + sb) * 32;
+      if (defer) pend_v = vrow0;
+      else store_tile(vrow0);
+    }
+    if (more && stager) {
+      // the last DMA of the stage was issued inside the second tile: only that tile's own store burst (16, if it was a whole
+      // tile stored right away) is younger and may stay in flight across the barrier.  Waves 4-7 issued no load: no wait.
+      if (!defer && n_counted == 32 && kb + 1 < kb1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+    buf ^= 1;
+  }
+  if (defer && pend_v >= 0) store_tile(pend_v);
+}
+
+static int g_corr6_debug = 0;
+static int g_corr6_cost_pro = 20000, g_corr6_cost_stage = 4600;
+void set_corr6_debug(int v) { g_corr6_debug = v; }
+
+int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int HWq, int HWk, float temperature, float* vol,
+                             hipStream_t s) {
+  const int m32 = HWq & 31;
+  int g = 32;
+  while (g > 1 && (m32 % g) != 0) g >>= 1;                 // gcd(m32, 32) (m32 == 0 -> 32)
+  int period = 32 / g;
+  if (period > 4 || (g_corr6_debug & 4)) period = 1;       // too many classes (or ablation): unshifted, straddling stores
+  const int n_q = cdiv(HWq + (period > 1 ? 31 : 0), 256);  // shifted classes start up to 31 queries early
+  const int n_vb = cdiv(cdiv(HWk, period), 32);            // 32-row blocks of virtual rows per class
+  // key blocks per workgroup: the number of key chunks that minimises  rounds over the 256 CUs x (prologue + stages per chunk)
+  int kchunk = n_vb + (n_vb & 1);
+  {
+    long long best = -1;
+    for (int c = 1; c <= 32; ++c) {
+      int kc = cdiv(n_vb, c);
+      kc += kc & 1;                                         // whole 64-key stages
+      const long long wgs = (long long)n_q * period * cdiv(n_vb, kc);
+      const long long cost = ((wgs + 255) / 256) * ((long long)g_corr6_cost_pro + (long long)g_corr6_cost_stage * (kc / 2));
+      if (best < 0 || cost < best) {
+        best = cost;
+        kchunk = kc;
+      }
+    }
+  }
+  if (g_corr6_debug >> 8) kchunk = g_corr6_debug >> 8;
+  dim3 grid(n_q, cdiv(n_vb, kchunk), period);
+  const float out_scale = 1.0f / (temperature * F6_S * F6_S);
+  const int mm = period > 1 ? m32 : 0;
+#define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, kchunk, period, mm)
+  switch (g_corr6_debug & 11) {
+    case 0: FGVC_C6(0); break;
+    case 1: FGVC_C6(1); break;
+    case 2: FGVC_C6(2); break;
+    case 3: FGVC_C6(3); break;
+    case 8: FGVC_C6(8); break;
+    case 9: FGVC_C6(9); break;
+    case 10: FGVC_C6(10); break;
+    default: FGVC_C6(11); break;
+  }
+#undef FGVC_C6
+  FGVC_CHECK_LAUNCH("fgvc_corr_volume_f16f6");
+  return FGVC_OK;
+}
+
+}  // namespace fgvc

@@ -258,11 +258,24 @@ def split_f16f8(feat: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_f16f6(feat: torch.Tensor) -> torch.Tensor:
+    """(…, 256) f32 L2-normalised rows -> (…, 1024) uint8: per pixel [h = f16(256 x) | h6 | l6 | scales | pad] with h6 / l6 the
+    block-scaled e2m3 forms of h and of its residual (one E8M0 scale per 32 channels; layout: csrc/corr_volume_f6.hip),
+    the operand format of fgvc_corr_volume_f16f6."""
+    feat = _chk(feat, torch.float32, "feat")
+    Cc = feat.shape[-1]
+    n = feat.numel() // Cc
+    out = torch.empty((*feat.shape[:-1], 4 * Cc), device=feat.device, dtype=torch.uint8)
+    _lib.call("fgvc_split_f16f6", _ptr(feat), _ptr(out), n, Cc, _stream(feat))
+    return out
+
+
 def corr_volume(qfeat: torch.Tensor, kfeat: torch.Tensor, temperature: float = 1.0, precision: str = "f32",
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Dense volume vol[key j][query i] = <k_j, q_i>/temperature, (HWk, HWq) f32.
     precision 'f32': qfeat (HWq,C), kfeat (HWk,C) f32.  'bf16x3' / 'bf16': the split_bf16() forms (HW,2,C).
-    'f16f8': the split_f16f8() forms (HW, 4C) uint8 of L2-normalised rows, C == 256 (parity-grade, the fastest)."""
+    'f16f6' / 'f16f8': the split_f16f6() / split_f16f8() forms (HW, 4C) uint8 of L2-normalised rows, C == 256 (parity-grade;
+    f16f6 is the fastest)."""
     HWq, HWk, Cc = qfeat.shape[0], kfeat.shape[0], qfeat.shape[-1]
     if out is None:
         out = torch.empty((HWk, HWq), device=qfeat.device, dtype=torch.float32)
@@ -272,10 +285,10 @@ def corr_volume(qfeat: torch.Tensor, kfeat: torch.Tensor, temperature: float = 1
         qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
         _lib.call("fgvc_corr_volume_f32", _ptr(qfeat), _ptr(kfeat), Cc, HWq, HWk, float(temperature), _ptr(out),
                   _stream(qfeat))
-    elif precision == "f16f8":
+    elif precision in ("f16f8", "f16f6"):
         qfeat, kfeat = _chk(qfeat, torch.uint8, "qfeat"), _chk(kfeat, torch.uint8, "kfeat")
         assert qfeat.dim() == 2 and qfeat.shape[1] % 4 == 0 and kfeat.shape[1] == qfeat.shape[1]
-        _lib.call("fgvc_corr_volume_f16f8", _ptr(qfeat), _ptr(kfeat), qfeat.shape[1] // 4, HWq, HWk, float(temperature), _ptr(out),
+        _lib.call("fgvc_corr_volume_" + precision, _ptr(qfeat), _ptr(kfeat), qfeat.shape[1] // 4, HWq, HWk, float(temperature), _ptr(out),
                   _stream(qfeat))
     elif precision in ("bf16x3", "bf16"):
         qfeat, kfeat = _chk(qfeat, torch.int16, "qfeat"), _chk(kfeat, torch.int16, "kfeat")

@@ -162,6 +162,17 @@ int fgvc_split_f16f8(const float* feat, uint8_t* out, int64_t n_pixels, int C, v
 int fgvc_corr_volume_f16f8(const uint8_t* q_split, const uint8_t* k_split, int C, int HWq, int HWk,
                            float temperature, float* vol, void* stream);
 
+/* The same volume (replaces affinity_utils.py:6-21 `compute_affinity`, local_attention.py:231) at 1.5 bf16-MFMA times per tile: the
+ * cross sums in block-scaled FP6 (e2m3, one E8M0 scale per 32 consecutive channels) on v_mfma_scale_f32_16x16x128_f8f6f4, which
+ * retires FP6 at four times the f16 rate.  Same accuracy as f16f8 (simulated and measured; asserted bound 1e-3 logit), rows must be
+ * L2-normalised, C == 256.
+ *   fgvc_split_f16f6: feat [n][256] f32 -> out [n][1024] bytes = [h: 256 f16 | h6: 192 B | l6: 192 B | 16 scale bytes | zero pad]
+ *   (exact layout: fgvc_amd/csrc/corr_volume_f6.hip).
+ *   fgvc_corr_volume_f16f6: q, k in that format -> vol [HWk][HWq] f32 = <k, q> / temperature. */
+int fgvc_split_f16f6(const float* feat, uint8_t* out, int64_t n_pixels, int C, void* stream);
+int fgvc_corr_volume_f16f6(const uint8_t* q_split, const uint8_t* k_split, int C, int HWq, int HWk,
+                           float temperature, float* vol, void* stream);
+
 /* ---- A5, topk=None branch: weights over EVERY unmasked key instead of the k best
  * replaces local_attention.py:376-383 (`cur_affinity.softmax(dim=1)` / `.clamp(min=0)**2` over the (T*HWk x step) slab and the
  * einsum with value_vec).  Called once per key slot t with that slot's dense volume vol[HWk][HWq] (fgvc_corr_volume_*, already
