@@ -133,7 +133,9 @@ __device__ __forceinline__ i32x8 f6_operand(const i32x4& a, const i32x2& b) {
   return __builtin_shufflevector(a8, b8, 0, 1, 2, 3, 8, 9, -1, -1);
 }
 
-template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong), 8 = no wave stagger (results right)
+template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong); results right: 8 = no wave stagger,
+                               // 16 = DMA spread over both tiles of a stage, 64 = F fragments re-read in one piece;
+                               // 32 = s_memtime probe of one workgroup, written over the first floats of vol
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const unsigned char* __restrict__ q_sp,
                                                                       const unsigned char* __restrict__ k_sp, int HWq, int HWk,
                                                                       float out_scale, float* __restrict__ vol, int kchunk,
@@ -148,6 +150,10 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   const int qw0 = blockIdx.x * (NW * 32) + wave * 32 - shift;   // wave-uniform: first query of this wave's tile
   const int n_v = (HWk - cls + period - 1) / period;            // virtual rows of this class
 
+  const bool probe = (DEBUG & 32) != 0;   // s_memtime probe: waves 0 and 4 of every workgroup leave a record in row 0 of vol
+  long long p_start = 0, p_pro = 0, p_comp = 0, p_store = 0, p_sync = 0, c0 = 0;
+  int p_stages = 0;
+  if (probe) p_start = __builtin_amdgcn_s_memtime();
   // query fragments (B operands) of the two query halves
   f16x8 bq16[2][8];
   i32x8 bq6h[2][2], bq6l[2][2];
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   static_assert(2 * ROWS / NW == 16, "two DMA rows per multiply part of a staging wave: 2 tiles x 4 parts");
   stage_load(kb0, 0);
   __syncthreads();
+  if (probe) p_pro = __builtin_amdgcn_s_memtime() - p_start;
 
   const size_t row_pitch = (size_t)period * HWq;
   const int scol = qw0 + (lane & 31);                                // the column this lane STORES (after the lane swap)
@@ -281,11 +288,38 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     for (int kt = 0; kt < 2; ++kt) S[kt] = *reinterpret_cast<const int*>(ka + 16 * kt * LDB + F6_SC + 4 * g);
   };
 
+  auto load_F_half = [&](const unsigned char* ka, int u, int half) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int tt = 2 * half; tt < 2 * half + 2; ++tt)
+        F[kt][tt] = *reinterpret_cast<const f16x8*>(ka + 16 * kt * LDB + 16 * g + 64 * (4 * u + tt));
+  };
+  // DMA placement.  vmcnt counts loads and stores in issue order, so the wait that retires a stage's DMA also waits for every
+  // OLDER store to be acknowledged by memory -- microseconds under a saturated write stream.  All 16 rows of a staging wave are
+  // therefore issued inside the stage's FIRST tile, ahead of both store bursts of the stage: the wait before the barrier is then
+  // vmcnt(32) and covers nothing younger than the previous stage's stores.  (DEBUG & 16: the earlier placement, 8 rows per tile,
+  // vmcnt(16): waits for the first tile's burst.)
+  constexpr bool DMA_EARLY = !(DEBUG & 16);
+  constexpr bool F_HALVES = !(DEBUG & 64);
+  auto stage_rows = [&](int kb, int buf, int sb, int slot) {   // slot 0..3 of tile sb
+    if constexpr (DMA_EARLY) {
+      if (sb == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_row(kb, buf, 4 * slot + i);
+      }
+    } else {
+      stage_row(kb, buf, 8 * sb + 2 * slot);
+      stage_row(kb, buf, 8 * sb + 2 * slot + 1);
+    }
+  };
+
   int buf = 0;
   for (int kb = kb0; kb < kb1; kb += SUB) {
     const bool more = kb + SUB < kb1;
     n_counted = 0;
     load_F(&smem[buf * BUFB + r * LDB], 0);
+    if (probe) c0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int sb = 0; sb < SUB; ++sb) {
       if (kb + sb >= kb1) break;                       // wave-uniform (ragged tail of the chunk)
@@ -293,6 +327,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
       const bool next_here = sb + 1 < SUB && kb + sb + 1 < kb1;
       __builtin_amdgcn_sched_barrier(0);
       if (defer && pend_v >= 0) store_tile(pend_v);    // waves 4-7: the previous tile leaves under the partner's multiplies
+      if (probe && defer) { const long long c1 = __builtin_amdgcn_s_memtime(); p_store += c1 - c0; c0 = c1; }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -302,32 +337,37 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         load_P(ka, u);                                 // lands during the F part
-        if (more && stager) {
-          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u);
-          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 1);
-        }
+        if (more && stager) stage_rows(kb + SUB, buf ^ 1, sb, 2 * u);
+        // the F fragments of the NEXT block: the first two K-32 steps are re-read as soon as their last reader has issued, the
+        // other two at the start of the P part (256 pipe cycles before their first reader: not enough on their own)
+        const unsigned char* nka = (u == 0) ? ka : ka + 32 * LDB;
+        const bool nxt = (u == 0) || next_here;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(DEBUG & 2)) {
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt)
+        for (int half = 0; half < 2; ++half) {
+          if constexpr (!(DEBUG & 2)) {
+#pragma unroll
+            for (int tt = 2 * half; tt < 2 * half + 2; ++tt)
+#pragma unroll
+              for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                  acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F[kt][tt], bq16[qt][4 * u + tt], acc[kt][qt], 0, 0, 0);
+          } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-              for (int qt = 0; qt < 2; ++qt)
-                acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F[kt][tt], bq16[qt][4 * u + tt], acc[kt][qt], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) asm volatile("" ::"v"(F[kt][tt]));
+              for (int tt = 2 * half; tt < 2 * half + 2; ++tt) asm volatile("" ::"v"(F[kt][tt]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (F_HALVES) {
+            if (nxt) load_F_half(nka, 1 - u, half);
+          } else if (half == 1) {
+            if (nxt) load_F(nka, 1 - u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (u == 0) load_F(ka, 1);                     // lands during the P part
-        else if (next_here) load_F(ka + 32 * LDB, 0);
-        if (more && stager) {
-          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 2);
-          stage_row(kb + SUB, buf ^ 1, 8 * sb + 4 * u + 3);
-        }
+        if (more && stager) stage_rows(kb + SUB, buf ^ 1, sb, 2 * u + 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(DEBUG & 2)) {
           // scale bytes (opsel): 0 / 1 = h6 of block u = 0 / 1, 2 / 3 = l6; each is 2^(s - 4), so a product enters at 2^-8
@@ -359,19 +399,35 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
         __builtin_amdgcn_sched_barrier(0);
       }
       const int vrow0 = (kb + sb) * 32;
+      if (probe) { const long long c1 = __builtin_amdgcn_s_memtime(); p_comp += c1 - c0; c0 = c1; }
       if (defer) pend_v = vrow0;
       else store_tile(vrow0);
+      if (probe && !defer) { const long long c1 = __builtin_amdgcn_s_memtime(); p_store += c1 - c0; c0 = c1; }
     }
     if (more && stager) {
-      // the last DMA of the stage was issued inside the second tile: only that tile's own store burst (16, if it was a whole
-      // tile stored right away) is younger and may stay in flight across the barrier.  Waves 4-7 issued no load: no wait.
-      if (!defer && n_counted == 32 && kb + 1 < kb1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      // staging waves never defer: their stores of this stage are the 16 x (whole tiles stored) youngest operations
+      if (DMA_EARLY && n_counted == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (!DMA_EARLY && n_counted == 32 && kb + 1 < kb1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
+    if (probe) { p_sync += __builtin_amdgcn_s_memtime() - c0; ++p_stages; }
     buf ^= 1;
   }
   if (defer && pend_v >= 0) store_tile(pend_v);
+  if (probe && lane == 0 && (wave & 3) == 0) {
+    // 48-byte records over the first floats of vol (tools/time_corr6.py); row 0 is only written by the first stage of the
+    // class-0 workgroups of the first key chunk, long before any workgroup ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int* o = reinterpret_cast<int*>(vol) + 12 * (2 * wg + (wave >> 2));
+    const long long now = __builtin_amdgcn_s_memtime();
+    o[0] = (int)p_pro; o[1] = (int)p_comp; o[2] = (int)p_store; o[3] = (int)p_sync; o[4] = (int)(now - p_start); o[5] = p_stages;
+    *reinterpret_cast<long long*>(o + 6) = p_start;
+    *reinterpret_cast<long long*>(o + 8) = (long long)__builtin_amdgcn_s_memrealtime();
+    o[10] = (int)__builtin_amdgcn_s_getreg(6 << 11 | 20);   // HW_REG_XCC_ID
+    o[11] = wg;
+  }
 }
 
 static int g_corr6_debug = 0;
@@ -407,15 +463,22 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
   const float out_scale = 1.0f / (temperature * F6_S * F6_S);
   const int mm = period > 1 ? m32 : 0;
 #define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, kchunk, period, mm)
-  switch (g_corr6_debug & 11) {
+  switch (g_corr6_debug & 123) {
+    case 32: FGVC_C6(32); break;
+    case 33: FGVC_C6(33); break;
+    case 34: FGVC_C6(34); break;
     case 0: FGVC_C6(0); break;
     case 1: FGVC_C6(1); break;
     case 2: FGVC_C6(2); break;
     case 3: FGVC_C6(3); break;
     case 8: FGVC_C6(8); break;
     case 9: FGVC_C6(9); break;
-    case 10: FGVC_C6(10); break;
-    default: FGVC_C6(11); break;
+    case 16: FGVC_C6(16); break;
+    case 64: FGVC_C6(64); break;
+    case 80: FGVC_C6(80); break;
+    default:
+      set_error("fgvc_corr_volume_f16f6: corr6_debug = %d is not an instantiated variant", g_corr6_debug);
+      return FGVC_ERR_INVALID_ARG;
   }
 #undef FGVC_C6
   FGVC_CHECK_LAUNCH("fgvc_corr_volume_f16f6");

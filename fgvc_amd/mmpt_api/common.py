@@ -178,17 +178,18 @@ def masked_attention(query, key, value, mask, temperature=1, topk=None, normaliz
 def compute_affinity(src_img, dst_img, temperature=1.0, normalize=True, softmax_dim=None, mask=None,
                      precision: str = "f32"):
     """affinity_utils.py:6-30: (N, HWsrc, HWdst) dense affinity = the materialised correlation volume.
-    `precision` ('f32' | 'f16f8' | 'bf16x3' | 'bf16') is an extension selecting the MFMA arithmetic ('f16f8': C == 256 and
-    normalize=True; the fastest form inside the 1e-3 score bar)."""
+    `precision` ('f32' | 'f16f6' | 'f16f8' | 'bf16x3' | 'bf16') is an extension selecting the MFMA arithmetic ('f16f6' / 'f16f8':
+    C == 256 and normalize=True; 'f16f6' is the fastest form inside the 1e-3 score bar)."""
     n = src_img.shape[0]
     outs = []
     for b in range(n):
         sf = ops.normalize_to_hwc(src_img[b:b + 1].float(), normalize, pad=True)[0]
         df = ops.normalize_to_hwc(dst_img[b:b + 1].float(), normalize, pad=True)[0]
-        if precision == "f16f8":
+        if precision in ("f16f8", "f16f6"):
             if sf.shape[-1] != 256 or not normalize:
-                raise NotImplementedError("f16f8 volume needs C == 256 and normalize=True")
-            sf, df = ops.split_f16f8(sf), ops.split_f16f8(df)
+                raise NotImplementedError(f"{precision} volume needs C == 256 and normalize=True")
+            split = ops.split_f16f8 if precision == "f16f8" else ops.split_f16f6
+            sf, df = split(sf), split(df)
         elif precision != "f32":
             if sf.shape[-1] % 64:
                 raise NotImplementedError("bf16 volume needs C % 64 == 0")

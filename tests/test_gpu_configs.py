@@ -128,6 +128,14 @@ def test_cfg5_dense_volume_bf16_full_size_and_accuracy_report(dev, clip5):
     assert e8max < 5e-4, e8max
     REPORT["cfg5_f16f8_vs_bf16x3_max_abs_logit_err"] = e8max
     del vol8, sp
+    sp = ops.split_f16f6(clip5[:2])                      # and the f16 + block-scaled FP6 variant
+    vol6 = ops.corr_volume(sp[1], sp[0], TAU, "f16f6")
+    e6max = 0.0
+    for r0 in range(0, HW5, 2048):
+        e6max = max(e6max, float((vol6[r0:r0 + 2048] - vol3[r0:r0 + 2048]).abs().max()))
+    assert e6max < 5e-4, e6max
+    REPORT["cfg5_f16f6_vs_bf16x3_max_abs_logit_err"] = e6max
+    del vol6, sp
     expect_sum = float((k.double().sum(0) * q.double().sum(0)).sum() / TAU)
     g = torch.Generator().manual_seed(12)
     kk = torch.randint(0, HW5, (8192,), generator=g).to(dev)

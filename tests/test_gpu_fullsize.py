@@ -138,11 +138,11 @@ def test_dense_volume_linearity_and_samples(dev, clip):
     kk = torch.randint(0, HW, (4096,), generator=g).to(dev)
     qq = torch.randint(0, HW, (4096,), generator=g).to(dev)
     ref = (k[kk].double() * q[qq].double()).sum(1) / TAU
-    sp = ops.split_f16f8(clip[:2])
-    for prec, tol in (("f32", 2e-5), ("bf16x3", 1e-3), ("f16f8", 1e-3)):
+    sp = {"f16f8": ops.split_f16f8(clip[:2]), "f16f6": ops.split_f16f6(clip[:2])}
+    for prec, tol in (("f32", 2e-5), ("bf16x3", 1e-3), ("f16f8", 1e-3), ("f16f6", 1e-3)):
         vol = vols.get(prec)
         if vol is None:
-            vol = ops.corr_volume(sp[1], sp[0], TAU, prec) if prec == "f16f8" else ops.corr_volume(hl[1], hl[0], TAU, prec)
+            vol = ops.corr_volume(sp[prec][1], sp[prec][0], TAU, prec) if prec in sp else ops.corr_volume(hl[1], hl[0], TAU, prec)
         assert vol.shape == (HW, HW)
         assert abs(float(vol.double().sum()) - expect_sum) <= 1e-6 * HW * HW * 0.2 + 1e-3 * abs(expect_sum)
         assert float((vol[kk, qq].double() - ref).abs().max()) < tol

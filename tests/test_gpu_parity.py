@@ -167,11 +167,14 @@ def test_corr_volume(dev):
             v8 = ops.corr_volume(ops.split_f16f8(qf), ops.split_f16f8(kf), 0.07, "f16f8").cpu()
             e8 = float((v8.double() - ref64).abs().max())
             assert e8 < TOL / 2, e8
+            v6 = ops.corr_volume(ops.split_f16f6(qf), ops.split_f16f6(kf), 0.07, "f16f6").cpu()     # FP6 cross terms: 1.5 MFMA times
+            e6 = float((v6.double() - ref64).abs().max())
+            assert e6 < TOL / 2, e6
         print(f"C={C}: max |err| logits  f32 {e32:.2e}  bf16x3 {ex3:.2e}  f16f8 {e8:.2e}  bf16 {eb:.2e}")
 
 
 def test_corr_volume_f16f8_ragged_shapes_and_adversarial_rows(dev):
-    """fgvc_corr_volume_f16f8 on grids whose HW is not a multiple of 32 (row classes of equal line phase: periods 1, 2, 4 and the
+    """fgvc_corr_volume_f16f8 and fgvc_corr_volume_f16f6 on grids whose HW is not a multiple of 32 (row classes of equal line phase: periods 1, 2, 4 and the
     unshifted fallback), non-square query/key grids, and on rows built to stress the split (one-hot, heavy-tailed, tiny and
     negative-zero components): every entry within 1e-3 of the float64 product."""
     from fgvc_amd import ops
@@ -191,10 +194,64 @@ def test_corr_volume_f16f8_ragged_shapes_and_adversarial_rows(dev):
                 x = torch.relu(torch.randn(1, 256, generator=g) + 0.3 * x)
             return torch.nn.functional.normalize(x, dim=1)
         q, k = rows(HWq), rows(HWk)
-        vol = ops.corr_volume(ops.split_f16f8(q.to(dev)), ops.split_f16f8(k.to(dev)), 0.07, "f16f8").cpu()
-        assert vol.shape == (HWk, HWq)
-        err = float((vol.double() - (k.double() @ q.double().t()) / 0.07).abs().max())
-        assert err < TOL, (HWq, HWk, kind, err)
+        ref = (k.double() @ q.double().t()) / 0.07
+        for prec, split in (("f16f8", ops.split_f16f8), ("f16f6", ops.split_f16f6)):
+            vol = ops.corr_volume(split(q.to(dev)), split(k.to(dev)), 0.07, prec).cpu()
+            assert vol.shape == (HWk, HWq)
+            err = float((vol.double() - ref).abs().max())
+            assert err < TOL, (prec, HWq, HWk, kind, err)
+
+
+def _decode_f16f6(sp):
+    """fgvc_split_f16f6 rows (n, 1024) uint8 -> h, h6, l6 as (n, 256) float64 (h6 / l6 dequantised with their 2^(s-4) scales);
+    the layout is documented in fgvc_amd/csrc/corr_volume_f6.hip"""
+    import numpy as np
+    sp = sp.cpu().numpy()
+    n = sp.shape[0]
+    h = sp[:, :512].copy().view(np.float16).astype(np.float64)
+    lut = np.array([(m / 8.0 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 1)) for e in range(4) for m in range(8)])
+    lut = np.concatenate([lut, -lut])
+    outs = []
+    for base in (512, 704):
+        vals = np.zeros((n, 256))
+        for u in range(2):
+            for g in range(4):
+                b16 = sp[:, base + 96 * u + 16 * g: base + 96 * u + 16 * g + 16]
+                b8 = sp[:, base + 96 * u + 64 + 8 * g: base + 96 * u + 64 + 8 * g + 8]
+                bits = np.unpackbits(np.concatenate([b16, b8], axis=1), axis=1, bitorder="little")     # (n, 192)
+                codes = (bits.reshape(n, 32, 6) * (1 << np.arange(6))).sum(-1)
+                sc = sp[:, 896 + 4 * g + (u if base == 512 else 2 + u)].astype(np.int64) - 127
+                vals[:, 128 * u + 32 * g: 128 * u + 32 * g + 32] = lut[codes] * (2.0 ** sc)[:, None]
+        outs.append(vals)
+    return h, outs[0], outs[1]
+
+
+def test_split_f16f6_format(dev):
+    """The operand rows of fgvc_corr_volume_f16f6 decoded on the host: h is exactly f16(256 x); h6 / l6 (block-scaled e2m3, one
+    E8M0 scale per 32 channels) reproduce h and its residual to half an e2m3 step of their block; the pad is zero."""
+    import numpy as np
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    f = torch.nn.functional.normalize(torch.randn(2048, 256, generator=g), dim=1)
+    f[:64] = 0
+    f[:64, 3] = 1.0                                           # one-hot rows: all-zero blocks next to a block holding 256
+    f[64:128] = torch.nn.functional.normalize(f[64:128] * (torch.rand(64, 256, generator=g) < 0.05) + 1e-6, dim=1)
+    sp = ops.split_f16f6(f.to(dev))
+    assert sp.shape == (2048, 1024) and sp.dtype == torch.uint8
+    h, h6, l6 = _decode_f16f6(sp)
+    x = f.double().numpy()
+    h_ref = (f.numpy() * np.float32(256)).astype(np.float16).astype(np.float64)
+    l_ref = (x * 256 - h_ref) * 256
+    assert (h == h_ref).all()
+    assert (sp[:, 912:] == 0).all()
+    for got, ref in ((h6 * 16, h_ref), (l6 * 16, l_ref)):     # each stored scale carries 2^-4
+        bm = np.abs(ref).reshape(-1, 8, 32).max(-1, keepdims=True).repeat(32, -1).reshape(ref.shape)
+        bound = np.maximum(np.abs(ref) / 16, bm / 7.5 / 8) * 1.0001 + 1e-30
+        assert (np.abs(got - ref) <= bound).all()
+    # the three sums the kernel forms reproduce the float64 product to the parity bar
+    k, q = slice(0, 1024), slice(1024, 2048)
+    tot = h[k] @ h[q].T + (h6[k] @ l6[q].T + l6[k] @ h6[q].T)
+    assert float(np.abs(tot / 65536.0 / 0.07 - (x[k] @ x[q].T) / 0.07).max()) < TOL
 
 
 def test_dense_golden(dev, golden):

@@ -27,7 +27,7 @@ def per_kernel(d):
 
 fetch, write, tcc, mfma = (per_kernel(d) for d in sys.argv[1:5])
 names = {"fgvc_pair_topk_bf16x4": "pair_topk_kernel_v4", "fgvc_pair_topk_f32": "pair_topk_kernel_v3",
-         "fgvc_corr_volume_f16f8": "corr_volume_f16f8_v2_kernel", "fgvc_corr_volume_bf16x3": "corr_volume_bf16_kernel<256, 3",
+         "fgvc_corr_volume_f16f6": "corr_volume_f16f6_kernel", "fgvc_corr_volume_f16f8": "corr_volume_f16f8_v2_kernel", "fgvc_corr_volume_bf16x3": "corr_volume_bf16_kernel<256, 3",
          "fgvc_corr_volume_bf16": "corr_volume_bf16_kernel<256, 1", "fgvc_corr_volume_f32": "corr_volume_f32_kernel",
          "fgvc_conv_split_f32": "conv_split_kernel<3, 256", "fgvc_conv64_split_f32": "conv64_kernel",
          "fgvc_stem7_split_f32": "stem7_kernel", "fgvc_conv_s2_split_f32": "conv_s2_kernel<3>"}
@@ -35,7 +35,7 @@ HW = 120 * 214
 tiles = -(-HW // 32) * -(-HW // 32)
 # matrix-pipe cycles the dense kernels execute by construction (ragged tiles included), for the cross-check
 expect = {"fgvc_corr_volume_bf16x3": tiles * 48 * 32, "fgvc_corr_volume_bf16": tiles * 16 * 32,
-          "fgvc_corr_volume_f16f8": tiles * 1024, "fgvc_corr_volume_f32": tiles * 128 * 64}
+          "fgvc_corr_volume_f16f6": tiles * 768, "fgvc_corr_volume_f16f8": tiles * 1024, "fgvc_corr_volume_f32": tiles * 128 * 64}
 res = {}
 for key, sub in names.items():
     def avg(tbl, cn):

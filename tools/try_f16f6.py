@@ -80,7 +80,7 @@ for (H, W) in sizes:
     ref = (f[0][kk].double() * f[1][qq].double()).sum(1) / tau
     v3 = ops.corr_volume(hl[1], hl[0], tau, "bf16x3")
     errs = {}
-    for dbg, label in ((0, "default"), (8, "no stagger"), (4, "no classes")):
+    for dbg, label in ((0, "default"), (8, "no stagger"), (4, "no classes"), (16, "late dma"), (64, "whole F"), (80, "both")):
         ops.set_option("corr6_debug", dbg)
         v6 = ops.corr_volume(s6[1], s6[0], tau, "f16f6")
         errs[label] = (float((v6[kk, qq].double() - ref).abs().max()), float((v6 - v3).abs().max()))
@@ -91,8 +91,9 @@ for (H, W) in sizes:
     del v3
     if quick:
         continue
-    cfgs = [("f16f6", 0), ("f6 no stagger", 8), ("f6 no stores", 1), ("f6 no mfma", 2), ("f6 neither", 3)]
-    for kc in (20, 40, 60, 82, 100, 134, 202):
+    cfgs = [("f16f6", 0), ("f6 no stagger", 8), ("f6 late dma", 16), ("f6 whole F", 64), ("f6 late dma whole F", 80), ("f6 no stores", 1), ("f6 no mfma", 2),
+            ("f6 neither", 3)]
+    for kc in (60, 82, 100, 134):
         cfgs.append((f"f6 kchunk {kc}", kc << 8))
     best, last = {}, {}
 
