@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr-volume", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="MIOpen immediate mode (clean profiles)")
+    ap.add_argument("--pair-fmt", default="f16", choices=["f16", "bf16"],
+                    help="operands of the split pair kernel: f16 = fgvc_pair_topk_f16x3 (default), bf16 = fgvc_pair_topk_bf16x4 (A/B)")
     ap.add_argument("--pair-precision", default="auto", choices=["auto", "f32", "split"],
                     help="pair top-k kernel: split = fgvc_pair_topk_bf16x4 (default where it applies), f32 = fgvc_pair_topk_f32")
     ap.add_argument("--encoder-lanes", type=int, default=None,
@@ -240,6 +242,7 @@ def main():
     if a.no_conv64:
         ResNet.use_conv64 = False
     model = build_tracker(wl, dev)
+    model.test_cfg["pair_split_fmt"] = a.pair_fmt                    # the encoder writes the bank in the pair kernel's operand format
     cfg = model.engine_config()
     cfg.pair_precision = a.pair_precision
     cfg.regroup = False                                              # all points are given at frame 0 of the video
@@ -354,16 +357,18 @@ def main():
         fl = 2.0 * HW * n_disc * C * pair_tag[1]                       # windowed FLOPs of the launch's pairs
         f32_tf = fl / (pair_ms * 1e-3) / 1e12
         split = pair_tag[0] == "pair_split"
-        name = "fgvc_pair_topk_bf16x4" if split else "fgvc_pair_topk_f32"
+        name = ("fgvc_pair_topk_f16x3" if cfg.pair_split_fmt == "f16" else "fgvc_pair_topk_bf16x4") if split else "fgvc_pair_topk_f32"
+        n_prod = (3 if cfg.pair_split_fmt == "f16" else SPLIT_PRODUCTS) if split else 1
         pm = pmc(name)
         kernels["pair_topk"] = {
             "kernel": name, "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": f32_tf / (BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS),
             "what": "ALGORITHMIC windowed f32 FLOPs (2 HW N_disc C per pair, N_disc = 697) / mean launch duration",
-            "executed_tflops": (SPLIT_PRODUCTS if split else 1) * f32_tf,
-            "frac_executed": (SPLIT_PRODUCTS * f32_tf / BF16_MFMA_PEAK_TFLOPS) if split else f32_tf / F32_MFMA_PEAK_TFLOPS,
-            "executed_note": "4 bf16 partial products per f32-grade product, in-window candidates only (the 4x8-block tiling "
-                             "multiplies 1312 candidates per query for 697 in the disc)" if split else "exact f32 MFMA",
+            "executed_tflops": n_prod * f32_tf,
+            "frac_executed": (n_prod * f32_tf / BF16_MFMA_PEAK_TFLOPS) if split else f32_tf / F32_MFMA_PEAK_TFLOPS,
+            "executed_note": f"{n_prod} 16-bit partial products per f32-grade product (f16: h*h + l*h + h*l; bf16: + lo*lo), in-window "
+                             "candidates only (the 4x8-block tiling multiplies 1312 candidates per query for 697 in the disc)"
+                             if split else "exact f32 MFMA",
             "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
             "ms_per_launch": pair_ms, "pairs_per_launch": pair_tag[1], "launches_timed": n_l,
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch")}
@@ -376,7 +381,8 @@ def main():
         "value": n_frames_total / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (encoder stages and correlation: every f32 value as 2 x bf16, partial products on the bf16 MFMA pipe, f32 accumulate)",
+        "dtype": "f32 (every f32 value as two 16-bit parts -- bf16 hi/lo in the encoder, f16 h/l in the correlation -- partial products on "
+                 "the 16-bit MFMA pipe, f32 accumulate)",
         "data": "synthetic",
         "config": {"workload": (f"{a.workload}: one {T}x{h}x{w} video per step = {world} clip(s) of {Tc} frames, one per rank -> {Hf}x{Wf}x{C} "
                                 f"features, top-10, radius 15, tau 0.07, P={P}" if a.mode == "video" else

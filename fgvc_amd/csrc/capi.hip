@@ -45,7 +45,7 @@ int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, fl
 int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
-int normalize_nhwc_launch(const float*, float*, uint16_t*, int, int, int, int, int, hipStream_t);
+int normalize_nhwc_launch(const float*, float*, uint16_t*, int, int, int, int, int, int, hipStream_t);
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
 
 void set_conv_cot_cap(int);
@@ -59,6 +59,12 @@ void set_conv_s2_debug(int);
 void set_pair_v4_products(int);
 int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, int32_t*,
                         float*, hipStream_t);
+int split_f16x2_launch(const float*, uint16_t*, long long, int, hipStream_t);
+int pair_topk_v5_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, int32_t*,
+                        float*, hipStream_t);
+void set_pair_v5_debug(int);
+int pair_v5_timeout_flag();
+int pair_v5_probe_read(long long*);
 void set_corr_debug(int);
 int split_f16f8_launch(const float*, unsigned char*, long long, int, hipStream_t);
 int corr_volume_f16f8_launch(const unsigned char*, const unsigned char*, int, int, float, float*, hipStream_t);
@@ -121,6 +127,10 @@ int fgvc_set_option(const char* name, int value) {
                                                    // for similar vectors that term is a one-signed ~4e-6, not noise
     FGVC_REQUIRE(value == 3 || value == 4, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_bf16_products must be 3 or 4");
     set_pair_v4_products(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "pair_f16_debug") == 0) {   // fgvc_pair_topk_f16x3 ablations (results wrong): 1 = no selection, 2 = no MFMA, 4 = no staging,
+    set_pair_v5_debug(value);                  // 16 = prologue only, 32 = no epilogue, 64 = no main loop
     return FGVC_OK;
   }
   if (strcmp(name, "pair_bf16_debug") == 0) {   // same for fgvc_pair_topk_bf16x4: 1 = no selection, 2 = no MFMA, 4 = no staging
@@ -202,6 +212,50 @@ int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const 
   if (n_pairs == 0) return FGVC_OK;
   return pair_topk_v4_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked != 0 && any_limit,
                              idx_out, score_out, (hipStream_t)stream);
+}
+
+int fgvc_split_f16x2(const float* feat, uint16_t* h_l, int64_t n_pixels, int C, void* stream) {
+  FGVC_REQUIRE(feat && h_l, FGVC_ERR_INVALID_ARG, "fgvc_split_f16x2: null pointer");
+  FGVC_REQUIRE(n_pixels >= 0 && C > 0 && C % 4 == 0, FGVC_ERR_INVALID_ARG, "fgvc_split_f16x2: C must be a multiple of 4");
+  FGVC_REQUIRE(aligned16(feat) && aligned16(h_l), FGVC_ERR_INVALID_ARG, "fgvc_split_f16x2: 16-byte alignment required");
+  if (n_pixels == 0) return FGVC_OK;
+  return split_f16x2_launch(feat, h_l, n_pixels, C, (hipStream_t)stream);
+}
+
+int fgvc_pair_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq,
+                         int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
+                         float* score_out, void* stream) {
+  FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16x3: null pointer");
+  FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_f16x3: qsplit/ksplit/pairs must be 16-byte aligned");
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: C=%d unsupported (256 only; use fgvc_pair_topk_f32)", C);
+  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && n_pairs >= 0, FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_f16x3: bad shape Hq=%d Wq=%d Hk=%d Wk=%d n_pairs=%d", Hq, Wq, Hk, Wk, n_pairs);
+  FGVC_REQUIRE(topk >= 1 && topk <= 10, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: topk=%d outside 1..10", topk);
+  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16x3: negative mask parameter");
+  FGVC_REQUIRE(n_pairs <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: n_pairs=%d > 65535 per call", n_pairs);
+  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
+  FGVC_REQUIRE(!any_limit || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
+               "fgvc_pair_topk_f16x3: a spatial mask needs equal query/key grids (local_attention.py:331)");
+  FGVC_REQUIRE(Hk < 32768 && Wk < 32768 && Hq < 32768 && Wq < 32768 && (long long)Hk * Wk < (1ll << 30) &&
+                   (long long)Hq * Wq < (1ll << 30),
+               FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: grid too large");
+  if (n_pairs == 0) return FGVC_OK;
+  return pair_topk_v5_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked != 0 && any_limit,
+                             idx_out, score_out, (hipStream_t)stream);
+}
+
+/* 1 if a wave of an earlier fgvc_pair_topk_f16x3 launch gave up waiting on its key-block ring (a bug, never expected: the spins are
+ * bounded so that it cannot hang the GPU), 0 if not, -1 if the flag cannot be read.  Synchronises the device. */
+/* debug: the 32 s_memtime words one workgroup leaves with fgvc_set_option("pair_f16_debug", 256) (tools/time_pair_v5.py) */
+int fgvc_pair_topk_f16x3_probe(int64_t* out32) {
+  if (!out32 || hipDeviceSynchronize() != hipSuccess) return FGVC_ERR_INVALID_ARG;
+  return pair_v5_probe_read(reinterpret_cast<long long*>(out32)) == 0 ? FGVC_OK : FGVC_ERR_LAUNCH;
+}
+
+int fgvc_pair_topk_f16x3_timed_out(void) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return pair_v5_timeout_flag();
 }
 
 int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, int n_out, int T,
@@ -478,14 +532,23 @@ int fgvc_nhwc_to_split_f32(float* x, uint16_t* out, int N, int C, int H, int W, 
   return nhwc_to_split_launch(x, out, N, C, H, W, Hp, Wp, relu, (hipStream_t)stream);
 }
 
+static int normalize_split_common(const char* what, const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
+                                  int normalize, int fmt, void* stream) {
+  FGVC_REQUIRE(in && (out_f32 || out_split), FGVC_ERR_INVALID_ARG, "%s: null pointer", what);
+  FGVC_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "%s: bad shape", what);
+  FGVC_REQUIRE(aligned16(in) && aligned16(out_f32) && aligned16(out_split), FGVC_ERR_INVALID_ARG, "%s: 16-byte alignment required", what);
+  if (N == 0) return FGVC_OK;
+  return normalize_nhwc_launch(in, out_f32, out_split, N, C, H, W, normalize, fmt, (hipStream_t)stream);
+}
+
 int fgvc_normalize_split_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W, int normalize,
                                   void* stream) {
-  FGVC_REQUIRE(in && (out_f32 || out_split), FGVC_ERR_INVALID_ARG, "fgvc_normalize_split_nhwc_f32: null pointer");
-  FGVC_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_normalize_split_nhwc_f32: bad shape");
-  FGVC_REQUIRE(aligned16(in) && aligned16(out_f32) && aligned16(out_split), FGVC_ERR_INVALID_ARG,
-               "fgvc_normalize_split_nhwc_f32: 16-byte alignment required");
-  if (N == 0) return FGVC_OK;
-  return normalize_nhwc_launch(in, out_f32, out_split, N, C, H, W, normalize, (hipStream_t)stream);
+  return normalize_split_common("fgvc_normalize_split_nhwc_f32", in, out_f32, out_split, N, C, H, W, normalize, 0, stream);
+}
+
+int fgvc_normalize_split_f16x2_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
+                                        int normalize, void* stream) {
+  return normalize_split_common("fgvc_normalize_split_f16x2_nhwc_f32", in, out_f32, out_split, N, C, H, W, normalize, 1, stream);
 }
 
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream) {

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __
 
 // dense NHWC f32 -> L2-normalised rows: [n][H*W][C] f32 (the layout of fgvc_normalize_chw_to_hwc_f32's output) and / or their
 // (hi, lo) bf16 split [n][H*W][hi C | lo C] (fgvc_split_bf16's output: what fgvc_pair_topk_bf16x4 reads); one wave per pixel
+template <int FMT>   // split format: 0 = (hi, lo) bf16 (fgvc_split_bf16), 1 = (h, l) f16 at scale 2^14 (fgvc_split_f16x2)
 __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               uint16_t* __restrict__ out_split, int C, int normalize,
                                                               long long npix) {
@@ -401,7 +402,20 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
     if (out) *reinterpret_cast<f32x4*>(out + pixel * C + c) = v;
     if (out_split) {
       ushort4 hv, lv;
-      split_bf16_4(v, hv, lv);
+      if constexpr (FMT == 0) {
+        split_bf16_4(v, hv, lv);
+      } else {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xs = v[i] * 16384.f;
+          h[i] = (_Float16)xs;
+          l[i] = (_Float16)(xs - (float)h[i]);
+        }
+        hv = __builtin_bit_cast(ushort4, h);
+        lv = __builtin_bit_cast(ushort4, l);
+      }
       *reinterpret_cast<ushort4*>(out_split + pixel * 2 * C + c) = hv;
       *reinterpret_cast<ushort4*>(out_split + pixel * 2 * C + C + c) = lv;
     }
@@ -482,9 +496,10 @@ int nhwc_to_split_launch(float* x, uint16_t* out, int N, int C, int H, int W, in
 }
 
 int normalize_nhwc_launch(const float* in, float* out, uint16_t* out_split, int N, int C, int H, int W, int normalize,
-                          hipStream_t s) {
+                          int split_fmt, hipStream_t s) {
   const long long npix = (long long)N * H * W;
-  normalize_nhwc_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
+  if (split_fmt == 0) normalize_nhwc_kernel<0><<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
+  else normalize_nhwc_kernel<1><<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
   FGVC_CHECK_LAUNCH("fgvc_normalize_nhwc_f32");
   return FGVC_OK;
 }

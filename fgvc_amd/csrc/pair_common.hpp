@@ -80,4 +80,51 @@ struct HalfCursor {
   }
 };
 
+// ---- shared by the split-operand kernels (pair_topk_v4.hip: bf16 x 4 products, pair_topk_v5.hip: f16 x 3 products)
+struct PairParamsB {
+  const uint16_t* q_hl;   // [frame][pixel][2][256] bf16 bit patterns (hi part, lo part)
+  const uint16_t* k_hl;
+  const int4* pairs;
+  int Hq, Wq, Hk, Wk;
+  int r2max, ry, rx;
+  int reach_y, reach_x;
+  int n_ty, n_tx;
+  int kout;
+  int debug;              // profiling ablations (results WRONG): 1 = no selection, 2 = no MFMA, 4 = no staging,
+                          // 16 = prologue only, 32 = no epilogue, 64 = no main loop, 128 = no s_setprio around the MFMA chain
+  int32_t* idx_out;
+  float* score_out;
+};
+
+// block-to-block reach test of the mask predicate (all operands wave-uniform or per-lane, no state)
+struct ReachTest {
+  int r2max, ry, rx;
+  __device__ __forceinline__ bool operator()(int wy0, int wx0, int ky0, int kx0) const {
+    const int dy = imax(0, imax(ky0 - (wy0 + QBH - 1), wy0 - (ky0 + QBH - 1)));
+    const int dx = imax(0, imax(kx0 - (wx0 + QBW - 1), wx0 - (kx0 + QBW - 1)));
+    return dy * dy + dx * dx <= r2max && dy <= ry && dx <= rx;
+  }
+};
+
+constexpr int V4_LIST_CAP = 4096;   // key blocks a super-tile may have to visit (host-checked)
+
+constexpr int KEY_EMPTY = (int)0x80000000;
+
+// One LDS-DMA wave instruction (64 lanes x 16 B -> 1 KiB at lds_dst), as inline assembly on purpose: for the builtin the
+// compiler cannot tell the ring slot being filled from the slot being read and puts `s_waitcnt vmcnt(0)` -- the whole
+// global-memory latency -- in front of every following ds_read.  The synchronisation (vmcnt(0) + barrier before the
+// slot is read) is explicit in the kernel.
+__device__ __forceinline__ void lds_dma_16(const void* src_lane, const void* lds_dst_uniform) {
+  const uint32_t lds = (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst_uniform;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory");
+}
+
+#define FGVC_V4_DESC(a, I, J)                  \
+  {                                            \
+    const int hi_ = max(a[I], a[J]);           \
+    const int lo_ = min(a[I], a[J]);           \
+    a[I] = hi_;                                \
+    a[J] = lo_;                                \
+  }
+
 }  // namespace fgvc

@@ -49,6 +49,7 @@ class TrackerConfig:
     test_mode: str = "v1"              # anything else = masked_attention_efficient_v2 (:379-392)
     sigma: float = 6.0
     pair_precision: str = "auto"   # ops.pair_topk_auto: "auto" | "f32" | "split" (not a reference key)
+    pair_split_fmt: str = "f16"    # operand format of the split pair kernel: "f16" (fgvc_pair_topk_f16x3) | "bf16" (fgvc_pair_topk_bf16x4)
 
     @staticmethod
     def from_test_cfg(cfg) -> "TrackerConfig":
@@ -74,7 +75,8 @@ class TrackerConfig:
             precede_frames=g("precede_frames", 5), topk=g("topk", 10), temperature=g("temperature", 0.07),
             neighbor_range=neighbor_range, mask_mode=mask_mode,
             with_first=bool(g("with_first", True)), regroup=bool(g("with_first", False)),
-            with_first_neighbor=with_first_neighbor, with_norm=with_norm, sim_mode=sim_mode, test_mode=test_mode)
+            with_first_neighbor=with_first_neighbor, with_norm=with_norm, sim_mode=sim_mode, test_mode=test_mode,
+            pair_precision=g("pair_precision", "auto"), pair_split_fmt=g("pair_split_fmt", "f16"))   # the last two: extension keys
 
     @property
     def mask(self) -> MaskSpec:
@@ -208,7 +210,8 @@ def merge_pairs(pl: PairLists, cfg: TrackerConfig, rows: Optional[Sequence[int]]
 def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
               pair_chunk: int = 16384, events=None, channels: Optional[int] = None) -> PairLists:
     """Phase 1.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip, f32 -- or their
-    split_bf16() form (T, HW, 2, C) int16 where the split pair kernel applies (VanillaTracker.get_feats_hwc(split=True)).
+    split form (T, HW, 2, C) int16 in the format cfg.pair_split_fmt names, where the split pair kernel applies
+    (VanillaTracker.get_feats_hwc(split=True)).
     `events` = (start, end) torch.cuda.Events recorded around the pair top-k launch(es); `channels` = the encoder's channel
     count where it differs from the (zero-padded) row length."""
     dev = feats_hwc.device
@@ -223,9 +226,11 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
         cfg.pair_precision == "auto" and ops.split_path_ok(feats_hwc.shape[-1], Hf, Wf, k, cfg.with_norm, None, cfg.mask, all_masked))
     if pre_split and not use_split:
         raise ValueError("run_affinity: split features given, but the split pair kernel does not apply to this configuration")
-    if use_split:      # bf16 matrix pipe on the hi/lo split of the (normalised) features, f32-grade scores
-        split = feats_hwc if pre_split else ops.split_bf16(feats_hwc)
-        pair_fn = lambda prs: ops.pair_topk_split(split, split, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False, all_masked=all_masked)
+    if use_split:      # 16-bit matrix pipe on the two-part split of the (normalised) features, f32-grade scores
+        fmt = cfg.pair_split_fmt
+        split = feats_hwc if pre_split else (ops.split_f16x2 if fmt == "f16" else ops.split_bf16)(feats_hwc)
+        pair_fn = lambda prs: ops.pair_topk_split(split, split, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False, all_masked=all_masked,
+                                                  fmt=fmt)
     else:
         pair_fn = lambda prs: ops.pair_topk(feats_hwc, feats_hwc, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
     if events is not None:

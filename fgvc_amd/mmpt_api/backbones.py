@@ -414,11 +414,12 @@ class ResNet(nn.Module):
         outs = [stage_out[i] for i in want]
         return outs[0] if len(outs) == 1 else tuple(outs)
 
-    def forward_hwc(self, x, normalize: bool = True, split_if=None):
+    def forward_hwc(self, x, normalize: bool = True, split_if=None, split_fmt: str = "bf16"):
         """The tracker's fast path: features of the single requested stage as (N, H*W, C) f32 rows, L2-normalised if
         `normalize` -- straight from the dense NHWC buffer when the stage ran on the bf16 pipe (no NCHW round trip).
         `split_if(C, H, W) -> bool`: when given and true for the stage's shape, the rows come back as their (hi, lo) bf16
-        split (N, H*W, 2, C) int16 instead (what the split pair kernel reads), made in the same pass.  Returns (feats, H, W)."""
+        split (N, H*W, 2, C) int16 instead (what the split pair kernel reads; `split_fmt` "bf16" = ops.split_bf16, "f16" =
+        ops.split_f16x2), made in the same pass.  Returns (feats, H, W)."""
         from .. import ops
         assert len(self.out_indices) == 1
         box = {}
@@ -433,7 +434,7 @@ class ResNet(nn.Module):
                 box["split"] = as_split
             elif torch.cuda.current_stream(x.device) != main:
                 torch.cuda.current_stream(x.device).wait_stream(main)
-            ops.normalize_nhwc(y_slice, normalize, split=box["split"], out=box["out"][lo:hi])
+            ops.normalize_nhwc(y_slice, normalize, split=split_fmt if box["split"] else False, out=box["out"][lo:hi])
 
         main = torch.cuda.current_stream(x.device) if x.is_cuda else None
         _, y, nhwc, H, W = self._trunk(x, self.out_indices[0], post=post)
@@ -442,7 +443,7 @@ class ResNet(nn.Module):
         C = y.shape[1]
         as_split = bool(split_if is not None and split_if(C, H, W))
         f = ops.normalize_to_hwc(y.float(), normalize, pad=True)
-        return (ops.split_bf16(f) if as_split and f.shape[-1] == C else f), H, W
+        return ((ops.split_f16x2 if split_fmt == "f16" else ops.split_bf16)(f) if as_split and f.shape[-1] == C else f), H, W
 
 
 def torchvision_key(name: str) -> str:

@@ -77,9 +77,9 @@ class VanillaTracker(BaseTracker):
     @torch.no_grad()
     def get_feats_hwc(self, frames: torch.Tensor, split: bool = False):
         """frames (T,3,h,w) -> normalised channels-last (T, HfWf, C'), Hf, Wf.
-        batch_step frames per encoder call (vanilla_tracker.py:135-147).  split=True: the bank comes back as its (hi, lo) bf16
-        split (T, HfWf, 2, C') int16 wherever the engine's split pair kernel applies (one pass less; engine.run_affinity takes
-        either form), f32 otherwise."""
+        batch_step frames per encoder call (vanilla_tracker.py:135-147).  split=True: the bank comes back as its two-part 16-bit
+        split (T, HfWf, 2, C') int16, in the format engine_config().pair_split_fmt names, wherever the engine's split pair kernel
+        applies (one pass less; engine.run_affinity takes either form), f32 otherwise."""
         step = int(self.test_cfg.get("batch_step", 5))
         norm = bool(self.test_cfg.get("with_norm", True))
         chunks = []
@@ -90,14 +90,16 @@ class VanillaTracker(BaseTracker):
         fast = (hasattr(self.backbone, "forward_hwc") and self.head is None and not self.stride_sample
                 and len(getattr(self.backbone, "out_indices", ())) == 1)
         split_if = None
+        split_fmt = "bf16"
         if split and fast:
             cfg = self.engine_config()
+            split_fmt = cfg.pair_split_fmt
             if cfg.pair_precision in ("auto", "split"):
                 split_if = lambda C, H, W: ops.split_path_ok(C, H, W, cfg.topk, cfg.with_norm, None, cfg.mask,
                                                              cfg.with_first_neighbor or not cfg.with_first)
         for i in range(0, frames.shape[0], step):
             if fast:       # backbone writes normalised channels-last rows itself (no NCHW round trip)
-                f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm, split_if=split_if)
+                f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm, split_if=split_if, split_fmt=split_fmt)
                 chunks.append(f)
                 continue
             f = self.extract_feat(frames[i:i + step])

@@ -135,10 +135,12 @@ def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq:
 
 def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int,
                     Wk: int, mask: MaskSpec, topk: int, validate: bool = True,
-                    all_masked: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
-    """pair_topk() on the bf16 matrix pipe (fgvc_pair_topk_bf16x4): qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256)
-    int16 = split_bf16() of L2-NORMALISED features.  Same outputs as pair_topk().  all_masked=True: the caller built `pairs`
-    with PAIR_MASKED on every row (then only the mask's reach, not the whole key grid, must fit the kernel's block list)."""
+                    all_masked: bool = False, fmt: str = "bf16") -> Tuple[torch.Tensor, torch.Tensor]:
+    """pair_topk() on the 16-bit matrix pipe: qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256) int16 = the split of
+    L2-NORMALISED features, fmt "bf16": split_bf16() -> fgvc_pair_topk_bf16x4; fmt "f16": split_f16x2() -> fgvc_pair_topk_f16x3
+    (the faster one).  Same outputs as pair_topk().  all_masked=True: the caller built `pairs` with PAIR_MASKED on every row
+    (then only the mask's reach, not the whole key grid, must fit the kernel's block list)."""
+    assert fmt in ("bf16", "f16")
     qsplit, ksplit = _chk(qsplit, torch.int16, "qsplit"), _chk(ksplit, torch.int16, "ksplit")
     pairs = _chk(pairs, torch.int32, "pairs")
     assert qsplit.dim() == 4 and ksplit.dim() == 4 and qsplit.shape[2] == 2 and ksplit.shape[2] == 2
@@ -150,9 +152,16 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
         assert not all_masked or bool((pairs[:, 2] & PAIR_MASKED).all()), "all_masked=True but a pair is not masked"
     idx = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.int32)
     score = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.float32)
-    _lib.call("fgvc_pair_topk_bf16x4", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n, qsplit.shape[3], Hq, Wq, Hk, Wk,
-              mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(idx), _ptr(score), _stream(qsplit))
+    _lib.call("fgvc_pair_topk_bf16x4" if fmt == "bf16" else "fgvc_pair_topk_f16x3", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n,
+              qsplit.shape[3], Hq, Wq, Hk, Wk, mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(idx), _ptr(score),
+              _stream(qsplit))
     return idx, score
+
+
+def pair_f16x3_timed_out() -> bool:
+    """True if a wave of an earlier fgvc_pair_topk_f16x3 launch gave up waiting on its key-block ring (a kernel bug: its spins are
+    bounded so that it cannot hang the GPU).  Synchronises the device; tests call it after every use of the kernel."""
+    return _lib.load().fgvc_pair_topk_f16x3_timed_out() != 0
 
 
 V4_LIST_CAP = 4096   # key blocks (4x8 pixels) one query tile may visit in fgvc_pair_topk_bf16x4 (csrc/pair_topk_v4.hip)
@@ -179,10 +188,12 @@ def split_path_ok(C: int, Hk: int, Wk: int, topk: int, normalized: bool, dense_m
 
 def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
                    mask: MaskSpec, topk: int, normalized: bool, precision: str = "auto", validate: bool = True,
-                   dense_mask: Optional[torch.Tensor] = None, all_masked: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                   dense_mask: Optional[torch.Tensor] = None, all_masked: bool = False,
+                   split_fmt: str = "f16") -> Tuple[torch.Tensor, torch.Tensor]:
     """pair_topk() with the kernel chosen by `precision`:
       "f32"   fgvc_pair_topk_f32 (f32 MFMA);
-      "split" fgvc_pair_topk_bf16x4 on split_bf16() of the features (raises when it does not apply);
+      "split" fgvc_pair_topk_f16x3 on split_f16x2() of the features (split_fmt "bf16": fgvc_pair_topk_bf16x4 on split_bf16());
+              raises when it does not apply;
       "auto"  "split" where split_path_ok(), else "f32".
     qfeat/kfeat are the f32 channels-last features either way (the split costs one extra pass over them)."""
     if precision not in ("auto", "f32", "split"):
@@ -192,11 +203,12 @@ def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor
     if not use_split:
         return pair_topk(qfeat, kfeat, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, dense_mask)
     if not ok:
-        raise ValueError("fgvc_pair_topk_bf16x4 needs C == 256, topk <= 10, an analytic mask, normalised features and "
+        raise ValueError("the split pair kernels need C == 256, topk <= 10, an analytic mask, normalised features and "
                          f"<= {V4_LIST_CAP} key blocks per query tile")
-    ks = split_bf16(kfeat)
-    qs = ks if qfeat is kfeat else split_bf16(qfeat)
-    return pair_topk_split(qs, ks, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, all_masked)
+    split = split_f16x2 if split_fmt == "f16" else split_bf16
+    ks = split(kfeat)
+    qs = ks if qfeat is kfeat else split(qfeat)
+    return pair_topk_split(qs, ks, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, all_masked, fmt=split_fmt)
 
 
 def merge_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pair: torch.Tensor, HWk: int, topk: int,
@@ -244,6 +256,17 @@ def split_bf16(feat: torch.Tensor) -> torch.Tensor:
     n = feat.numel() // Cc
     out = torch.empty((*feat.shape[:-1], 2, Cc), device=feat.device, dtype=torch.int16)
     _lib.call("fgvc_split_bf16", _ptr(feat), _ptr(out), n, Cc, _stream(feat))
+    return out
+
+
+def split_f16x2(feat: torch.Tensor) -> torch.Tensor:
+    """(…, C) f32 L2-normalised rows -> (…, 2, C) int16 holding f16 bit patterns: h = f16(2^14 x), l = f16(2^14 x - h), the
+    operand format of fgvc_pair_topk_f16x3."""
+    feat = _chk(feat, torch.float32, "feat")
+    Cc = feat.shape[-1]
+    n = feat.numel() // Cc
+    out = torch.empty((*feat.shape[:-1], 2, Cc), device=feat.device, dtype=torch.int16)
+    _lib.call("fgvc_split_f16x2", _ptr(feat), _ptr(out), n, Cc, _stream(feat))
     return out
 
 
@@ -579,9 +602,12 @@ def stem7_split(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, relu: bool
               int(relu), _stream(x))
 
 
-def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dense NHWC f32 (N,H,W,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc); split=True returns
-    split_bf16() of those rows instead, (N, H*W, 2, C) int16, produced in the same single pass over x.  `out`: write there."""
+def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split=False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dense NHWC f32 (N,H,W,C) -> (N, H*W, C) f32 rows, L2-normalised (the layout of normalize_to_hwc); split=True / "bf16"
+    returns split_bf16() of those rows instead, split="f16" their split_f16x2(), (N, H*W, 2, C) int16, produced in the same
+    single pass over x.  `out`: write there."""
+    fmt = "bf16" if split is True else split
+    assert fmt in (False, "bf16", "f16")
     x = _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
     shape, dt = ((N, H * W, 2, C), torch.int16) if split else ((N, H * W, C), torch.float32)
@@ -589,9 +615,15 @@ def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split: bool = False,
         out = torch.empty(shape, device=x.device, dtype=dt)
     else:
         assert tuple(out.shape) == shape and out.dtype == dt and out.is_contiguous() and out.device == x.device
-    _lib.call("fgvc_normalize_split_nhwc_f32", _ptr(x), _ptr(None if split else out), _ptr(out if split else None), N, C, H, W,
-              int(normalize), _stream(x))
+    _lib.call("fgvc_normalize_split_f16x2_nhwc_f32" if fmt == "f16" else "fgvc_normalize_split_nhwc_f32", _ptr(x),
+              _ptr(None if split else out), _ptr(out if split else None), N, C, H, W, int(normalize), _stream(x))
     return out
+
+
+def unsplit_f16x2(split: torch.Tensor) -> torch.Tensor:
+    """(…, 2, C) int16 split_f16x2() features -> (…, C) f32 = (h + l) / 2^14 (2^-22-relative approximation of the rows)."""
+    v = split.view(torch.float16).float()
+    return (v[..., 0, :] + v[..., 1, :]) * (1.0 / 16384.0)
 
 
 def unsplit_bf16(split: torch.Tensor) -> torch.Tensor:

@@ -114,6 +114,18 @@ int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const 
                           int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked,
                           int32_t* idx_out, float* score_out, void* stream);
 
+/* The same operator, faster (replaces local_attention.py:331-371 like fgvc_pair_topk_f32): f16 operands h = f16(2^14 x),
+ * l = f16(2^14 x - h) as fgvc_split_f16x2 writes them ([pixel][h C | l C], the container of fgvc_split_bf16), three products
+ * h h + l h + h l on v_mfma_f32_32x32x16_f16 (22 significand bits per element; scores within ~1e-7 of the f32 dot product), the
+ * selection of a tile in the instruction stream of the next tile's MFMAs, and a producer / consumer ring of key blocks without
+ * workgroup barriers.  Same arguments, outputs and tie order as fgvc_pair_topk_bf16x4; rows must be L2-normalised. */
+int fgvc_split_f16x2(const float* feat, uint16_t* h_l /* [n][2][C] f16: h then l */, int64_t n_pixels, int C, void* stream);
+int fgvc_pair_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
+                         int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
+                         float* score_out, void* stream);
+int fgvc_pair_topk_f16x3_timed_out(void);
+int fgvc_pair_topk_f16x3_probe(int64_t* out32);   /* debug: s_memtime words of one workgroup (pair_f16_debug = 256) */
+
 /* ---- A5 step 2: merge the per-pair lists of the T key slots of each query frame, divide by the
  * temperature and turn the k logits into weights.  Replaces the global topk over T*HW
  * (local_attention.py:356) and :368-371.
@@ -284,6 +296,9 @@ int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, in
  * fgvc_pair_topk_bf16x4 reads) in ONE pass over the trunk output; either output may be NULL */
 int fgvc_normalize_split_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
                                   int normalize, void* stream);
+/* the same with the split in the (h, l) f16 form of fgvc_split_f16x2 (what fgvc_pair_topk_f16x3 reads) */
+int fgvc_normalize_split_f16x2_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
+                                        int normalize, void* stream);
 
 /* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
  * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).

@@ -357,6 +357,8 @@ def test_split_feature_bank_equals_f32_bank(dev):
     assert torch.equal(ops.normalize_nhwc(y, True, split=True), ops.split_bf16(f))
     assert torch.equal(ops.normalize_nhwc(y, False, split=True), ops.split_bf16(ops.normalize_nhwc(y, False)))
     assert float((ops.unsplit_bf16(ops.split_bf16(f)) - f).abs().max()) < 1e-5
+    assert torch.equal(ops.normalize_nhwc(y, True, split="f16"), ops.split_f16x2(f))       # the f16 (h, l) form of fgvc_pair_topk_f16x3
+    assert float((ops.unsplit_f16x2(ops.split_f16x2(f)) - f).abs().max()) < 2e-7
     model = api.build_model(dict(type="VanillaTracker",
                                  backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")),
                             train_cfg=None,
@@ -366,8 +368,9 @@ def test_split_feature_bank_equals_f32_bank(dev):
     bank_s, Hf, Wf = model.get_feats_hwc(frames, split=True)            # 3 encoder calls (2 + 2 + 1 frames), concatenated
     bank_f, Hf2, Wf2 = model.get_feats_hwc(frames)
     assert bank_s.dtype == torch.int16 and bank_s.shape == (5, Hf * Wf, 2, 256) and (Hf, Wf) == (Hf2, Wf2) == (16, 24)
-    assert torch.equal(ops.split_bf16(bank_f), bank_s)                  # the hand-written trunk is deterministic call to call
     cfg = model.engine_config()
+    assert cfg.pair_split_fmt == "f16"
+    assert torch.equal(ops.split_f16x2(bank_f), bank_s)                 # the hand-written trunk is deterministic call to call
     plan = engine.plan_clip(5, [0], cfg)
     a = engine.run_affinity(bank_s, Hf, Wf, plan, cfg)
     b = engine.run_affinity(bank_f, Hf, Wf, plan, cfg)                  # f32 form: split inside
@@ -375,6 +378,14 @@ def test_split_feature_bank_equals_f32_bank(dev):
     cfg32 = engine.TrackerConfig(**{**cfg.__dict__, "pair_precision": "f32"})
     with pytest.raises(ValueError):
         engine.run_affinity(bank_s, Hf, Wf, plan, cfg32)
+    # the (hi, lo) bf16 form and its kernel stay selectable and give the same lists
+    model.test_cfg["pair_split_fmt"] = "bf16"
+    cfgb = model.engine_config()
+    bank_b, _, _ = model.get_feats_hwc(frames, split=True)
+    assert torch.equal(ops.split_bf16(bank_f), bank_b)
+    c = engine.run_affinity(bank_b, Hf, Wf, plan, cfgb)
+    assert float((c.idx == a.idx).all(-1).float().mean()) > 0.999 and float((c.logit - a.logit).abs().max()) < 1e-4
+    assert not ops.pair_f16x3_timed_out()
 
 
 def test_c2f_operator_256_channels_vs_oracle(dev):
@@ -618,14 +629,19 @@ def split_affinity(dev, q, key, topk, temperature, neighbor_range, mask_mode="ci
     Tn = key.shape[1]
     frames = torch.cat([q.unsqueeze(0), key.permute(1, 0, 2, 3)], 0).to(dev)
     feats = ops.normalize_to_hwc(frames)
-    hl = ops.split_bf16(feats)
     mask = ops.MaskSpec.from_neighbor_range(neighbor_range, mask_mode)
     pairs = ops.make_pairs([(0, 1 + t, not mask.is_none) for t in range(Tn)], dev)
-    ops.set_option("pair_bf16_products", products)
-    try:
-        pidx, pscore = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, topk)
-    finally:
-        ops.set_option("pair_bf16_products", 4)
+    if products == "f16":                          # fgvc_pair_topk_f16x3 (the engine's default)
+        h16 = ops.split_f16x2(feats)
+        pidx, pscore = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, topk, fmt="f16")
+        assert not ops.pair_f16x3_timed_out()
+    else:
+        hl = ops.split_bf16(feats)
+        ops.set_option("pair_bf16_products", products)
+        try:
+            pidx, pscore = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, topk)
+        finally:
+            ops.set_option("pair_bf16_products", 4)
     fidx, fscore = ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, topk)
     slot_pair = torch.arange(Tn, dtype=torch.int32, device=dev).view(1, Tn)
     idx, logit, weight = ops.merge_topk(pidx, pscore, slot_pair, H * W, topk, temperature, "softmax")
@@ -635,10 +651,16 @@ def split_affinity(dev, q, key, topk, temperature, neighbor_range, mask_mode="ci
 @pytest.mark.parametrize("shape", [(3, 30, 44, 30, "circle", 10, 3), (3, 30, 44, 30, "circle", 10, 4),
                                    (2, 17, 23, 9, "square", 10, 3), (1, 33, 70, 30, "circle", 5, 3),
                                    (2, 5, 3, 4, "circle", 5, 3), (2, 20, 20, None, "circle", 10, 3),
-                                   (1, 9, 130, 12, "circle", 3, 4), (6, 8, 8, 30, "circle", 10, 3)])
+                                   (1, 9, 130, 12, "circle", 3, 4), (6, 8, 8, 30, "circle", 10, 3),
+                                   (3, 30, 44, 30, "circle", 10, "f16"), (2, 17, 23, 9, "square", 10, "f16"),
+                                   (1, 33, 70, 30, "circle", 5, "f16"), (2, 5, 3, 4, "circle", 5, "f16"),
+                                   (2, 20, 20, None, "circle", 10, "f16"), (1, 9, 130, 12, "circle", 3, "f16"),
+                                   (6, 8, 8, 30, "circle", 10, "f16"), (2, 37, 53, 30, "circle", 10, "f16"),
+                                   (1, 61, 47, 14, "square", 7, "f16")])
 def test_split_pair_topk_vs_oracle(dev, shape):
-    """Ragged grids, both mask modes, no mask, k in {3,5,10}, 3 and 4 partial products: indices exact wherever the f64
-    ranks are clear, scores within the north_star bar (and within 1e-5 of the f32-MFMA kernel)."""
+    """Ragged grids, both mask modes, no mask, k in {3,5,7,10}; fgvc_pair_topk_bf16x4 with 3 and 4 partial products and
+    fgvc_pair_topk_f16x3 ("f16"): indices exact wherever the f64 ranks are clear, scores within the north_star bar (and within
+    1e-5 of the f32-MFMA kernel)."""
     Tn, H, W, nr, mm, topk, products = shape
     g = torch.Generator().manual_seed(sum(v for v in shape if isinstance(v, int)))
     q, key = torch.randn(256, H, W, generator=g), torch.randn(256, Tn, H, W, generator=g)
@@ -661,22 +683,26 @@ def test_split_pair_topk_exact_ties_and_identical_frames(dev):
     g = torch.Generator().manual_seed(4)
     H, W = 21, 37
     f = ops.normalize_to_hwc(torch.randn(1, 256, H, W, generator=g).to(dev))
-    hl = ops.split_bf16(f)
     mask = ops.MaskSpec.from_neighbor_range(30)
     pairs = ops.make_pairs([(0, 0, True)], dev)
-    idx, score = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, 10)
-    assert torch.equal(idx[0, :, 0].cpu(), torch.arange(H * W, dtype=torch.int32))
-    self64 = (f[0].double() ** 2).sum(1)
-    assert float((score[0, :, 0].double() - self64).abs().max()) < 2.5e-6
     const = torch.ones(1, 256, H, W)
     fc = ops.normalize_to_hwc(const.to(dev))
-    idx, score = ops.pair_topk_split(ops.split_bf16(fc), ops.split_bf16(fc), pairs, H, W, H, W, mask, 10)
-    assert float((score.double() - float((fc[0, 0].double() ** 2).sum())).abs().max()) < 2.5e-6
-    assert float(score.max() - score.min()) == 0.0                 # identical operands -> identical fixed-point keys
     qy, qx = torch.arange(H * W) // W, torch.arange(H * W) % W
-    ii = idx[0].cpu().long()
-    d2 = (ii // W - qy.view(-1, 1)) ** 2 + (ii % W - qx.view(-1, 1)) ** 2
-    assert int(d2.max()) <= mask.r2max and all(len(set(r.tolist())) == 10 for r in ii[:: 37])
+    for fmt, split in (("bf16", ops.split_bf16), ("f16", ops.split_f16x2)):
+        hl = split(f)
+        idx, score = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, 10, fmt=fmt)
+        assert torch.equal(idx[0, :, 0].cpu(), torch.arange(H * W, dtype=torch.int32))
+        self64 = (f[0].double() ** 2).sum(1)
+        assert float((score[0, :, 0].double() - self64).abs().max()) < 2.5e-6
+        idx, score = ops.pair_topk_split(split(fc), split(fc), pairs, H, W, H, W, mask, 10, fmt=fmt)
+        assert float((score.double() - float((fc[0, 0].double() ** 2).sum())).abs().max()) < 2.5e-6
+        assert float(score.max() - score.min()) == 0.0                 # identical operands -> identical fixed-point keys
+        ii = idx[0].cpu().long()
+        d2 = (ii // W - qy.view(-1, 1)) ** 2 + (ii % W - qx.view(-1, 1)) ** 2
+        assert int(d2.max()) <= mask.r2max and all(len(set(r.tolist())) == 10 for r in ii[:: 37])
+        # canonical order among exact ties: ascending pixel index
+        assert bool((ii[:, 1:] > ii[:, :-1]).all())
+    assert not ops.pair_f16x3_timed_out()
 
 
 def test_split_pair_topk_rejects_what_it_cannot_do(dev):
@@ -690,6 +716,8 @@ def test_split_pair_topk_rejects_what_it_cannot_do(dev):
     hl = ops.split_bf16(f)
     with pytest.raises(_lib.FgvcHipError):
         ops.pair_topk_split(hl, hl, pairs, 8, 8, 8, 8, ops.MaskSpec.from_neighbor_range(6), 11)      # topk > 10
+    with pytest.raises(_lib.FgvcHipError):
+        ops.pair_topk_split(hl, hl, pairs, 8, 8, 8, 8, ops.MaskSpec.from_neighbor_range(6), 11, fmt="f16")
     assert not ops.split_path_ok(256, 8, 8, 10, normalized=False)
     assert not ops.split_path_ok(64, 8, 8, 10, normalized=True)
     assert ops.split_path_ok(256, 120, 214, 10, normalized=True)

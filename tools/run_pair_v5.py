@@ -1,0 +1,72 @@
+"""fgvc_pair_topk_f16x3 against fgvc_pair_topk_f32 / fgvc_pair_topk_bf16x4: agreement on ragged sizes, then round-robin timing and
+ablations at the bench size (8 x 120x214x256, radius-15 disc, 27 pairs).   python tools/run_pair_v5.py [check] [debug values...]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fgvc_amd import engine, ops
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+
+
+def compare(H, W, nr, mode="circle", topk=10, T=3):
+    f = ops.normalize_to_hwc(torch.randn(T, 256, H, W, device=dev))
+    hl, h16 = ops.split_bf16(f), ops.split_f16x2(f)
+    mask = ops.MaskSpec.from_neighbor_range(nr, mode)
+    pairs = ops.make_pairs([(2, 0, nr is not None), (2, 1, nr is not None), (1, 0, nr is not None)][:T], dev)
+    i3, s3 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, topk)
+    i4, s4 = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, topk)
+    i5, s5 = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, topk, fmt="f16")
+    assert not ops.pair_f16x3_timed_out(), "ring wait timed out"
+    fin = torch.isfinite(s3) & torch.isfinite(s5)
+    same3 = (i3 == i5).all(-1).float().mean().item()
+    same4 = (i4 == i5).all(-1).float().mean().item()
+    ds = (s3 - s5)[fin].abs().max().item() if fin.any() else 0.0
+    infeq = bool((torch.isfinite(s3) == torch.isfinite(s5)).all())
+    # rows that differ: is it a near-tie (scores within 2e-7)?
+    bad = ~(i3 == i5).all(-1)
+    worst = 0.0
+    if bad.any():
+        worst = (s3[bad] - s5[bad]).abs().max().item()
+    print(f"H={H} W={W} nr={nr} {mode} k={topk}: rows identical to f32 {same3:.5f} / to bf16x4 {same4:.5f}  max|ds| {ds:.2e}  "
+          f"max|ds| on differing rows {worst:.2e}  inf-pattern-equal {infeq}", flush=True)
+    return same3, ds
+
+
+if "check" in sys.argv:
+    for a in [(37, 53, 30), (8, 8, 30), (5, 3, 4), (33, 70, 30), (20, 20, None), (17, 23, 9, "square"), (64, 64, 12, "circle", 5),
+              (120, 214, 30)]:
+        compare(*a)
+
+H, W, C, T = 120, 214, 256, 8
+feats = ops.normalize_to_hwc(torch.randn(T, C, H, W, device=dev))
+hl, h16 = ops.split_bf16(feats), ops.split_f16x2(feats)
+cfg = engine.TrackerConfig()
+plan = engine.plan_clip(T, [0], cfg)
+pairs = ops.make_pairs(plan.pairs, dev)
+
+
+def timeit(fn, reps=10):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+f4 = lambda: ops.pair_topk_split(hl, hl, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True)
+f5 = lambda: ops.pair_topk_split(h16, h16, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16")
+dbgs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]
+best = {}
+for rnd in range(3):
+    t = timeit(f4); best["bf16x4"] = min(best.get("bf16x4", 1e9), t)
+    for d in dbgs:
+        ops.set_option("pair_f16_debug", d)
+        t = timeit(f5); best[f"f16x3 debug={d}"] = min(best.get(f"f16x3 debug={d}", 1e9), t)
+    ops.set_option("pair_f16_debug", 0)
+assert not ops.pair_f16x3_timed_out(), "ring wait timed out"
+for k, v in best.items():
+    print(f"{k:20s} {v:.3f} ms / 27 pairs", flush=True)
