@@ -73,6 +73,7 @@ __device__ long long g_pair_v5_probe[32];      // debug & 256: s_memtime stamps 
 
 // bounded spin on an LDS word (wave-uniform): true = the word reached `target`.  A wave that has given up once (`dead`) never
 // waits again: a broken protocol costs milliseconds, not a hung GPU.
+template <int SLEEP = 2>
 __device__ __forceinline__ bool spin_ge(volatile int* w, int target, bool& dead, long long* waited = nullptr) {
   if (dead) return false;
   const long long t0 = waited ? __builtin_amdgcn_s_memtime() : 0;
@@ -83,7 +84,7 @@ __device__ __forceinline__ bool spin_ge(volatile int* w, int target, bool& dead,
   for (int it = 0; it < (1 << 16); ++it) {
     const int v = __builtin_amdgcn_readfirstlane(*w);
     if (v >= target) return true;
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(SLEEP);
   }
   g_pair_v5_timeout = 1;
   dead = true;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
       for (int e = 0; e < n_steps; ++e) {
         if (e + 1 < n_steps) {
           const int s1 = (e + 1) & (NSLOT - 1), gen1 = (e + 1) / NSLOT;
-          if (gen1 > 0) spin_ge(&done[s1], 4 * gen1, dead, probe ? &pw : nullptr);                  // block e + 1 - NSLOT released by all four consumers
+          if (gen1 > 0) spin_ge<6>(&done[s1], 4 * gen1, dead, probe ? &pw : nullptr);   // slots free up a tile time apart: poll rarely                  // block e + 1 - NSLOT released by all four consumers
           asm volatile("" ::: "memory");
           stage(e + 1);
           asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // block e landed, block e + 1 in flight
