@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
       const unsigned long long bal = __ballot(ent != 0u);
       if (ent) {
         const int r = count + __popcll(bal & ((1ull << lane) - 1));
-        blist[r < head ? 2 * r : 2 * (total - 1 - r) + 1] = ent;
+        blist[(p.debug & 8) ? r : (r < head ? 2 * r : 2 * (total - 1 - r) + 1)] = ent;      // debug & 8: plain row-major order
       }
       count += __popcll(bal);
     }
