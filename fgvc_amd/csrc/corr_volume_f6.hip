@@ -138,16 +138,25 @@ template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (res
                                // 32 = s_memtime probe of one workgroup, written over the first floats of vol
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const unsigned char* __restrict__ q_sp,
                                                                       const unsigned char* __restrict__ k_sp, int HWq, int HWk,
-                                                                      float out_scale, float* __restrict__ vol, int kchunk,
-                                                                      int period, int m32) {
+                                                                      float out_scale, float* __restrict__ vol, int s_tile,
+                                                                      int c_half, int n_tiles, int period, int m32) {
   constexpr int SUB = 2, ROWB = F6_ROWB, LDB = ROWB + 32, ROWS = 32 * SUB, BUFB = ROWS * LDB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
-  const int cls = blockIdx.z;                                   // row class: key rows j = period * v + cls
+  // Work split.  A tile = (256-query column tile xq, row class cls) with s_tile 64-key stages; tiles are taken in PAIRS (2 P, 2 P + 1)
+  // and a pair's 2 s_tile stages are cut into c_half equal pieces, one per workgroup: c_half / 2 key chunks per tile.  An odd c_half
+  // lets a workgroup run from the tail of one tile into the head of the next (two segments = two prologues): 2.5 chunks per tile at
+  // 480p are 505 workgroups = 1.97 rounds over the 256 CUs, 2.4 prologues per CU instead of the 4 of five whole chunks.  Workgroups
+  // with the same piece index walk the same key rows in step (the L2 serves them once).
+  const int pair = blockIdx.x / c_half, piece = blockIdx.x - pair * c_half;
+  const int r0 = (int)((long long)piece * 2 * s_tile / c_half), r1 = (int)((long long)(piece + 1) * 2 * s_tile / c_half);
+  auto run_segment = [&](int tile_idx, int st0, int st1) {        // stages [st0, st1) of tile tile_idx
+  const int xq = tile_idx / period;
+  const int cls = tile_idx - xq * period;                       // row class: key rows j = period * v + cls
   const int shift = (cls * m32) & 31;                           // its query tiles start `shift` queries early
-  const int qw0 = blockIdx.x * (NW * 32) + wave * 32 - shift;   // wave-uniform: first query of this wave's tile
+  const int qw0 = xq * (NW * 32) + wave * 32 - shift;           // wave-uniform: first query of this wave's tile
   const int n_v = (HWk - cls + period - 1) / period;            // virtual rows of this class
 
   const bool probe = (DEBUG & 32) != 0;   // s_memtime probe: waves 0 and 4 of every workgroup leave a record in row 0 of vol
@@ -183,8 +192,8 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     }
     asm volatile("" ::"v"(sq[qt]));
   }
-  const int kb0 = blockIdx.y * kchunk;                // in units of 32 virtual rows
-  const int kb1 = imin(kb0 + kchunk, cdiv(n_v, 32));
+  const int kb0 = 2 * st0;                            // in units of 32 virtual rows
+  const int kb1 = imin(2 * st1, cdiv(n_v, 32));
   auto stage_load = [&](int kb, int buf) {
 #pragma unroll
     for (int i = 0; i < ROWS / NW; ++i) {
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     // 48-byte records over the first floats of vol (tools/time_corr6.py); row 0 is only written by the first stage of the
     // class-0 workgroups of the first key chunk, long before any workgroup ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int wg = blockIdx.x;
     int* o = reinterpret_cast<int*>(vol) + 12 * (2 * wg + (wave >> 2));
     const long long now = __builtin_amdgcn_s_memtime();
     o[0] = (int)p_pro; o[1] = (int)p_comp; o[2] = (int)p_store; o[3] = (int)p_sync; o[4] = (int)(now - p_start); o[5] = p_stages;
@@ -428,10 +437,18 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     o[10] = (int)__builtin_amdgcn_s_getreg(6 << 11 | 20);   // HW_REG_XCC_ID
     o[11] = wg;
   }
+  };   // run_segment
+  // at most two segments; the LDS buffers of the first are free once its last stage barrier has passed (the deferred tile lives
+  // in registers)
+  for (int seg = 0; seg < 2; ++seg) {
+    const int t = 2 * pair + seg;
+    const int a = imax(r0, seg * s_tile) - seg * s_tile, b = imin(r1, (seg + 1) * s_tile) - seg * s_tile;
+    if (t < n_tiles && a < b) run_segment(t, a, b);
+  }
 }
 
 static int g_corr6_debug = 0;
-static int g_corr6_cost_pro = 20000, g_corr6_cost_stage = 4600;
+static int g_corr6_cost_pro = 20000, g_corr6_cost_stage = 5700;      // cycles, tools/time_corr6.py
 void set_corr6_debug(int v) { g_corr6_debug = v; }
 
 int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int HWq, int HWk, float temperature, float* vol,
@@ -443,26 +460,28 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
   if (period > 4 || (g_corr6_debug & 4)) period = 1;       // too many classes (or ablation): unshifted, straddling stores
   const int n_q = cdiv(HWq + (period > 1 ? 31 : 0), 256);  // shifted classes start up to 31 queries early
   const int n_vb = cdiv(cdiv(HWk, period), 32);            // 32-row blocks of virtual rows per class
-  // key blocks per workgroup: the number of key chunks that minimises  rounds over the 256 CUs x (prologue + stages per chunk)
-  int kchunk = n_vb + (n_vb & 1);
+  // half-chunks per tile pair: the c that minimises  rounds over the 256 CUs x (prologues + stages per workgroup)
+  const int s_tile = cdiv(n_vb, 2), n_tiles = n_q * period, n_pairs = cdiv(n_tiles, 2);
+  int c_half = 2;
   {
-    long long best = -1;
-    for (int c = 1; c <= 32; ++c) {
-      int kc = cdiv(n_vb, c);
-      kc += kc & 1;                                         // whole 64-key stages
-      const long long wgs = (long long)n_q * period * cdiv(n_vb, kc);
-      const long long cost = ((wgs + 255) / 256) * ((long long)g_corr6_cost_pro + (long long)g_corr6_cost_stage * (kc / 2));
+    double best = -1;
+    for (int c = 1; c <= 64; ++c) {
+      const long long wgs = (long long)n_pairs * c;
+      const double stages = 2.0 * s_tile / c;
+      if (stages < 4) break;
+      const double prologues = (c & 1) ? 1.0 + 1.0 / c : 1.0;      // one workgroup in c runs across the tile boundary
+      const double cost = (double)((wgs + 255) / 256) * (g_corr6_cost_pro * prologues + g_corr6_cost_stage * stages);
       if (best < 0 || cost < best) {
         best = cost;
-        kchunk = kc;
+        c_half = c;
       }
     }
   }
-  if (g_corr6_debug >> 8) kchunk = g_corr6_debug >> 8;
-  dim3 grid(n_q, cdiv(n_vb, kchunk), period);
+  if (g_corr6_debug >> 8) c_half = g_corr6_debug >> 8;
+  dim3 grid(n_pairs * c_half);
   const float out_scale = 1.0f / (temperature * F6_S * F6_S);
   const int mm = period > 1 ? m32 : 0;
-#define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, kchunk, period, mm)
+#define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, s_tile, c_half, n_tiles, period, mm)
   switch (g_corr6_debug & 123) {
     case 32: FGVC_C6(32); break;
     case 33: FGVC_C6(33); break;

@@ -93,8 +93,8 @@ for (H, W) in sizes:
         continue
     cfgs = [("f16f6", 0), ("f6 no stagger", 8), ("f6 late dma", 16), ("f6 whole F", 64), ("f6 late dma whole F", 80), ("f6 no stores", 1), ("f6 no mfma", 2),
             ("f6 neither", 3)]
-    for kc in (60, 82, 100, 134):
-        cfgs.append((f"f6 kchunk {kc}", kc << 8))
+    for c in (3, 4, 5, 6, 7, 10):
+        cfgs.append((f"f6 {c / 2:g} chunks/tile", c << 8))
     best, last = {}, {}
 
     def run_all():
