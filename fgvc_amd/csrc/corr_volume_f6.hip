@@ -150,6 +150,9 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   // lets a workgroup run from the tail of one tile into the head of the next (two segments = two prologues): 2.5 chunks per tile at
   // 480p are 505 workgroups = 1.97 rounds over the 256 CUs, 2.4 prologues per CU instead of the 4 of five whole chunks.  Workgroups
   // with the same piece index walk the same key rows in step (the L2 serves them once).
+  // (Tried: the linear stage space of all tiles in 256 / 512 / 768 / 1024 equal pieces -- any grid size, e.g. exactly one workgroup
+  // per CU, but no two workgroups in step on the same key rows: 0.86 ms against 0.65 at 480p for every grid size.  The L2 sharing of
+  // the key rows between the workgroups of a piece index is worth more than the rounds.)
   const int pair = blockIdx.x / c_half, piece = blockIdx.x - pair * c_half;
   const int r0 = (int)((long long)piece * 2 * s_tile / c_half), r1 = (int)((long long)(piece + 1) * 2 * s_tile / c_half);
   auto run_segment = [&](int tile_idx, int st0, int st1) {        // stages [st0, st1) of tile tile_idx
