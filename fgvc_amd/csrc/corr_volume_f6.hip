@@ -134,7 +134,7 @@ __device__ __forceinline__ i32x8 f6_operand(const i32x4& a, const i32x2& b) {
 }
 
 template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong); results right: 8 = no wave stagger,
-                               // 16 = DMA spread over both tiles of a stage, 64 = F fragments re-read in one piece;
+                               // 16 = DMA spread over both tiles of a stage, 64 = F fragments re-read in one piece, 128 = pair-major workgroup ids;
                                // 32 = s_memtime probe of one workgroup, written over the first floats of vol
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const unsigned char* __restrict__ q_sp,
                                                                       const unsigned char* __restrict__ k_sp, int HWq, int HWk,
@@ -153,7 +153,19 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   // (Tried: the linear stage space of all tiles in 256 / 512 / 768 / 1024 equal pieces -- any grid size, e.g. exactly one workgroup
   // per CU, but no two workgroups in step on the same key rows: 0.86 ms against 0.65 at 480p for every grid size.  The L2 sharing of
   // the key rows between the workgroups of a piece index is worth more than the rounds.)
-  const int pair = blockIdx.x / c_half, piece = blockIdx.x - pair * c_half;
+  // Workgroup -> (piece, pair), piece-major over an XCD-contiguous rank: blocks b and b + 8 share an XCD (and its private L2), so the
+  // ~n_pairs workgroups of a piece index -- the ones that read the same key rows in step -- sit on 2-3 XCDs instead of all 8 and
+  // a key row crosses the fabric 2-3 times per piece instead of 8 (DEBUG & 128: pair-major ids, every piece on every XCD).
+  const int n_pairs_ = (int)gridDim.x / c_half;
+  int pair, piece;
+  if constexpr (DEBUG & 128) {
+    pair = blockIdx.x / c_half;
+    piece = blockIdx.x - pair * c_half;
+  } else {
+    const int rank = xcd_remap(blockIdx.x, gridDim.x);
+    piece = rank / n_pairs_;
+    pair = rank - piece * n_pairs_;
+  }
   const int r0 = (int)((long long)piece * 2 * s_tile / c_half), r1 = (int)((long long)(piece + 1) * 2 * s_tile / c_half);
   auto run_segment = [&](int tile_idx, int st0, int st1) {        // stages [st0, st1) of tile tile_idx
   const int xq = tile_idx / period;
@@ -485,7 +497,8 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
   const float out_scale = 1.0f / (temperature * F6_S * F6_S);
   const int mm = period > 1 ? m32 : 0;
 #define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, s_tile, c_half, n_tiles, period, mm)
-  switch (g_corr6_debug & 123) {
+  switch (g_corr6_debug & 251) {
+    case 128: FGVC_C6(128); break;
     case 32: FGVC_C6(32); break;
     case 33: FGVC_C6(33); break;
     case 34: FGVC_C6(34); break;
