@@ -177,7 +177,11 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   const bool probe = (DEBUG & 32) != 0;   // s_memtime probe: waves 0 and 4 of every workgroup leave a record in row 0 of vol
   long long p_start = 0, p_pro = 0, p_comp = 0, p_store = 0, p_sync = 0, c0 = 0;
   int p_stages = 0;
-  if (probe) p_start = __builtin_amdgcn_s_memtime();
+  long long p_rt0 = 0;
+  if (probe) {
+    p_start = __builtin_amdgcn_s_memtime();
+    p_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+  }
   // query fragments (B operands) of the two query halves
   f16x8 bq16[2][8];
   i32x8 bq6h[2][2], bq6l[2][2];
@@ -444,10 +448,10 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     // class-0 workgroups of the first key chunk, long before any workgroup ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int wg = blockIdx.x;
-    int* o = reinterpret_cast<int*>(vol) + 12 * (2 * wg + (wave >> 2));
+    int* o = reinterpret_cast<int*>(vol) + 12 * (2 * (2 * wg + (tile_idx & 1)) + (wave >> 2));   // one record per segment and wave
     const long long now = __builtin_amdgcn_s_memtime();
     o[0] = (int)p_pro; o[1] = (int)p_comp; o[2] = (int)p_store; o[3] = (int)p_sync; o[4] = (int)(now - p_start); o[5] = p_stages;
-    *reinterpret_cast<long long*>(o + 6) = p_start;
+    *reinterpret_cast<long long*>(o + 6) = p_rt0;                       // 100 MHz, the same counter on every CU
     *reinterpret_cast<long long*>(o + 8) = (long long)__builtin_amdgcn_s_memrealtime();
     o[10] = (int)__builtin_amdgcn_s_getreg(6 << 11 | 20);   // HW_REG_XCC_ID
     o[11] = wg;

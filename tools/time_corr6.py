@@ -1,6 +1,7 @@
-"""s_memtime probe of fgvc_corr_volume_f16f6 (corr6_debug = 32; + 1 without stores, + 2 without MFMAs): waves 0 and 4 of every
-workgroup record cycles in the prologue and, per 64-key stage, in the multiply parts, the store bursts and wait + barrier, their
-start stamp and the XCD.  Prints per dispatch round (start-time order, 256 workgroups each) the averages and the in-kernel clock."""
+"""s_memtime / s_memrealtime probe of fgvc_corr_volume_f16f6 (corr6_debug = 32; + 1 without stores, + 2 without MFMAs): waves 0 and 4 of
+every workgroup segment record cycles in the prologue and, per 64-key stage, in the multiply parts, the store bursts and wait +
+barrier, their start and end on the chip-wide 100 MHz clock, and the XCD.  Prints averages, the in-kernel clock, and how much of the
+launch's span the 256 CUs were occupied."""
 import os, sys
 import numpy as np
 import torch
@@ -26,22 +27,23 @@ for dbg, name in ((32, "with stores"), (33, "no stores"), (34, "no MFMAs")):
     raw = vol[0].view(torch.int32).cpu().numpy()
     n = len(raw) // 12
     rec = raw[:n * 12].reshape(n, 12)
-    rec = rec[rec[:, 5] > 0]
-    start = rec[:, 6:8].copy().view(np.int64)[:, 0]
-    real = rec[:, 8:10].copy().view(np.int64)[:, 0]
-    t0 = start.min()
-    end = start + rec[:, 4]
-    span = end.max() - t0
-    # s_memrealtime ticks at 100 MHz: clock = d(memtime) / d(realtime) * 100 MHz over the whole launch
-    clk = span / max(1, (real.max() - (real - rec[:, 4] * 0).min())) * 0.1
-    print(f"{name}: {ms:.3f} ms (event), {len(rec)} wave records, launch span {span} cycles -> {span / ms / 1e6:.2f} GHz by the event time")
-    order = np.argsort(start)
-    rec, start = rec[order], start[order]
-    per = 2 * 256
-    for r0 in range(0, len(rec), per):
-        r = rec[r0:r0 + per]
-        ns = r[:, 5]
-        print(f"  workgroups started {r0 // 2:4d}..: start +{(start[r0:r0 + per] - t0).mean():9.0f}  prologue {r[:, 0].mean():7.0f} (min {r[:, 0].min()}, max {r[:, 0].max()})"
-              f" | per stage: multiply {(r[:, 1] / ns).mean():6.0f} stores {(r[:, 2] / ns).mean():6.0f} wait+barrier {(r[:, 3] / ns).mean():6.0f}"
-              f" | total {r[:, 4].mean():8.0f}, stages {ns.mean():.1f}")
-    w0, w4 = rec[(rec[:, 11] >= 0)][0::1], None
+    ok = (rec[:, 5] > 0) & (rec[:, 5] < 1000) & (rec[:, 4] > 0) & (rec[:, 0] > 0) & (rec[:, 0] < 200000)
+    w0 = rec[ok & (np.arange(n) % 2 == 0)]                    # wave 0 of each segment
+    rt0 = w0[:, 6:8].copy().view(np.int64)[:, 0].astype(np.float64) / 100.0      # us
+    rt1 = w0[:, 8:10].copy().view(np.int64)[:, 0].astype(np.float64) / 100.0
+    good = (rt1 > rt0) & (rt1 - rt0 < 5000)
+    w0, rt0, rt1 = w0[good], rt0[good], rt1[good]
+    span = rt1.max() - rt0.min()
+    dur = rt1 - rt0
+    clk = w0[:, 4] / dur / 1e3                                # cycles / us -> GHz
+    ns = w0[:, 5]
+    print(f"{name}: {ms:.3f} ms by events; {len(w0)} segments recorded; span first start -> last end {span:.1f} us; "
+          f"sum of segment times {dur.sum() / 256:.1f} us per CU = {dur.sum() / 256 / span:.3f} of the span; "
+          f"in-kernel clock {np.median(clk):.2f} GHz (median), {clk.min():.2f}-{clk.max():.2f}")
+    print(f"   per segment: prologue {w0[:, 0].mean():7.0f} cycles; per stage: multiply {(w0[:, 1] / ns).mean():6.0f} stores {(w0[:, 2] / ns).mean():6.0f} "
+          f"wait+barrier {(w0[:, 3] / ns).mean():6.0f} = {((w0[:, 1] + w0[:, 2] + w0[:, 3]) / ns).mean():6.0f}; stages {ns.mean():.1f}; "
+          f"segment {dur.mean():.1f} us (min {dur.min():.1f}, max {dur.max():.1f})")
+    order = np.argsort(rt0)
+    st = rt0[order] - rt0.min()
+    print(f"   segment starts (us after the first): 10 % {np.percentile(st, 10):.1f}  50 % {np.percentile(st, 50):.1f}  90 % {np.percentile(st, 90):.1f}; "
+          f"ends: 10 % {np.percentile(rt1 - rt0.min(), 10):.1f}  50 % {np.percentile(rt1 - rt0.min(), 50):.1f}  90 % {np.percentile(rt1 - rt0.min(), 90):.1f}  last {span:.1f}")
