@@ -102,7 +102,7 @@ int fgvc_set_option(const char* name, int value) {
     set_corr8_debug(value);                 // classes, 8 = wave stagger, 16 = the 32x32-shape kernel (results right); >> 8 = key blocks per workgroup
     return FGVC_OK;
   }
-  if (strcmp(name, "corr6_debug") == 0) {   // fgvc_corr_volume_f16f6 ablations: the bits of corr8_debug (1, 2, 4, 8; >> 8 = key blocks per workgroup)
+  if (strcmp(name, "corr6_debug") == 0) {   // fgvc_corr_volume_f16f6 ablations: 1 = no stores, 2 = no MFMA, 4 = no row classes, 8 = no stagger, ...; >> 12 = half-chunks per tile pair
     set_corr6_debug(value);
     return FGVC_OK;
   }

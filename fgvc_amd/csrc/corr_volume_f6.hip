@@ -134,7 +134,7 @@ __device__ __forceinline__ i32x8 f6_operand(const i32x4& a, const i32x2& b) {
 }
 
 template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong); results right: 8 = no wave stagger,
-                               // 16 = DMA spread over both tiles of a stage, 64 = F fragments re-read in one piece, 128 = pair-major workgroup ids;
+                               // 16 = DMA spread over both tiles of a stage, 64 = F fragments re-read in one piece, 128 = pair-major workgroup ids; 256 / 512 = no f16 / no FP6 MFMAs (results wrong);
                                // 32 = s_memtime probe of one workgroup, written over the first floats of vol
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const unsigned char* __restrict__ q_sp,
                                                                       const unsigned char* __restrict__ k_sp, int HWq, int HWk,
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          if constexpr (!(DEBUG & 2)) {
+          if constexpr (!(DEBUG & 2) && !(DEBUG & 256)) {
 #pragma unroll
             for (int tt = 2 * half; tt < 2 * half + 2; ++tt)
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
         }
         if (more && stager) stage_rows(kb + SUB, buf ^ 1, sb, 2 * u + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(DEBUG & 2)) {
+        if constexpr (!(DEBUG & 2) && !(DEBUG & 512)) {
           // scale bytes (opsel): 0 / 1 = h6 of block u = 0 / 1, 2 / 3 = l6; each is 2^(s - 4), so a product enters at 2^-8
 #define FGVC_F6_MFMA(A, B, OA, OB) \
   acc[kt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc[kt][qt], 2, 2, OA, S[kt], OB, sq[qt])
@@ -496,13 +496,15 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
       }
     }
   }
-  if (g_corr6_debug >> 8) c_half = g_corr6_debug >> 8;
+  if (g_corr6_debug >> 12) c_half = g_corr6_debug >> 12;      // tuning override: half-chunks per tile pair
   dim3 grid(n_pairs * c_half);
   const float out_scale = 1.0f / (temperature * F6_S * F6_S);
   const int mm = period > 1 ? m32 : 0;
 #define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, s_tile, c_half, n_tiles, period, mm)
-  switch (g_corr6_debug & 251) {
+  switch (g_corr6_debug & 1019) {
     case 128: FGVC_C6(128); break;
+    case 32 + 256: FGVC_C6(288); break;      // probe, no f16 MFMAs (results wrong)
+    case 32 + 512: FGVC_C6(544); break;      // probe, no FP6 MFMAs (results wrong)
     case 32: FGVC_C6(32); break;
     case 33: FGVC_C6(33); break;
     case 34: FGVC_C6(34); break;

@@ -13,7 +13,7 @@ HW = H * W
 f = torch.nn.functional.normalize(torch.randn(2, HW, 256, device=dev), dim=2)
 sp = ops.split_f16f6(f)
 vol = torch.empty((HW, HW), device=dev)
-for dbg, name in ((32, "with stores"), (33, "no stores"), (34, "no MFMAs")):
+for dbg, name in ((32, "with stores"), (33, "no stores"), (34, "no MFMAs"), (32 + 256, "no f16 MFMAs"), (32 + 512, "no FP6 MFMAs")):
     for _ in range(3):
         ops.set_option("corr6_debug", dbg)
         vol[0].zero_()

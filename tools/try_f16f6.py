@@ -94,7 +94,7 @@ for (H, W) in sizes:
     cfgs = [("f16f6", 0), ("f6 pair-major ids", 128), ("f6 no stagger", 8), ("f6 late dma", 16), ("f6 whole F", 64), ("f6 late dma whole F", 80), ("f6 no stores", 1), ("f6 no mfma", 2),
             ("f6 neither", 3)]
     for c in (4, 5, 7, 10):
-        cfgs.append((f"f6 {c / 2:g} chunks/tile", c << 8))
+        cfgs.append((f"f6 {c / 2:g} chunks/tile", c << 12))
     best, last = {}, {}
 
     def run_all():
