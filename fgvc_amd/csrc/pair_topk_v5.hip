@@ -11,17 +11,17 @@
 //     the score in 2^-28 fixed point as it stands; rows must be L2-normalised (|x| <= 1: 2^14 x fits f16).
 //   * Roles: waves 0-3 = consumers, one 4 x 8 query block each (B operands resident); waves 4-7 = producers, one pixel row of
 //     every key block each, by LDS-DMA.  A consumer multiplies key block e and, IN THE SAME STREAM, selects the candidates of the
-//     tile it computed before: the VALU work (~300 operations: mask predicate, integer keys, 60-comparator selection network,
-//     bitonic merge into the running list) is cut into 8 pieces, one per group of 6 MFMAs; the scheduler interleaves a piece with
-//     its group's MFMAs (an MFMA holds the SIMD's vector issue for 8 of its 32 cycles).
+//     tile it computed before: the VALU work (~290 operations: mask predicate, integer keys, 60-comparator selection network,
+//     bitonic merge into the running list) is cut into 48 slices, one behind each MFMA, every slice one generated inline-asm
+//     statement (pair_v5_chain.inc, tools/gen_pair_v5_chain.py: an MFMA holds the SIMD's vector issue for 8 of its 32 cycles).
 //   * Ring: 4 slots, two counters per slot in LDS.  filled[s] counts producer arrivals (4 per key block), done[s] consumer
 //     releases (4 per key block, also by the consumers that do not reach the block).  A producer refills slot s with block e + 4
 //     once done[s] shows block e released by all four consumers; a consumer reads block e once filled[s] shows its four rows
 //     landed.  No workgroup barrier after the prologue: a consumer whose query block does not reach a key block moves on, up to
 //     the ring's depth ahead of the others.  With the list in alternating order (first, last, second, ...) every window of 4
-//     entries is reached about evenly, and the loop takes ~42 tile times instead of 56 (tools/... simulation in DESIGN.md).
+//     entries is reached about evenly, and the loop takes ~42 tile times instead of 56 (tools/sim_pair_ring.py).
 //     Every spin is bounded: after 2^16 polls a wave raises g_pair_v5_timeout and stops waiting (results are then wrong, the
-//     launch still ends; fgvc_pair_topk_f16x3 reports it at the next call).
+//     launch still ends; fgvc_pair_topk_f16x3_timed_out() reports it).
 #include "pair_common.hpp"
 
 namespace fgvc {
@@ -29,16 +29,6 @@ namespace fgvc {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float F16X2_SCALE = 16384.f;
-
-// the comparator lists of sortnet.hpp as tables, so that any sub-range can be issued behind one MFMA
-#define FGVC_V5_PAIR(a, b) {a, b},
-constexpr unsigned char kSel10[][2] = {FGVC_SELNET_16_TOP10(FGVC_V5_PAIR)};
-constexpr unsigned char kSel5[][2] = {FGVC_SELNET_16_TOP5(FGVC_V5_PAIR)};
-constexpr unsigned char kVm10[][2] = {FGVC_VMERGE_ASC_10(FGVC_V5_PAIR)};
-constexpr unsigned char kVm5[][2] = {FGVC_VMERGE_ASC_5(FGVC_V5_PAIR)};
-#undef FGVC_V5_PAIR
-template <int N>
-constexpr int part_bound(int i, int parts) { return (N * i + parts - 1) / parts; }   // i-th boundary of N items in `parts` near-equal parts
 
 // f32 rows -> [h C | l C] f16 per pixel
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ feat, uint16_t* __restrict__ out,
