@@ -29,6 +29,7 @@ SIGNATURES = {
     "fgvc_pair_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "fgvc_pair_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "fgvc_pair_topk_f16x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "fgvc_pair_topk_f16x3_runs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "fgvc_split_f16x2": (_i, [_p, _p, C.c_int64, _i, _p]),
     "fgvc_pair_topk_f16x3_timed_out": (_i, []),
     "fgvc_pair_topk_f16x3_probe": (_i, [_p]),

@@ -60,8 +60,8 @@ void set_pair_v4_products(int);
 int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, int32_t*,
                         float*, hipStream_t);
 int split_f16x2_launch(const float*, uint16_t*, long long, int, hipStream_t);
-int pair_topk_v5_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, int32_t*,
-                        float*, hipStream_t);
+int pair_topk_v5_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, const int32_t*,
+                        int, int32_t*, float*, hipStream_t);
 void set_pair_v5_debug(int);
 int pair_v5_timeout_flag();
 int pair_v5_probe_read(long long*);
@@ -222,31 +222,46 @@ int fgvc_split_f16x2(const float* feat, uint16_t* h_l, int64_t n_pixels, int C, 
   return split_f16x2_launch(feat, h_l, n_pixels, C, (hipStream_t)stream);
 }
 
+static int pair_f16x3_common(const char* what, const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C,
+                             int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs,
+                             int n_runs, int32_t* idx_out, float* score_out, void* stream) {
+  FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "%s: null pointer", what);
+  FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
+               "%s: qsplit/ksplit/pairs must be 16-byte aligned", what);
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "%s: C=%d unsupported (256 only; use fgvc_pair_topk_f32)", what, C);
+  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && n_pairs >= 0, FGVC_ERR_INVALID_ARG,
+               "%s: bad shape Hq=%d Wq=%d Hk=%d Wk=%d n_pairs=%d", what, Hq, Wq, Hk, Wk, n_pairs);
+  FGVC_REQUIRE(topk >= 1 && topk <= 10, FGVC_ERR_UNSUPPORTED, "%s: topk=%d outside 1..10", what, topk);
+  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "%s: negative mask parameter", what);
+  FGVC_REQUIRE(n_pairs <= 65535, FGVC_ERR_UNSUPPORTED, "%s: n_pairs=%d > 65535 per call", what, n_pairs);
+  FGVC_REQUIRE(!runs || (n_runs >= 1 && n_runs <= n_pairs && (reinterpret_cast<uintptr_t>(runs) & 7u) == 0), FGVC_ERR_INVALID_ARG,
+               "%s: runs must be 8-byte aligned, 1 <= n_runs <= n_pairs", what);
+  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
+  FGVC_REQUIRE(!any_limit || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
+               "%s: a spatial mask needs equal query/key grids (local_attention.py:331)", what);
+  FGVC_REQUIRE(Hk < 32768 && Wk < 32768 && Hq < 32768 && Wq < 32768 && (long long)Hk * Wk < (1ll << 30) &&
+                   (long long)Hq * Wq < (1ll << 30),
+               FGVC_ERR_UNSUPPORTED, "%s: grid too large", what);
+  if (n_pairs == 0) return FGVC_OK;
+  return pair_topk_v5_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked != 0 && any_limit, runs,
+                             n_runs, idx_out, score_out, (hipStream_t)stream);
+}
+
 int fgvc_pair_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq,
                          int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
                          float* score_out, void* stream) {
-  FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16x3: null pointer");
-  FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
-               "fgvc_pair_topk_f16x3: qsplit/ksplit/pairs must be 16-byte aligned");
-  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: C=%d unsupported (256 only; use fgvc_pair_topk_f32)", C);
-  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && n_pairs >= 0, FGVC_ERR_INVALID_ARG,
-               "fgvc_pair_topk_f16x3: bad shape Hq=%d Wq=%d Hk=%d Wk=%d n_pairs=%d", Hq, Wq, Hk, Wk, n_pairs);
-  FGVC_REQUIRE(topk >= 1 && topk <= 10, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: topk=%d outside 1..10", topk);
-  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16x3: negative mask parameter");
-  FGVC_REQUIRE(n_pairs <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: n_pairs=%d > 65535 per call", n_pairs);
-  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
-  FGVC_REQUIRE(!any_limit || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
-               "fgvc_pair_topk_f16x3: a spatial mask needs equal query/key grids (local_attention.py:331)");
-  FGVC_REQUIRE(Hk < 32768 && Wk < 32768 && Hq < 32768 && Wq < 32768 && (long long)Hk * Wk < (1ll << 30) &&
-                   (long long)Hq * Wq < (1ll << 30),
-               FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_f16x3: grid too large");
-  if (n_pairs == 0) return FGVC_OK;
-  return pair_topk_v5_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked != 0 && any_limit,
-                             idx_out, score_out, (hipStream_t)stream);
+  return pair_f16x3_common("fgvc_pair_topk_f16x3", qsplit, ksplit, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
+                           nullptr, 0, idx_out, score_out, stream);
 }
 
-/* 1 if a wave of an earlier fgvc_pair_topk_f16x3 launch gave up waiting on its key-block ring (a bug, never expected: the spins are
- * bounded so that it cannot hang the GPU), 0 if not, -1 if the flag cannot be read.  Synchronises the device. */
+int fgvc_pair_topk_f16x3_runs(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq,
+                              int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs,
+                              int n_runs, int32_t* idx_out, float* score_out, void* stream) {
+  FGVC_REQUIRE(runs, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16x3_runs: null runs");
+  return pair_f16x3_common("fgvc_pair_topk_f16x3_runs", qsplit, ksplit, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
+                           runs, n_runs, idx_out, score_out, stream);
+}
+
 /* debug: the 32 s_memtime words one workgroup leaves with fgvc_set_option("pair_f16_debug", 256) (tools/time_pair_v5.py) */
 int fgvc_pair_topk_f16x3_probe(int64_t* out32) {
   if (!out32 || hipDeviceSynchronize() != hipSuccess) return FGVC_ERR_INVALID_ARG;

@@ -94,6 +94,8 @@ struct PairParamsB {
                           // 16 = prologue only, 32 = no epilogue, 64 = no main loop, 128 = no s_setprio around the MFMA chain
   int32_t* idx_out;
   float* score_out;
+  const int2* groups;     // pair_topk_v5 only: optional [n_groups] (first pair, count) -- runs of pairs with one query frame and one
+                          // mask flag that a workgroup takes in one go (query prologue once, the ring never drains); null: each pair alone
 };
 
 // block-to-block reach test of the mask predicate (all operands wave-uniform or per-lane, no state)

@@ -412,6 +412,7 @@ int pair_topk_v4_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_
   p.kout = topk;
   p.n_ty = cdiv(Hq, 2 * QBH); p.n_tx = cdiv(Wq, 2 * QBW);
   p.idx_out = idx_out; p.score_out = score_out;
+  p.groups = nullptr;
   p.debug = g_pair_v4_debug;
   {  // the per-workgroup block list must hold every key block a super-tile can reach: the mask's reach for a masked pair,
      // the whole key grid for a pair without FGVC_PAIR_MASKED (the caller says whether there is one: pairs live on the device)

@@ -17,8 +17,9 @@
 //   * Ring: 4 slots, two counters per slot in LDS.  filled[s] counts producer arrivals (4 per key block), done[s] consumer
 //     releases (4 per key block, also by the consumers that do not reach the block).  A producer refills slot s with block e + 4
 //     once done[s] shows block e released by all four consumers; a consumer reads block e once filled[s] shows its four rows
-//     landed.  No workgroup barrier after the prologue: a consumer whose query block does not reach a key block moves on, up to
-//     the ring's depth ahead of the others.  With the list in alternating order (first, last, second, ...) every window of 4
+//     landed.  No workgroup barrier after the prologue: a consumer whose query block does not reach a key block moves on (once the
+//     block has landed: a release must never be sent for a block that is not staged yet, the slot's counter would take it for the
+//     block before), up to the ring's depth ahead of the others.  With the list in alternating order (first, last, second, ...) every window of 4
 //     entries is reached about evenly, and the loop takes ~42 tile times instead of 56 (tools/sim_pair_ring.py).
 //     Every spin is bounded: after 2^16 polls a wave raises g_pair_v5_timeout and stops waiting (results are then wrong, the
 //     launch still ends; fgvc_pair_topk_f16x3_timed_out() reports it).
@@ -99,8 +100,16 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
   const int qb = wave & 3, par = wave >> 2;      // par 0 = consumer of query block qb, par 1 = producer of pixel row qb
   const int n = lane & 31, hi = lane >> 5;
 
-  const int4 pr = p.pairs[blockIdx.y];
-  const int qf = pr.x, kf = pr.y;
+  // a workgroup takes a RUN of pairs that share the query frame and the mask flag (blockIdx.y = run): the query rows, the block list
+  // and the B operands are set up once, and the producers run from the last key block of one pair into the first of the next
+  int g_start = blockIdx.y, g_count = 1;
+  if (p.groups) {
+    const int2 gr = p.groups[blockIdx.y];
+    g_start = gr.x;
+    g_count = gr.y;
+  }
+  const int4 pr = p.pairs[g_start];
+  const int qf = pr.x;
   const bool masked = (pr.z & FGVC_PAIR_MASKED) != 0;
   const int reach_y = masked ? p.reach_y : FGVC_NO_LIMIT;
   const int reach_x = masked ? p.reach_x : FGVC_NO_LIMIT;
@@ -178,37 +187,45 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
     // =========================================== producer: pixel row qb of every key block ===========================================
     __syncthreads();                                                 // the consumers have read their query fragments: the ring is free
     if (p.debug & (16 | 64)) return;
-    const unsigned char* kbase = reinterpret_cast<const unsigned char*>(p.k_hl) + (size_t)kf * p.Hk * p.Wk * (4 * C);
     const uint32_t lane16 = 16u * lane;
-    auto stage = [&](int e) {
+    const int n_total = g_count * n_steps;                             // key blocks of the whole run, numbered G = pair * n_steps + e
+    int cur_pair = -1;
+    const unsigned char* kbase = nullptr;
+    auto stage = [&](int G) {
+      const int pi = G / n_steps, e = G - pi * n_steps;
+      if (pi != cur_pair) {                                            // wave-uniform
+        cur_pair = pi;
+        const int kf = p.pairs[g_start + pi].y;
+        kbase = reinterpret_cast<const unsigned char*>(p.k_hl) + (size_t)kf * p.Hk * p.Wk * (4 * C);
+      }
       const uint32_t ent = __builtin_amdgcn_readfirstlane(blist[e]);
       const int sby = ent & 0xfff, sbx = (ent >> 12) & 0xfff;
       const int ky = imin(sby * QBH + qb, p.Hk - 1), kx0 = sbx * QBW;
       const unsigned char* src = kbase + ((size_t)ky * p.Wk + kx0) * (4 * C) + lane16;
       const int xmax = p.Wk - 1 - kx0;                                 // >= 0: the block starts inside the frame
-      unsigned char* dst = &smem[(e & (NSLOT - 1)) * BUFB + (qb * 8) * LDB];
+      unsigned char* dst = &smem[(G & (NSLOT - 1)) * BUFB + (qb * 8) * LDB];
 #pragma unroll
       for (int i = 0; i < 8; ++i) lds_dma_16(src + (size_t)imin(i, xmax) * (4 * C), dst + i * LDB);
     };
     const bool probe = (p.debug & 256) && blockIdx.x == 100 && blockIdx.y == 5;
     long long pw = 0, pt0 = probe ? __builtin_amdgcn_s_memtime() : 0;
-    if ((p.debug & 4) == 0 && n_steps > 0) {
+    if ((p.debug & 4) == 0 && n_total > 0) {
       stage(0);
-      for (int e = 0; e < n_steps; ++e) {
-        if (e + 1 < n_steps) {
-          const int s1 = (e + 1) & (NSLOT - 1), gen1 = (e + 1) / NSLOT;
-          if (gen1 > 0) spin_ge<6>(&done[s1], 4 * gen1, dead, probe ? &pw : nullptr);   // slots free up a tile time apart: poll rarely                  // block e + 1 - NSLOT released by all four consumers
-          asm volatile("" ::: "memory");
-          stage(e + 1);
-          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // block e landed, block e + 1 in flight
+      for (int G = 0; G < n_total; ++G) {
+        if (G + 1 < n_total) {
+          const int s1 = (G + 1) & (NSLOT - 1), gen1 = (G + 1) / NSLOT;
+          if (gen1 > 0) spin_ge<6>(&done[s1], 4 * gen1, dead, probe ? &pw : nullptr);   // block G + 1 - NSLOT released by all four consumers
+          asm volatile("" ::: "memory");                                                // (slots free up a tile time apart: poll rarely)
+          stage(G + 1);
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // block G landed, block G + 1 in flight
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (lane == 0) __hip_atomic_fetch_add(&filled[e & (NSLOT - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_add(&filled[G & (NSLOT - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    } else if (n_steps > 0) {                                          // ablation: no staging, every block "arrives" at once
-      for (int e = 0; e < n_steps; ++e)
-        if (lane == 0) __hip_atomic_fetch_add(&filled[e & (NSLOT - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (n_total > 0) {                                          // ablation: no staging, every block "arrives" at once
+      for (int G = 0; G < n_total; ++G)
+        if (lane == 0) __hip_atomic_fetch_add(&filled[G & (NSLOT - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (probe && lane == 0) {
       g_pair_v5_probe[16 + 4 * qb] = __builtin_amdgcn_s_memtime() - pt0;     // producer: loop cycles, cycles waiting for a free slot
@@ -238,11 +255,6 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
   if (p.debug & 16) return;                      // ablation: prologue only
 
   int lk[K], lb[K];                              // running list, ASCENDING: lk[0] = K-th best ... lk[K-1] = best
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    lk[j] = KEY_EMPTY;
-    lb[j] = -1;
-  }
   f32x16 acc;
   int ck[16];                                    // the pending tile: fixed-point scores, turned into keys in place by pieces 0 and 1
 #pragma unroll
@@ -274,18 +286,30 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
   const bool probe = (p.debug & 256) && blockIdx.x == 100 && blockIdx.y == 5;
   long long cw = 0, cchain = 0, ct0 = probe ? __builtin_amdgcn_s_memtime() : 0;
   int n_comp = 0;
+  for (int pi = 0; pi < g_count; ++pi) {           // ---- the pairs of the run, one after the other through the same ring
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    lk[j] = KEY_EMPTY;
+    lb[j] = -1;
+  }
+  s_r2lim = -1;                                    // no pending tile
   uint32_t ent_next = n_loop > 0 ? blist[0] : 0u;
   for (int e = 0; e < n_loop; ++e) {
     const uint32_t ent = __builtin_amdgcn_readfirstlane(ent_next);
     ent_next = e + 1 < n_loop ? blist[e + 1] : 0u;          // lands during this entry's work
-    const int slot = e & (NSLOT - 1), gen = e / NSLOT;
+    const int G = pi * n_steps + e;                          // the ring counts key blocks over the whole run
+    const int slot = G & (NSLOT - 1), gen = G / NSLOT;
     const bool comp = ((ent >> (24 + qb)) & 1) != 0;
+    // Block G has landed (its four pixel rows).  A consumer that does not reach the block waits for this too before it releases the
+    // slot: the counters are per SLOT, so a release sent before block G was staged would be counted for block G - NSLOT, which a
+    // slower consumer may still be reading -- the producers would then refill the slot under it (seen as rare wrong scores with one
+    // pair per workgroup and often with runs of pairs, where half of the consumers skip the first blocks of a pair).
+    spin_ge(&filled[slot], 4 * (gen + 1), dead, probe ? &cw : nullptr);
+    asm volatile("" ::: "memory");
     if (!comp) {                                  // not within this query block's reach: release and move on
       if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       continue;
     }
-    spin_ge(&filled[slot], 4 * (gen + 1), dead, probe ? &cw : nullptr);  // the four pixel rows of block e have landed
-    asm volatile("" ::: "memory");
     const long long cc0 = probe ? __builtin_amdgcn_s_memtime() : 0;
     if constexpr (do_mfma) {
       const unsigned char* ka = &smem[slot * BUFB + n * LDB + 16 * hi];
@@ -359,14 +383,8 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
     }
     if (probe) { cchain += __builtin_amdgcn_s_memtime() - cc0; ++n_comp; }
   }
-  if (probe && lane == 0) {
-    g_pair_v5_probe[4 * qb] = __builtin_amdgcn_s_memtime() - ct0;     // consumer: loop cycles, cycles waiting for data, chain cycles, tiles
-    g_pair_v5_probe[4 * qb + 1] = cw;
-    g_pair_v5_probe[4 * qb + 2] = cchain;
-    g_pair_v5_probe[4 * qb + 3] = n_comp;
-  }
   if constexpr (do_sel) flush_pending();          // the last pending tile
-  if (p.debug & 32) return;                      // ablation: no epilogue
+  if (p.debug & 32) continue;                    // ablation: no epilogue
 
   // ---- epilogue: two partial lists per query (the two lane halves) -> canonical top-K.  Entries become 64-bit words
   //      (score_fx : ~pixel), larger = better (higher score, then LOWER pixel index)
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
 #undef X
   }
   if (hi == 0 && qy < p.Hq && qx < p.Wq) {
-    const size_t oo = ((size_t)blockIdx.y * p.Hq * p.Wq + (size_t)qy * p.Wq + qx) * p.kout;
+    const size_t oo = ((size_t)(g_start + pi) * p.Hq * p.Wq + (size_t)qy * p.Wq + qx) * p.kout;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       if (j < p.kout) {
@@ -426,6 +444,13 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
         p.score_out[oo + j] = em ? -INFINITY : (float)sk * 0x1p-28f;
       }
     }
+  }
+  }   // pairs of the run
+  if (probe && lane == 0) {
+    g_pair_v5_probe[4 * qb] = __builtin_amdgcn_s_memtime() - ct0;     // consumer: loop cycles, cycles waiting for data, chain cycles, tiles
+    g_pair_v5_probe[4 * qb + 1] = cw;
+    g_pair_v5_probe[4 * qb + 2] = cchain;
+    g_pair_v5_probe[4 * qb + 3] = n_comp;
   }
 }
 
@@ -443,8 +468,8 @@ int pair_v5_timeout_flag() {
 }
 
 int pair_topk_v5_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_t* pairs, int n_pairs, int Hq, int Wq,
-                        int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
-                        float* score_out, hipStream_t s) {
+                        int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* groups, int n_groups,
+                        int32_t* idx_out, float* score_out, hipStream_t s) {
   PairParamsB p;
   p.q_hl = q_hl; p.k_hl = k_hl; p.pairs = reinterpret_cast<const int4*>(pairs);
   p.Hq = Hq; p.Wq = Wq; p.Hk = Hk; p.Wk = Wk;
@@ -455,6 +480,7 @@ int pair_topk_v5_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_
   p.kout = topk;
   p.n_ty = cdiv(Hq, 2 * QBH); p.n_tx = cdiv(Wq, 2 * QBW);
   p.idx_out = idx_out; p.score_out = score_out;
+  p.groups = reinterpret_cast<const int2*>(groups);
   p.debug = g_pair_v5_debug;
   {  // the per-workgroup block list must hold every key block a super-tile can reach: the mask's reach for a masked pair, the whole key grid for a pair without FGVC_PAIR_MASKED
     const long long nby = imin(cdiv(Hk, QBH), (2 * QBH - 1 + 2 * (long long)imin(p.reach_y, Hk)) / QBH + 2);
@@ -467,7 +493,7 @@ int pair_topk_v5_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_
       return FGVC_ERR_UNSUPPORTED;
     }
   }
-  dim3 grid(p.n_ty * p.n_tx, n_pairs);
+  dim3 grid(p.n_ty * p.n_tx, groups ? n_groups : n_pairs);
   if (topk <= 5) pair_topk_kernel_v5<5, 0><<<grid, 512, 0, s>>>(p);
   else switch (g_pair_v5_debug & 3) {
     case 0: pair_topk_kernel_v5<10, 0><<<grid, 512, 0, s>>>(p); break;

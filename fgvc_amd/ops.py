@@ -105,7 +105,31 @@ def make_pairs(pairs, device, masked=True) -> torch.Tensor:
     for p in pairs:
         m = masked if len(p) < 3 else p[2]
         rows.append((int(p[0]), int(p[1]), PAIR_MASKED if m else 0, 0))
-    return torch.tensor(rows, dtype=torch.int32, device=device).reshape(-1, 4)
+    t = torch.tensor(rows, dtype=torch.int32, device=device).reshape(-1, 4)
+    t._fgvc_rows = rows                      # host copy: pair_runs() groups the pairs without a device read-back
+    return t
+
+
+def pair_runs(pairs: torch.Tensor) -> Optional[torch.Tensor]:
+    """Runs of consecutive pairs with one query frame and one mask flag, as fgvc_pair_topk_f16x3_runs takes them: int32 (n_runs, 2)
+    = (first pair, count) on the pairs' device, longest runs first.  None when the pairs were not built by make_pairs() (no host
+    copy to group by).  Cached on the tensor."""
+    rows = getattr(pairs, "_fgvc_rows", None)
+    if rows is None or len(rows) != pairs.shape[0]:
+        return None
+    cached = getattr(pairs, "_fgvc_runs", None)
+    if cached is None:
+        runs, i = [], 0
+        while i < len(rows):
+            j = i
+            while j + 1 < len(rows) and rows[j + 1][0] == rows[i][0] and rows[j + 1][2] == rows[i][2]:
+                j += 1
+            runs.append((i, j - i + 1))
+            i = j + 1
+        runs.sort(key=lambda r: -r[1])
+        cached = torch.tensor(runs, dtype=torch.int32, device=pairs.device).reshape(-1, 2)
+        pairs._fgvc_runs = cached
+    return cached
 
 
 def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
@@ -135,7 +159,7 @@ def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq:
 
 def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int,
                     Wk: int, mask: MaskSpec, topk: int, validate: bool = True,
-                    all_masked: bool = False, fmt: str = "bf16") -> Tuple[torch.Tensor, torch.Tensor]:
+                    all_masked: bool = False, fmt: str = "bf16", use_runs: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """pair_topk() on the 16-bit matrix pipe: qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256) int16 = the split of
     L2-NORMALISED features, fmt "bf16": split_bf16() -> fgvc_pair_topk_bf16x4; fmt "f16": split_f16x2() -> fgvc_pair_topk_f16x3
     (the faster one).  Same outputs as pair_topk().  all_masked=True: the caller built `pairs` with PAIR_MASKED on every row
@@ -152,6 +176,12 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
         assert not all_masked or bool((pairs[:, 2] & PAIR_MASKED).all()), "all_masked=True but a pair is not masked"
     idx = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.int32)
     score = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.float32)
+    runs = pair_runs(pairs) if (fmt == "f16" and use_runs and n) else None
+    if runs is not None:            # a query frame's pairs in one workgroup (query prologue once, the key-block ring never drains)
+        _lib.call("fgvc_pair_topk_f16x3_runs", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n, qsplit.shape[3], Hq, Wq, Hk, Wk,
+                  mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(runs), runs.shape[0], _ptr(idx), _ptr(score),
+                  _stream(qsplit))
+        return idx, score
     _lib.call("fgvc_pair_topk_bf16x4" if fmt == "bf16" else "fgvc_pair_topk_f16x3", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n,
               qsplit.shape[3], Hq, Wq, Hk, Wk, mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(idx), _ptr(score),
               _stream(qsplit))

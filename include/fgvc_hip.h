@@ -123,6 +123,14 @@ int fgvc_split_f16x2(const float* feat, uint16_t* h_l /* [n][2][C] f16: h then l
 int fgvc_pair_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
                          int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
                          float* score_out, void* stream);
+/* ... with the pairs taken in RUNS: runs[n_runs][2] (device, int32) = (first pair, count) of consecutive pairs that share the query
+ * frame AND the FGVC_PAIR_MASKED flag (the driver's pair list has them that way: a query frame against its <= 6 key frames,
+ * vanilla_tracker.py:353-362); every pair belongs to exactly one run.  A workgroup then sets the query block up once per run and
+ * streams the key blocks of its pairs through one ring.  Outputs are indexed by pair as before.  The caller vouches for the runs
+ * (they live on the device); list longer runs first (the launch does not reorder). */
+int fgvc_pair_topk_f16x3_runs(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
+                              int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs, int n_runs,
+                              int32_t* idx_out, float* score_out, void* stream);
 int fgvc_pair_topk_f16x3_timed_out(void);
 int fgvc_pair_topk_f16x3_probe(int64_t* out32);   /* debug: s_memtime words of one workgroup (pair_f16_debug = 256) */
 

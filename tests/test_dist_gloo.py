@@ -2,7 +2,6 @@
 first-frame broadcast, all_gather order, replicated sweep) with an ORACLE-backed compute backend,
 checked against the un-sharded oracle driver.  The HIP backend runs the same code on the GPUs."""
 import os
-import socket
 
 import pytest
 import torch
@@ -56,16 +55,17 @@ class OracleBackend:
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous FILE, not a TCP port: a port probed free here can be taken before rank 0 binds it."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="fgvc_rdzv_")
+    os.close(fd)
+    os.unlink(path)
+    return path
 
 
 def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from fgvc_amd import dist as D
     from fgvc_amd.engine import TrackerConfig
@@ -152,8 +152,8 @@ def test_halo_message_plan():
 
 
 def _collect_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from fgvc_amd import apis
     # rank r ran videos r, r + world, ... (mmpt/datasets/samplers/distributed_sampler.py:53); video i's result carries i
     mine = [tuple(torch.full((1, 2, 3), float(i)) for _ in range(5)) for i in range(rank, 7, world)]

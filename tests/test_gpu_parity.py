@@ -705,6 +705,35 @@ def test_split_pair_topk_exact_ties_and_identical_frames(dev):
     assert not ops.pair_f16x3_timed_out()
 
 
+def test_pair_f16x3_runs_of_pairs_equal_pair_by_pair(dev):
+    """fgvc_pair_topk_f16x3_runs (a query frame's pairs in one workgroup: one query prologue, the key-block ring never drains) gives
+    bit-identical lists to one workgroup per pair, on a grid with edge tiles, for runs of 1-4 pairs, masked and not -- and both equal
+    the f32-MFMA kernel wherever scores are not within rounding of each other.  (This is the configuration in which a consumer that
+    released a ring slot before its block was staged let the producers overwrite a block another consumer was still reading.)"""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(77)
+    H, W, T = 33, 70, 6
+    f = ops.normalize_to_hwc(torch.randn(T, 256, H, W, generator=g).to(dev))
+    h16 = ops.split_f16x2(f)
+    rows = [(1, 0, True), (2, 0, True), (2, 1, True), (3, 0, False), (3, 1, True), (3, 2, True), (5, 0, True), (5, 1, True), (5, 3, True),
+            (5, 4, True), (4, 4, True)]
+    pairs = ops.make_pairs(rows, dev)
+    assert ops.pair_runs(pairs).tolist() == [[6, 4], [1, 2], [4, 2], [0, 1], [3, 1], [10, 1]]     # longest first; a mask flag splits a run
+    mask = ops.MaskSpec.from_neighbor_range(30)
+    for _ in range(3):                                            # the race was timing dependent
+        ia, sa = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, 10, fmt="f16")
+        ib, sb = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, 10, fmt="f16", use_runs=False)
+        assert torch.equal(ia, ib) and torch.equal(sa, sb)
+    assert not ops.pair_f16x3_timed_out()
+    i3, s3 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+    fin = torch.isfinite(s3)
+    assert torch.equal(fin, torch.isfinite(sa)) and float((sa - s3)[fin].abs().max()) < 2.5e-6   # f32 accumulation of the f32 kernel
+    differ = ~(ia == i3).all(-1)
+    assert float(differ.float().mean()) < 2e-3                    # ... and only where two scores are within rounding of each other
+    if differ.any():
+        assert float((torch.sort(sa[differ], dim=-1).values - torch.sort(s3[differ], dim=-1).values).abs().max()) < 2.5e-6
+
+
 def test_split_pair_topk_rejects_what_it_cannot_do(dev):
     from fgvc_amd import ops, _lib
     f = ops.normalize_to_hwc(torch.randn(1, 128, 8, 8).to(dev))

@@ -16,7 +16,7 @@ def compare(H, W, nr, mode="circle", topk=10, T=3):
     pairs = ops.make_pairs([(2, 0, nr is not None), (2, 1, nr is not None), (1, 0, nr is not None)][:T], dev)
     i3, s3 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, topk)
     i4, s4 = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, topk)
-    i5, s5 = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, topk, fmt="f16")
+    i5, s5 = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, topk, fmt="f16", use_runs="noruns" not in sys.argv)
     assert not ops.pair_f16x3_timed_out(), "ring wait timed out"
     fin = torch.isfinite(s3) & torch.isfinite(s5)
     same3 = (i3 == i5).all(-1).float().mean().item()
@@ -59,6 +59,10 @@ def timeit(fn, reps=10):
 
 f4 = lambda: ops.pair_topk_split(hl, hl, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True)
 f5 = lambda: ops.pair_topk_split(h16, h16, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16")
+f5n = lambda: ops.pair_topk_split(h16, h16, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16", use_runs=False)
+ia, sa = f5()
+ib, sb = f5n()
+print("runs of pairs == pair by pair:", bool(torch.equal(ia, ib) and torch.equal(sa, sb)), " runs:", ops.pair_runs(pairs).tolist())
 dbgs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]
 best = {}
 for rnd in range(3):
@@ -67,6 +71,7 @@ for rnd in range(3):
         ops.set_option("pair_f16_debug", d)
         t = timeit(f5); best[f"f16x3 debug={d}"] = min(best.get(f"f16x3 debug={d}", 1e9), t)
     ops.set_option("pair_f16_debug", 0)
+    t = timeit(f5n); best["f16x3 pair by pair"] = min(best.get("f16x3 pair by pair", 1e9), t)
 assert not ops.pair_f16x3_timed_out(), "ring wait timed out"
 for k, v in best.items():
     print(f"{k:20s} {v:.3f} ms / 27 pairs", flush=True)
