@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="extra blocks of 20 steps after the timed region, for the spread")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="fgvc_set_option knobs for A/B runs, e.g. --set-option conv_narrow=1")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks on ONE GPU over gloo (device tensors staged through the host by fgvc_amd.dist): exercises every "
+                         "line of the multi-rank path on a one-GPU box; the number it prints is NOT a measurement (RCCL refuses two "
+                         "ranks on one device, hence gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,10 +226,15 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if a.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
 
     from fgvc_amd import _lib, dist as fdist, engine, ops
     _lib.load()
@@ -396,6 +405,9 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
     }
+    if a.rehearse_on_one_gpu:
+        out["rehearsal"] = (f"{world} ranks on ONE GPU over gloo, device tensors staged through the host: a functional rehearsal of the "
+                            "multi-rank path, not a measurement")
     if a.mode == "video":
         torch.cuda.synchronize()
         ph = timing.report()

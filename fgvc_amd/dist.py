@@ -14,9 +14,12 @@ Per rank r (one process per GPU, torch.distributed; backend "nccl" = RCCL over x
          together (`batch_isend_irecv`): p x 26 MB = 131 MB over one xGMI link (~153 GB/s) = 0.9 ms, against
          ~2.5 ms for encoding five more 480p frames;
        halo="recompute": every rank encodes its own halo (no message, 5 more encoder frames per rank);
-  4. correlation + top-k + merge for its own frames (no communication);
+  4. correlation + top-k + merge for its own frames (no communication).  The halo messages are posted BEFORE it and the
+     pairs that touch no halo frame (33 of a later rank's 48 at p = 5 and 8-frame clips) are launched while they are in
+     flight; the stream waits for the messages only in front of the remaining pairs;
   5. EXCHANGE STEP 2 -- `all_gather` of the merged per-frame lists (idx int32 + weight f32 =
-     HW*k*8 B = 2 MB per frame);
+     HW*k*8 B = 2 MB per frame), on the backend's side stream when it has one: together with the sweep it then runs
+     under whatever the caller enqueues next (the next video's encoder);
   6. every rank runs the (cheap, deterministic) sequential label sweep + read-out, so no final
      broadcast of the coordinates is needed.
 There is no all-reduce anywhere; the ring-bound per-link limit of xGMI is irrelevant at these sizes.
@@ -96,6 +99,75 @@ def halo_messages(ranges: List[Tuple[int, int]], own: List[Tuple[int, int]], s_m
     return msgs
 
 
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """gloo moves host memory only (its CUDA support covers broadcast / all_reduce): device tensors are staged through the host.
+    That is how the HIP backend is exercised with two ranks on ONE GPU in tests (RCCL refuses two ranks on a device)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _wire(t: torch.Tensor) -> torch.Tensor:
+    """The tensor as the process group moves it: int16 (the split bank) is a dtype neither RCCL nor gloo knows; its bytes
+    travel as uint8 (a view: what is received lands in `t`)."""
+    return t.view(torch.uint8) if t.dtype == torch.int16 else t
+
+
+def _broadcast(buf: torch.Tensor, src: int, group) -> None:
+    buf = _wire(buf)
+    if _host_staged(buf, group):
+        tmp = buf.cpu()
+        dist.broadcast(tmp, src=src, group=group)
+        buf.copy_(tmp)
+    else:
+        dist.broadcast(buf, src=src, group=group)
+
+
+def _all_gather(outs: List[torch.Tensor], t: torch.Tensor, group) -> None:
+    if _host_staged(t, group):
+        tmp = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(tmp, t.cpu(), group=group)
+        for o, c in zip(outs, tmp):
+            o.copy_(c)
+    else:
+        dist.all_gather(outs, t, group=group)
+
+
+class _Messages:
+    """Point-to-point messages posted together (`batch_isend_irecv`), completed by .wait(): on RCCL that makes the CURRENT
+    STREAM wait for the transfers (the host does not block), so kernels launched in between overlap them."""
+
+    def __init__(self, group):
+        self.group, self.ops, self.keep, self.land, self.reqs = group, [], [], [], None
+
+    def send(self, t: torch.Tensor, dst: int):
+        t = _wire(t.contiguous())
+        if _host_staged(t, self.group):
+            t = t.cpu()
+        self.keep.append(t)
+        self.ops.append(dist.P2POp(dist.isend, t, dst, self.group))
+
+    def recv(self, into: torch.Tensor, src: int):
+        assert into.is_contiguous()
+        into = _wire(into)
+        if _host_staged(into, self.group):
+            tmp = torch.empty(into.shape, dtype=into.dtype)
+            self.land.append((into, tmp))
+            into = tmp
+        self.keep.append(into)
+        self.ops.append(dist.P2POp(dist.irecv, into, src, self.group))
+
+    def post(self):
+        if self.ops:
+            self.reqs = dist.batch_isend_irecv(self.ops)
+        return self
+
+    def wait(self):
+        for req in self.reqs or []:
+            req.wait()
+        for into, tmp in self.land:
+            into.copy_(tmp)
+        self.reqs, self.land, self.keep = None, [], []
+
+
 class Timing:
     """Optional per-phase timing of track_points_sharded: CUDA events on the current stream when the work is on a GPU (read
     with .report() after a synchronize), wall clock otherwise."""
@@ -143,8 +215,9 @@ class HipBackend:
         # the bank in the form the pair kernel reads ((hi, lo) bf16 split where it applies): no second pass, same bytes to ship
         return self.model.get_feats_hwc(frames, split=True)
 
-    def affinity(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig):
-        tk = engine.run_affinity(bank, Hf, Wf, plan, cfg)
+    def affinity(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig, phases=None):
+        """`phases` = (plan indices of the pairs to launch first, callable to run before the others): see engine.run_pairs."""
+        tk = engine.run_affinity(bank, Hf, Wf, plan, cfg, phases=phases)
         return tk.idx, tk.weight
 
     def sweep(self, idx, weight, slot_frame, plan: Plan, start: int, pts, Hf, Wf, h, w, cfg):
@@ -241,83 +314,107 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
             if rank == 0:
                 vals = [Hf, Wf, 1 if frame_dtype == torch.int16 else 0, len(frame_shape)] + list(frame_shape)
                 meta[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
-            dist.broadcast(meta, src=0, group=group)
+            _broadcast(meta, 0, group)
             m = meta.tolist()
             sc["geom"] = (int(m[0]), int(m[1]), torch.int16 if m[2] else torch.float32, tuple(int(v) for v in m[4:4 + int(m[3])]))
         Hf, Wf, frame_dtype, frame_shape = sc["geom"]
     HW = Hf * Wf
+    k = cfg.topk
 
-    # ---- 2. exchange step 1: broadcast every group's first-frame features from its owner
-    with _span(timing, "broadcast_first_frames"):
-        for s in starts:
-            src = owner_of(s, enc)
-            buf = feats[s].contiguous() if (s in feats and rank == src) else torch.empty(frame_shape, device=dev, dtype=frame_dtype)
-            if world > 1:
-                dist.broadcast(buf, src=src, group=group)
-            if s not in feats:
-                feats[s] = buf
+    pending, halo_frames = None, set()
+    if world > 1:
+        # ---- the local bank: every frame this rank will hold, ascending, in ONE tensor the pair kernel reads; what arrives from
+        #      other ranks lands in its slices directly
+        mine = [(src, a, b) for (src, dst, a, b) in msgs if dst == rank]
+        halo_frames = {f for (_, a, b) in mine for f in range(a, b)} - set(feats)
+        local_ids = sorted(set(feats) | set(starts) | halo_frames)
+        pos = {f: i for i, f in enumerate(local_ids)}
+        bank = torch.empty((len(local_ids),) + tuple(frame_shape), device=dev, dtype=frame_dtype)
+        if enc_bank is not None:
+            bank[pos[e_lo]:pos[e_lo] + (e_hi - e_lo)].copy_(enc_bank)          # consecutive frames = consecutive bank rows
+        for f, t in feats.items():
+            if not (e_lo <= f < e_hi):
+                bank[pos[f]].copy_(t)
+        have = set(feats)
+        feats = {f: bank[pos[f]] for f in local_ids}
 
-    # ---- 3. halo: the p frames in front of this rank's clip, from the rank(s) that encoded them
-    with _span(timing, "halo_exchange"):
-        if msgs:
-            ops_, recvs = [], []
+        # ---- 2. exchange step 1: broadcast every group's first-frame features from its owner
+        with _span(timing, "broadcast_first_frames"):
+            for s_ in starts:
+                _broadcast(bank[pos[s_]], owner_of(s_, enc), group)
+                have.add(s_)
+
+        # ---- 3. halo: the p frames in front of this rank's clip, from the rank(s) that encoded them -- posted here, awaited in
+        #      front of the first pair that reads one of them
+        with _span(timing, "halo_exchange"):
+            pending = _Messages(group)
             for (src, dst, a, b) in msgs:
                 if src == rank:
-                    t = torch.stack([feats[f] for f in range(a, b)], 0) if b - a > 1 else feats[a].unsqueeze(0).contiguous()
-                    ops_.append(dist.P2POp(dist.isend, t, dst, group))
+                    pending.send(bank[pos[a]:pos[a] + (b - a)], dst)
                 elif dst == rank:
-                    t = torch.empty((b - a,) + frame_shape, device=dev, dtype=frame_dtype)
-                    ops_.append(dist.P2POp(dist.irecv, t, src, group))
-                    recvs.append((a, b, t))
-            if ops_:
-                for req in dist.batch_isend_irecv(ops_):
-                    req.wait()
-            for a, b, t in recvs:
-                for i in range(b - a):
-                    feats.setdefault(a + i, t[i])
+                    pending.recv(bank[pos[a]:pos[a] + (b - a)], src)
+            pending.post()
+    else:
+        with _span(timing, "broadcast_first_frames"):
+            pass
+        with _span(timing, "halo_exchange"):
+            pass
+        local_ids = sorted(feats)
+        bank = None
 
-    # ---- 4. local affinity on a compact local bank
-    local_ids = sorted(feats)
-    k = cfg.topk
+    # ---- 4. local affinity on the compact local bank
+    def halo_landed():
+        if pending is not None:
+            with _span(timing, "halo_wait"):
+                pending.wait()
+
     with _span(timing, "affinity"):
         if plan.pairs:
             if sc["lplan"] is None or sc["lplan"][0] != local_ids:
                 remap = {f: i for i, f in enumerate(local_ids)}
                 needed = {f for (q, kk, _) in plan.pairs for f in (q, kk)}
                 assert needed <= set(local_ids), f"rank {rank}: frames {sorted(needed - set(local_ids))} missing"
-                sc["lplan"] = (local_ids, replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={}))
-            if enc_bank is not None and local_ids == list(range(e_lo, e_hi)):
-                bank = enc_bank                                        # nothing came from elsewhere: the encoder's own tensor, no copy
+                first = [i for i, (q, kf, _) in enumerate(plan.pairs) if q not in halo_frames and kf not in halo_frames]
+                sc["lplan"] = (local_ids, replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={}), first)
+            if bank is None:
+                if enc_bank is not None and local_ids == list(range(e_lo, e_hi)):
+                    bank = enc_bank                                    # nothing came from elsewhere: the encoder's own tensor, no copy
+                else:
+                    bank = torch.stack([feats[f] for f in local_ids], 0)
+            if pending is not None and _takes_phases(backend):
+                idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg, phases=(sc["lplan"][2], halo_landed))
             else:
-                bank = torch.stack([feats[f] for f in local_ids], 0)
-            idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg)
+                halo_landed()
+                idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg)
         else:
+            halo_landed()
             idx = torch.empty((0, HW, k), device=dev, dtype=torch.int32)
             weight = torch.empty((0, HW, k), device=dev, dtype=torch.float32)
 
-    # ---- 5. exchange step 2: all_gather of the merged lists (padded to the largest shard)
+    # ---- 5. exchange step 2: all_gather of the merged lists (padded to the largest shard), on the side stream when there is one
     rows = sc["rows"]
-    with _span(timing, "all_gather_lists"):
-        if world > 1:
-            mx = max(rows)
-            pad_i = torch.zeros((mx, HW, k), device=dev, dtype=torch.int32)
-            pad_w = torch.zeros((mx, HW, k), device=dev, dtype=torch.float32)
-            pad_i[: idx.shape[0]] = idx
-            pad_w[: weight.shape[0]] = weight
-            all_i = [torch.empty_like(pad_i) for _ in range(world)]
-            all_w = [torch.empty_like(pad_w) for _ in range(world)]
-            dist.all_gather(all_i, pad_i, group=group)
-            dist.all_gather(all_w, pad_w, group=group)
-            idx = torch.cat([all_i[r][: rows[r]] for r in range(world)], 0)
-            weight = torch.cat([all_w[r][: rows[r]] for r in range(world)], 0)
     gplan, slot_frame_dev = sc["gplan"], sc["slot_frame_dev"]
-
-    # ---- 6. sequential sweep + read-out, replicated on every rank
     tail = getattr(backend, "tail_stream", None)
     if tail is not None:
         tail.wait_stream(torch.cuda.current_stream(dev))
         for t in (idx, weight, slot_frame_dev):
             t.record_stream(tail)                      # keep them from the caching allocator until the side stream is done
+    with (torch.cuda.stream(tail) if tail is not None else _Null()):
+        with _span(timing, "all_gather_lists"):
+            if world > 1:
+                mx = max(rows)
+                pad_i = torch.zeros((mx, HW, k), device=dev, dtype=torch.int32)
+                pad_w = torch.zeros((mx, HW, k), device=dev, dtype=torch.float32)
+                pad_i[: idx.shape[0]] = idx
+                pad_w[: weight.shape[0]] = weight
+                all_i = [torch.empty_like(pad_i) for _ in range(world)]
+                all_w = [torch.empty_like(pad_w) for _ in range(world)]
+                _all_gather(all_i, pad_i, group)
+                _all_gather(all_w, pad_w, group)
+                idx = torch.cat([all_i[r][: rows[r]] for r in range(world)], 0)
+                weight = torch.cat([all_w[r][: rows[r]] for r in range(world)], 0)
+
+    # ---- 6. sequential sweep + read-out, replicated on every rank
     col = 0
     with _span(timing, "sweep_readout"):
         with (torch.cuda.stream(tail) if tail is not None else _Null()):
@@ -330,6 +427,14 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                 backend.tail_event = torch.cuda.Event()
                 backend.tail_event.record(tail)
     return traj, sc["order"]
+
+
+def _takes_phases(backend) -> bool:
+    import inspect
+    try:
+        return "phases" in inspect.signature(backend.affinity).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 class _Null:

@@ -181,9 +181,9 @@ class PairLists:
 
 
 def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
-                 pair_chunk: int = 16384, events=None) -> DeviceTopk:
+                 pair_chunk: int = 16384, events=None, phases=None) -> DeviceTopk:
     """Phases 1 and 2 (= merge_pairs(run_pairs(...)))."""
-    return merge_pairs(run_pairs(feats_hwc, Hf, Wf, plan, cfg, pair_chunk, events), cfg)
+    return merge_pairs(run_pairs(feats_hwc, Hf, Wf, plan, cfg, pair_chunk, events, phases=phases), cfg)
 
 
 def merge_pairs(pl: PairLists, cfg: TrackerConfig, rows: Optional[Sequence[int]] = None) -> DeviceTopk:
@@ -208,12 +208,15 @@ def merge_pairs(pl: PairLists, cfg: TrackerConfig, rows: Optional[Sequence[int]]
 
 
 def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
-              pair_chunk: int = 16384, events=None, channels: Optional[int] = None) -> PairLists:
+              pair_chunk: int = 16384, events=None, channels: Optional[int] = None, phases=None) -> PairLists:
     """Phase 1.  feats_hwc (T, HW, C) normalised channels-last features of the whole clip, f32 -- or their
     split form (T, HW, 2, C) int16 in the format cfg.pair_split_fmt names, where the split pair kernel applies
     (VanillaTracker.get_feats_hwc(split=True)).
     `events` = (start, end) torch.cuda.Events recorded around the pair top-k launch(es); `channels` = the encoder's channel
-    count where it differs from the (zero-padded) row length."""
+    count where it differs from the (zero-padded) row length.
+    `phases` = (first, between): the pairs whose plan indices are in `first` are launched, then `between()` is called, then the
+    rest -- clip sharding launches the pairs that touch no halo frame while the halo messages are in flight and lets
+    `between` make the stream wait for them (the frames of the later pairs need not be valid in `feats_hwc` before that)."""
     dev = feats_hwc.device
     HW = Hf * Wf
     k = cfg.topk
@@ -235,7 +238,25 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
         pair_fn = lambda prs: ops.pair_topk(feats_hwc, feats_hwc, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False)
     if events is not None:
         events[0].record()
-    if n <= pair_chunk:
+    if phases is not None:
+        first, between = phases
+        fs = set(int(i) for i in first)
+        key = ("phases", str(dev), tuple(sorted(fs)))
+        if key not in plan._dev:
+            sel = [[i for i in range(n) if i in fs], [i for i in range(n) if i not in fs]]
+            plan._dev[key] = [(torch.tensor(ix, dtype=torch.int64, device=dev), ops.make_pairs([plan.pairs[i] for i in ix], dev))
+                              for ix in sel]
+        pidx = torch.empty((n, HW, k), device=dev, dtype=torch.int32)
+        pscore = torch.empty((n, HW, k), device=dev, dtype=torch.float32)
+        for ph, (ix, prs) in enumerate(plan._dev[key]):
+            if ph == 1:
+                between()
+            for c0 in range(0, prs.shape[0], pair_chunk):
+                c1 = min(prs.shape[0], c0 + pair_chunk)
+                i, s_ = pair_fn(prs if (c0 == 0 and c1 == prs.shape[0]) else ops.make_pairs([plan.pairs[j] for j in ix[c0:c1].tolist()], dev))
+                pidx.index_copy_(0, ix[c0:c1], i)
+                pscore.index_copy_(0, ix[c0:c1], s_)
+    elif n <= pair_chunk:
         pidx, pscore = pair_fn(pairs_dev)
     else:
         pidx = torch.empty((n, HW, k), device=dev, dtype=torch.int32)

@@ -14,6 +14,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The two-rank run of the product backend on one GPU is a tree of child processes.  It is started HERE, before any test has
+    touched the GPU from this process (a process that has initialised the GPU must not start other programs on the GPU boxes;
+    counting devices does not initialise it), and its verdict is read by tests/test_gpu_api.py."""
+    import subprocess
+    TWO_RANKS = session.config._fgvc_two_ranks = {}
+    expr = session.config.getoption("-m") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_ranks_one_gpu.py"), "--tail-stream"],
+                           capture_output=True, text=True, timeout=600)
+        TWO_RANKS.update(rc=r.returncode, out=r.stdout[-6000:], err=r.stderr[-3000:])
+    except Exception as e:   # reported by the test
+        TWO_RANKS.update(rc=-1, out="", err=repr(e))
+
+
+@pytest.fixture(scope="session")
+def two_ranks(request):
+    """Verdict of tools/two_ranks_one_gpu.py (dict with rc / out / err; empty when the session is not a GPU run)."""
+    return getattr(request.config, "_fgvc_two_ranks", {})
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -18,10 +18,26 @@ class OracleBackend:
         n, C, Hf, Wf = frames.shape
         return O.l2_normalize(frames, 1).flatten(2).transpose(1, 2).contiguous(), Hf, Wf
 
-    def affinity(self, bank, Hf, Wf, plan, cfg):
+    def affinity(self, bank, Hf, Wf, plan, cfg, phases=None):
+        """`phases` as HipBackend.affinity: rows made only of pairs in `first` are computed BEFORE between() (= before the halo
+        frames are awaited), the others after."""
         C = bank.shape[-1]
-        idxs, ws = [], []
-        for row in range(len(plan.slot_pair)):
+        n_rows = len(plan.slot_pair)
+        first, between = phases if phases is not None else (range(len(plan.pairs)), lambda: None)
+        first = set(first)
+        early = [r for r in range(n_rows) if all(p in first for p in plan.slot_pair[r] if p >= 0)]
+        late = [r for r in range(n_rows) if r not in early]
+        self.phase_rows = (len(early), len(late))
+        out = {}
+        for r in early:
+            out[r] = self._row(bank, Hf, Wf, plan, cfg, C, r)
+        between()
+        for r in late:
+            out[r] = self._row(bank, Hf, Wf, plan, cfg, C, r)
+        return torch.stack([out[r][0] for r in range(n_rows)], 0), torch.stack([out[r][1] for r in range(n_rows)], 0)
+
+    def _row(self, bank, Hf, Wf, plan, cfg, C, row):
+        if True:
             pids = [p for p in plan.slot_pair[row] if p >= 0]
             q = plan.pairs[pids[0]][0]
             ks = [plan.pairs[p][1] for p in pids]
@@ -29,9 +45,7 @@ class OracleBackend:
             km = torch.stack([bank[k].t().reshape(C, Hf, Wf) for k in ks], 1)
             idx, logit = O.affinity_topk(qm, km, cfg.topk, cfg.temperature, neighbor_range=cfg.neighbor_range,
                                          normalize=False)
-            idxs.append(idx.to(torch.int32))
-            ws.append(O.topk_weights(logit))
-        return torch.stack(idxs, 0), torch.stack(ws, 0)
+            return idx.to(torch.int32), O.topk_weights(logit)
 
     def sweep(self, idx, weight, slot_frame, plan, start, pts, Hf, Wf, h, w, cfg):
         T = plan.n_frames
@@ -73,9 +87,14 @@ def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5):
     h, w = feats.shape[-2] * 2, feats.shape[-1] * 2
     try:
         timing = D.Timing()
-        traj, order = _run(D, OracleBackend(), feats, qp, cfg, h, w, halo=halo, timing=timing)
+        be = OracleBackend()
+        traj, order = _run(D, be, feats, qp, cfg, h, w, halo=halo, timing=timing)
         rep = timing.report()
-        assert set(rep) == {"encode", "broadcast_first_frames", "halo_exchange", "affinity", "all_gather_lists", "sweep_readout"}
+        if halo == "exchange" and rank > 0:          # some rows were computed while the halo was in flight, some had to wait for it
+            assert (be.phase_rows[0] > 0 or world > 2) and be.phase_rows[1] > 0 and "halo_wait" in rep, (be.phase_rows, rep)
+        if halo == "recompute":
+            assert be.phase_rows[1] == 0
+        assert set(rep) >= {"encode", "broadcast_first_frames", "halo_exchange", "affinity", "all_gather_lists", "sweep_readout"}
         q.put((rank, traj, order))
     except Exception as e:  # surface the failure instead of letting the parent time out
         q.put((rank, repr(e), None))

@@ -253,3 +253,20 @@ def test_jhmdb_adapter_end_to_end(dev, tmp_path):
     pck = datasets.jhmdb_evaluate(model, ds)
     assert set(pck) == {"PCK@0.1", "PCK@0.2", "PCK@0.3", "PCK@0.4", "PCK@0.5"}
     assert pck["PCK@0.2"] > 80.0 and pck["PCK@0.1"] <= pck["PCK@0.2"] <= pck["PCK@0.5"], pck
+
+
+def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
+    """World size 2 with the PRODUCT backend: tools/two_ranks_one_gpu.py (started by conftest before this process touched the
+    GPU) runs fgvc_amd.dist.track_points_sharded(HipBackend) in two processes on this GPU -- over gloo with host staging, RCCL
+    refuses two ranks on a device -- in both halo modes, with and without the side stream, twice each (cached schedule), and
+    compares every rank's trajectories with the un-sharded tracker: order equal, max |diff| < 1e-3 px (observed 0.0)."""
+    import json
+    assert two_ranks, "the session-start hook did not run (is this a `-m gpu` session?)"
+    assert two_ranks["rc"] == 0, (two_ranks["out"][-2000:], two_ranks["err"][-2000:])
+    line = [l for l in two_ranks["out"].splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["ok"] and res["world"] == 2 and set(res["ranks"]) == {"0", "1"}
+    for r in res["ranks"].values():
+        assert set(r) == {"exchange", "exchange+tail", "recompute", "recompute+tail"}
+        for v in r.values():
+            assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 and "halo_wait" in v["phases"]
