@@ -405,6 +405,13 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
     }
+    if a.mode == "video":
+        rr = fdist.shard_frames(T, world, first=1)
+        out["config"]["query_frames_per_rank"] = [hi_ - lo_ for lo_, hi_ in rr]
+        out["config"]["pairs_per_rank"] = [len(engine.plan_clip(T, [0], cfg, frame_range=r_).pairs) for r_ in rr]
+        out["config"]["pairs_note"] = ("unique (query frame, key frame) pairs: frame t of a video has min(t, 6) key frames (frame 0 + the 5 "
+                                       "before it), so every rank after the first carries 6 per frame where an 8-frame clip has 27 in all -- "
+                                       "per-GPU frames are fixed as N grows (weak scaling), per-GPU pair work grows from 27 to 48")
     if a.rehearse_on_one_gpu:
         out["rehearsal"] = (f"{world} ranks on ONE GPU over gloo, device tensors staged through the host: a functional rehearsal of the "
                             "multi-rank path, not a measurement")
