@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--sync-tail", action="store_true",
                     help="label sweep + read-out on the main stream (default: on a side stream, so that the next step's encoder "
                          "overlaps this step's chain of small launches; every step is complete before the closing barrier)")
+    ap.add_argument("--tail-from", default="sweep", choices=["sweep", "pairs"],
+                    help="what runs on the side stream: the label sweep + read-out only, or everything after the encoder (pair top-k, "
+                         "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
     ap.add_argument("--repeats", type=int, default=5, help="extra blocks of 20 steps after the timed region, for the spread")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
@@ -279,7 +282,7 @@ def main():
     ops.pair_topk = probe.wrap(ops.pair_topk, lambda q, k_, prs, *r, **kw: ("pair_f32", prs.shape[0]))
 
     tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
-    backend = fdist.HipBackend(model, tail_stream=tail_stream)
+    backend = fdist.HipBackend(model, tail_stream=tail_stream, tail_from=a.tail_from)
     timing = fdist.Timing(dev)
     plan1 = engine.plan_clip(Tc, [0], cfg)
     state = {}

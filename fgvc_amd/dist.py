@@ -203,12 +203,16 @@ class Timing:
 class HipBackend:
     """The product backend: encoder through the tracker model, kernels through fgvc_amd.engine.
     `tail_stream`: run the replicated sweep + read-out (a chain of small launches that leaves most CUs idle) on this side stream,
-    so that whatever the caller enqueues next -- the next video's encoder -- starts under it.  The returned trajectories are then
+    so that whatever the caller enqueues next -- the next video's encoder -- starts under it; `tail_from="pairs"` moves the pair
+    top-k, the merge and the exchange steps there as well.  The returned trajectories are then
     produced on that stream: wait for `backend.tail_event` (or synchronise) before reading them."""
 
-    def __init__(self, model, tail_stream: Optional["torch.cuda.Stream"] = None):
+    def __init__(self, model, tail_stream: Optional["torch.cuda.Stream"] = None, tail_from: str = "sweep"):
+        if tail_from not in ("sweep", "pairs"):
+            raise ValueError(f"tail_from={tail_from!r}")
         self.model = model
         self.tail_stream = tail_stream
+        self.tail_from = tail_from          # "pairs": everything after the encoder runs on the side stream
         self.tail_event = None
 
     def encode(self, frames: torch.Tensor):
@@ -307,126 +311,136 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                 f, Hf, Wf = backend.encode(rgbs[s:s + 1].to(dev))
                 frame_shape, frame_dtype = tuple(f.shape[1:]), f.dtype
                 feats[s] = f[0]
-    # ranks with an empty range still take part in the collectives: learn the bank's geometry from rank 0
-    if world > 1:
-        if sc["geom"] is None:
-            meta = torch.zeros(8, dtype=torch.int64, device=dev)
-            if rank == 0:
-                vals = [Hf, Wf, 1 if frame_dtype == torch.int16 else 0, len(frame_shape)] + list(frame_shape)
-                meta[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
-            _broadcast(meta, 0, group)
-            m = meta.tolist()
-            sc["geom"] = (int(m[0]), int(m[1]), torch.int16 if m[2] else torch.float32, tuple(int(v) for v in m[4:4 + int(m[3])]))
-        Hf, Wf, frame_dtype, frame_shape = sc["geom"]
-    HW = Hf * Wf
-    k = cfg.topk
+    # Everything after the encoder can run on the backend's side stream (`HipBackend(tail_from="pairs")`): the caller's next video
+    # then encodes UNDER this video's pair top-k (a kernel paced by key-block traffic and vector issue, beside convolutions paced by
+    # the matrix pipe and the LDS).  The bank is a fresh allocation per call; record_stream keeps it alive for the side stream.
+    tail = getattr(backend, "tail_stream", None)
+    early = tail is not None and getattr(backend, "tail_from", "sweep") == "pairs"
+    if early:
+        tail.wait_stream(torch.cuda.current_stream(dev))
+        for t in ([enc_bank] if enc_bank is not None else []) + [t for f_, t in feats.items() if not (e_lo <= f_ < e_hi)]:
+            t.record_stream(tail)
+    with (torch.cuda.stream(tail) if early else _Null()):
+        # ranks with an empty range still take part in the collectives: learn the bank's geometry from rank 0
+        if world > 1:
+            if sc["geom"] is None:
+                meta = torch.zeros(8, dtype=torch.int64, device=dev)
+                if rank == 0:
+                    vals = [Hf, Wf, 1 if frame_dtype == torch.int16 else 0, len(frame_shape)] + list(frame_shape)
+                    meta[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
+                _broadcast(meta, 0, group)
+                m = meta.tolist()
+                sc["geom"] = (int(m[0]), int(m[1]), torch.int16 if m[2] else torch.float32, tuple(int(v) for v in m[4:4 + int(m[3])]))
+            Hf, Wf, frame_dtype, frame_shape = sc["geom"]
+        HW = Hf * Wf
+        k = cfg.topk
 
-    pending, halo_frames = None, set()
-    if world > 1:
-        # ---- the local bank: every frame this rank will hold, ascending, in ONE tensor the pair kernel reads; what arrives from
-        #      other ranks lands in its slices directly
-        mine = [(src, a, b) for (src, dst, a, b) in msgs if dst == rank]
-        halo_frames = {f for (_, a, b) in mine for f in range(a, b)} - set(feats)
-        local_ids = sorted(set(feats) | set(starts) | halo_frames)
-        pos = {f: i for i, f in enumerate(local_ids)}
-        bank = torch.empty((len(local_ids),) + tuple(frame_shape), device=dev, dtype=frame_dtype)
-        if enc_bank is not None:
-            bank[pos[e_lo]:pos[e_lo] + (e_hi - e_lo)].copy_(enc_bank)          # consecutive frames = consecutive bank rows
-        for f, t in feats.items():
-            if not (e_lo <= f < e_hi):
-                bank[pos[f]].copy_(t)
-        have = set(feats)
-        feats = {f: bank[pos[f]] for f in local_ids}
+        pending, halo_frames = None, set()
+        if world > 1:
+            # ---- the local bank: every frame this rank will hold, ascending, in ONE tensor the pair kernel reads; what arrives from
+            #      other ranks lands in its slices directly
+            mine = [(src, a, b) for (src, dst, a, b) in msgs if dst == rank]
+            halo_frames = {f for (_, a, b) in mine for f in range(a, b)} - set(feats)
+            local_ids = sorted(set(feats) | set(starts) | halo_frames)
+            pos = {f: i for i, f in enumerate(local_ids)}
+            bank = torch.empty((len(local_ids),) + tuple(frame_shape), device=dev, dtype=frame_dtype)
+            if enc_bank is not None:
+                bank[pos[e_lo]:pos[e_lo] + (e_hi - e_lo)].copy_(enc_bank)          # consecutive frames = consecutive bank rows
+            for f, t in feats.items():
+                if not (e_lo <= f < e_hi):
+                    bank[pos[f]].copy_(t)
+            have = set(feats)
+            feats = {f: bank[pos[f]] for f in local_ids}
 
-        # ---- 2. exchange step 1: broadcast every group's first-frame features from its owner
-        with _span(timing, "broadcast_first_frames"):
-            for s_ in starts:
-                _broadcast(bank[pos[s_]], owner_of(s_, enc), group)
-                have.add(s_)
+            # ---- 2. exchange step 1: broadcast every group's first-frame features from its owner
+            with _span(timing, "broadcast_first_frames"):
+                for s_ in starts:
+                    _broadcast(bank[pos[s_]], owner_of(s_, enc), group)
+                    have.add(s_)
 
-        # ---- 3. halo: the p frames in front of this rank's clip, from the rank(s) that encoded them -- posted here, awaited in
-        #      front of the first pair that reads one of them
-        with _span(timing, "halo_exchange"):
-            pending = _Messages(group)
-            for (src, dst, a, b) in msgs:
-                if src == rank:
-                    pending.send(bank[pos[a]:pos[a] + (b - a)], dst)
-                elif dst == rank:
-                    pending.recv(bank[pos[a]:pos[a] + (b - a)], src)
-            pending.post()
-    else:
-        with _span(timing, "broadcast_first_frames"):
-            pass
-        with _span(timing, "halo_exchange"):
-            pass
-        local_ids = sorted(feats)
-        bank = None
+            # ---- 3. halo: the p frames in front of this rank's clip, from the rank(s) that encoded them -- posted here, awaited in
+            #      front of the first pair that reads one of them
+            with _span(timing, "halo_exchange"):
+                pending = _Messages(group)
+                for (src, dst, a, b) in msgs:
+                    if src == rank:
+                        pending.send(bank[pos[a]:pos[a] + (b - a)], dst)
+                    elif dst == rank:
+                        pending.recv(bank[pos[a]:pos[a] + (b - a)], src)
+                pending.post()
+        else:
+            with _span(timing, "broadcast_first_frames"):
+                pass
+            with _span(timing, "halo_exchange"):
+                pass
+            local_ids = sorted(feats)
+            bank = None
 
-    # ---- 4. local affinity on the compact local bank
-    def halo_landed():
-        if pending is not None:
-            with _span(timing, "halo_wait"):
-                pending.wait()
+        # ---- 4. local affinity on the compact local bank
+        def halo_landed():
+            if pending is not None:
+                with _span(timing, "halo_wait"):
+                    pending.wait()
 
-    with _span(timing, "affinity"):
-        if plan.pairs:
-            if sc["lplan"] is None or sc["lplan"][0] != local_ids:
-                remap = {f: i for i, f in enumerate(local_ids)}
-                needed = {f for (q, kk, _) in plan.pairs for f in (q, kk)}
-                assert needed <= set(local_ids), f"rank {rank}: frames {sorted(needed - set(local_ids))} missing"
-                first = [i for i, (q, kf, _) in enumerate(plan.pairs) if q not in halo_frames and kf not in halo_frames]
-                sc["lplan"] = (local_ids, replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={}), first)
-            if bank is None:
-                if enc_bank is not None and local_ids == list(range(e_lo, e_hi)):
-                    bank = enc_bank                                    # nothing came from elsewhere: the encoder's own tensor, no copy
+        with _span(timing, "affinity"):
+            if plan.pairs:
+                if sc["lplan"] is None or sc["lplan"][0] != local_ids:
+                    remap = {f: i for i, f in enumerate(local_ids)}
+                    needed = {f for (q, kk, _) in plan.pairs for f in (q, kk)}
+                    assert needed <= set(local_ids), f"rank {rank}: frames {sorted(needed - set(local_ids))} missing"
+                    first = [i for i, (q, kf, _) in enumerate(plan.pairs) if q not in halo_frames and kf not in halo_frames]
+                    sc["lplan"] = (local_ids, replace(plan, pairs=[(remap[q], remap[kf], m) for (q, kf, m) in plan.pairs], _dev={}), first)
+                if bank is None:
+                    if enc_bank is not None and local_ids == list(range(e_lo, e_hi)):
+                        bank = enc_bank                                    # nothing came from elsewhere: the encoder's own tensor, no copy
+                    else:
+                        bank = torch.stack([feats[f] for f in local_ids], 0)
+                if pending is not None and _takes_phases(backend):
+                    idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg, phases=(sc["lplan"][2], halo_landed))
                 else:
-                    bank = torch.stack([feats[f] for f in local_ids], 0)
-            if pending is not None and _takes_phases(backend):
-                idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg, phases=(sc["lplan"][2], halo_landed))
+                    halo_landed()
+                    idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg)
             else:
                 halo_landed()
-                idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg)
-        else:
-            halo_landed()
-            idx = torch.empty((0, HW, k), device=dev, dtype=torch.int32)
-            weight = torch.empty((0, HW, k), device=dev, dtype=torch.float32)
+                idx = torch.empty((0, HW, k), device=dev, dtype=torch.int32)
+                weight = torch.empty((0, HW, k), device=dev, dtype=torch.float32)
 
-    # ---- 5. exchange step 2: all_gather of the merged lists (padded to the largest shard), on the side stream when there is one
-    rows = sc["rows"]
-    gplan, slot_frame_dev = sc["gplan"], sc["slot_frame_dev"]
-    tail = getattr(backend, "tail_stream", None)
-    if tail is not None:
-        tail.wait_stream(torch.cuda.current_stream(dev))
-        for t in (idx, weight, slot_frame_dev):
-            t.record_stream(tail)                      # keep them from the caching allocator until the side stream is done
-    with (torch.cuda.stream(tail) if tail is not None else _Null()):
-        with _span(timing, "all_gather_lists"):
-            if world > 1:
-                mx = max(rows)
-                pad_i = torch.zeros((mx, HW, k), device=dev, dtype=torch.int32)
-                pad_w = torch.zeros((mx, HW, k), device=dev, dtype=torch.float32)
-                pad_i[: idx.shape[0]] = idx
-                pad_w[: weight.shape[0]] = weight
-                all_i = [torch.empty_like(pad_i) for _ in range(world)]
-                all_w = [torch.empty_like(pad_w) for _ in range(world)]
-                _all_gather(all_i, pad_i, group)
-                _all_gather(all_w, pad_w, group)
-                idx = torch.cat([all_i[r][: rows[r]] for r in range(world)], 0)
-                weight = torch.cat([all_w[r][: rows[r]] for r in range(world)], 0)
-
-    # ---- 6. sequential sweep + read-out, replicated on every rank
-    col = 0
-    with _span(timing, "sweep_readout"):
+        # ---- 5. exchange step 2: all_gather of the merged lists (padded to the largest shard), on the side stream when there is one
+        rows = sc["rows"]
+        gplan, slot_frame_dev = sc["gplan"], sc["slot_frame_dev"]
+        tail = getattr(backend, "tail_stream", None)
+        if tail is not None:
+            tail.wait_stream(torch.cuda.current_stream(dev))
+            for t in (idx, weight, slot_frame_dev):
+                t.record_stream(tail)                      # keep them from the caching allocator until the side stream is done
         with (torch.cuda.stream(tail) if tail is not None else _Null()):
-            traj = torch.zeros((T, sc["n_points"], 2), device=dev, dtype=torch.float64)
-            for s, n_sel, pts in sc["groups"]:
-                coords = backend.sweep(idx, weight, slot_frame_dev, gplan, s, pts, Hf, Wf, h, w, cfg)
-                traj[s:, col:col + n_sel] = coords
-                col += n_sel
-            if tail is not None:
-                backend.tail_event = torch.cuda.Event()
-                backend.tail_event.record(tail)
-    return traj, sc["order"]
+            with _span(timing, "all_gather_lists"):
+                if world > 1:
+                    mx = max(rows)
+                    pad_i = torch.zeros((mx, HW, k), device=dev, dtype=torch.int32)
+                    pad_w = torch.zeros((mx, HW, k), device=dev, dtype=torch.float32)
+                    pad_i[: idx.shape[0]] = idx
+                    pad_w[: weight.shape[0]] = weight
+                    all_i = [torch.empty_like(pad_i) for _ in range(world)]
+                    all_w = [torch.empty_like(pad_w) for _ in range(world)]
+                    _all_gather(all_i, pad_i, group)
+                    _all_gather(all_w, pad_w, group)
+                    idx = torch.cat([all_i[r][: rows[r]] for r in range(world)], 0)
+                    weight = torch.cat([all_w[r][: rows[r]] for r in range(world)], 0)
+
+        # ---- 6. sequential sweep + read-out, replicated on every rank
+        col = 0
+        with _span(timing, "sweep_readout"):
+            with (torch.cuda.stream(tail) if tail is not None else _Null()):
+                traj = torch.zeros((T, sc["n_points"], 2), device=dev, dtype=torch.float64)
+                for s, n_sel, pts in sc["groups"]:
+                    coords = backend.sweep(idx, weight, slot_frame_dev, gplan, s, pts, Hf, Wf, h, w, cfg)
+                    traj[s:, col:col + n_sel] = coords
+                    col += n_sel
+                if tail is not None:
+                    backend.tail_event = torch.cuda.Event()
+                    backend.tail_event.record(tail)
+        return traj, sc["order"]
 
 
 def _takes_phases(backend) -> bool:

@@ -267,6 +267,6 @@ def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
     res = json.loads(line)
     assert res["ok"] and res["world"] == 2 and set(res["ranks"]) == {"0", "1"}
     for r in res["ranks"].values():
-        assert set(r) == {"exchange", "exchange+tail", "recompute", "recompute+tail"}
+        assert set(r) == {"exchange", "exchange+tail", "exchange+tail_from_pairs", "recompute", "recompute+tail", "recompute+tail_from_pairs"}
         for v in r.values():
             assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 and "halo_wait" in v["phases"]

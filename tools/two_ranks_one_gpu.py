@@ -45,9 +45,9 @@ def worker(rank, world, path, a, q):
         cfg = model.engine_config()
         out = {}
         for halo in ("exchange", "recompute"):
-            for tail in ((False, True) if a.tail_stream else (False,)):
+            for tail in ((False, True, "pairs") if a.tail_stream else (False,)):
                 ts = torch.cuda.Stream(dev) if tail else None
-                be = fdist.HipBackend(model, tail_stream=ts)
+                be = fdist.HipBackend(model, tail_stream=ts, tail_from="pairs" if tail == "pairs" else "sweep")
                 timing = fdist.Timing(dev)
                 cache = {}
                 for _ in range(2):                               # second call: cached schedule, buffers of the first still in use
@@ -56,7 +56,7 @@ def worker(rank, world, path, a, q):
                 feats, Hf, Wf = model.get_feats_hwc(rgbs.to(dev))
                 traj, order = engine.track_points(feats, Hf, Wf, h, w, qp, cfg)
                 rep = timing.report()
-                out[f"{halo}{'+tail' if tail else ''}"] = dict(
+                out[halo + {False: "", True: "+tail", "pairs": "+tail_from_pairs"}[tail]] = dict(
                     max_abs_diff_px=float((traj_s.cpu() - traj.cpu()).abs().max()), order_equal=bool(torch.equal(order_s, order)),
                     finite=bool(torch.isfinite(traj_s).all()), phases=sorted(rep))
         q.put((rank, out))
