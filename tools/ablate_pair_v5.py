@@ -24,7 +24,8 @@ def ms(reps=10):
     return e0.elapsed_time(e1) / reps
 
 
-names = {0: "full", 1: "no selection", 2: "no MFMA", 3: "neither", 16: "prologue only", 64: "prologue + epilogue"}
+names = {0: "three roles (default)", 2048: "three roles, hand-over only (no selection)", 1024: "two roles", 1025: "two roles, no selection", 1026: "two roles, no MFMA", 1027: "two roles, neither",
+         1024 + 16: "prologue only", 1024 + 64: "prologue + epilogue"}
 res = {k: [] for k in names}
 for _ in range(200):
     ops.pair_topk_split(h16, h16, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16")
@@ -35,4 +36,4 @@ for rnd in range(4):
         res[dbg].append(ms())
 ops.set_option("pair_f16_debug", 0)
 for dbg, name in names.items():
-    print(f"{name:22s} {min(res[dbg]):.3f} ms")
+    print(f"{name:46s} {min(res[dbg]):.3f} ms")

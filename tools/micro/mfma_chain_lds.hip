@@ -75,6 +75,23 @@ __global__ __launch_bounds__(MODE == 4 ? 768 : 512, 1) void k(long long* out, co
   const long long t0 = __builtin_amdgcn_s_memtime();
   for (int r = 0; r < reps; ++r) {
     const unsigned char* ka = &smem[(r & 1) * 32 * LDB + n * LDB + 16 * hi];
+#ifdef RING2
+    // two-deep fragment rings: ah[j + 2] is read right after the second MFMA of step j (the last reader of ah[j]), al[j + 2] after the third
+    f16x8 ah[2], al[2];
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = *reinterpret_cast<const f16x8*>(ka + 32 * i);
+      al[i] = *reinterpret_cast<const f16x8*>(ka + 512 + 32 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(ah[0]), "v"(b));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[j & 1]), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[j & 1]), "v"(b));
+      if (j + 2 < 16) ah[j & 1] = *reinterpret_cast<const f16x8*>(ka + 32 * (j + 2));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(al[j & 1]), "v"(b));
+      if (j + 2 < 16) al[j & 1] = *reinterpret_cast<const f16x8*>(ka + 512 + 32 * (j + 2));
+    }
+#else
     f16x8 ah[3], al[3];
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const f16x8*>(ka + 32 * i);
@@ -91,6 +108,7 @@ __global__ __launch_bounds__(MODE == 4 ? 768 : 512, 1) void k(long long* out, co
       asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[j % 3]), "v"(b));
       asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(al[j % 3]), "v"(b));
     }
+#endif
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
     if (acc[0] == 12345.f) out[2] = 1;
   }
