@@ -665,6 +665,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
         // first two MFMAs of every tile.  The LDS returns a wave's reads in order, so the waits are counted by hand: when a fragment
         // is needed, the three reads issued after it may still be in flight (the last step waits for everything).
         f16x8 ah[2], al[2];
+        int peek = 0;
         const uint32_t ka_l = lds_addr_of(ka);
 #define V6_READ(DST, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ka_l), "n"(OFF) : "memory")
         V6_READ(ah[0], 0); V6_READ(al[0], 2 * C); V6_READ(ah[1], 32); V6_READ(al[1], 2 * C + 32);
@@ -676,6 +677,8 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
           else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[j & 1]), "v"(qh[j]));
           asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[j & 1]), "v"(ql[j]));
           if (j + 2 < KS) V6_READ(ah[j & 1], 32 * (j + 2));
+          if (j == KS - 1)         // has the selector read the previous tile?  Asked before the last MFMA, needed ~60 cycles later
+            asm volatile("ds_read_b32 %0, %1" : "=v"(peek) : "v"(lds_addr_of(&hand_free[qb])) : "memory");
           if (j < KS - 1) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
           asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(al[j & 1]), "v"(qh[j]));
           if (j + 2 < KS) V6_READ(al[j & 1], 2 * C + 32 * (j + 2));
@@ -687,9 +690,9 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
         }
 #undef V6_READ
         // MFMA result -> vector read: the last MFMA's passes must have written back
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
-        // hand the tile over: the selector has read the one before
-        spin_ge<2, false>(&hand_free[qb], t_con, dead);
+        asm volatile("s_nop 15\n\ts_nop 7\n\ts_waitcnt lgkmcnt(0)" : "+v"(acc), "+v"(peek));     // (and the peek has landed)
+        // hand the tile over once the selector has read the one before (it normally has: the answer came with the last fragments)
+        if (__builtin_amdgcn_readfirstlane(peek) < t_con) spin_ge<2, false>(&hand_free[qb], t_con, dead);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
           v.x = (int)acc[4 * g4 + 0]; v.y = (int)acc[4 * g4 + 1]; v.z = (int)acc[4 * g4 + 2]; v.w = (int)acc[4 * g4 + 3];
           *reinterpret_cast<int4*>(hw + g4 * 256) = v;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");                 // the LDS executes a wave's operations in order: the count follows the data
         if (lane == 0) __hip_atomic_fetch_add(&hand_full[qb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++t_con;
       }
