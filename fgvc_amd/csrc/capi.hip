@@ -51,6 +51,7 @@ int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, h
 void set_conv_cot_cap(int);
 void set_conv_narrow(int);
 void set_conv_debug(int);
+void set_corr6_skew(int);
 void set_pair_kernel(int);
 void set_pair_debug(int);
 void set_pair_v4_debug(int);
@@ -108,6 +109,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
     set_pair_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "corr6_skew") == 0) {   // fgvc_corr_volume_f16f6: stages taken from the two-segment piece and given to the others
+    set_corr6_skew(value);
     return FGVC_OK;
   }
   if (strcmp(name, "conv_debug") == 0) {   // profiling ablations of fgvc_conv_split_f32; results are wrong when non-zero

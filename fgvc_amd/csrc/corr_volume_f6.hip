@@ -139,7 +139,7 @@ template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (res
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const unsigned char* __restrict__ q_sp,
                                                                       const unsigned char* __restrict__ k_sp, int HWq, int HWk,
                                                                       float out_scale, float* __restrict__ vol, int s_tile,
-                                                                      int c_half, int n_tiles, int period, int m32) {
+                                                                      int c_half, int n_tiles, int period, int m32, int skew) {
   constexpr int SUB = 2, ROWB = F6_ROWB, LDB = ROWB + 32, ROWS = 32 * SUB, BUFB = ROWS * LDB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -166,7 +166,15 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     piece = rank / n_pairs_;
     pair = rank - piece * n_pairs_;
   }
-  const int r0 = (int)((long long)piece * 2 * s_tile / c_half), r1 = (int)((long long)(piece + 1) * 2 * s_tile / c_half);
+  // piece boundaries: equal cuts, except that with an odd c_half the middle piece -- the one that runs from one tile into the next
+  // and pays a second prologue -- is `(c_half - 1) skew` stages shorter and every other piece `skew` stages longer
+  auto cut = [&](int i) {
+    const int base = (int)((long long)i * 2 * s_tile / c_half);
+    if (!(c_half & 1) || i == 0 || i == c_half) return base;
+    const int m = c_half >> 1;
+    return base + (i <= m ? skew * i : skew * (i - 1) - (c_half - 1) * skew);
+  };
+  const int r0 = cut(piece), r1 = cut(piece + 1);
   auto run_segment = [&](int tile_idx, int st0, int st1) {        // stages [st0, st1) of tile tile_idx
   const int xq = tile_idx / period;
   const int cls = tile_idx - xq * period;                       // row class: key rows j = period * v + cls
@@ -467,6 +475,8 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
 }
 
 static int g_corr6_debug = 0;
+static int g_corr6_skew = 2;   // -1 % at 480p (tools/try_corr6_skew.py: 0 / 2 / 4 / 6 / 8 / 10 / 14 stages: 0.674 / 0.668 / 0.674 / 0.673 / 0.683 / 0.694 / 0.712 ms)
+void set_corr6_skew(int v) { g_corr6_skew = v; }
 static int g_corr6_cost_pro = 20000, g_corr6_cost_stage = 5700;      // cycles, tools/time_corr6.py
 void set_corr6_debug(int v) { g_corr6_debug = v; }
 
@@ -500,7 +510,7 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
   dim3 grid(n_pairs * c_half);
   const float out_scale = 1.0f / (temperature * F6_S * F6_S);
   const int mm = period > 1 ? m32 : 0;
-#define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, s_tile, c_half, n_tiles, period, mm)
+#define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, s_tile, c_half, n_tiles, period, mm, g_corr6_skew)
   switch (g_corr6_debug & 1019) {
     case 128: FGVC_C6(128); break;
     case 32 + 256: FGVC_C6(288); break;      // probe, no f16 MFMAs (results wrong)

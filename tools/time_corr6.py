@@ -43,6 +43,10 @@ for dbg, name in ((32, "with stores"), (33, "no stores"), (34, "no MFMAs"), (32 
     print(f"   per segment: prologue {w0[:, 0].mean():7.0f} cycles; per stage: multiply {(w0[:, 1] / ns).mean():6.0f} stores {(w0[:, 2] / ns).mean():6.0f} "
           f"wait+barrier {(w0[:, 3] / ns).mean():6.0f} = {((w0[:, 1] + w0[:, 2] + w0[:, 3]) / ns).mean():6.0f}; stages {ns.mean():.1f}; "
           f"segment {dur.mean():.1f} us (min {dur.min():.1f}, max {dur.max():.1f})")
+    xcc = w0[:, 10] & 15
+    per = "  ".join(f"{x}: {dur[xcc == x].mean():5.1f} us x {int((xcc == x).sum()):3d} seg, busy {dur[xcc == x].sum() / 32:5.1f}, last end {(rt1[xcc == x].max() - rt0.min()):5.1f}"
+                    for x in sorted(set(xcc.tolist())))
+    print(f"   per XCD (mean segment, segments, busy us per CU, last end): {per}")
     order = np.argsort(rt0)
     st = rt0[order] - rt0.min()
     print(f"   segment starts (us after the first): 10 % {np.percentile(st, 10):.1f}  50 % {np.percentile(st, 50):.1f}  90 % {np.percentile(st, 90):.1f}; "
