@@ -736,6 +736,43 @@ def test_pair_f16x3_runs_of_pairs_equal_pair_by_pair(dev):
         assert float((torch.sort(sa[differ], dim=-1).values - torch.sort(s3[differ], dim=-1).values).abs().max()) < 2.5e-6
 
 
+def test_pair_f16x3_three_roles_equal_two_roles_and_large_lists_fall_back(dev):
+    """The default form of fgvc_pair_topk_f16x3 (consumer / selector / producer waves, accumulators handed over through the LDS) gives
+    bit-identical lists to the two-role form (pair_f16_debug = 1024) -- same products, same keys, same networks -- on grids with
+    edge tiles, K = 10 and K = 5, disc and rectangular windows, masked and unmasked pairs.  An unmasked pair on a grid whose block
+    list exceeds the three-role form's 2048 entries (here 65 x 33 = 2145 blocks) runs on the two-role form: checked against the
+    f32-MFMA kernel."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (H, W, T, topk, nr, rect) in [(33, 70, 4, 10, 30, None), (17, 41, 3, 5, 12, None), (24, 24, 3, 10, 14, (5, 3))]:
+        f = ops.normalize_to_hwc(torch.randn(T, 256, H, W, generator=g).to(dev))
+        h16 = ops.split_f16x2(f)
+        rows = [(1, 0, True), (2, 0, True), (2, 1, True), (T - 1, 0, False)]
+        pairs = ops.make_pairs(rows, dev)
+        mask = ops.MaskSpec.from_neighbor_range(nr)
+        if rect is not None:
+            mask = ops.MaskSpec(r2max=mask.r2max, ry=rect[0], rx=rect[1])
+        outs = []
+        for dbg in (0, 1024):
+            ops.set_option("pair_f16_debug", dbg)
+            try:
+                outs.append(ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, topk, fmt="f16"))
+            finally:
+                ops.set_option("pair_f16_debug", 0)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (H, W, topk)
+    assert not ops.pair_f16x3_timed_out()
+    # block list beyond the three-role capacity: an unmasked pair scans the whole 260 x 260 key grid
+    H = W = 260
+    f = ops.normalize_to_hwc(torch.randn(2, 256, H, W, generator=g).to(dev))
+    pairs = ops.make_pairs([(1, 0, False)], dev)
+    mask = ops.MaskSpec.from_neighbor_range(30)
+    i16, s16 = ops.pair_topk_split(ops.split_f16x2(f), ops.split_f16x2(f), pairs, H, W, H, W, mask, 10, fmt="f16")
+    i32, s32 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+    assert float((s16 - s32).abs().max()) < 2.5e-6
+    assert float((i16 == i32).all(-1).float().mean()) > 0.995
+    assert not ops.pair_f16x3_timed_out()
+
+
 def test_split_pair_topk_rejects_what_it_cannot_do(dev):
     from fgvc_amd import ops, _lib
     f = ops.normalize_to_hwc(torch.randn(1, 128, 8, 8).to(dev))
