@@ -639,6 +639,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
     __syncthreads();                               // the ring is free for key blocks
     f32x16 acc;
     int t_con = 0;                                 // tiles handed over so far (over the whole run)
+    int fnext = -1;                                // filled[] of the NEXT key block's slot, asked for between a chain and its hand-over
     int* const hw = &hand[qb][4 * lane];
     for (int pi = 0; pi < g_count; ++pi) {
       uint32_t ent_next = n_loop > 0 ? blist[0] : 0u;
@@ -649,7 +650,9 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
         const int slot = G & (NSLOT - 1), gen = G / NSLOT;
         const bool comp = ((ent >> (24 + qb)) & 1) != 0;
         // block G has landed; a consumer that does not reach it waits for this too before it releases the slot (see the two-role form)
-        spin_ge<2, false>(&filled[slot], 4 * (gen + 1), dead);
+        // (after a chain the counter has been asked for before the hand-over: normally the block is there and nothing is waited for)
+        if (fnext < 4 * (gen + 1)) spin_ge<2, false>(&filled[slot], 4 * (gen + 1), dead);
+        fnext = -1;
         asm volatile("" ::: "memory");
         if (!comp) {
           if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -691,6 +694,8 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
 #undef V6_READ
         // MFMA result -> vector read: the last MFMA's passes must have written back
         asm volatile("s_nop 15\n\ts_nop 7\n\ts_waitcnt lgkmcnt(0)" : "+v"(acc), "+v"(peek));     // (and the peek has landed)
+        int peek2;                                     // is the next key block there?  The answer lands under the hand-over
+        asm volatile("ds_read_b32 %0, %1" : "=v"(peek2) : "v"(lds_addr_of(&filled[(G + 1) & (NSLOT - 1)])) : "memory");
         // hand the tile over once the selector has read the one before (it normally has: the answer came with the last fragments)
         if (__builtin_amdgcn_readfirstlane(peek) < t_con) spin_ge<2, false>(&hand_free[qb], t_con, dead);
         asm volatile("" ::: "memory");
@@ -703,6 +708,8 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
         asm volatile("" ::: "memory");                 // the LDS executes a wave's operations in order: the count follows the data
         if (lane == 0) __hip_atomic_fetch_add(&hand_full[qb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++t_con;
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(peek2) : : "memory");   // the read is older than the four stores and the count
+        fnext = __builtin_amdgcn_readfirstlane(peek2);
       }
     }
     if (dead) g_pair_v5_timeout = 1;
