@@ -436,6 +436,23 @@ int fgvc_local_corr_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, 
                             weight_out, (hipStream_t)stream);
 }
 
+int fgvc_local_corr_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_slots, int C,
+                               int H, int W, int R, int topk, float temperature, int32_t* pair_idx_ws,
+                               float* pair_score_ws, int32_t* idx_out, float* logit_out, float* weight_out,
+                               void* stream) {
+  FGVC_REQUIRE(pair_idx_ws && pair_score_ws && idx_out && logit_out && weight_out, FGVC_ERR_INVALID_ARG,
+               "fgvc_local_corr_topk_f16x3: null pointer");
+  FGVC_REQUIRE(R >= 0 && n_slots >= 1 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_local_corr_topk_f16x3: bad R/n_slots/temperature");
+  FGVC_REQUIRE((long long)n_slots * (2 * R + 1) * (2 * R + 1) < (1ll << 31), FGVC_ERR_UNSUPPORTED,
+               "fgvc_local_corr_topk_f16x3: index overflow");
+  // every slot of a local window is a masked pair (the window IS the mask): all_masked = 1
+  int rc = fgvc_pair_topk_f16x3(qsplit, ksplit, pairs, n_slots, C, H, W, H, W, FGVC_NO_LIMIT, R, R, topk, 1, pair_idx_ws,
+                                pair_score_ws, stream);
+  if (rc != FGVC_OK) return rc;
+  return local_merge_launch(pair_idx_ws, pair_score_ws, n_slots, H, W, R, topk, temperature, idx_out, logit_out,
+                            weight_out, (hipStream_t)stream);
+}
+
 int fgvc_topk_coord_f32(const int32_t* idx, const float* weight, int H, int W, int R, int topk, int scale, float* out,
                         void* stream) {
   FGVC_REQUIRE(idx && weight && out, FGVC_ERR_INVALID_ARG, "fgvc_topk_coord_f32: null pointer");

@@ -391,21 +391,24 @@ def dense_attend(qfeat: torch.Tensor, kfeat: torch.Tensor, labels: torch.Tensor,
 
 
 def local_corr_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, H: int, W: int, R: int, topk: int,
-                    temperature: float, normalized: bool = False):
+                    temperature: float, normalized: bool = False, split_fmt: str = "f16"):
     """A7: qfeat (1, HW, C), kfeat (K, HW, C) -> idx (HW,k) int32 = slot*(2R+1)^2 + tap, logit, weight.
-    normalized=True (rows are L2-normalised) lets C == 256 / k <= 10 run on the bf16 pipe (fgvc_local_corr_topk_bf16x4)."""
+    normalized=True (rows are L2-normalised) lets C == 256 / k <= 10 run on the 16-bit matrix pipe: fgvc_local_corr_topk_f16x3
+    (split_fmt="f16", default) or fgvc_local_corr_topk_bf16x4 (split_fmt="bf16")."""
     qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
     K = kfeat.shape[0]
     dev = qfeat.device
+    if split_fmt not in ("f16", "bf16"):
+        raise ValueError(f"split_fmt={split_fmt!r}")
     if split_path_ok(qfeat.shape[-1], H, W, topk, normalized, None, MaskSpec(ry=R, rx=R), True):
-        qs, ks = split_bf16(qfeat), split_bf16(kfeat)
+        qs, ks = (split_f16x2(qfeat), split_f16x2(kfeat)) if split_fmt == "f16" else (split_bf16(qfeat), split_bf16(kfeat))
         pairs = make_pairs([(0, t) for t in range(K)], dev)
         ws_i = torch.empty((K, H * W, topk), device=dev, dtype=torch.int32)
         ws_s = torch.empty((K, H * W, topk), device=dev, dtype=torch.float32)
         idx = torch.empty((H * W, topk), device=dev, dtype=torch.int32)
         logit = torch.empty((H * W, topk), device=dev, dtype=torch.float32)
         weight = torch.empty_like(logit)
-        _lib.call("fgvc_local_corr_topk_bf16x4", _ptr(qs), _ptr(ks), _ptr(pairs), K, qfeat.shape[-1], H, W, R, topk,
+        _lib.call("fgvc_local_corr_topk_f16x3" if split_fmt == "f16" else "fgvc_local_corr_topk_bf16x4", _ptr(qs), _ptr(ks), _ptr(pairs), K, qfeat.shape[-1], H, W, R, topk,
                   float(temperature), _ptr(ws_i), _ptr(ws_s), _ptr(idx), _ptr(logit), _ptr(weight), _stream(qfeat))
         return idx, logit, weight
     pairs = make_pairs([(0, t) for t in range(K)], dev)

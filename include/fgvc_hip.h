@@ -224,6 +224,12 @@ int fgvc_local_corr_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, 
                                 int C, int H, int W, int R, int topk, float temperature,
                                 int32_t* pair_idx_ws, float* pair_score_ws,
                                 int32_t* idx_out, float* logit_out, float* weight_out, void* stream);
+/* ... and on the f16 pipe: features as written by fgvc_split_f16x2 (fgvc_pair_topk_f16x3 with the square window, then the same
+ * merge): three products instead of four, 22-bit operands instead of 16 -- the default of the HR driver for C == 256 */
+int fgvc_local_corr_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_slots,
+                               int C, int H, int W, int R, int topk, float temperature,
+                               int32_t* pair_idx_ws, float* pair_score_ws,
+                               int32_t* idx_out, float* logit_out, float* weight_out, void* stream);
 
 /* ---- A7 get_coord (vanilla_tracker.py:445-488): expected image coordinate of every query pixel under the top-k
  * window weights of fgvc_local_corr_topk_f32 with ONE key slot (taps outside the grid contribute (0,0), like the

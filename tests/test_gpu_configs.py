@@ -241,7 +241,7 @@ def test_cfg3_local_window_full_size(dev):
     want = (A.reshape(T3 * HW3, P)[(slot * HW3 + ky.clamp(0, H3 - 1) * W3 + kx.clamp(0, W3 - 1))] * (weight * inb).unsqueeze(-1)).sum(1)
     assert torch.allclose(f(A), want, atol=1e-5)
     REPORT["cfg3_local_window"] = dict(grid=[H3, W3, C], radius=R3, slots=T3, sampled_queries=int(sample.numel()),
-                                       clear_gap_queries=int(clear.sum()), kernel="fgvc_local_corr_topk_bf16x4")
+                                       clear_gap_queries=int(clear.sum()), kernel="fgvc_local_corr_topk_f16x3")
 
 
 def test_cfg3_c2f_full_size(dev):

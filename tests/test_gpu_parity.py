@@ -1124,7 +1124,9 @@ def test_local_corr_split_path_vs_oracle(dev):
     v = torch.rand(5, K, H, W, generator=g)
     qf = ops.normalize_to_hwc(q[None].to(dev))
     kf = ops.normalize_to_hwc(key.permute(1, 0, 2, 3).contiguous().to(dev))
-    i1, l1, w1 = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07, normalized=True)
+    i1, l1, w1 = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07, normalized=True)                       # fgvc_local_corr_topk_f16x3
+    ib, lb, wb = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07, normalized=True, split_fmt="bf16")   # fgvc_local_corr_topk_bf16x4
+    assert torch.allclose(lb, l1, atol=1e-4) and (ib == i1).all(1).float().mean() > 0.98 and torch.allclose(wb, w1, atol=1e-4)
     i0, l0, w0 = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07)
     o_out, o_idx, o_logit = O.local_corr_topk(q, key.transpose(0, 1), v.transpose(0, 1), R, topk, 0.07)
     assert torch.allclose(l1.cpu(), o_logit, atol=TOL) and torch.allclose(l1, l0, atol=1e-4)

@@ -39,5 +39,6 @@ lw = ops.normalize_to_hwc(torch.randn(T + 1, C, H, W, device=dev))
 for R in (6, 12):
     t_f32 = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07))
     t_split = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07, normalized=True))
-    print(f"local window (A7) radius {R}, {T} key slots at {H}x{W}x{C}: f32-MFMA kernel {t_f32:.3f} ms, bf16-pipe kernel "
-          f"{t_split:.3f} ms per query frame")
+    t_b = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07, normalized=True, split_fmt="bf16"))
+    print(f"local window (A7) radius {R}, {T} key slots at {H}x{W}x{C}: f32-MFMA kernel {t_f32:.3f} ms, f16x3 kernel "
+          f"{t_split:.3f} ms, bf16x4 kernel {t_b:.3f} ms per query frame (the 16-bit forms include their split pass)")
