@@ -57,6 +57,25 @@ WORKLOADS = {
 }
 
 
+def encoder_flops(wl, n_frames: int) -> float:
+    """ALGORITHMIC f32 FLOPs (2 x MACs) of the ResNet-18 trunk up to the output stage for n_frames frames: 7x7 stride-2 stem, no pool,
+    stages of two BasicBlocks (two 3x3 convolutions each, a 1x1 projection where the block changes width or stride) --
+    resnet.py:457-466, 254-325."""
+    h, w = (wl["h"] - 1) // 2 + 1, (wl["w"] - 1) // 2 + 1
+    fl = 2.0 * h * w * 3 * 64 * 49
+    cin = 64
+    for stage in range(wl["out_indices"][0] + 1):
+        cout, stride = 64 * 2 ** stage, wl["strides"][stage]
+        for blk in range(2):
+            st = stride if blk == 0 else 1
+            ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+            fl += 2.0 * ho * wo * cin * cout * 9 + 2.0 * ho * wo * cout * cout * 9
+            if blk == 0 and (st != 1 or cin != cout):
+                fl += 2.0 * ho * wo * cin * cout
+            h, w, cin = ho, wo, cout
+    return fl * n_frames
+
+
 def pmc(kernel: str):
     """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r02_pmc.json, written by tools/pmc_report.py from
     separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes); {} if absent."""
@@ -422,6 +441,18 @@ def main():
         torch.cuda.synchronize()
         ph = timing.report()
         out["sharding_ms_per_step"] = {k: v / a.steps for k, v in ph.items()}
+        enc_ms = ph.get("encode", 0.0) / a.steps
+        if enc_ms > 0:
+            n_enc = (hi - e_lo) if a.halo == "exchange" or world == 1 else (hi - max(0, lo - cfg.precede_frames))
+            efl = encoder_flops(wl, n_enc)
+            kernels["encoder_phase"] = {
+                "what": "the whole trunk on rank 0 (stem, 3x3 / 1x1 / stride-2 convolutions on both stream lanes, normalise + split): "
+                        "ALGORITHMIC f32 FLOPs of its convolutions / the encode phase's HIP-event time",
+                "frames": n_enc, "ms": enc_ms, "bound": "mfma", "achieved": efl / (enc_ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": efl / (enc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "executed_tflops": CONV_PRODUCTS * efl / (enc_ms * 1e-3) / 1e12,
+                "frac_executed": CONV_PRODUCTS * efl / (enc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "frac_of_f32_mfma_peak": efl / (enc_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
         out["sharding_note"] = ("HIP-event time per phase on rank 0's main stream (the sweep runs on a side stream and overlaps the next "
                                 "step's encoder; at N = 1 broadcast / halo / all_gather are skipped)")
 
