@@ -34,6 +34,10 @@ struct ConvSplitParams {
 __device__ __forceinline__ void conv_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_uniform) : "memory");
 }
+// ... with a wave-uniform base in SGPRs and a 32-bit lane offset (one VGPR instead of a 64-bit address pair)
+__device__ __forceinline__ void conv_lds_dma_16s(uint32_t lane_off, const void* base_uniform, uint32_t lds_uniform) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base_uniform), "s"(lds_uniform) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
@@ -50,7 +54,7 @@ __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^
 // NWR = waves along the pixel rows (4: an 8-row tile, 512 threads, one workgroup per CU; 2: a 4-row tile, 256 threads,
 // small enough in LDS and registers for TWO workgroups per CU -- for the narrow layers, whose short main loop cannot hide
 // its own prologue and epilogue, the second workgroup does).
-template <int KS, int COT, int TG, int NSLOT, int NWR>
+template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false>
 __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel(ConvSplitParams p) {
   constexpr int T = KS * KS;
   constexpr int PADK = KS / 2;                  // 1 for 3x3, 0 for 1x1
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     CV_PIECE_GEOM(J)                                                                                  \
     *reinterpret_cast<uint4*>(patch + (prow_ * CV_PW + pc0_) * 128 + lane * 16) = pre##J;             \
   }
+  const uint32_t w_lane_off = (uint32_t)(d_row * 128 + ((d_slot ^ (d_row >> 1)) << 4));
   // one 1-KiB piece (8 output channels of one tap) of the weight slab of stage q = chunk * SPC + tap group
   auto stage_weight_piece = [&](int q, int j) {
     const int chunk = q / SPC, tap0 = (q - chunk * SPC) * TG;
@@ -128,11 +133,12 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     const int piece = wave * PPW + j;                                  // always PPW pieces per wave (a short last group
     const int tg = piece / (COT / 8), c0 = (piece - tg * (COT / 8)) * 8;     // re-reads its last tap): the vmcnt
     const int tap = imin(tap0 + tg, T - 1);                            // arithmetic stays fixed
+    // wave-uniform base (tap, chunk, first output channel of the piece) + lane offset: row d_row of the piece, slot d_slot swizzled by
+    // the row's key ((c0 + d_row) >> 1) & 7 = (d_row >> 1) | ((c0 >> 1) & 4)  (c0 is a multiple of 8): one lane constant, XORed with 64
+    // for every other piece
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
-                              (((size_t)tap * nchunk + chunk) * p.Cout + co_base) * 128;
-    const int co = c0 + d_row;
-    const int sl = d_slot ^ ((co >> 1) & 7);
-    conv_lds_dma_16(wb + (size_t)co * 128 + sl * 16, lds_addr(dst + (tg * COT + c0) * 128));
+                              ((((size_t)tap * nchunk + chunk) * p.Cout + co_base) + c0) * 128;
+    conv_lds_dma_16s(w_lane_off ^ (uint32_t)((c0 & 8) << 3), wb, lds_addr(dst + (tg * COT + c0) * 128));
   };
   auto stage_weights = [&](int q) {
 #pragma unroll
@@ -181,6 +187,79 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     // (tried: let one wave of each SIMD issue its DMAs up front to shift it against its partner -- 10 % slower)
     if (timing) c2 = __builtin_amdgcn_s_memtime();
     const unsigned char* wslot = wring + (q % NSLOT) * CV_WSLOTB;
+    if constexpr (PINNED && TG == 1 && NA == 4 && KS == 3) {
+      // ---- the widest form's stage as volatile inline assembly in a fixed order (reads, counted waits, MFMAs).  Left to the compiler,
+      // every weight fragment is read right before its first use (2-4 MFMAs of cover for a ~130-cycle LDS round trip; 24 registers for
+      // fragments).  Here the pixel fragments of a K-16 step (16 registers) are read during the step before and the weight fragments
+      // of channel block a + 2 right after block a's six MFMAs have issued: a block of cover for every read, 48 fragment registers --
+      // which fit since the weight DMAs take a scalar base and one lane-offset register instead of 64-bit address pairs.  The LDS
+      // returns a wave's reads in order, so the waits are counted: when a fragment is needed, only the reads issued after it may still
+      // be in flight.  Bit-identical results; -1.6 % stand-alone, -0.7 % of the encoder (tools/try_conv_pinned.py): the partner wave
+      // already hid most of the latency.
+      const int tap = sg;
+      const int dy = tap / KS, dx = tap - dy * KS;
+      const int ka = (n >> 1) & 7;
+      const uint32_t wbase = lds_addr(wslot) + (uint32_t)((ch * (COT / 2) + n) * 128);
+      uint32_t pb[2], kb[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int P = (2 * pr + b + dy) * CV_PW + n + dx;
+        pb[b] = lds_addr(patch) + (uint32_t)(P * 128);
+        kb[b] = (uint32_t)((P >> 1) & 7);
+      }
+      bf16x8 A_h[2], A_l[2], B_h[2][2], B_l[2][2];
+#define CVR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define CVM(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+      auto read_A = [&](int buf, int a, int st) {
+        const uint32_t ah_ = wbase + (uint32_t)(((2 * st + h) ^ ka) << 4), al_ = wbase + (uint32_t)(((4 + 2 * st + h) ^ ka) << 4);
+        switch (a) {
+          case 0: CVR(A_h[buf], ah_, 0); CVR(A_l[buf], al_, 0); break;
+          case 1: CVR(A_h[buf], ah_, 4096); CVR(A_l[buf], al_, 4096); break;
+          case 2: CVR(A_h[buf], ah_, 8192); CVR(A_l[buf], al_, 8192); break;
+          default: CVR(A_h[buf], ah_, 12288); CVR(A_l[buf], al_, 12288); break;
+        }
+      };
+      auto read_B = [&](int buf, int st) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          CVR(B_h[buf][b], pb[b] + (((uint32_t)(2 * st + h) ^ kb[b]) << 4), 0);
+          CVR(B_l[buf][b], pb[b] + (((uint32_t)(4 + 2 * st + h) ^ kb[b]) << 4), 0);
+        }
+      };
+      read_B(0, 0);
+      read_A(0, 0, 0);
+      read_A(1, 1, 0);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int ab = a & 1;
+          if (a == 3 && st == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+          else if (a == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+          CVM(acc[a][0], A_h[ab], B_h[st][0]);
+          CVM(acc[a][1], A_h[ab], B_h[st][1]);
+          CVM(acc[a][0], A_h[ab], B_l[st][0]);
+          CVM(acc[a][1], A_h[ab], B_l[st][1]);
+          CVM(acc[a][0], A_l[ab], B_h[st][0]);
+          CVM(acc[a][1], A_l[ab], B_h[st][1]);
+          if (a < 2) read_A(ab, a + 2, st);
+          else if (st == 0) {
+            read_A(ab, a - 2, 1);
+            if (a == 2) read_B(1, 1);
+          }
+          if (stage_more && (a & 1)) {
+            constexpr int NIT = 4;
+            const int it = st * 2 + (a >> 1);
+#pragma unroll
+            for (int j = 0; j < PPW; ++j)
+              if (j * NIT / PPW == it) stage_weight_piece(q + LA, j);
+          }
+        }
+      }
+#undef CVR
+#undef CVM
+    } else
 #pragma unroll
     for (int tg = 0; tg < TG; ++tg) {
       const int tap = sg * TG + tg;
@@ -442,7 +521,8 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   if (KS == 3) {
-    if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4><<<grid, 512, 0, s>>>(p);
+    if (cot_eff == 256 && (g_conv_debug & 16)) conv_split_kernel<3, 256, 1, 3, 4><<<grid, 512, 0, s>>>(p);   // A/B: the compiler's operand schedule
+    else if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);             // hand-placed operand reads
     else if (cot_eff == 128 && narrow) conv_split_kernel<3, 128, 1, 3, 2><<<grid, 256, 0, s>>>(p);
     else if (cot_eff == 128) conv_split_kernel<3, 128, 3, 2, 4><<<grid, 512, 0, s>>>(p);
     else if (narrow) conv_split_kernel<3, 64, 3, 2, 2><<<grid, 256, 0, s>>>(p);
