@@ -340,6 +340,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(out_coords).all())
+    if ops.pair_f16x3_timed_out():
+        raise SystemExit("bench.py: fgvc_pair_topk_f16x3 reported a timed-out wait of its LDS protocol: results invalid")
     n_frames_total = T * a.steps if a.mode == "video" else world * T * a.steps
 
     # spread: a few more short blocks (not part of `value`)

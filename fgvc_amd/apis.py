@@ -10,12 +10,22 @@ import torch
 import torch.distributed as dist
 
 
+def _check_kernels():
+    """The pair kernel's LDS protocol waits with bounded spins; a wait that ever gave up leaves wrong lists behind.  Never seen -- but a
+    test loop must not return such results silently: checked once per loop (the check synchronises the device)."""
+    if torch.cuda.is_available():
+        from . import ops
+        if ops.pair_f16x3_timed_out():
+            raise RuntimeError("fgvc_pair_topk_f16x3: a bounded wait of the kernel's LDS protocol timed out; the results of this run are invalid")
+
+
 @torch.no_grad()
 def single_gpu_test(model, data_loader, **kw):
     model.eval()
     results = []
     for data in data_loader:
         results.append(model(test_mode=True, **data))
+    _check_kernels()
     return results
 
 
@@ -26,6 +36,7 @@ def multi_gpu_test(model, data_loader, tmpdir=None, gpu_collect=True, **kw):
     in dataset order."""
     model.eval()
     results = [model(test_mode=True, **data) for data in data_loader]
+    _check_kernels()
     return collect_results(results, getattr(data_loader, "total", None))
 
 
