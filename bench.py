@@ -407,7 +407,8 @@ def main():
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch")}
     head = kernels.get("encoder_conv") or kernels.get("pair_topk")
     roofline = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "what", "executed_tflops",
-                                     "frac_executed", "frac_of_f32_mfma_peak", "ms_per_launch", "mfma_util")} if head else None
+                                     "frac_executed", "frac_of_f32_mfma_peak", "ms_per_launch", "mfma_util", "launch_note", "pmc_note")
+                if k in head} if head else None
 
     out = {
         "metric": "frames/sec + ms/corr-volume, 480p 8-frame clip, 1/2/4/8 MI355X",
