@@ -346,3 +346,21 @@ def test_workspace_cache_is_bounded():
         live = {k[1] for k in cache if isinstance(k, tuple) and k[0] == "b"}
         assert len(live) <= net.max_workspace_shapes and sig in live
     assert {k[1] for k in cache if isinstance(k, tuple) and k[0] == "b"} == {(8, 256, 256, "cpu"), (2, 64, 64, "cpu")}
+
+
+def test_bench_encoder_flops_matches_hand_count():
+    """bench.py's FLOP count of the trunk (the numerator of kernels.encoder_phase): ResNet-18 up to stage 3 with strides (1, 2, 1)
+    on a 480 x 854 frame, counted by hand layer by layer (resnet.py:457-466, 254-325)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h1, w1 = 240, 427                      # after the stride-2 stem
+    h2, w2 = 120, 214                      # after stage 2's stride
+    want = 2.0 * h1 * w1 * 3 * 64 * 49                                        # stem 7x7
+    want += 4 * 2.0 * h1 * w1 * 64 * 64 * 9                                   # stage 1: four 3x3 64 -> 64
+    want += 2.0 * h2 * w2 * 64 * 128 * 9 + 3 * 2.0 * h2 * w2 * 128 * 128 * 9 + 2.0 * h2 * w2 * 64 * 128      # stage 2 (+ 1x1 projection)
+    want += 2.0 * h2 * w2 * 128 * 256 * 9 + 3 * 2.0 * h2 * w2 * 256 * 256 * 9 + 2.0 * h2 * w2 * 128 * 256    # stage 3 (+ 1x1 projection)
+    got = bench.encoder_flops(bench.WORKLOADS["cfg2_480p_8f"], 8)
+    assert abs(got - 8 * want) < 1e-6 * got
