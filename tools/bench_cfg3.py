@@ -42,3 +42,20 @@ for R in (6, 12):
     t_b = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07, normalized=True, split_fmt="bf16"))
     print(f"local window (A7) radius {R}, {T} key slots at {H}x{W}x{C}: f32-MFMA kernel {t_f32:.3f} ms, f16x3 kernel "
           f"{t_split:.3f} ms, bf16x4 kernel {t_b:.3f} ms per query frame (the 16-bit forms include their split pass)")
+
+# ---- the configuration as BASELINE.json states it: the single-scale local window on the stride-1 grid (480 x 854 x 256, radius 6, 6
+#      key slots): 409 920 queries x 6 x 169 candidates x 256 channels = 2.13e11 FLOP, 7 frames x 420 MB of f32 features
+del coarse, fine, vfine, lw
+torch.cuda.empty_cache()
+H1, W1, R1 = 480, 854, 6
+g = torch.Generator(device=dev).manual_seed(3)
+big = torch.empty(T + 1, H1 * W1, C, device=dev)
+for t in range(T + 1):                                            # frame by frame: the f32 NCHW source of a frame is 420 MB
+    big[t] = ops.normalize_to_hwc(torch.randn(1, C, H1, W1, device=dev, generator=g))[0]
+t_split = timeit(lambda: ops.local_corr_topk(big[:1], big[1:], H1, W1, R1, k, 0.07, normalized=True), reps=3)
+q16, k16 = ops.split_f16x2(big[:1]), ops.split_f16x2(big[1:])
+t_s = timeit(lambda: (ops.split_f16x2(big[:1]), ops.split_f16x2(big[1:])), reps=3)
+fl = 2.0 * H1 * W1 * T * (2 * R1 + 1) ** 2 * C
+print(f"local window (A7) radius {R1}, {T} key slots at {H1}x{W1}x{C} (configs[2] as stated): f16x3 kernel {t_split:.2f} ms per query frame "
+      f"incl. {t_s:.2f} ms for splitting the 7 frames ({fl / 1e9:.0f} GFLOP windowed -> {fl / ((t_split - t_s) * 1e-3) / 1e12:.0f} TFLOP/s f32-grade "
+      f"without the split; features read: {(T + 1) * H1 * W1 * C * 4 / 1e9:.2f} GB)")
