@@ -52,6 +52,7 @@ void set_conv_cot_cap(int);
 void set_conv_narrow(int);
 void set_conv_debug(int);
 void set_corr6_skew(int);
+void set_corr6_sdma(int);
 void set_pair_kernel(int);
 void set_pair_debug(int);
 void set_pair_v4_debug(int);
@@ -109,6 +110,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "pair_debug") == 0) {   // profiling ablations; results are wrong when non-zero
     set_pair_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "corr6_sdma") == 0) {   // A/B: staging DMAs of fgvc_corr_volume_f16f6 with a scalar base (1) or 64-bit lane addresses (0)
+    set_corr6_sdma(value);
     return FGVC_OK;
   }
   if (strcmp(name, "corr6_skew") == 0) {   // fgvc_corr_volume_f16f6: stages taken from the two-segment piece and given to the others

@@ -133,7 +133,7 @@ __device__ __forceinline__ i32x8 f6_operand(const i32x4& a, const i32x2& b) {
   return __builtin_shufflevector(a8, b8, 0, 1, 2, 3, 8, 9, -1, -1);
 }
 
-template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong); results right: 8 = no wave stagger,
+template <int NW, int DEBUG, bool SDMA = true>   // SDMA: staging DMAs with a scalar base (A/B); DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong); results right: 8 = no wave stagger,
                                // 16 = DMA spread over both tiles of a stage, 64 = F fragments re-read in one piece, 128 = pair-major workgroup ids; 256 / 512 = no f16 / no FP6 MFMAs (results wrong);
                                // 32 = s_memtime probe of one workgroup, written over the first floats of vol
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const unsigned char* __restrict__ q_sp,
@@ -226,23 +226,38 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     for (int i = 0; i < ROWS / NW; ++i) {
       const int row = wave * (ROWS / NW) + i;
       const int pix = imin((kb * 32 + row) * period + cls, HWk - 1);
-      const unsigned char* src = k_sp + (size_t)pix * ROWB + 16 * lane;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
+      if constexpr (SDMA) {
+        const unsigned char* src = k_sp + (size_t)pix * ROWB;
+        const uint32_t dst = (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)&smem[buf * BUFB + row * LDB];
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(16u * (uint32_t)lane), "s"(src), "s"(dst) : "memory");
+      } else {
+        const unsigned char* src = k_sp + (size_t)pix * ROWB + 16 * lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
+      }
     }
   };
   // waves 0-3 (the older wave of each SIMD: it wins the issue arbitration and would otherwise wait at the stage barrier) stage
   // all 64 rows of the next stage, two per multiply part; waves 4-7 none (corr_volume_f8.hip, s_memtime probe)
   const bool stager = wave < NW / 2;
+  // (the row is wave-uniform: scalar base + one lane-offset register, no 64-bit vector address arithmetic per row)
+  const uint32_t dma_lane_off = 16u * (uint32_t)lane;
   auto stage_row = [&](int kb, int buf, int i) {
     const int row = wave * (2 * ROWS / NW) + i;
     const int pix = imin((kb * 32 + row) * period + cls, HWk - 1);
-    const unsigned char* src = k_sp + (size_t)pix * ROWB + 16 * lane;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
+    if constexpr (SDMA) {
+      const unsigned char* src = k_sp + (size_t)pix * ROWB;
+      const uint32_t dst = (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)&smem[buf * BUFB + row * LDB];
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane_off), "s"(src), "s"(dst) : "memory");
+    } else {
+      const unsigned char* src = k_sp + (size_t)pix * ROWB + 16 * lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)&smem[buf * BUFB + row * LDB], 16, 0, 0);
+    }
   };
   static_assert(2 * ROWS / NW == 16, "two DMA rows per multiply part of a staging wave: 2 tiles x 4 parts");
   stage_load(kb0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the DMAs are inline assembly: the compiler's own wait at the barrier does not count them
   __syncthreads();
   if (probe) p_pro = __builtin_amdgcn_s_memtime() - p_start;
 
@@ -475,7 +490,9 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
 }
 
 static int g_corr6_debug = 0;
-static int g_corr6_skew = 2;   // -1 % at 480p (tools/try_corr6_skew.py: 0 / 2 / 4 / 6 / 8 / 10 / 14 stages: 0.674 / 0.668 / 0.674 / 0.673 / 0.683 / 0.694 / 0.712 ms)
+static int g_corr6_sdma = 1;
+void set_corr6_sdma(int v) { g_corr6_sdma = v; }
+static int g_corr6_skew = 0;   // stages moved from the two-segment piece to the others: -0.8 % / 0 / +0.7 % on three boxes at 2 (tools/try_corr6_skew.py): off
 void set_corr6_skew(int v) { g_corr6_skew = v; }
 static int g_corr6_cost_pro = 20000, g_corr6_cost_stage = 5700;      // cycles, tools/time_corr6.py
 void set_corr6_debug(int v) { g_corr6_debug = v; }
@@ -518,7 +535,10 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
     case 32: FGVC_C6(32); break;
     case 33: FGVC_C6(33); break;
     case 34: FGVC_C6(34); break;
-    case 0: FGVC_C6(0); break;
+    case 0:
+      if (g_corr6_sdma) FGVC_C6(0);
+      else corr_volume_f16f6_kernel<8, 0, false><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, s_tile, c_half, n_tiles, period, mm, g_corr6_skew);
+      break;
     case 1: FGVC_C6(1); break;
     case 2: FGVC_C6(2); break;
     case 3: FGVC_C6(3); break;

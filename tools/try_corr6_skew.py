@@ -11,7 +11,7 @@ f = torch.nn.functional.normalize(torch.randn(2, HW, 256, device=dev), dim=2)
 sp = ops.split_f16f6(f)
 vol = torch.empty((HW, HW), device=dev)
 ref = None
-skews = [0, 2, 4, 6, 8, 10, 14, -4]
+skews = [2, 102, 0, 100]          # + 100: staging DMAs with 64-bit lane addresses (corr6_sdma = 0)
 res = {k: [] for k in skews}
 
 
@@ -30,7 +30,8 @@ for _ in range(300):
     ops.corr_volume(sp[1], sp[0], 0.07, "f16f6", out=vol)
 for rnd in range(5):
     for k in skews:
-        ops.set_option("corr6_skew", k)
+        ops.set_option("corr6_skew", k % 100)
+        ops.set_option("corr6_sdma", 0 if k >= 100 else 1)
         vol.fill_(float("nan"))
         ops.corr_volume(sp[1], sp[0], 0.07, "f16f6", out=vol)
         if ref is None:
@@ -38,7 +39,8 @@ for rnd in range(5):
         assert torch.equal(vol[::97], ref), k
         ms(3)
         res[k].append(ms())
-ops.set_option("corr6_skew", 2)
+ops.set_option("corr6_skew", 0)
+ops.set_option("corr6_sdma", 1)
 for k in skews:
     v = sorted(res[k])
     print(f"skew {k:3d}: min {v[0]:.4f}  median {v[len(v) // 2]:.4f} ms", flush=True)
