@@ -194,6 +194,42 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   f16x8 bq16[2][8];
   i32x8 bq6h[2][2], bq6l[2][2];
   int sq[2];
+  if constexpr (SDMA && NW == 8) {
+    // The query rows come through the LDS, whole rows by LDS-DMA (one coalesced KiB per instruction), in two passes of 128 rows (the
+    // two stage buffers hold 128): read straight from global memory in the MFMA layout, every 16-lane group of a load touches 16
+    // different rows -- 64 cache-line requests per instruction, 13 000 cycles of address path per prologue.
+    const int xq0 = xq * (NW * 32) - shift;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = wave * 16 + i;                                   // row of the staging area, 0..127
+        const int qrow = imin(imax(xq0 + pass * 128 + j, 0), HWq - 1);
+        const unsigned char* src = q_sp + (size_t)qrow * ROWB;
+        const uint32_t dst = (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)&smem[j * LDB];
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(16u * (uint32_t)lane), "s"(src), "s"(dst) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if ((wave >> 2) == pass) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const unsigned char* qp = &smem[((wave & 3) * 32 + 16 * qt + r) * LDB];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) bq16[qt][t] = *reinterpret_cast<const f16x8*>(qp + 16 * g + 64 * t);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            bq6h[qt][u] = f6_operand(*reinterpret_cast<const i32x4*>(qp + F6_H6 + 96 * u + 16 * g),
+                                     *reinterpret_cast<const i32x2*>(qp + F6_H6 + 96 * u + 64 + 8 * g));
+            bq6l[qt][u] = f6_operand(*reinterpret_cast<const i32x4*>(qp + F6_L6 + 96 * u + 16 * g),
+                                     *reinterpret_cast<const i32x2*>(qp + F6_L6 + 96 * u + 64 + 8 * g));
+          }
+          sq[qt] = *reinterpret_cast<const int*>(qp + F6_SC + 4 * g);
+        }
+      }
+      __syncthreads();                                                 // the rows have been read: the area is free again
+    }
+  } else {
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const unsigned char* qp = q_sp + (size_t)imin(imax(qw0 + 16 * qt + r, 0), HWq - 1) * ROWB;
@@ -207,6 +243,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
                                *reinterpret_cast<const i32x2*>(qp + F6_L6 + 96 * u + 64 + 8 * g));
     }
     sq[qt] = *reinterpret_cast<const int*>(qp + F6_SC + 4 * g);
+  }
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
