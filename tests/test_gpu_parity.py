@@ -736,6 +736,34 @@ def test_pair_f16x3_runs_of_pairs_equal_pair_by_pair(dev):
         assert float((torch.sort(sa[differ], dim=-1).values - torch.sort(s3[differ], dim=-1).values).abs().max()) < 2.5e-6
 
 
+def test_conv256_forms_are_bit_identical(dev):
+    """The three builds of the 256-channel-tile convolution -- hand-ordered assembly stage (default), the compiler's schedule
+    (conv_debug = 16), one wave per SIMD with a 4 x 4 register tile (conv_debug = 32) -- accumulate in the same order and must
+    agree bit for bit, with residual + ReLU + both outputs, on a ragged grid (edge tiles) and two input widths."""
+    from fgvc_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for Cin, H, W in ((128, 19, 45), (256, 24, 70)):
+        wt = (torch.randn(256, Cin, 3, 3, generator=g) * 0.03).to(dev)
+        bn = torch.nn.BatchNorm2d(256).eval().to(dev)
+        bn.running_mean.copy_(torch.randn(256, generator=g).to(dev) * 0.1)
+        bn.running_var.copy_(torch.rand(256, generator=g).to(dev) + 0.5)
+        wp, bs = ops.prepare_conv_split(wt, bn)
+        xs = ops.nchw_to_split_nhwc(torch.randn(3, Cin, H, W, generator=g).to(dev))
+        res = ops.alloc_nhwc(3, 256, H, W, dev)
+        res.copy_(torch.randn(res.shape, generator=g).to(dev))
+        outs = []
+        for dbg in (0, 16, 32):
+            ys, yf = ops.alloc_split_nhwc(3, 256, H, W, dev), ops.alloc_nhwc(3, 256, H, W, dev)
+            ops.set_option("conv_debug", dbg)
+            try:
+                ops.conv_split(xs, wp, bs, H, W, True, out_split=ys, out_f32=yf, residual=res)
+            finally:
+                ops.set_option("conv_debug", 0)
+            outs.append((ys, yf))
+        for ys, yf in outs[1:]:
+            assert torch.equal(ys, outs[0][0]) and torch.equal(yf, outs[0][1])
+
+
 def test_pair_f16x3_three_roles_equal_two_roles_and_large_lists_fall_back(dev):
     """The default form of fgvc_pair_topk_f16x3 (consumer / selector / producer waves, accumulators handed over through the LDS) gives
     bit-identical lists to the two-role form (pair_f16_debug = 1024) -- same products, same keys, same networks -- on grids with

@@ -26,17 +26,17 @@ def ms(reps=40):
 
 for _ in range(500):
     fn()
-res = {0: [], 16: []}
+res = {0: [], 16: [], 32: []}
 ref = None
 for rnd in range(6):
-    for m in (0, 16):
+    for m in (0, 16, 32):
         ops.set_option("conv_debug", m)
         fn()
         if rnd == 0:
             out = ys.clone()
             if ref is None:
                 ref = out
-            assert torch.equal(out, ref)
+            print(m, 'equal to the default form:', bool(torch.equal(out, ref)), float((out.float() - ref.float()).abs().max()), flush=True)
         res[m].append(ms())
 ops.set_option("conv_debug", 0)
 print({m: (round(min(v), 4), round(sorted(v)[len(v) // 2], 4)) for m, v in res.items()})
