@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_kernel_4x4(ConvSplitParams 
       C4_PREFETCH(8, chunk + 1) C4_PREFETCH(9, chunk + 1) C4_PREFETCH(10, chunk + 1) C4_PREFETCH(11, chunk + 1)
       C4_PREFETCH(12, chunk + 1)
     }
-    const bool stage_more = q + LA < n_stage;
+    const bool stage_more = q + LA < n_stage && (p.debug & 64) == 0;     // 64: ablation (results wrong): no weight DMAs in the loop
     const int dy = tap / KS, dx = tap - dy * KS;
     const uint32_t wbase = lds_addr(wring + (q % NSLOT) * WSLOTB) + (uint32_t)((ch * 128 + n) * 128);
     uint32_t pb[4], kb[4];
