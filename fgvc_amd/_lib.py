@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfgvc_hip.so")
 FGVC_OK = 0
 NO_LIMIT = 0x3FFFFFFF
 PAIR_MASKED = 1
-WEIGHT_SOFTMAX, WEIGHT_COSINE = 0, 1
+WEIGHT_SOFTMAX, WEIGHT_COSINE, WEIGHT_RAW = 0, 1, 2
 
 _p = C.c_void_p
 _i = C.c_int
@@ -55,6 +55,8 @@ SIGNATURES = {
     "fgvc_dense_attend_splits": (_i, [_i, _i]),
     "fgvc_dense_attend_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "fgvc_dense_attend_finish_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "fgvc_dense_kth_f32": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
+    "fgvc_dense_propagate_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "fgvc_local_corr_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "fgvc_local_corr_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "fgvc_local_corr_topk_f16x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),

@@ -75,7 +75,8 @@ int split_f16f6_launch(const float*, unsigned char*, long long, hipStream_t);
 int corr_volume_f16f6_launch(const unsigned char*, const unsigned char*, int, int, float, float*, hipStream_t);
 void set_corr6_debug(int);
 int dense_attend_splits(int, int);
-int dense_attend_launch(const float*, const float*, int, int, int, int, int, int, int, int, int, int, int, float*, int, hipStream_t);
+int dense_attend_launch(const float*, const float*, int, int, int, int, int, int, int, int, int, int, int, float*, int, hipStream_t, const float*);
+int dense_kth_launch(const float*, int, int, int, float*, int, float*, hipStream_t);
 int dense_attend_finish_launch(const float*, int, int, int, int, float*, hipStream_t);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -394,19 +395,41 @@ int fgvc_dense_attend_f32(const float* vol, const float* labels, int Hq, int Wq,
                "fgvc_dense_attend_f32: grid too large");
   FGVC_REQUIRE(P >= 1 && P <= 32, FGVC_ERR_UNSUPPORTED, "fgvc_dense_attend_f32: P=%d outside 1..32", P);
   FGVC_REQUIRE(nsplit >= 1 && nsplit <= 65535, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_f32: nsplit=%d", nsplit);
-  FGVC_REQUIRE(weight_mode == FGVC_WEIGHT_SOFTMAX || weight_mode == FGVC_WEIGHT_COSINE, FGVC_ERR_INVALID_ARG,
+  FGVC_REQUIRE(weight_mode == FGVC_WEIGHT_SOFTMAX || weight_mode == FGVC_WEIGHT_COSINE || weight_mode == FGVC_WEIGHT_RAW, FGVC_ERR_INVALID_ARG,
                "fgvc_dense_attend_f32: unknown weight mode %d", weight_mode);
   FGVC_REQUIRE(!masked || (r2max >= 0 && ry >= 0 && rx >= 0), FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_f32: negative mask parameter");
   FGVC_REQUIRE(!masked || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
                "fgvc_dense_attend_f32: a spatial mask needs equal query/key grids (local_attention.py:331)");
-  return dense_attend_launch(vol, labels, Hq, Wq, Hk, Wk, P, masked != 0, r2max, ry, rx, weight_mode == FGVC_WEIGHT_COSINE,
-                             first != 0, state, nsplit, (hipStream_t)stream);
+  return dense_attend_launch(vol, labels, Hq, Wq, Hk, Wk, P, masked != 0, r2max, ry, rx, weight_mode,
+                             first != 0, state, nsplit, (hipStream_t)stream, nullptr);
+}
+
+int fgvc_dense_kth_f32(const float* aff, int HWk, int HWq, int k, float* part, int nsplit, float* thr, void* stream) {
+  FGVC_REQUIRE(aff && part && thr, FGVC_ERR_INVALID_ARG, "fgvc_dense_kth_f32: null pointer");
+  FGVC_REQUIRE(HWk > 0 && HWq > 0 && (long long)HWk < (1ll << 30) && (long long)HWq < (1ll << 30), FGVC_ERR_INVALID_ARG, "fgvc_dense_kth_f32: bad shape");
+  FGVC_REQUIRE(k >= 1 && k <= 64 && k <= HWk, FGVC_ERR_UNSUPPORTED, "fgvc_dense_kth_f32: k=%d outside 1..min(64, HWk)", k);
+  FGVC_REQUIRE(nsplit >= 1 && nsplit <= 65535, FGVC_ERR_INVALID_ARG, "fgvc_dense_kth_f32: nsplit=%d", nsplit);
+  return dense_kth_launch(aff, HWk, HWq, k, part, nsplit, thr, (hipStream_t)stream);
+}
+
+int fgvc_dense_propagate_f32(const float* aff, const float* labels, int HWk, int HWq, int P, const float* thr, float* state,
+                             int nsplit, float* out, void* stream) {
+  FGVC_REQUIRE(aff && labels && state && out, FGVC_ERR_INVALID_ARG, "fgvc_dense_propagate_f32: null pointer");
+  FGVC_REQUIRE(HWk > 0 && HWq > 0 && (long long)HWk < (1ll << 30) && (long long)HWq < (1ll << 30), FGVC_ERR_INVALID_ARG, "fgvc_dense_propagate_f32: bad shape");
+  FGVC_REQUIRE(P >= 1 && P <= 32, FGVC_ERR_UNSUPPORTED, "fgvc_dense_propagate_f32: P=%d outside 1..32 (call per 32 channels)", P);
+  FGVC_REQUIRE(nsplit >= 1 && nsplit <= 65535, FGVC_ERR_INVALID_ARG, "fgvc_dense_propagate_f32: nsplit=%d", nsplit);
+  const int mode = thr ? 3 : 2;
+  int rc = dense_attend_launch(aff, labels, 1, HWq, 1, HWk, P, 0, FGVC_NO_LIMIT, FGVC_NO_LIMIT, FGVC_NO_LIMIT, mode, 1, state, nsplit,
+                               (hipStream_t)stream, thr);
+  if (rc != FGVC_OK) return rc;
+  return dense_attend_finish_launch(state, nsplit, HWq, P, mode, out, (hipStream_t)stream);
 }
 
 int fgvc_dense_attend_finish_f32(const float* state, int nsplit, int HWq, int P, int weight_mode, float* out, void* stream) {
   FGVC_REQUIRE(state && out, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_finish_f32: null pointer");
   FGVC_REQUIRE(HWq > 0 && P >= 1 && P <= 32 && nsplit >= 1, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_finish_f32: bad shape");
-  return dense_attend_finish_launch(state, nsplit, HWq, P, weight_mode == FGVC_WEIGHT_COSINE, out, (hipStream_t)stream);
+  FGVC_REQUIRE(weight_mode >= 0 && weight_mode <= 2, FGVC_ERR_INVALID_ARG, "fgvc_dense_attend_finish_f32: unknown weight mode %d", weight_mode);
+  return dense_attend_finish_launch(state, nsplit, HWq, P, weight_mode, out, (hipStream_t)stream);
 }
 
 int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pairs, int n_slots, int C, int H,

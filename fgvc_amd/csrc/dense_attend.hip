@@ -11,6 +11,10 @@
 //                         state[split][i] = {m, s, acc[0..P)} is carried from key slot to key slot in HBM;
 //   dense_attend_finish   merges the splits' states and divides.
 // HBM-bound by the slab read: HWk*HWq*4 bytes per key slot.
+//
+// The same streaming pass carries `propagate` (reference affinity_utils.py:33-50: new_img = img @ affinity for a GIVEN dense
+// affinity): mode RAW takes the slab's entries as the weights, mode SHIFT takes max(a - thr[i], 0) / max(sum, 1e-12) with thr[i] the
+// k-th largest entry of column i (the reference's `topk` branch, :36-44), found by dense_kth_kernel in one more pass over the slab.
 #include "common.hpp"
 
 namespace fgvc {
@@ -42,8 +46,10 @@ __device__ __forceinline__ void merge_state(float& m, float& s, float (&a)[PMAX]
 template <int PMAX>
 __global__ __launch_bounds__(DA_THREADS) void dense_attend_kernel(const float* __restrict__ vol, const float* __restrict__ labels,
                                                                  int Hq, int Wq, int Hk, int Wk, int P, int masked, int r2max,
-                                                                 int ry, int rx, int reach_y, int cosine, int first,
-                                                                 float* __restrict__ state, int nsplit) {
+                                                                 int ry, int rx, int reach_y, int mode, int first,
+                                                                 float* __restrict__ state, int nsplit,
+                                                                 const float* __restrict__ thr) {
+  const bool cosine = mode != 0;                          // every mode but the softmax keeps plain sums (no running maximum)
   __shared__ float sh[DA_WAVES - 1][WAVE][PMAX + 2];
   const int HWq = Hq * Wq, HWk = Hk * Wk;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -62,6 +68,7 @@ __global__ __launch_bounds__(DA_THREADS) void dense_attend_kernel(const float* _
   float m = -INFINITY, s = 0.f, acc[PMAX];
 #pragma unroll
   for (int p = 0; p < PMAX; ++p) acc[p] = 0.f;
+  const float th = (mode == 3 && live) ? thr[i] : 0.f;
   const int stride = DA_WAVES * nsplit;
   for (int j = jbeg + blockIdx.y * DA_WAVES + wave; j < jend; j += stride) {
     const int ky = j / Wk, kx = j - ky * Wk;          // wave-uniform
@@ -72,8 +79,13 @@ __global__ __launch_bounds__(DA_THREADS) void dense_attend_kernel(const float* _
       a = keep ? a : -INFINITY;
     }
     const float* lab = labels + (size_t)j * P;        // uniform address: scalar loads
-    if (cosine) {                                      // clamp(min=0)^2, no normalisation (local_attention.py:379-380)
-      const float w = a > 0.f ? a * a : 0.f;
+    if (cosine) {                                      // 1: clamp(min=0)^2, no normalisation (local_attention.py:379-380)
+      float w = a > 0.f ? a * a : 0.f;
+      if (mode == 2) w = a;                            // 2: the entry itself (propagate, affinity_utils.py:45-49)
+      if (mode == 3) {                                 // 3: max(a - k-th largest of the column, 0) (:36-44); s = their sum
+        w = fmaxf(a - th, 0.f);
+        s += w;
+      }
 #pragma unroll
       for (int p = 0; p < PMAX; ++p)
         if (p < P) acc[p] = fmaf(w, lab[p], acc[p]);
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(DA_THREADS) void dense_attend_kernel(const float* _
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) a2[p] = d[2 + p];
     if (cosine) {
+      s += d[1];
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) acc[p] += a2[p];
     } else {
@@ -121,6 +134,7 @@ __global__ __launch_bounds__(DA_THREADS) void dense_attend_kernel(const float* _
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) a2[p] = p < P ? st[2 + p] : 0.f;
     if (cosine) {
+      s += st[1];
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) acc[p] += a2[p];
     } else {
@@ -136,7 +150,8 @@ __global__ __launch_bounds__(DA_THREADS) void dense_attend_kernel(const float* _
 
 template <int PMAX>
 __global__ __launch_bounds__(256) void dense_attend_finish_kernel(const float* __restrict__ state, int nsplit, int HWq, int P,
-                                                                int cosine, float* __restrict__ out) {
+                                                                int mode, float* __restrict__ out) {
+  const bool cosine = mode != 0;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= HWq) return;
   float m = -INFINITY, s = 0.f, acc[PMAX];
@@ -148,6 +163,7 @@ __global__ __launch_bounds__(256) void dense_attend_finish_kernel(const float* _
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) a2[p] = p < P ? st[2 + p] : 0.f;
     if (cosine) {
+      s += st[1];
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) acc[p] += a2[p];
     } else {
@@ -155,13 +171,97 @@ __global__ __launch_bounds__(256) void dense_attend_finish_kernel(const float* _
     }
   }
   // softmax over an all-masked column is NaN in the reference (0/0); same here
-  const float inv = cosine ? 1.f : 1.f / s;
+  const float inv = mode == 3 ? 1.f / fmaxf(s, 1e-12f) : cosine ? 1.f : 1.f / s;
 #pragma unroll
   for (int p = 0; p < PMAX; ++p)
     if (p < P) out[(size_t)i * P + p] = acc[p] * inv;
 }
 
+// k-th largest entry of every column of a dense [HWk][HWq] slab (the threshold of propagate's `topk` branch, affinity_utils.py:39):
+// one lane per column, a descending list of the K largest values seen (predicated insertion, no branches around the list), the
+// waves of a workgroup and the `nsplit` workgroups of a column band take interleaved rows; partial lists [split][i][K] are merged
+// by dense_kth_finish_kernel.
+template <int K>
+__global__ __launch_bounds__(DA_THREADS) void dense_kth_kernel(const float* __restrict__ vol, int HWk, int HWq, float* __restrict__ part,
+                                                               int nsplit) {
+  __shared__ float sh[DA_WAVES - 1][WAVE][K];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int i = blockIdx.x * WAVE + lane;
+  const bool live = i < HWq;
+  float v[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) v[r] = -INFINITY;
+  auto insert = [&](float a) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const bool b = a > v[r];
+      const float t = v[r];
+      v[r] = b ? a : t;
+      a = b ? t : a;
+    }
+  };
+  for (int j = blockIdx.y * DA_WAVES + wave; j < HWk; j += DA_WAVES * nsplit) {
+    const float a = live ? __builtin_nontemporal_load(vol + (size_t)j * HWq + i) : -INFINITY;
+    if (__builtin_amdgcn_ballot_w64(a > v[K - 1]) != 0ull) insert(a);        // wave-uniform skip: most rows beat nobody's K-th
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) sh[wave - 1][lane][r] = v[r];
+  }
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  for (int w = 0; w < DA_WAVES - 1; ++w)
+#pragma unroll
+    for (int r = 0; r < K; ++r) insert(sh[w][lane][r]);
+  float* o = part + ((size_t)blockIdx.y * HWq + i) * K;
+#pragma unroll
+  for (int r = 0; r < K; ++r) o[r] = v[r];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dense_kth_finish_kernel(const float* __restrict__ part, int nsplit, int HWq, int k,
+                                                               float* __restrict__ thr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HWq) return;
+  float v[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) v[r] = -INFINITY;
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const float* o = part + ((size_t)sp * HWq + i) * K;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      float a = o[r];
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const bool b = a > v[q];
+        const float t = v[q];
+        v[q] = b ? a : t;
+        a = b ? t : a;
+      }
+    }
+  }
+  float out = v[0];
+#pragma unroll
+  for (int r = 0; r < K; ++r)
+    if (r == k - 1) out = v[r];
+  thr[i] = out;
+}
+
 }  // namespace
+
+int dense_kth_launch(const float* vol, int HWk, int HWq, int k, float* part, int nsplit, float* thr, hipStream_t stream) {
+  const dim3 grid((HWq + WAVE - 1) / WAVE, nsplit), fgrid((HWq + 255) / 256);
+  if (k <= 16) {
+    hipLaunchKernelGGL(dense_kth_kernel<16>, grid, dim3(DA_THREADS), 0, stream, vol, HWk, HWq, part, nsplit);
+    hipLaunchKernelGGL(dense_kth_finish_kernel<16>, fgrid, dim3(256), 0, stream, part, nsplit, HWq, k, thr);
+  } else {
+    hipLaunchKernelGGL(dense_kth_kernel<64>, grid, dim3(DA_THREADS), 0, stream, vol, HWk, HWq, part, nsplit);
+    hipLaunchKernelGGL(dense_kth_finish_kernel<64>, fgrid, dim3(256), 0, stream, part, nsplit, HWq, k, thr);
+  }
+  FGVC_CHECK_LAUNCH("fgvc_dense_kth_f32");
+  return FGVC_OK;
+}
 
 int dense_attend_splits(int HWq, int HWk) {
   // enough workgroups to cover the chip a few times, never more splits than key rows per wave
@@ -172,14 +272,14 @@ int dense_attend_splits(int HWq, int HWk) {
 }
 
 int dense_attend_launch(const float* vol, const float* labels, int Hq, int Wq, int Hk, int Wk, int P, int masked, int r2max, int ry,
-                        int rx, int cosine, int first, float* state, int nsplit, hipStream_t stream) {
+                        int rx, int cosine, int first, float* state, int nsplit, hipStream_t stream, const float* thr) {
   int reach = ry;
   if (r2max < FGVC_NO_LIMIT) reach = min(reach, (int)floor(sqrt((double)r2max)));
   reach = min(reach, Hk);
   const dim3 grid((Hq * Wq + WAVE - 1) / WAVE, nsplit);
 #define FGVC_DA(PM)                                                                                                       \
   hipLaunchKernelGGL(dense_attend_kernel<PM>, grid, dim3(DA_THREADS), 0, stream, vol, labels, Hq, Wq, Hk, Wk, P, masked, \
-                     r2max, ry, rx, reach, cosine, first, state, nsplit)
+                     r2max, ry, rx, reach, cosine, first, state, nsplit, thr)
   if (P <= 8) FGVC_DA(8);
   else if (P <= 16) FGVC_DA(16);
   else FGVC_DA(32);

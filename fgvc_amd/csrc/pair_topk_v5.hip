@@ -21,8 +21,9 @@
 //     block has landed: a release must never be sent for a block that is not staged yet, the slot's counter would take it for the
 //     block before), up to the ring's depth ahead of the others.  With the list in alternating order (first, last, second, ...) every window of 4
 //     entries is reached about evenly, and the loop takes ~42 tile times instead of 56 (tools/sim_pair_ring.py).
-//     Every spin is bounded: after 2^16 polls a wave raises g_pair_v5_timeout and stops waiting (results are then wrong, the
-//     launch still ends; fgvc_pair_topk_f16x3_timed_out() reports it).
+//     Every spin is bounded: after 2^16 polls a wave raises g_pair_v5_timeout and the workgroup's LDS flag and stops waiting; the
+//     launch still ends, and the lists that workgroup writes from then on are POISON (index 0, score +inf -> NaN weights, labels and
+//     trajectories downstream): fail closed.  fgvc_pair_topk_f16x3_timed_out() reports (and clears) the flag.
 #include "pair_common.hpp"
 
 namespace fgvc {
@@ -68,8 +69,14 @@ __device__ long long g_pair_v5_probe[32];      // debug & 256: s_memtime stamps 
 
 // bounded spin on an LDS word (wave-uniform): true = the word reached `target`.  A wave that has given up once (`dead`) never
 // waits again: a broken protocol costs milliseconds, not a hung GPU.
-template <int SLEEP = 2, bool REPORT = true>   // REPORT = false: the caller raises the flag itself when it ends (two registers less across its loop)
-__device__ __forceinline__ bool spin_ge(volatile int* w, int target, bool& dead, long long* waited = nullptr) {
+// Fail closed: the wave that gives up also raises the workgroup's LDS flag `wg_dead`; the role that owns the output lists reads it
+// before every store and writes POISON lists (index 0, score +inf: the merge's softmax turns that into NaN weights, the sweep into NaN
+// labels and trajectories) for every pair that may have seen an unsynchronised key block -- a consumer of the lists cannot mistake them
+// for results.  (A producer raises the flag BEFORE it stages anything unsynchronised, and the LDS executes a wave's operations in order:
+// whoever sees the block's `filled` count also sees the flag.)
+constexpr float PAIR_POISON_SCORE = INFINITY;
+template <int SLEEP = 2, bool REPORT = true>   // REPORT = false: the caller raises the global flag itself when it ends (two registers less across its loop)
+__device__ __forceinline__ bool spin_ge(volatile int* w, int target, bool& dead, volatile int* wg_dead, long long* waited = nullptr) {
   if (dead) return false;
   const long long t0 = waited ? __builtin_amdgcn_s_memtime() : 0;
   struct Stamp {
@@ -84,6 +91,7 @@ __device__ __forceinline__ bool spin_ge(volatile int* w, int target, bool& dead,
     __builtin_amdgcn_s_sleep(SLEEP);
   }
   if (REPORT) g_pair_v5_timeout = 1;
+  *wg_dead = 1;
   dead = true;
   return false;
 }
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
   __shared__ uint32_t blist[V4_LIST_CAP];      // by | bx << 12 | (query blocks that reach it) << 24
   __shared__ int blist_n;
   __shared__ int filled[NSLOT], done[NSLOT];
+  __shared__ int wg_dead;                        // a wave of this workgroup gave up waiting: the lists written from here on are poison
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
     filled[tid] = 0;
     done[tid] = 0;
   }
+  if (tid == 0) wg_dead = (p.debug & 4096) ? 1 : 0;      // 4096: fault injection for the fail-closed test
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int n_steps = blist_n;
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
       for (int G = 0; G < n_total; ++G) {
         if (G + 1 < n_total) {
           const int s1 = (G + 1) & (NSLOT - 1), gen1 = (G + 1) / NSLOT;
-          if (gen1 > 0) spin_ge<6>(&done[s1], 4 * gen1, dead, probe ? &pw : nullptr);   // block G + 1 - NSLOT released by all four consumers
+          if (gen1 > 0) spin_ge<6>(&done[s1], 4 * gen1, dead, &wg_dead, probe ? &pw : nullptr);   // block G + 1 - NSLOT released by all four consumers
           asm volatile("" ::: "memory");                                                // (slots free up a tile time apart: poll rarely)
           stage(G + 1);
           asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // block G landed, block G + 1 in flight
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
     // slot: the counters are per SLOT, so a release sent before block G was staged would be counted for block G - NSLOT, which a
     // slower consumer may still be reading -- the producers would then refill the slot under it (seen as rare wrong scores with one
     // pair per workgroup and often with runs of pairs, where half of the consumers skip the first blocks of a pair).
-    spin_ge(&filled[slot], 4 * (gen + 1), dead, probe ? &cw : nullptr);
+    spin_ge(&filled[slot], 4 * (gen + 1), dead, &wg_dead, probe ? &cw : nullptr);
     asm volatile("" ::: "memory");
     if (!comp) {                                  // not within this query block's reach: release and move on
       if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -438,6 +448,8 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
     else { FGVC_VMERGE_ASC_5(X) }
 #undef X
   }
+  const bool poison = dead || __builtin_amdgcn_readfirstlane(*(volatile int*)&wg_dead) != 0;
+  if (poison) g_pair_v5_timeout = 1;
   if (hi == 0 && qy < p.Hq && qx < p.Wq) {
     const size_t oo = ((size_t)(g_start + pi) * p.Hq * p.Wq + (size_t)qy * p.Wq + qx) * p.kout;
 #pragma unroll
@@ -446,8 +458,8 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
         const long long v = L[K - 1 - j];
         const int sk = (int)(v >> 32);
         const bool em = sk < (int)0xC0000000;
-        p.idx_out[oo + j] = em ? -1 : (int)~(uint32_t)v;
-        p.score_out[oo + j] = em ? -INFINITY : (float)sk * 0x1p-28f;
+        p.idx_out[oo + j] = poison ? 0 : em ? -1 : (int)~(uint32_t)v;
+        p.score_out[oo + j] = poison ? PAIR_POISON_SCORE : em ? -INFINITY : (float)sk * 0x1p-28f;
       }
     }
   }
@@ -483,6 +495,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
   __shared__ int hand_full[4], hand_free[4];
   __shared__ int blist_n;
   __shared__ int filled[NSLOT], done[NSLOT];
+  __shared__ int wg_dead;                        // a wave of this workgroup gave up waiting: the lists written from here on are poison
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -571,6 +584,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
     hand_full[tid] = 0;
     hand_free[tid] = 0;
   }
+  if (tid == 0) wg_dead = (p.debug & 4096) ? 1 : 0;      // 4096: fault injection for the fail-closed test
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int n_steps = blist_n;
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
       for (int G = 0; G < n_total; ++G) {
         if (G + 1 < n_total) {
           const int s1 = (G + 1) & (NSLOT - 1), gen1 = (G + 1) / NSLOT;
-          if (gen1 > 0) spin_ge<6, false>(&done[s1], 4 * gen1, dead);   // block G + 1 - NSLOT released by all four consumers
+          if (gen1 > 0) spin_ge<6, false>(&done[s1], 4 * gen1, dead, &wg_dead);   // block G + 1 - NSLOT released by all four consumers
           asm volatile("" ::: "memory");                                                // (slots free up a tile time apart: poll rarely)
           stage(G + 1);
           asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // block G landed, block G + 1 in flight
@@ -651,7 +665,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
         const bool comp = ((ent >> (24 + qb)) & 1) != 0;
         // block G has landed; a consumer that does not reach it waits for this too before it releases the slot (see the two-role form)
         // (after a chain the counter has been asked for before the hand-over: normally the block is there and nothing is waited for)
-        if (fnext < 4 * (gen + 1)) spin_ge<2, false>(&filled[slot], 4 * (gen + 1), dead);
+        if (fnext < 4 * (gen + 1)) spin_ge<2, false>(&filled[slot], 4 * (gen + 1), dead, &wg_dead);
         fnext = -1;
         asm volatile("" ::: "memory");
         if (!comp) {
@@ -697,7 +711,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
         int peek2;                                     // is the next key block there?  The answer lands under the hand-over
         asm volatile("ds_read_b32 %0, %1" : "=v"(peek2) : "v"(lds_addr_of(&filled[(G + 1) & (NSLOT - 1)])) : "memory");
         // hand the tile over once the selector has read the one before (it normally has: the answer came with the last fragments)
-        if (__builtin_amdgcn_readfirstlane(peek) < t_con) spin_ge<2, false>(&hand_free[qb], t_con, dead);
+        if (__builtin_amdgcn_readfirstlane(peek) < t_con) spin_ge<2, false>(&hand_free[qb], t_con, dead, &wg_dead);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -751,7 +765,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
   for (int e = 0; e < n_loop; ++e) {
     const uint32_t ent = __builtin_amdgcn_readfirstlane(blist[e]);
     if (((ent >> (24 + qb)) & 1) == 0) continue;   // not a tile of this query block
-    spin_ge<2, false>(&hand_full[qb], t_sel + 1, dead);
+    spin_ge<2, false>(&hand_full[qb], t_sel + 1, dead, &wg_dead);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -836,6 +850,8 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
     else { FGVC_VMERGE_ASC_5(X) }
 #undef X
   }
+  const bool poison = dead || __builtin_amdgcn_readfirstlane(*(volatile int*)&wg_dead) != 0;
+  if (poison) g_pair_v5_timeout = 1;
   if (hi == 0 && qy < p.Hq && qx < p.Wq) {
     const size_t oo = ((size_t)(g_start + pi) * p.Hq * p.Wq + (size_t)qy * p.Wq + qx) * p.kout;
 #pragma unroll
@@ -844,8 +860,8 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
         const long long v = L[K - 1 - j];
         const int sk = (int)(v >> 32);
         const bool em = sk < (int)0xC0000000;
-        p.idx_out[oo + j] = em ? -1 : (int)~(uint32_t)v;
-        p.score_out[oo + j] = em ? -INFINITY : (float)sk * 0x1p-28f;
+        p.idx_out[oo + j] = poison ? 0 : em ? -1 : (int)~(uint32_t)v;
+        p.score_out[oo + j] = poison ? PAIR_POISON_SCORE : em ? -INFINITY : (float)sk * 0x1p-28f;
       }
     }
   }
@@ -860,9 +876,14 @@ int pair_v5_probe_read(long long* out32) {
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_pair_v5_probe), 32 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 
+// read and clear: one event fails one check, not every later one of the process
 int pair_v5_timeout_flag() {
   int v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_pair_v5_timeout), sizeof(int)) != hipSuccess) return -1;
+  if (v != 0) {
+    const int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pair_v5_timeout), &zero, sizeof(int)) != hipSuccess) return -1;
+  }
   return v;
 }
 

@@ -111,8 +111,15 @@ def _wire(t: torch.Tensor) -> torch.Tensor:
     return t.view(torch.uint8) if t.dtype == torch.int16 else t
 
 
+def _global_rank(group, r: int) -> int:
+    """The schedule counts ranks inside `group` (enumerate(ranges)); torch.distributed's src / dst / peer arguments are GLOBAL ranks."""
+    return r if group is None or group is dist.group.WORLD else dist.get_global_rank(group, r)
+
+
 def _broadcast(buf: torch.Tensor, src: int, group) -> None:
+    """`src`: rank within `group`."""
     buf = _wire(buf)
+    src = _global_rank(group, src)
     if _host_staged(buf, group):
         tmp = buf.cpu()
         dist.broadcast(tmp, src=src, group=group)
@@ -138,12 +145,12 @@ class _Messages:
     def __init__(self, group):
         self.group, self.ops, self.keep, self.land, self.reqs = group, [], [], [], None
 
-    def send(self, t: torch.Tensor, dst: int):
+    def send(self, t: torch.Tensor, dst: int):            # dst / src: ranks within the group
         t = _wire(t.contiguous())
         if _host_staged(t, self.group):
             t = t.cpu()
         self.keep.append(t)
-        self.ops.append(dist.P2POp(dist.isend, t, dst, self.group))
+        self.ops.append(dist.P2POp(dist.isend, t, _global_rank(self.group, dst), self.group))
 
     def recv(self, into: torch.Tensor, src: int):
         assert into.is_contiguous()
@@ -153,7 +160,7 @@ class _Messages:
             self.land.append((into, tmp))
             into = tmp
         self.keep.append(into)
-        self.ops.append(dist.P2POp(dist.irecv, into, src, self.group))
+        self.ops.append(dist.P2POp(dist.irecv, into, _global_rank(self.group, src), self.group))
 
     def post(self):
         if self.ops:
@@ -221,7 +228,7 @@ class HipBackend:
 
     def affinity(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig, phases=None):
         """`phases` = (plan indices of the pairs to launch first, callable to run before the others): see engine.run_pairs."""
-        tk = engine.run_affinity(bank, Hf, Wf, plan, cfg, phases=phases)
+        tk = engine.run_affinity(bank, Hf, Wf, plan, cfg, phases=phases, channels=getattr(self.model, "feat_channels", None))
         return tk.idx, tk.weight
 
     def sweep(self, idx, weight, slot_frame, plan: Plan, start: int, pts, Hf, Wf, h, w, cfg):
@@ -411,8 +418,11 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
         tail = getattr(backend, "tail_stream", None)
         if tail is not None:
             tail.wait_stream(torch.cuda.current_stream(dev))
-            for t in (idx, weight, slot_frame_dev):
-                t.record_stream(tail)                      # keep them from the caching allocator until the side stream is done
+            # everything the side stream reads that was allocated on another stream: keep it from the caching allocator until the side
+            # stream is done (without a `cache` the schedule -- slot table, the groups' query points -- dies when this function returns)
+            for t in [idx, weight, slot_frame_dev] + [pts for (_, _, pts) in sc["groups"]]:
+                if t.is_cuda:
+                    t.record_stream(tail)
         with (torch.cuda.stream(tail) if tail is not None else _Null()):
             with _span(timing, "all_gather_lists"):
                 if world > 1:

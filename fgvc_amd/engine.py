@@ -181,9 +181,9 @@ class PairLists:
 
 
 def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
-                 pair_chunk: int = 16384, events=None, phases=None) -> DeviceTopk:
+                 pair_chunk: int = 16384, events=None, phases=None, channels: Optional[int] = None) -> DeviceTopk:
     """Phases 1 and 2 (= merge_pairs(run_pairs(...)))."""
-    return merge_pairs(run_pairs(feats_hwc, Hf, Wf, plan, cfg, pair_chunk, events, phases=phases), cfg)
+    return merge_pairs(run_pairs(feats_hwc, Hf, Wf, plan, cfg, pair_chunk, events, channels=channels, phases=phases), cfg)
 
 
 def merge_pairs(pl: PairLists, cfg: TrackerConfig, rows: Optional[Sequence[int]] = None) -> DeviceTopk:
@@ -229,6 +229,10 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
         cfg.pair_precision == "auto" and ops.split_path_ok(feats_hwc.shape[-1], Hf, Wf, k, cfg.with_norm, None, cfg.mask, all_masked))
     if pre_split and not use_split:
         raise ValueError("run_affinity: split features given, but the split pair kernel does not apply to this configuration")
+    if cfg.sim_mode == "l2-distance" and channels is None:
+        # the softmax divisor of this mode is sqrt(C) / 2 with the encoder's OWN channel count (local_attention.py:327 uses
+        # att_channels); the row length may be that count rounded up with zero channels (normalize_to_hwc(pad=True)), so it must be given
+        raise ValueError("run_pairs: sim_mode='l2-distance' needs channels= (the encoder's un-padded channel count)")
     if use_split:      # 16-bit matrix pipe on the two-part split of the (normalised) features, f32-grade scores
         fmt = cfg.pair_split_fmt
         split = feats_hwc if pre_split else (ops.split_f16x2 if fmt == "f16" else ops.split_bf16)(feats_hwc)
@@ -316,17 +320,18 @@ def run_propagation_async(topk, start: int, points_xy: torch.Tensor, Hf: int, Wf
 
 
 def track_points(feats_hwc: torch.Tensor, Hf: int, Wf: int, h: int, w: int, query_points: torch.Tensor,
-                 cfg: TrackerConfig):
+                 cfg: TrackerConfig, channels: Optional[int] = None):
     """The whole post-encoder path for one clip.  query_points (P,3) = (t, x, y) (any device).
     Returns traj_pred (T, P', 2) f64 on the device with points re-ordered by query time (the
-    reference's regrouping, vanilla_tracker.py:257-299) and `order` (P',) original indices."""
+    reference's regrouping, vanilla_tracker.py:257-299) and `order` (P',) original indices.
+    `channels`: the encoder's channel count where the rows are zero-padded beyond it (read by sim_mode='l2-distance' only)."""
     T = feats_hwc.shape[0]
     dev = feats_hwc.device
     qp = query_points.detach().to("cpu")
     times = qp[:, 0].to(torch.int64)
     starts = sorted(set(times.tolist())) if cfg.regroup else [0]
     plan = plan_clip(T, starts, cfg)
-    pl = run_pairs(feats_hwc, Hf, Wf, plan, cfg)
+    pl = run_pairs(feats_hwc, Hf, Wf, plan, cfg, channels=channels)
     traj = torch.zeros((T, qp.shape[0], 2), device=dev, dtype=torch.float64)
     order = []
     K = 0

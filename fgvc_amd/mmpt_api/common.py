@@ -16,7 +16,8 @@ from ..ops import MaskSpec
 __all__ = [
     "NeighborMask", "spatial_neighbor", "masked_attention_efficient", "masked_attention_efficient_v2",
     "masked_attention", "masked_attention_efficient_c2f", "masked_attention_efficient_correlation_v2",
-    "compute_affinity", "coords_grid", "cat", "video2images", "images2video", "bilinear_sample",
+    "compute_affinity", "propagate", "non_local_attention", "local_square_attention", "coords_grid", "cat", "video2images",
+    "images2video", "bilinear_sample",
 ]
 
 
@@ -206,14 +207,101 @@ def compute_affinity(src_img, dst_img, temperature=1.0, normalize=True, softmax_
     return aff
 
 
+def propagate(img, affinity, topk=None):
+    """affinity_utils.py:33-50: new_img[b] = img[b] (C x HW) @ affinity[b] (HW_src x HW_dst) for a GIVEN dense affinity (what
+    compute_affinity returned); `topk`: per destination column subtract the k-th largest entry, clamp at 0, normalise by the sum
+    (:36-44).  The affinity is streamed once by fgvc_dense_propagate_f32 (+ once by fgvc_dense_kth_f32 for the thresholds).
+    The reference rewrites the caller's `affinity` in place on the topk branch ("to save memory"); this one leaves it untouched."""
+    batches, channels, height, width = img.size()
+    assert affinity.shape == (batches, height * width, height * width), "propagate: affinity must be (N, HW, HW)"
+    outs = []
+    for b in range(batches):
+        labels = img[b].reshape(channels, height * width).t().float().contiguous()
+        out = ops.dense_propagate(affinity[b].float().contiguous(), labels, topk)
+        outs.append(out.t().reshape(channels, height, width))
+    return torch.stack(outs, 0).to(img.dtype)
+
+
+def non_local_attention(tar, refs, per_ref=True, flatten=True, temprature=1.0, mask=None, scaling=False, norm=False,
+                        att_only=False, mode="dot"):
+    """correlation.py:32-83: att[b, t, i, j] = <tar_i, ref_{t,j}> / temprature (sic), the dense volume per reference frame
+    (fgvc_corr_volume_f32 with the roles swapped: the volume kernel writes [key][query], here key = target pixel i).
+    Returns what the reference returns: `att` if att_only, else (batch size, softmaxed attention) -- its first return value is
+    the variable `_` that `_, t, feat_dim, w_, h_ = refs.shape` bound (:46), i.e. the batch size; the transformed frames
+    it computes are dropped there too.  mode='l2' is refused: the reference's own `.view` of a transposed tensor (:62)
+    fails for more than one reference frame."""
+    if isinstance(refs, (list, tuple)):
+        refs = torch.stack(list(refs), 1)
+    if mode != "dot":
+        raise NotImplementedError("fgvc_amd non_local_attention: mode='dot' only (the reference's 'l2' branch cannot run for t > 1)")
+    B, t, feat_dim = refs.shape[:3]
+    atts = []
+    for b in range(B):
+        tf = ops.normalize_to_hwc(tar[b:b + 1].float(), bool(norm), pad=True)[0]                     # (HW_tar, C')
+        rf = ops.normalize_to_hwc(refs[b].float().contiguous(), bool(norm), pad=True)                # (t, HW_ref, C')
+        atts.append(torch.stack([ops.corr_volume(rf[k], tf, temprature, "f32") for k in range(t)], 0))   # [t][tar i][ref j]
+    att = torch.stack(atts, 0)
+    if scaling:
+        att = att / torch.sqrt(torch.tensor(feat_dim).float()).to(att.device)
+    if mask is not None:
+        att.masked_fill_(~(mask.dense() if isinstance(mask, NeighborMask) else mask.bool()), float("-inf"))
+    if att_only:
+        return att.to(tar.dtype)
+    if per_ref:
+        return B, torch.softmax(att, dim=-1).to(tar.dtype)
+    return B, torch.softmax(att.permute(0, 2, 1, 3).flatten(2), -1).to(tar.dtype)
+
+
+def local_square_attention(query, key, value, kernel_size, temperature=1, topk=None, batch_as_context=False):
+    """local_attention.py:38-103: zero-padded (kh x kw) window around every query pixel (F.unfold, padding k // 2), RAW dot products
+    / temperature (no normalisation, no softmax: the attention values themselves weight the values), optionally only the `topk`
+    largest.  batch_as_context: the windows of ALL key batch entries form one context (the reference's gather then needs a query
+    batch of 1).  Kernels: fgvc_local_corr_topk_f32 + fgvc_propagate_topk_f32 with the logits as weights (topk), or the
+    box-masked dense pass fgvc_dense_attend_f32 in raw mode (topk=None: zero-padded taps contribute 0)."""
+    assert query.ndim == key.ndim == 4
+    assert query.shape[1:] == key.shape[1:]
+    assert value.shape[2:] == key.shape[2:], f"{value.shape} {key.shape}"
+    assert value.shape[0] == key.shape[0]
+    ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+    if ks[0] % 2 == 0 or ks[1] % 2 == 0:
+        raise ValueError("local_square_attention: even kernel sizes do not survive the reference's own reshape (F.unfold yields (H+1)(W+1) columns)")
+    C, H, W = query.shape[1:]
+    P = value.shape[1]
+    Ry, Rx = ks[0] // 2, ks[1] // 2
+    if batch_as_context:
+        assert query.shape[0] == 1, "batch_as_context: the reference's gather needs a query batch of 1"
+        groups = [(0, list(range(key.shape[0])))]
+    else:
+        assert query.shape[0] == key.shape[0]
+        groups = [(b, [b]) for b in range(query.shape[0])]
+    outs = []
+    for qb, kbs in groups:
+        qf = ops.normalize_to_hwc(query[qb:qb + 1].float(), False, pad=True)                        # raw rows, zero-padded channels
+        kf = ops.normalize_to_hwc(key[kbs].float().contiguous(), False, pad=True)                   # (K, HW, C')
+        labels = value[kbs].permute(0, 2, 3, 1).reshape(len(kbs), H * W, P).float().contiguous()
+        if topk is None:
+            out = ops.dense_attend(qf[0], kf, labels, H, W, H, W, MaskSpec(ry=Ry, rx=Rx), temperature, "raw")
+        else:
+            if Ry != Rx:
+                raise NotImplementedError("fgvc_amd local_square_attention: topk with a non-square window")
+            idx, logit, _ = ops.local_corr_topk(qf, kf, H, W, Ry, topk, temperature, normalized=False)
+            out = ops.propagate_topk(labels, torch.arange(len(kbs), dtype=torch.int32, device=query.device), idx, logit, H, W, H, W,
+                                     window_L=2 * Ry + 1)
+        outs.append(out.t().reshape(P, H, W))
+    return torch.stack(outs, 0).to(query.dtype)
+
+
 def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask, temperature=1, topk=None,
                                    normalize=True, step=32, non_mask_len=0, mode="softmax",
                                    sim_mode="dot_product", radius_fine=12):
     """local_attention.py:721-880.  Coarse stage = fgvc_pair_topk_bf16x4 / fgvc_pair_topk_f32 with topk=1 per key slot (arg-max of
     the per-frame softmax, :835-837); fine stage = fgvc_c2f_refine_f32."""
     _check_common(query, key, value, mode, sim_mode, normalize)
-    if mode != "softmax" or sim_mode != "dot_product" or topk is None:
-        raise NotImplementedError("fgvc_amd c2f: mode='softmax', sim_mode='dot_product' and an integer topk only")
+    if topk is None:
+        # the reference's own branch is `pass` followed by `output[...] = cur_output` with cur_output unbound (:866-870): it raises
+        raise NotImplementedError("masked_attention_efficient_c2f: topk=None cannot run in the reference either (local_attention.py:866-870)")
+    if mode != "softmax" or sim_mode != "dot_product":
+        raise NotImplementedError("fgvc_amd c2f: mode='softmax' and sim_mode='dot_product' only")
     if key.ndim == 4:
         key, value = key.unsqueeze(2), value.unsqueeze(2)
         key_fine = key_fine.unsqueeze(2) if key_fine.ndim == 4 else key_fine

@@ -64,6 +64,7 @@ class VanillaTracker(BaseTracker):
         super().__init__(*args, **kwargs)
         g = self.test_cfg.get
         self.stride_sample = g("stride_sample", False)
+        self.feat_channels = None          # the encoder's (un-padded) channel count, known after the first get_feats_hwc()
 
     # ---- A1/A2: encoder, every frame exactly once, features stay on the device ------------------
     def extract_feat(self, imgs):
@@ -100,17 +101,27 @@ class VanillaTracker(BaseTracker):
         for i in range(0, frames.shape[0], step):
             if fast:       # backbone writes normalised channels-last rows itself (no NCHW round trip)
                 f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm, split_if=split_if, split_fmt=split_fmt)
+                self.feat_channels = f.shape[-1]                      # (this path never pads)
                 chunks.append(f)
                 continue
             f = self.extract_feat(frames[i:i + step])
             if isinstance(f, (tuple, list)):
                 f = f[0]
             Hf, Wf = f.shape[-2:]
+            self.feat_channels = f.shape[1]                           # before the zero padding to a kernel width
             chunks.append(ops.normalize_to_hwc(f.float(), norm, pad=True))
         return (chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)), Hf, Wf       # (cat of one tensor is a copy)
 
     def engine_config(self) -> engine.TrackerConfig:
         return engine.TrackerConfig.from_test_cfg(self.test_cfg)
+
+    def _check_kernels(self):
+        """Fail closed, per video: the pair kernel's LDS protocol waits with bounded spins, and a workgroup whose wait gave up writes
+        poison lists (NaN trajectories downstream) and raises a device flag.  The flag is read -- and cleared -- here, at the point
+        where the reference synchronises anyway (`.cpu().numpy()` of the label maps, vanilla_tracker.py:404).  `check_kernels=False`
+        in test_cfg (an extension key) skips the device synchronisation; the poison still marks the results."""
+        if self.test_cfg.get("check_kernels", True) and ops.pair_f16x3_timed_out():
+            raise RuntimeError("fgvc_pair_topk_f16x3: a bounded wait of the kernel's LDS protocol timed out; this video's results are invalid")
 
     # ---- A10: regrouping by query time ----------------------------------------------------------
     @torch.no_grad()
@@ -128,19 +139,21 @@ class VanillaTracker(BaseTracker):
             # single group that starts at frame 0 regardless of the query times (vanilla_tracker.py:302-303)
             feats, Hf, Wf = self.get_feats_hwc(rgbs[0], split=True)
             plan = engine.plan_clip(T, [0], cfg)
-            tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
+            tk = engine.run_affinity(feats, Hf, Wf, plan, cfg, channels=self.feat_channels)
             _, coords = engine.run_propagation(tk, 0, qp[:, 1:].to(dev, torch.float32), Hf, Wf, h, w, cfg)
             traj_pred = coords.unsqueeze(0)                                   # float64, like torch.from_numpy(...)
+            self._check_kernels()
             return trajectories, visibilities, traj_pred, torch.zeros_like(visibilities), query_points
         t_min = int(qp[:, 0].min().item())
         # frames before the earliest query time are never used by any group
         feats, Hf, Wf = self.get_feats_hwc(rgbs[0, t_min:], split=True)
         qp_rel = qp.clone()
         qp_rel[:, 0] -= t_min
-        traj, order = engine.track_points(feats, Hf, Wf, h, w, qp_rel, cfg)     # (T-t_min, P, 2) f64, regrouped
+        traj, order = engine.track_points(feats, Hf, Wf, h, w, qp_rel, cfg, channels=self.feat_channels)   # (T-t_min, P, 2) f64, regrouped
         order = order.to(dev)
         traj_pred = torch.zeros_like(trajectories)
         traj_pred[0, t_min:] = traj.to(traj_pred.dtype)
+        self._check_kernels()
         return (trajectories[:, :, order], visibilities[:, :, order], traj_pred,
                 torch.zeros_like(visibilities), query_points[:, order])
 
@@ -151,9 +164,10 @@ class VanillaTracker(BaseTracker):
         T, h, w = rgbs.shape[1], rgbs.shape[-2], rgbs.shape[-1]
         feats, Hf, Wf = self.get_feats_hwc(rgbs[0], split=True)
         plan = engine.plan_clip(T, [0], cfg)
-        tk = engine.run_affinity(feats, Hf, Wf, plan, cfg)
+        tk = engine.run_affinity(feats, Hf, Wf, plan, cfg, channels=self.feat_channels)
         pts = query_points[0, :, 1:].to(rgbs.device, torch.float32)
         _, coords = engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)
+        self._check_kernels()
         return trajectories, visibilities, coords.unsqueeze(0), torch.zeros_like(visibilities), query_points
 
 
@@ -215,6 +229,7 @@ class HRVanillaTracker(VanillaTracker):
         h, w = rgbs.shape[-2], rgbs.shape[-1]
         feats, Hf, Wf, norm = self._feats_hwc(rgbs[0])
         coords = self._sweep(feats, Hf, Wf, norm, h, w, query_points[0, :, 1:].to(rgbs.device, torch.float32))
+        self._check_kernels()
         vis = torch.zeros_like(visibilities) if visibilities is not None else None
         return trajectories, visibilities, coords.unsqueeze(0), vis, query_points
 
@@ -276,5 +291,6 @@ class HRVanillaTracker(VanillaTracker):
             order.extend(sel.tolist())
             col += sel.numel()
         order = torch.tensor(order, device=rgbs.device)
+        self._check_kernels()
         return (trajectories[:, :, order], visibilities[:, :, order], traj_pred, torch.zeros_like(visibilities),
                 query_points[:, order])

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import NO_LIMIT, PAIR_MASKED, WEIGHT_COSINE, WEIGHT_SOFTMAX  # noqa: F401
+from ._lib import NO_LIMIT, PAIR_MASKED, WEIGHT_COSINE, WEIGHT_RAW, WEIGHT_SOFTMAX  # noqa: F401
 
 
 @dataclass(frozen=True)
@@ -190,7 +190,8 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
 
 def pair_f16x3_timed_out() -> bool:
     """True if a wave of an earlier fgvc_pair_topk_f16x3 launch gave up waiting on its key-block ring (a kernel bug: its spins are
-    bounded so that it cannot hang the GPU).  Synchronises the device; tests call it after every use of the kernel."""
+    bounded so that it cannot hang the GPU; the workgroup then writes poison lists -- index 0, score +inf, NaN weights after the
+    merge -- so the results cannot pass for valid ones).  Read-and-clear; synchronises the device."""
     return _lib.load().fgvc_pair_topk_f16x3_timed_out() != 0
 
 
@@ -358,14 +359,15 @@ def dense_attend(qfeat: torch.Tensor, kfeat: torch.Tensor, labels: torch.Tensor,
                  dense_mask: Optional[torch.Tensor] = None, precision: str = "f32") -> torch.Tensor:
     """topk=None branch (local_attention.py:376-383): weights over every unmasked key of every key slot.
     qfeat (HWq, C) f32 rows, kfeat (T, HWk, C), labels (T, HWk, P) -> (HWq, P).  One HWk x HWq volume slab lives at a time
-    (fgvc_corr_volume_f32, or _bf16x3 with precision='bf16x3' for C % 64 == 0), streamed once by fgvc_dense_attend_f32."""
+    (fgvc_corr_volume_f32, or _bf16x3 with precision='bf16x3' for C % 64 == 0), streamed once by fgvc_dense_attend_f32.
+    mode: 'softmax' | 'cosine' (clamp(min=0)^2) | 'raw' (the affinity itself is the weight: local_square_attention, :38-103)."""
     qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
     labels = _chk(labels, torch.float32, "labels")
     T, HWk, P = labels.shape
     HWq = qfeat.shape[0]
     assert HWq == Hq * Wq and HWk == Hk * Wk and kfeat.shape[:2] == (T, HWk) and 0 <= non_mask_len <= T
     dev = qfeat.device
-    wm = {"softmax": WEIGHT_SOFTMAX, "cosine": WEIGHT_COSINE}[mode]
+    wm = {"softmax": WEIGHT_SOFTMAX, "cosine": WEIGHT_COSINE, "raw": WEIGHT_RAW}[mode]
     ns = _lib.load().fgvc_dense_attend_splits(HWq, HWk)
     state = torch.empty((ns, HWq, P + 2), device=dev, dtype=torch.float32)
     vol = torch.empty((HWk, HWq), device=dev, dtype=torch.float32)
@@ -387,6 +389,34 @@ def dense_attend(qfeat: torch.Tensor, kfeat: torch.Tensor, labels: torch.Tensor,
                   _stream(qfeat))
     out = torch.empty((HWq, P), device=dev, dtype=torch.float32)
     _lib.call("fgvc_dense_attend_finish_f32", _ptr(state), ns, HWq, P, wm, _ptr(out), _stream(qfeat))
+    return out
+
+
+def dense_propagate(aff: torch.Tensor, labels: torch.Tensor, topk: Optional[int] = None) -> torch.Tensor:
+    """`propagate` for a GIVEN dense affinity (affinity_utils.py:33-50): aff (HWk, HWq) f32, labels (HWk, P) f32 -> (HWq, P)
+    = labels^T-weighted column sums; topk: weights max(aff - k-th largest of the column, 0), normalised by their sum (:36-44).
+    One streaming pass over `aff` per 32 label channels (fgvc_dense_propagate_f32) + one for the thresholds (fgvc_dense_kth_f32)."""
+    aff, labels = _chk(aff, torch.float32, "aff"), _chk(labels, torch.float32, "labels")
+    HWk, HWq = aff.shape
+    assert labels.shape[0] == HWk and labels.dim() == 2
+    P = labels.shape[1]
+    dev = aff.device
+    ns = _lib.load().fgvc_dense_attend_splits(HWq, HWk)
+    thr = None
+    if topk is not None:
+        if not 1 <= topk <= min(64, HWk):
+            raise _lib.FgvcHipError(f"propagate: topk={topk} outside 1..min(64, HWk)")
+        part = torch.empty((ns, HWq, 16 if topk <= 16 else 64), device=dev, dtype=torch.float32)
+        thr = torch.empty((HWq,), device=dev, dtype=torch.float32)
+        _lib.call("fgvc_dense_kth_f32", _ptr(aff), HWk, HWq, int(topk), _ptr(part), ns, _ptr(thr), _stream(aff))
+    out = torch.empty((HWq, P), device=dev, dtype=torch.float32)
+    for p0 in range(0, P, 32):
+        lab = labels[:, p0:p0 + 32].contiguous()
+        pp = lab.shape[1]
+        state = torch.empty((ns, HWq, pp + 2), device=dev, dtype=torch.float32)
+        o = torch.empty((HWq, pp), device=dev, dtype=torch.float32)
+        _lib.call("fgvc_dense_propagate_f32", _ptr(aff), _ptr(lab), HWk, HWq, pp, _ptr(thr), _ptr(state), ns, _ptr(o), _stream(aff))
+        out[:, p0:p0 + pp] = o
     return out
 
 

@@ -49,6 +49,7 @@ extern "C" {
 /* weight modes of fgvc_merge_topk_f32 (local_attention.py:368-373) */
 #define FGVC_WEIGHT_SOFTMAX 0
 #define FGVC_WEIGHT_COSINE 1
+#define FGVC_WEIGHT_RAW 2     /* fgvc_dense_attend_f32 only: the affinity itself is the weight, no normalisation (local_square_attention, topk=None) */
 
 const char* fgvc_version(void);
 const char* fgvc_last_error(void);
@@ -199,7 +200,8 @@ int fgvc_corr_volume_f16f6(const uint8_t* q_split, const uint8_t* k_split, int C
  * divided by the temperature; -inf entries are skipped) and labels[HWk][P]:
  *   softmax mode: per query an online softmax state {running max, denominator, P weighted label sums} in
  *     state[nsplit][HWq][P+2] f32, `first` != 0 starts it, later calls merge into it;
- *   cosine mode (weight_mode = FGVC_WEIGHT_COSINE): plain sums of max(a,0)^2 * label.
+ *   cosine mode (weight_mode = FGVC_WEIGHT_COSINE): plain sums of max(a,0)^2 * label;
+ *   raw mode (FGVC_WEIGHT_RAW): plain sums of a * label over the unmasked keys (reference local_attention.py:38-103 with topk=None).
  * masked != 0 applies the predicate (r2max, ry, rx) on key - query offsets (equal grids required) and visits only the key
  * rows a band of queries can reach.  nsplit = fgvc_dense_attend_splits(HWq, HWk) (host helper) workgroups share a band's key rows.
  * fgvc_dense_attend_finish_f32 merges the splits and normalises: out[HWq][P]. P <= 32. */
@@ -207,6 +209,18 @@ int fgvc_dense_attend_splits(int HWq, int HWk);
 int fgvc_dense_attend_f32(const float* vol, const float* labels, int Hq, int Wq, int Hk, int Wk, int P, int masked,
                           int r2max, int ry, int rx, int weight_mode, int first, float* state, int nsplit, void* stream);
 int fgvc_dense_attend_finish_f32(const float* state, int nsplit, int HWq, int P, int weight_mode, float* out, void* stream);
+
+/* ---- A5'': `propagate` (reference affinity_utils.py:33-50): new_img = img @ affinity for a GIVEN dense affinity aff[HWk][HWq]
+ * (e.g. what fgvc_corr_volume_* wrote, softmaxed or not), labels [HWk][P] pixel-major, out [HWq][P], P <= 32 per call:
+ *   thr == NULL   out[i][p] = sum_j aff[j][i] * labels[j][p]                                               (:45-49)
+ *   thr != NULL   w = max(aff[j][i] - thr[i], 0);  out[i][p] = sum_j w * labels[j][p] / max(sum_j w, 1e-12)  (the `topk` branch, :36-44)
+ * One streaming pass over the slab (the kernel of fgvc_dense_attend_f32); state = nsplit * HWq * (P + 2) floats of workspace,
+ * nsplit = fgvc_dense_attend_splits(HWq, HWk).
+ * fgvc_dense_kth_f32: thr[i] = k-th largest entry of column i of aff (1 <= k <= 64), one more pass; part = workspace of
+ * nsplit * HWq * (k <= 16 ? 16 : 64) floats. */
+int fgvc_dense_kth_f32(const float* aff, int HWk, int HWq, int k, float* part, int nsplit, float* thr, void* stream);
+int fgvc_dense_propagate_f32(const float* aff, const float* labels, int HWk, int HWq, int P, const float* thr, float* state,
+                             int nsplit, float* out, void* stream);
 
 /* ---- A7: single-scale local-window correlation + top-k (mmcv.ops.Correlation semantics as used at
  * vanilla_tracker.py:435-443,547-566; torch twin local_attention.py:1190-1240).

@@ -278,6 +278,67 @@ def masked_attention_efficient(query, key, value, mask=None, temperature=1, topk
 
 
 # ----------------------------------------------------------------------------
+# A5''  dense formulations without a shipped caller: propagate, non_local_attention, local_square_attention
+# ----------------------------------------------------------------------------
+def propagate(img: torch.Tensor, affinity: torch.Tensor, topk: Optional[int] = None) -> torch.Tensor:
+    """affinity_utils.py:33-50: img (N,C,H,W), affinity (N, HW src, HW dst) -> img @ affinity; topk: subtract each column's k-th
+    largest entry (:39-41), clamp at 0 (:43), normalise by the column sum clamped at 1e-12 (:45).  (Out of place: the
+    reference rewrites the caller's affinity.)"""
+    N, C, H, W = img.shape
+    if topk is not None:
+        kth = affinity.topk(dim=1, k=topk)[0][:, topk - 1].view(N, 1, H * W)
+        affinity = (affinity - kth).clamp(min=0)
+        affinity = affinity / affinity.sum(keepdim=True, dim=1).clamp(min=1e-12)
+    return torch.bmm(img.reshape(N, C, -1), affinity).reshape(N, C, H, W)
+
+
+def non_local_attention(tar: torch.Tensor, refs: torch.Tensor, per_ref: bool = True, temperature: float = 1.0, mask=None,
+                        scaling: bool = False, norm: bool = False, att_only: bool = False):
+    """correlation.py:32-83, mode='dot': tar (B,C,H,W), refs (B,t,C,H,W) -> att (B,t,HW tar,HW ref) = <tar_i, ref_tj> / temperature
+    (:52-56) [/ sqrt(C) (:64-66)] [masked_fill(-inf) (:69-71)]; att_only returns it (:73); else softmax over the reference
+    pixels of each frame (per_ref, :77-80) or over all frames' pixels pooled (:81-85).  Returns (B, att) like the reference,
+    whose first value is the batch size bound by `_, t, feat_dim, w_, h_ = refs.shape` (:46)."""
+    B, t, C = refs.shape[:3]
+    tv = tar.flatten(2).permute(0, 2, 1)
+    rv = refs.flatten(3).permute(0, 1, 3, 2)
+    if norm:
+        tv, rv = F.normalize(tv, dim=-1), F.normalize(rv, dim=-1)
+    att = torch.einsum("bic,btjc->btij", tv, rv) / temperature
+    if scaling:
+        att = att / math.sqrt(C)
+    if mask is not None:
+        att = att.masked_fill(~mask.bool(), NEG_INF)
+    if att_only:
+        return att
+    if per_ref:
+        return B, att.softmax(-1)
+    return B, att.permute(0, 2, 1, 3).flatten(2).softmax(-1)
+
+
+def local_square_attention(query, key, value, kernel_size, temperature: float = 1.0, topk: Optional[int] = None,
+                           batch_as_context: bool = False) -> torch.Tensor:
+    """local_attention.py:38-103: RAW dot products of each query pixel with the zero-padded (kh x kw) window of the key around it
+    (F.unfold, padding k // 2, :67-68) / temperature (:96), optionally the topk largest (:99-104); the attention values themselves
+    weight the unfolded values (:106, no softmax).  batch_as_context (:83-92): the windows of all key batch entries are one
+    context for a single query."""
+    ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+    pad = (ks[0] // 2, ks[1] // 2)
+    N, C, H, W = key.shape
+    P = value.shape[1]
+    uk = F.unfold(key, ks, padding=pad).view(N, C, ks[0] * ks[1], H * W)
+    uv = F.unfold(value, ks, padding=pad).view(N, P, ks[0] * ks[1], H * W)
+    uq = query.reshape(query.shape[0], C, 1, H * W)
+    if batch_as_context:
+        uk = uk.transpose(0, 1).reshape(1, C, N * ks[0] * ks[1], H * W)
+        uv = uv.transpose(0, 1).reshape(1, P, N * ks[0] * ks[1], H * W)
+    att = (uq * uk).sum(1, keepdim=True) / temperature
+    if topk is not None:
+        att, ti = att.topk(k=topk, dim=2)
+        uv = uv.gather(2, ti.expand(-1, P, -1, -1))
+    return (att * uv).sum(2).reshape(-1, P, H, W)
+
+
+# ----------------------------------------------------------------------------
 # A7 / A7'  single-scale local-window correlation + top-k
 # ----------------------------------------------------------------------------
 def local_corr(query: torch.Tensor, keys: torch.Tensor, radius: int, normalize: bool = True) -> torch.Tensor:

@@ -29,12 +29,19 @@ def pytest_sessionstart(session):
             return
     except Exception:
         return
+    tool = os.path.join(ROOT, "tools", "two_ranks_one_gpu.py")
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_ranks_one_gpu.py"), "--tail-stream"],
-                           capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, tool, "--tail-stream"], capture_output=True, text=True, timeout=600)
         TWO_RANKS.update(rc=r.returncode, out=r.stdout[-6000:], err=r.stderr[-3000:])
     except Exception as e:   # reported by the test
         TWO_RANKS.update(rc=-1, out="", err=repr(e))
+    try:   # BASELINE configs[3]: a 64-frame TAP-Vid-DAVIS-shape video (256 x 256 -> 128 x 128 x 256 features, P = 32) over the two ranks
+        r = subprocess.run([sys.executable, tool, "--frames", "64", "--size", "256", "256", "--strides", "1", "1", "1", "4", "--precede", "5",
+                            "--neighbor-range", "30", "--points", "32", "--halos", "exchange", "--tail-stream"],
+                           capture_output=True, text=True, timeout=900)
+        TWO_RANKS["cfg4"] = dict(rc=r.returncode, out=r.stdout[-6000:], err=r.stderr[-3000:])
+    except Exception as e:
+        TWO_RANKS["cfg4"] = dict(rc=-1, out="", err=repr(e))
 
 
 @pytest.fixture(scope="session")

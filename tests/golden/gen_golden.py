@@ -330,6 +330,94 @@ def gen_tv_keymap():
     print(f"  tv_keymap.json  {sum(v is not None for v in keymap.values())} of {len(keymap)} own tensors filled from the checkpoint")
 
 
+def gen_dense_api():
+    """tests/golden/dense_api_10x12.npz: the three dense / window operators of the A5'' row that have no shipped caller --
+    `propagate` (affinity_utils.py:33-50, with and without topk), `non_local_attention` (correlation.py:32-83: att_only, per_ref,
+    pooled, scaling, mask) and `local_square_attention` (local_attention.py:38-103: whole window, topk, batch_as_context)."""
+    ref = ref_import.load()
+    g = torch.Generator().manual_seed(1100)
+    N, C, H, W, P, T = 2, 32, 10, 12, 5, 3
+    HW = H * W
+    src, dst = rnd(g, N, C, H, W), rnd(g, N, C, H, W)
+    img = torch.rand(N, P, H, W, generator=g)
+    aff = ref.compute_affinity(src, dst, temperature=0.07, softmax_dim=1)                 # (N, HW src, HW dst), columns sum to 1
+    out = {"src": src, "dst": dst, "img": img,
+           "prop": ref.propagate(img, aff.clone()), "prop_top7": ref.propagate(img, aff.clone(), topk=7),
+           "prop_raw": ref.propagate(img, ref.compute_affinity(src, dst, temperature=1.0))}
+    wide = torch.rand(1, 40, H, W, generator=g)                                            # more than 32 channels: two kernel passes
+    out.update(img_wide=wide, prop_wide_top3=ref.propagate(wide, aff[:1].clone(), topk=3))
+    Hn, Wn, Tn = 8, 10, 2                                                                  # (a smaller grid: these outputs are dense)
+    tar, refs = rnd(g, 1, C, Hn, Wn), rnd(g, 1, Tn, C, Hn, Wn)
+    mask = ref.spatial_neighbor(1, Hn, Wn, neighbor_range=6, device="cpu", dtype=torch.float32).reshape(Hn * Wn, Hn * Wn)
+    out.update(tar=tar, refs=refs, nl_mask_nr=6,
+               nl_att=ref.non_local_attention(tar, refs, temprature=0.07, norm=True, att_only=True),
+               nl_att_scaled_masked=ref.non_local_attention(tar, refs, temprature=2.0, scaling=True, mask=mask, att_only=True),
+               nl_per_ref=ref.non_local_attention(tar, [refs[:, t] for t in range(Tn)], temprature=0.07, norm=True)[1],
+               nl_pooled=ref.non_local_attention(tar, refs, per_ref=False, temprature=0.07, norm=True)[1],
+               nl_first=int(ref.non_local_attention(tar, refs, temprature=0.07, norm=True)[0]))
+    q, k = rnd(g, N, C, H, W) * 0.3, rnd(g, N, C, H, W) * 0.3
+    v = torch.rand(N, P, H, W, generator=g)
+    out.update(lq=q, lk=k, lv=v,
+               lsa_all=ref.local_square_attention(q, k, v, 5, temperature=0.5),
+               lsa_rect=ref.local_square_attention(q, k, v, (3, 7), temperature=0.5),
+               lsa_top4=ref.local_square_attention(q, k, v, 5, temperature=0.5, topk=4),
+               lsa_ctx_top6=ref.local_square_attention(q[:1], k, v, 7, temperature=0.5, topk=6, batch_as_context=True),
+               lsa_ctx_all=ref.local_square_attention(q[:1], k, v, 3, temperature=0.5, batch_as_context=True))
+    save("dense_api_10x12", **out)
+
+
+def gen_tracker_cfg0():
+    """tests/golden/tracker_cfg0_2x256x256.npz: BASELINE.json configs[0] / the reference's only shipped eval geometry
+    (configs/eval/res18_d1_eval.py:8,12-22): the genuine VanillaTracker.forward_test on 2 x 256 x 256 frames, ResNet-18 with
+    strides (1,1,1,4) -> 128 x 128 x 256 features, neighbor_range 30, top-10, with_first (frame 0 sits in key slots 0 AND 1 of
+    frame 1).  Stored: the frames (values on a 1/32 grid, as int8), the trajectories, and for 512 sampled query pixels of frame 1
+    what the reference's own `topk` call returned (spied) plus a float64 top-(k + 2) of the same rows computed from the
+    REFERENCE's features -- the gaps that say which queries' ranks are clear of f32 rounding."""
+    ref = ref_import.load()
+    cfg = ref.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512,
+                         with_first=True, with_first_neighbor=True)
+    model = ref.builder.build_model(
+        dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4),
+                                                  out_indices=(2,), pool_type="none")),
+        train_cfg=None, test_cfg=cfg)
+    sd = O.seeded_resnet_state(seed=13, strides=(1, 1, 1, 4), pool_type="none")
+    model.backbone.load_state_dict(sd, strict=True)
+    model.eval()
+    g = torch.Generator().manual_seed(1300)
+    T, h, w, P = 2, 256, 256, 8
+    # video-like frames: a smooth field that moves by (3, -2) pixels between the frames, plus noise; values on a 1/32 grid in [-4, 4)
+    base = torch.nn.functional.interpolate(torch.randn(1, 3, 40, 40, generator=g), size=(h + 16, w + 16), mode="bicubic", align_corners=False)[0]
+    frames = torch.stack([base[:, 8:8 + h, 8:8 + w], base[:, 10:10 + h, 5:5 + w]], 0) * 1.2 + 0.25 * torch.randn(T, 3, h, w, generator=g)
+    rgbs_i8 = torch.clamp(torch.round(frames * 32), -128, 127).to(torch.int8)
+    rgbs = (rgbs_i8.float() / 32.0).unsqueeze(0)
+    qp = torch.cat([torch.zeros(P, 1), torch.rand(P, 2, generator=g) * 200 + 28], 1).unsqueeze(0)
+    traj_gt = torch.rand(1, T, P, 2, generator=g) * 256
+    vis_gt = (torch.rand(1, T, P, generator=g) > 0.3).float()
+    with ref_import.cuda_as_cpu(), torch.no_grad(), TopkSpy() as spy:
+        outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj_gt, visibilities=vis_gt)
+    with torch.no_grad():
+        feats = model.backbone(rgbs[0])                                   # (2, 256, 128, 128)
+    HW, k = 128 * 128, 10
+    calls = [c for c in spy.calls if c[0].shape[1] == k]
+    tv = torch.cat([c[0][0] for c in calls], dim=1)                     # (k, HW): the chunks of frame 1's one attention call
+    ti = torch.cat([c[1][0] for c in calls], dim=1)
+    assert tv.shape == (k, HW), tv.shape
+    sample = torch.cat([torch.tensor([0, 127, HW - 128, HW - 1, 64 * 128 + 64]), torch.randint(0, HW, (507,), generator=g)])
+    # float64 top-(k + 2) of the sampled rows from the reference's features: key slots = [frame 0, frame 0] (with_first, idx <= 5)
+    fn = torch.nn.functional.normalize(feats.double(), dim=1).flatten(2)          # (2, C, HW)
+    aff = (fn[0].t() @ fn[1][:, sample]) / 0.07                                     # (HW keys of frame 0, n)
+    ky, kx = torch.arange(HW) // 128, torch.arange(HW) % 128
+    inside = ((ky.view(-1, 1) - ky[sample].view(1, -1)) ** 2 + (kx.view(-1, 1) - kx[sample].view(1, -1)) ** 2).double().sqrt() < 15
+    aff = aff.masked_fill(~inside, float("-inf"))
+    dv, di = aff.topk(7, dim=0)                                                     # 7 DISTINCT pixels: each appears in both slots
+    wsum = float(sum(v.double().abs().sum() for kk, v in sd.items() if v.dtype.is_floating_point))
+    save("tracker_cfg0_2x256x256", rgbs_i8=rgbs_i8, query_points=qp, trajectories=traj_gt, visibilities=vis_gt, seed=13,
+         weight_abs_sum=wsum, out_traj_pred=outs[2], out_query_points=outs[4],
+         sample=sample.to(torch.int32), ref_topk_val=tv.t()[sample].contiguous(), ref_topk_idx=ti.t()[sample].contiguous().to(torch.int32),
+         f64_distinct_val=dv.t().contiguous(), f64_distinct_idx=di.t().contiguous().to(torch.int32),
+         feats_sub=feats[:, ::16, ::8, ::8], feats_abs_sum=float(feats.double().abs().sum()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate single fixtures: python gen_golden.py gen_hr_tracker ...
         for name in sys.argv[1:]:
@@ -340,3 +428,5 @@ if __name__ == "__main__":
         gen_hr_tracker()
         gen_extra_modes()
         gen_tv_keymap()
+        gen_tracker_cfg0()
+        gen_dense_api()

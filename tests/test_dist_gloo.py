@@ -77,7 +77,7 @@ def _free_port():
     return path
 
 
-def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5):
+def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5, members=None):
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -85,11 +85,19 @@ def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5):
     from fgvc_amd.engine import TrackerConfig
     cfg = TrackerConfig(neighbor_range=8, regroup=True, precede_frames=precede)
     h, w = feats.shape[-2] * 2, feats.shape[-1] * 2
+    group = dist.new_group(members) if members is not None else None     # (every process of the job creates the group)
+    if members is not None and rank not in members:
+        q.put((rank, None, "not a member"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     try:
         timing = D.Timing()
         be = OracleBackend()
-        traj, order = _run(D, be, feats, qp, cfg, h, w, halo=halo, timing=timing)
+        traj, order = _run(D, be, feats, qp, cfg, h, w, halo=halo, timing=timing, group=group)
         rep = timing.report()
+        rank = dist.get_rank(group) if group is not None else rank
+        world = len(members) if members is not None else world
         if halo == "exchange" and rank > 0:          # some rows were computed while the halo was in flight, some had to wait for it
             assert (be.phase_rows[0] > 0 or world > 2) and be.phase_rows[1] > 0 and "halo_wait" in rep, (be.phase_rows, rep)
         if halo == "recompute":
@@ -123,9 +131,12 @@ def _run(D, backend, feats, qp, cfg, h, w, **kw):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,halo,precede", [(2, "exchange", 5), (2, "recompute", 5), (3, "exchange", 5)])
-def test_multi_rank_sharding_matches_unsharded_oracle(world, halo, precede):
-    """2 ranks in both halo modes; 3 ranks with clips SHORTER than the halo (a rank then needs frames of two other ranks)."""
+@pytest.mark.parametrize("world,halo,precede,members", [(2, "exchange", 5, None), (2, "recompute", 5, None), (3, "exchange", 5, None),
+                                                        (3, "exchange", 5, [1, 2])])
+def test_multi_rank_sharding_matches_unsharded_oracle(world, halo, precede, members):
+    """2 ranks in both halo modes; 3 ranks with clips SHORTER than the halo (a rank then needs frames of two other ranks); and a video
+    sharded over a SUB-GROUP whose members are not ranks 0..n-1 of the job (the schedule counts ranks inside the group, the
+    collectives take global ranks)."""
     g = torch.Generator().manual_seed(21)
     T, C, Hf, Wf = 11, 16, 10, 12
     feats = torch.randn(T, C, Hf, Wf, generator=g)
@@ -141,11 +152,13 @@ def test_multi_rank_sharding_matches_unsharded_oracle(world, halo, precede):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, feats, qp, q, halo, precede)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, feats, qp, q, halo, precede, members)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=400) for _ in range(world)], key=lambda r: r[0])
     assert all(r[2] is not None for r in res), res
+    res = [r for r in res if r[1] is not None]                          # (processes outside the sub-group report None)
+    assert len(res) == (len(members) if members is not None else world)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -1,5 +1,9 @@
-"""BASELINE.json configs[2] and configs[4] at their STATED shapes, through size-independent properties and sampled float64
+"""BASELINE.json configs[2], configs[3] and configs[4] at their STATED shapes, through size-independent properties and sampled float64
 re-computation (the CPU oracle would take hours here):
+
+  cfg4  (BASELINE configs[3], SURVEY section 8 "cfg4") 64 x 256x256 -> 128x128x256 features, P = 32, precede_frames 5: the 64-frame
+        plan (363 unique pairs, runs of 6), pair lists / merged lists by properties + sampled float64 top-k, and the tracker end to
+        end through the hand-written encoder (prefix property, and the oracle driver on the clip's first frames);
 
   cfg5  24 x 720x1280 -> 180x320x256 features (HW = 57 600): the 24-frame plan (123 unique pairs, 6-slot merges), pair lists and
         merged lists, and the full 13.3 GB dense volume in plain bf16 next to the parity-grade bf16x3 one -- linearity, sampled
@@ -7,7 +11,7 @@ re-computation (the CPU oracle would take hours here):
   cfg3  single-scale local window R = 6 on the 480x854x256 grid (HW = 409 920), 6 key slots, on the bf16 pipe; and the
         coarse-to-fine operator at coarse 120x214x256 / fine 480x854x64, scale 4, R_f = 6.
 
-Measured numbers go to gpurun_out/r02_configs_report.json (copied under profiles/ for the record).
+Measured numbers go to gpurun_out/r03_configs_report.json (copied under profiles/ for the record).
 """
 import json
 import os
@@ -30,7 +34,7 @@ def dev():
     yield torch.device("cuda:0")
     if REPORT:
         os.makedirs("gpurun_out", exist_ok=True)
-        with open("gpurun_out/r02_configs_report.json", "w") as f:
+        with open("gpurun_out/r03_configs_report.json", "w") as f:
             json.dump(REPORT, f, indent=1)
 
 
@@ -44,6 +48,157 @@ def _structured(dev, n, C, H, W, seed, noise=0.6):
     for _ in range(n):                                          # frame by frame: NCHW temporaries stay small
         out.append(ops.normalize_to_hwc(smooth + noise * torch.randn(1, C, H, W, generator=g, device=dev)))
     return torch.cat(out, 0)
+
+
+# =====================================================================================================================
+# cfg4 (BASELINE configs[3]): TAP-Vid-DAVIS shape, 64 frames of 256 x 256 -> 128 x 128 x 256, P = 32
+# =====================================================================================================================
+H4, W4, T4, P4 = 128, 128, 64, 32
+HW4 = H4 * W4
+
+
+def _check_pair_lists(dev, clip, plan, idx, score, H, W, cfg, pairs_to_sample, seed):
+    """Size-independent properties of per-pair top-k lists + exact float64 top-k on sampled queries."""
+    HW = H * W
+    n = idx.shape[0]
+    assert int(idx.min()) >= 0 and int(idx.max()) < HW
+    qy = (torch.arange(HW, device=dev) // W).view(1, HW, 1)
+    qx = (torch.arange(HW, device=dev) % W).view(1, HW, 1)
+    for c0 in range(0, n, 64):
+        sl = slice(c0, c0 + 64)
+        d2 = (idx[sl] // W - qy) ** 2 + (idx[sl] % W - qx) ** 2
+        assert int(d2.max()) <= cfg.mask.r2max                                      # inside the disc
+        ds = score[sl][..., 1:] - score[sl][..., :-1]
+        assert float(ds.max()) <= 0.0                                               # descending
+        tie = ds == 0
+        assert bool((idx[sl][..., 1:][tie] > idx[sl][..., :-1][tie]).all())         # canonical order among exact ties
+    g = torch.Generator().manual_seed(seed)
+    sample = torch.cat([torch.tensor([0, W - 1, HW - W, HW - 1]), torch.randint(0, HW, (252,), generator=g)]).to(dev)
+    ky = (torch.arange(HW, device=dev) // W).view(-1, 1)
+    kx = (torch.arange(HW, device=dev) % W).view(-1, 1)
+    inside = ((ky - (sample // W).view(1, -1)) ** 2 + (kx - (sample % W).view(1, -1)) ** 2) <= cfg.mask.r2max
+    n_clear = 0
+    for p in pairs_to_sample:
+        qf, kf, _ = plan.pairs[p]
+        dots = torch.einsum("qc,qkc->qk", clip[qf][sample], clip[kf][idx[p][sample].long()])
+        assert torch.allclose(dots, score[p][sample], atol=4e-6)                    # every score = the dot product with the row it names
+        full = (clip[kf].double() @ clip[qf][sample].double().t()).masked_fill(~inside, float("-inf"))
+        tv, ti = full.topk(K + 1, dim=0)
+        clear = (tv[:-1] - tv[1:]).min(0).values > 1e-6
+        n_clear += int(clear.sum())
+        assert torch.equal(idx[p][sample].t().long()[:, clear], ti[:K][:, clear])   # indices exact where float64 ranks are clear
+        assert torch.allclose(score[p][sample].t().double(), tv[:K], atol=1e-5)
+    return n_clear
+
+
+def test_cfg4_plan_pairs_and_merged_lists(dev):
+    from fgvc_amd import engine, ops
+    cfg = engine.TrackerConfig()
+    plan = engine.plan_clip(T4, [0], cfg)
+    assert len(plan.pairs) == 15 + 58 * 6 == 363 and len(plan.slot_pair) == T4 - 1 and plan.t_max == 6
+    assert plan.slot_frame[plan.out_rows[(0, 63)]] == [0, 58, 59, 60, 61, 62] and plan.slot_frame[plan.out_rows[(0, 1)]][:2] == [0, 0]
+    runs = ops.pair_runs(plan.tables(dev)[0]).tolist()
+    assert len(runs) == 63 and runs[0][1] == 6 and sorted(r[1] for r in runs) == [1, 2, 3, 4, 5] + [6] * 58 and sum(r[1] for r in runs) == 363
+    assert ops.split_path_ok(C, H4, W4, K, True, None, cfg.mask, True)
+    clip = _structured(dev, T4, C, H4, W4, seed=404)                                 # 64 x 16384 x 256 f32 = 1 GB
+    pl = engine.run_pairs(clip, H4, W4, plan, cfg)                                   # one launch: 363 pairs in 63 runs
+    assert not ops.pair_f16x3_timed_out()
+    assert pl.idx.shape == (363, HW4, K)
+    n_clear = _check_pair_lists(dev, clip, plan, pl.idx, pl.score, H4, W4, cfg, (0, 1, 14, 15, 180, 362), seed=44)
+    assert n_clear > 6 * 200
+    # merged lists: frame 1 holds frame 0 twice (slots 0 and 1: every entry doubled, lower slot first); frame 63 = best k of six lists
+    tk = engine.merge_pairs(pl, cfg)
+    assert tk.idx.shape == (T4 - 1, HW4, K)
+    assert torch.allclose(tk.weight.sum(-1), torch.ones_like(tk.weight[..., 0]), atol=1e-5)
+    r1 = plan.out_rows[(0, 1)]
+    assert torch.equal(tk.idx[r1][:, 0::2] + HW4, tk.idx[r1][:, 1::2]) and torch.equal(tk.idx[r1][:, 0::2], pl.idx[plan.slot_pair[r1][0]][:, :5])
+    row = plan.out_rows[(0, 63)]
+    sp = plan.slot_pair[row]
+    gid = pl.idx[sp].long() + (torch.arange(6, device=dev) * HW4).view(-1, 1, 1)
+    allv, alli = pl.score[sp].permute(1, 0, 2).reshape(HW4, -1), gid.permute(1, 0, 2).reshape(HW4, -1)
+    order = torch.argsort(alli, dim=1, stable=True)
+    allv, alli = allv.gather(1, order), alli.gather(1, order)
+    order = torch.argsort(allv, dim=1, descending=True, stable=True)[:, :K]
+    assert torch.equal(alli.gather(1, order), tk.idx[row].long())
+    assert torch.allclose(allv.gather(1, order) / cfg.temperature, tk.logit[row], atol=1e-5)
+    REPORT["cfg4_pairs"] = dict(grid=[H4, W4, C], frames=T4, pairs=363, runs=63, sampled_clear_queries=n_clear)
+
+
+def test_cfg4_tracker_end_to_end(dev):
+    """The tracker at the reference's eval geometry on a 64-frame clip, P = 32 (two query times -> two groups), through the
+    hand-written encoder: (i) frames 0..5 of the result are bit-identical to running the first 6 frames alone (a frame's labels
+    depend on earlier frames only: a schedule / slot-table error at 64 frames breaks this); (ii) the first 5 frames against the
+    oracle driver run on the GPU encoder's features (the CPU oracle needs ~5 s per frame at 128 x 128 x 256)."""
+    import fgvc_amd.mmpt_api as api
+    from oracle import fgvc_oracle as O
+    torch.manual_seed(64)
+    cfg = dict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512, with_first=True, with_first_neighbor=True)
+    model = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4), out_indices=(2,),
+                                                                      pool_type="none")), train_cfg=None, test_cfg=api.ConfigDict(cfg))
+    model.backbone.load_state_dict(O.seeded_resnet_state(64, (1, 1, 1, 4), "none"), strict=False)
+    model = model.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(640)
+    h = w = 256
+    base = torch.nn.functional.interpolate(torch.randn(1, 3, 48, 48, generator=g, device=dev), size=(h + 160, w + 160), mode="bicubic",
+                                           align_corners=False)[0]
+    # a textured field drifting by (+2, +1) pixels per frame, plus noise
+    rgbs = torch.stack([base[:, 10 + t: 10 + t + h, 20 + 2 * t: 20 + 2 * t + w] for t in range(T4)], 0) * 1.2
+    rgbs = (rgbs + 0.2 * torch.randn(rgbs.shape, generator=g, device=dev)).unsqueeze(0)
+    gq = torch.Generator().manual_seed(641)
+    qp = torch.cat([torch.zeros(P4, 1), torch.rand(P4, 2, generator=gq) * 120 + 100], 1)
+    qp[24:, 0] = 3.0                                                                  # 8 points queried at frame 3: a second group
+    qp = qp.unsqueeze(0).to(dev)
+    traj = torch.zeros(1, T4, P4, 2, device=dev)
+    vis = torch.ones(1, T4, P4, device=dev)
+    outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
+    pred = outs[2]
+    assert pred.shape == (1, T4, P4, 2) and bool(torch.isfinite(pred).all())
+    assert torch.equal(outs[4][0, :, 0].cpu(), torch.cat([torch.zeros(24), torch.full((8,), 3.0)]))           # regrouped by query time
+    assert float(pred[0, :3, 24:].abs().max()) == 0.0                                                          # zero before the query time
+    # the content moves by (-2, -1) px per frame in image coordinates (the crop window moves +2, +1): the tracks follow it
+    drift = (pred[0, 20, :24] - pred[0, 0, :24]).cpu()
+    assert float((drift - torch.tensor([-40.0, -20.0], dtype=drift.dtype)).abs().median()) < 4.0, drift
+    # (i) prefix property
+    o6 = model(test_mode=True, rgbs=rgbs[:, :6], query_points=qp, trajectories=traj[:, :6], visibilities=vis[:, :6])
+    assert torch.equal(o6[2], pred[:, :6])
+    # (ii) the oracle driver on the GPU encoder's features, frames 0..4, group of frame 0
+    feats, Hf, Wf = model.get_feats_hwc(rgbs[0, :5])
+    assert (Hf, Wf) == (H4, W4)
+    fc = feats.cpu().transpose(1, 2).reshape(5, C, Hf, Wf)
+    want = O.forward_test_main(fc, qp[0, :24, 1:].cpu(), h, w)                        # (5, 24, 2)
+    assert float((pred[0, :5, :24].cpu() - want).abs().max()) < 5e-3
+    REPORT["cfg4_tracker"] = dict(frames=T4, points=P4, groups=2, median_drift_error_px=float((drift - torch.tensor([-40.0, -20.0], dtype=drift.dtype)).abs().median()))
+
+
+@pytest.mark.parametrize("shape", [(120, 214), (128, 128)])
+def test_pair_kernel_soak(dev, shape):
+    """500 launches of fgvc_pair_topk_f16x3_runs (the barrier-free LDS protocol) on the 8-frame plan at the cfg2 and cfg4 grid shapes:
+    every launch bit-identical to the first, no bounded wait ever gave up.  (A protocol race would show as a rare differing score:
+    one such race existed in round 2 at about one launch in a few hundred.)"""
+    from fgvc_amd import engine, ops
+    H, W = shape
+    cfg = engine.TrackerConfig()
+    plan = engine.plan_clip(8, [0], cfg)
+    clip = ops.split_f16x2(_structured(dev, 8, C, H, W, seed=H))
+    ref = engine.run_pairs(clip, H, W, plan, cfg)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for i in range(500):
+        pl = engine.run_pairs(clip, H, W, plan, cfg)
+        bad += (pl.idx != ref.idx).sum() + (pl.score != ref.score).sum()
+        if i % 100 == 99:
+            assert int(bad) == 0, f"launch {i - 99}..{i}: {int(bad)} differing entries"
+    assert int(bad) == 0 and not ops.pair_f16x3_timed_out()
+    # ... and the fail-closed path: with the workgroup flag forced (fault injection), every list is poison and the flag is raised once
+    ops.set_option("pair_f16_debug", 4096)
+    try:
+        pl = engine.run_pairs(clip, H, W, plan, cfg)
+        tk = engine.merge_pairs(pl, cfg)
+        assert bool(torch.isinf(pl.score).all()) and bool(torch.isnan(tk.weight).all())
+        assert ops.pair_f16x3_timed_out() and not ops.pair_f16x3_timed_out()          # read-and-clear
+    finally:
+        ops.set_option("pair_f16_debug", 0)
+    pl = engine.run_pairs(clip, H, W, plan, cfg)
+    assert torch.equal(pl.idx, ref.idx) and not ops.pair_f16x3_timed_out()
 
 
 # =====================================================================================================================

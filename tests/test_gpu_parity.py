@@ -385,8 +385,22 @@ def test_split_feature_bank_equals_f32_bank(dev):
     bank_b, _, _ = model.get_feats_hwc(frames, split=True)
     assert torch.equal(ops.split_bf16(bank_f), bank_b)
     c = engine.run_affinity(bank_b, Hf, Wf, plan, cfgb)
-    same = (c.idx == a.idx).all(-1)                                     # rows may differ where two scores are within rounding of each other
-    assert float(same.float().mean()) > 0.99 and float((c.logit - a.logit).abs().max()) < 1e-4
+    # rows may differ only where two of the scores involved are within rounding of each other: every row that differs must hold,
+    # two neighbouring ranks closer than the two kernels' combined rounding (bf16x4 is within 5e-5 logit of float64, f16x3 within
+    # 4e-6: bound 1e-4, the same bound the score sequences are held to), inside the list or across its k-th place
+    assert float((c.logit - a.logit).abs().max()) < 1e-4
+    differ = ~(c.idx == a.idx).all(-1)
+    if bool(differ.any()):
+        assert float(differ.float().mean()) < 0.01
+        ai, ci, al, cl = a.idx[differ], c.idx[differ], a.logit[differ], c.logit[differ]
+        common = (ai.unsqueeze(-1) == ci.unsqueeze(-2)).any(-1).sum(-1)
+        kk = ai.shape[-1]
+        assert int(common.min()) >= kk - 1                               # the same candidates, or one swapped at the k-th place
+        perm = common == kk                                              # same set, two neighbours in the other order: a near-tie inside the list
+        if bool(perm.any()):
+            assert float((al[perm][..., :-1] - al[perm][..., 1:]).min(-1).values.max()) < 1e-4, "a differing row without a near-tie"
+        if bool((~perm).any()):                                          # k-th and (k+1)-th candidates tied: the two k-th scores coincide
+            assert float((al[~perm][..., -1] - cl[~perm][..., -1]).abs().max()) < 1e-4, "a swapped candidate without a near-tie"
     assert not ops.pair_f16x3_timed_out()
 
 

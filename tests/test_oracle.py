@@ -151,6 +151,81 @@ def test_tracker(golden):
     assert torch.equal(outs[3], T(g["out_vis_pred"]))
 
 
+def test_dense_api_operators(golden):
+    """propagate / non_local_attention / local_square_attention (no shipped caller in the reference) against the genuine functions."""
+    g = {k: T(v) if v.ndim else v for k, v in golden("dense_api_10x12").items()}
+    aff = O.corr_volume  # noqa: F841  (the affinity itself is pinned by dense_9x11)
+    import torch.nn.functional as Fn
+    src, dst, img = g["src"], g["dst"], g["img"]
+    a = torch.bmm(Fn.normalize(src.flatten(2), dim=1).transpose(1, 2), Fn.normalize(dst.flatten(2), dim=1)) / 0.07
+    a_sm = a.softmax(1)
+    assert torch.allclose(O.propagate(img, a_sm), g["prop"], atol=1e-5)
+    assert torch.allclose(O.propagate(img, a_sm, topk=7), g["prop_top7"], atol=1e-5)
+    assert torch.allclose(O.propagate(img, torch.bmm(Fn.normalize(src.flatten(2), dim=1).transpose(1, 2), Fn.normalize(dst.flatten(2), dim=1))),
+                          g["prop_raw"], atol=1e-4)
+    assert torch.allclose(O.propagate(g["img_wide"], a_sm[:1], topk=3), g["prop_wide_top3"], atol=1e-5)
+    tar, refs = g["tar"], g["refs"]
+    Hn, Wn = tar.shape[-2:]
+    mask = O.spatial_neighbor(Hn, Wn, int(g["nl_mask_nr"]))
+    assert torch.allclose(O.non_local_attention(tar, refs, temperature=0.07, norm=True, att_only=True), g["nl_att"], atol=1e-4)
+    got = O.non_local_attention(tar, refs, temperature=2.0, scaling=True, mask=mask, att_only=True)
+    fin = torch.isfinite(g["nl_att_scaled_masked"])
+    assert torch.equal(torch.isfinite(got), fin) and torch.allclose(got[fin], g["nl_att_scaled_masked"][fin], atol=1e-4)
+    b, pr = O.non_local_attention(tar, refs, temperature=0.07, norm=True)
+    assert b == int(g["nl_first"]) == 1 and torch.allclose(pr, g["nl_per_ref"], atol=1e-6)
+    assert torch.allclose(O.non_local_attention(tar, refs, per_ref=False, temperature=0.07, norm=True)[1], g["nl_pooled"], atol=1e-6)
+    q, k, v = g["lq"], g["lk"], g["lv"]
+    for name, args, kw in (("lsa_all", (q, k, v, 5), {}), ("lsa_rect", (q, k, v, (3, 7)), {}), ("lsa_top4", (q, k, v, 5), dict(topk=4)),
+                           ("lsa_ctx_top6", (q[:1], k, v, 7), dict(topk=6, batch_as_context=True)),
+                           ("lsa_ctx_all", (q[:1], k, v, 3), dict(batch_as_context=True))):
+        assert torch.allclose(O.local_square_attention(*args, temperature=0.5, **kw), g[name], atol=1e-4), name
+
+
+def _cfg0_compare_topk(g, idx, logit, HW=128 * 128, gap=1e-3, score_tol=1e-3):
+    """Shared by the oracle test (here) and the GPU test (tests/test_gpu_api.py): merged top-10 lists of the sampled queries of
+    frame 1 (idx = slot * HW + pixel, canonical order) against what the reference's own top-k returned.  Frame 0 sits in key slots
+    0 AND 1, so every candidate appears twice with equal scores and the reference returns each pair in either order: compared are
+    the pixel sequences.  Exact on every query whose DISTINCT float64 ranks 1..6 (from the reference's features) are more than `gap`
+    logits apart; scores within `score_tol` everywhere.  Returns (clear queries, max score error)."""
+    import numpy as np
+    ri, rv = np.asarray(g["ref_topk_idx"]).astype(np.int64), np.asarray(g["ref_topk_val"])
+    dv = np.asarray(g["f64_distinct_val"])
+    clear = (dv[:, :-1] - dv[:, 1:])[:, :5].min(1) > gap
+    idx, logit = np.asarray(idx).astype(np.int64), np.asarray(logit)
+    assert idx.shape == ri.shape == (len(clear), 10)
+    err = float(np.abs(logit - rv).max())
+    assert err < score_tol, err
+    assert (np.sort(idx[clear], 1) == np.sort(ri[clear], 1)).all()                      # the same ten (slot, pixel) entries
+    assert (idx[clear] % HW == ri[clear] % HW).all()                                    # in the same pixel order
+    assert (idx[clear][:, 0::2] < HW).all() and (idx[clear][:, 1::2] >= HW).all()       # canonical: the lower slot of a tie first
+    return int(clear.sum()), err
+
+
+def test_tracker_cfg0_geometry(golden):
+    """BASELINE configs[0] = the reference's shipped eval geometry (2 x 256 x 256 -> 128 x 128 x 256, radius 15, top-10): the oracle
+    network + driver against the genuine forward_test -- trajectories and the top-k lists of 512 sampled queries."""
+    g = golden("tracker_cfg0_2x256x256")
+    sd = O.seeded_resnet_state(int(g["seed"]), (1, 1, 1, 4), "none")
+    wsum = float(sum(v.double().abs().sum() for v in sd.values() if v.dtype.is_floating_point))
+    if abs(wsum - float(g["weight_abs_sum"])) > 1e-6 * wsum:
+        pytest.skip("torch RNG stream differs from the fixture's")
+    net = O.ResNet18((1, 1, 1, 4), 2, "none")
+    net.load_state_dict(sd)
+    net.eval()
+    rgbs = (T(g["rgbs_i8"]).float() / 32.0).unsqueeze(0)
+    qp = T(g["query_points"])
+    with torch.no_grad():
+        feats = net(rgbs[0])
+    assert torch.allclose(feats[:, ::16, ::8, ::8], T(g["feats_sub"]), atol=1e-4, rtol=1e-4)
+    traj = O.forward_test_main(feats, qp[0, :, 1:], 256, 256)
+    assert float((traj - T(g["out_traj_pred"])[0].double()).abs().max()) < 2e-3
+    sample = T(g["sample"]).long()
+    key = torch.stack([feats[0], feats[0]], 1)                                           # key slots of frame 1: [frame 0, frame 0]
+    idx, logit = O.affinity_topk(feats[1], key, 10, 0.07, neighbor_range=30, q_index=sample)
+    n_clear, err = _cfg0_compare_topk(g, idx.numpy(), logit.numpy())
+    assert n_clear > 450 and err < 1e-4
+
+
 def test_hr_tracker(golden):
     """The HR driver twins against the genuine HRVanillaTracker loops (run around the Correlation stand-in)."""
     g = golden("hr_tracker_5x48x64")

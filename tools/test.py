@@ -68,7 +68,12 @@ def main():
     else:
         dataset = SyntheticTapVid(a.videos, a.frames, tuple(a.size), a.points, a.query_mode, device=dev)
     loader = StridedLoader(dataset, rank, world) if dataset is not None else None          # :124-134
-    test_cfg = cfg["test_cfg_" + a.task]                                                     # :135
+    key = "test_cfg_" + a.task                                                               # :135
+    if key not in cfg and a.task == "jhmdb" and "test_cfg_davis" in cfg:
+        key = "test_cfg_davis"         # the pose task of DEFAULT_CFG (and of configs without a test_cfg_jhmdb) tracks with the TAP-Vid settings
+    if key not in cfg:
+        raise SystemExit(f"the config has no '{key}' (tasks it defines: {sorted(k[9:] for k in cfg if k.startswith('test_cfg_'))})")
+    test_cfg = cfg[key]
     model_cfg = dict(type=cfg.get("eval_arc", "VanillaTracker"), backbone=dict(cfg.model.backbone))   # :139
     for k in ("out_indices", "strides", "dilations"):                                        # :141-145
         if k in test_cfg:
@@ -80,11 +85,15 @@ def main():
     model = model.to(dev).eval()
 
     if a.task == "jhmdb":      # pose tracking: the 15 joints of frame 0 are the query points (fgvc_amd.datasets.JhmdbPoses)
-        pck = jhmdb_evaluate(model, JhmdbPoses(a.data_root, split="val", input_size=(320, 320), device=dev))
-        print(json.dumps({k: round(v, 2) for k, v in pck.items()}))
-        return
-    outputs = apis.multi_gpu_test(model, loader) if distributed else apis.single_gpu_test(model, loader)   # :160-190
-    if rank == 0:
+        # PCK is a mean over ALL videos' joints (jhmdb_dataset.py:174-256), so the set is scored by one process: rank 0 runs it, the
+        # other ranks of a `--launcher pytorch` job wait at the common teardown below
+        if rank == 0:
+            pck = jhmdb_evaluate(model, JhmdbPoses(a.data_root, split="val", input_size=(320, 320), device=dev))
+            print(json.dumps({k: round(v, 2) for k, v in pck.items()}))
+        outputs = None
+    else:
+        outputs = apis.multi_gpu_test(model, loader) if distributed else apis.single_gpu_test(model, loader)   # :160-190
+    if rank == 0 and outputs is not None:
         summary = metrics.tapvid_evaluate(outputs, a.query_mode)                             # :192-198
         keep = ("average_pts_within_thresh", "average_jaccard", "occlusion_accuracy", "ade_visible")
         print(json.dumps({k: round(summary[k], 3) for k in keep}))

@@ -9,6 +9,8 @@ Each rank checks its trajectories against the un-sharded tracker on the same GPU
 must be able to start children) prints one JSON line and exits non-zero on a mismatch.
 
   python tools/two_ranks_one_gpu.py [--frames 12] [--tail-stream]
+  python tools/two_ranks_one_gpu.py --frames 64 --size 256 256 --strides 1 1 1 4 --precede 5 --neighbor-range 30 --points 32 \
+         --halos exchange --tail-stream        # BASELINE configs[3]: a TAP-Vid-DAVIS-shape video (128 x 128 x 256 features) over two ranks
 """
 import argparse
 import json
@@ -34,17 +36,21 @@ def worker(rank, world, path, a, q):
         from fgvc_amd import dist as fdist, engine
         torch.manual_seed(5)                                     # the same random-init encoder on every rank
         model = api.build_model(dict(type="VanillaTracker",
-                                     backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")),
+                                     backbone=dict(type="ResNet", depth=18, strides=tuple(a.strides), out_indices=(2,), pool_type="none")),
                                 train_cfg=None,
-                                test_cfg=api.ConfigDict(precede_frames=a.precede, topk=10, temperature=0.07, neighbor_range=12,
+                                test_cfg=api.ConfigDict(precede_frames=a.precede, topk=10, temperature=0.07, neighbor_range=a.neighbor_range,
                                                         with_first=True, with_first_neighbor=True)).to(dev).eval()
         g = torch.Generator().manual_seed(21)
-        h, w = 64, 96
+        h, w = a.size
         rgbs = torch.randn(a.frames, 3, h, w, generator=g)
         qp = torch.tensor([[0, 20.0, 12.0], [0, 70.0, 40.0], [2, 33.0, 50.0], [0, 5.5, 60.25]])
+        if a.points > 4:                                         # more points, spread over the frame, a quarter of them queried at frame 2
+            extra = torch.rand(a.points - 4, 3, generator=g) * torch.tensor([0.0, w - 1.0, h - 1.0])
+            extra[::4, 0] = 2.0
+            qp = torch.cat([qp, extra], 0)
         cfg = model.engine_config()
         out = {}
-        for halo in ("exchange", "recompute"):
+        for halo in a.halos:
             for tail in ((False, True, "pairs") if a.tail_stream else (False,)):
                 ts = torch.cuda.Stream(dev) if tail else None
                 be = fdist.HipBackend(model, tail_stream=ts, tail_from="pairs" if tail == "pairs" else "sweep")
@@ -74,6 +80,11 @@ def main():
     ap.add_argument("--precede", type=int, default=3)
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--tail-stream", action="store_true")
+    ap.add_argument("--size", type=int, nargs=2, default=(64, 96))
+    ap.add_argument("--strides", type=int, nargs=4, default=(1, 2, 1, 1))
+    ap.add_argument("--neighbor-range", type=int, default=12)
+    ap.add_argument("--points", type=int, default=4)
+    ap.add_argument("--halos", nargs="+", default=["exchange", "recompute"], choices=["exchange", "recompute"])
     a = ap.parse_args()
     fd, path = tempfile.mkstemp(prefix="fgvc_rdzv_")
     os.close(fd)
@@ -88,7 +99,8 @@ def main():
         p.join(60)
     ok = all("error" not in r and all(v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 for v in r.values())
              for r in res.values()) and all(p.exitcode == 0 for p in procs)
-    print(json.dumps({"ok": ok, "world": a.world, "backend": "gloo (host-staged) on one GPU", "ranks": {str(k): v for k, v in sorted(res.items())}}))
+    print(json.dumps({"ok": ok, "world": a.world, "frames": a.frames, "size": list(a.size), "backend": "gloo (host-staged) on one GPU",
+                      "ranks": {str(k): v for k, v in sorted(res.items())}}))
     sys.exit(0 if ok else 1)
 
 
