@@ -8,7 +8,7 @@
 A "step" = one synthetic 480x854 video of N x 8 frames (BASELINE.json configs[1]: an 8-frame 480p clip per GPU) through the
 whole path, inputs resident in HBM, SHARDED BY CLIP over the N ranks exactly as BASELINE.json's north_star describes
 (fgvc_amd.dist.track_points_sharded with the product backend): every rank encodes its own 8-frame clip (hand-written HIP ResNet-18
-trunk on the bf16 pipe, f32-grade), rank 0 broadcasts the first-frame ("query") features over RCCL/xGMI, the 5-frame halo in front
+trunk on the 16-bit matrix pipe; `--enc-arith`: f16 main product + fp8 cross terms by default), rank 0 broadcasts the first-frame ("query") features over RCCL/xGMI, the 5-frame halo in front
 of a clip comes from the previous rank by a point-to-point message, windowed correlation + top-10 for the clip's (query, key) frame
 pairs (features as bf16 hi + lo, four partial products on the bf16 matrix pipe: f32-grade scores), slot merge + softmax,
 all_gather of the merged lists, then the sequential label sweep + fused upsample / top-5 soft-argmax read-out over the whole video
@@ -42,7 +42,9 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak (no sparsity)
 SPLIT_PRODUCTS = 4                # partial products per f32-grade product in fgvc_pair_topk_bf16x4 (hi*hi, hi*lo, lo*hi, lo*lo)
-CONV_PRODUCTS = 3                 # fgvc_conv_split_f32: hi*hi + hi*lo + lo*hi
+# pipe units (16-bit MFMA times) per f32-grade product of fgvc_conv_split_f32, by arithmetic: bf16x3 / f16x3 = three 16-bit products,
+# f16f8 = one f16 product + both cross sums in one K-64 fp8 MFMA (half a unit each)
+CONV_UNITS = {"bf16x3": 3.0, "f16x3": 3.0, "f16f8": 2.0}
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 
 WORKLOADS = {
@@ -79,7 +81,7 @@ def encoder_flops(wl, n_frames: int) -> float:
 def pmc(kernel: str):
     """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r02_pmc.json, written by tools/pmc_report.py from
     separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes); {} if absent."""
-    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -126,58 +128,73 @@ def host_cpu():
     return model, (len(phys) or None), (logical or os.cpu_count())
 
 
-def cpu_baseline(wl, budget_s=25.0):
-    """The oracle on the host cores, bounded sample of the same workload -> frames/s estimate."""
+def cpu_baseline(wl, runs=3):
+    """The oracle on the host cores: ONE whole query frame of the workload measured (median of `runs`): encoder for one frame, the
+    masked affinity + top-k + propagation of the clip's last frame (every 512-query chunk, all its key slots, plain torch.topk and a
+    pre-built mask like the reference), read-out of one frame; the clip's other frames are scaled by their key-slot counts."""
+    import statistics
     from oracle import fgvc_oracle as O
     model, phys, logical = host_cpu()
-    # torch CPU ops stop scaling (and then regress) long before 256 threads on these hosts: use up to 32
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
-    h, w, T = wl["h"], wl["w"], wl["frames"]
+    h, w, T, P = wl["h"], wl["w"], wl["frames"], wl["points"]
     net = O.ResNet18(wl["strides"], wl["out_indices"][0], "none").eval()
+    x = torch.randn(1, 3, h, w, generator=g)
     with torch.no_grad():
-        net(torch.randn(1, 3, 64, 64, generator=g))                    # spin up the thread pool / oneDNN
-        x = torch.randn(1, 3, h, w, generator=g)
-        t0 = time.perf_counter(); f = net(x); t_enc = time.perf_counter() - t0
+        f = net(torch.randn(1, 3, 64, 64, generator=g))                # spin up the thread pool / oneDNN
+        f = net(x)
     C, Hf, Wf = f.shape[1:]
     HW = Hf * Wf
+    ks = O.key_slots(T - 1)
     q = O.l2_normalize(torch.randn(C, Hf, Wf, generator=g), 0).reshape(C, -1)
-    key = O.l2_normalize(torch.randn(C, 6, Hf, Wf, generator=g), 0).reshape(C, -1)
-    val = torch.rand(wl["points"], 6 * HW, generator=g)
-    step, n_chunks, t_aff, t_mask = 512, 0, 0.0, 0.0
-    O.affinity_chunk(key[:, :4096], q[:, :64], None, 10, 0.07, canonical=False)          # warm-up
-    while t_aff < budget_s * 0.6 and n_chunks * step < HW and n_chunks < 8:
-        qi = torch.arange(n_chunks * step, min(HW, (n_chunks + 1) * step))
+    key = O.l2_normalize(torch.randn(C, len(ks), Hf, Wf, generator=g), 0).reshape(C, -1)
+    val = torch.rand(P, len(ks) * HW, generator=g)
+    lab = torch.rand(P, Hf, Wf, generator=g)
+    step = 512
+    chunks = [torch.arange(c0, min(HW, c0 + step)) for c0 in range(0, HW, step)]
+    slots = sum(len(O.key_slots(fi)) for fi in range(1, T))               # 32 key slots for an 8-frame clip
+
+    def one_frame():
         t0 = time.perf_counter()
-        m = O.mask_slab(Hf, Wf, Hf, Wf, 6, qi, 30, "circle")                             # the reference builds its
-        t_mask += time.perf_counter() - t0                                                # mask once per video
+        with torch.no_grad():
+            net(x)
+        t_enc = time.perf_counter() - t0
+        t_mask = t_aff = 0.0
+        for qi in chunks:
+            t0 = time.perf_counter()
+            m = O.mask_slab(Hf, Wf, Hf, Wf, len(ks), qi, 30, "circle")    # (the reference builds its mask once per video: timed apart)
+            t_mask += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            # the reference's per-chunk op sequence (local_attention.py:321-375): einsum, masked_fill_, plain topk, gather, softmax, sum
+            idx, logit = O.affinity_chunk(key, q[:, qi], m, 10, 0.07, canonical=False)
+            O.propagate_topk(val, idx, O.topk_weights(logit))
+            t_aff += time.perf_counter() - t0
         t0 = time.perf_counter()
-        # the reference's per-chunk op sequence (local_attention.py:321-375): einsum, masked_fill_, plain topk,
-        # gather, softmax, weighted sum
-        idx, logit = O.affinity_chunk(key, q[:, qi], m, 10, 0.07, canonical=False)
-        O.propagate_topk(val, idx, O.topk_weights(logit))
-        t_aff += time.perf_counter() - t0
-        n_chunks += 1
-    t_chunk = t_aff / n_chunks
-    lab = torch.rand(wl["points"], Hf, Wf, generator=g)
-    t0 = time.perf_counter()
-    up = O.upsample_bilinear(lab, h, w)
-    O.img2coord(up.unsqueeze(0).numpy())
-    t_read = time.perf_counter() - t0
-    chunks_per_frame = (HW + step - 1) // step
-    slots = sum(len(O.key_slots(fi)) for fi in range(1, T))           # 32 key slots for an 8-frame clip
-    t_mask_video = t_mask / n_chunks * chunks_per_frame / 6.0                              # one (HW x HW) mask per video
-    clip_s = T * t_enc + chunks_per_frame * t_chunk * slots / 6.0 + T * t_read + t_mask_video
-    return dict(value=T / clip_s, unit="frames/s", cores=cores, kind="port",
-                host_cpu=dict(model=model, physical_cores=phys, logical_cpus=logical, threads_used=cores),
-                sample=(f"oracle/fgvc_oracle.py on {cores} threads of {model} ({phys} physical cores, {logical} logical): "
-                        f"1 frame through ResNet-18 ({t_enc:.2f}s), "
-                        f"{n_chunks} of {chunks_per_frame} 512-query chunks of affinity_topk+propagate at T=6 "
-                        f"({t_chunk:.3f}s each, plain torch.topk like the reference), mask build "
-                        f"{t_mask_video:.1f}s per video, 1 frame read-out ({t_read:.2f}s); extrapolated to the "
-                        f"{T}-frame clip ({slots} key slots)"),
-                clip_seconds_est=clip_s)
+        O.img2coord(O.upsample_bilinear(lab, h, w).unsqueeze(0).numpy())
+        t_read = time.perf_counter() - t0
+        return t_enc, t_aff, t_read, t_mask / len(ks)
+
+    def measure(threads, n):
+        torch.set_num_threads(threads)
+        O.affinity_chunk(key[:, :4096], q[:, :64], None, 10, 0.07, canonical=False)      # warm-up at this thread count
+        rs = [one_frame() for _ in range(n)]
+        med = [statistics.median(r[i] for r in rs) for i in range(4)]
+        clip_s = T * med[0] + med[1] * slots / len(ks) + T * med[2] + med[3]
+        return dict(threads=threads, runs=n, encoder_s_per_frame=med[0], attention_s_last_frame=med[1], readout_s_per_frame=med[2],
+                    mask_build_s_per_video=med[3], clip_seconds=clip_s, frames_per_s=T / clip_s)
+
+    cores = min(os.cpu_count() or 1, 32)                                  # torch CPU ops stop scaling long before 256 threads here
+    res = [measure(cores, runs)]
+    if phys and phys > cores and phys <= (os.cpu_count() or 1):
+        res.append(measure(phys, 2))                                       # all physical cores as well (slower or equal on these hosts)
+    best = max(res, key=lambda r: r["frames_per_s"])
+    return dict(value=best["frames_per_s"], unit="frames/s", cores=best["threads"], kind="port", measurement="measured frame",
+                runs=best["runs"],
+                sample=f"1 whole frame x{best['runs']} (median): encoder, all {len(chunks)} chunks x {len(ks)} key slots, read-out",
+                host_cpu=dict(model=model, physical_cores=phys, logical_cpus=logical),
+                thread_counts=res,
+                note=(f"oracle/fgvc_oracle.py (plain torch.topk, pre-built mask like the reference); the clip's {T} frames = {T} encoder + "
+                      f"read-out passes and {slots} key slots of attention, the measured last frame has {len(ks)}"),
+                clip_seconds_est=best["clip_seconds"])
 
 
 class KernelProbe:
@@ -231,6 +248,9 @@ def main():
                     help="what runs on the side stream: the label sweep + read-out only, or everything after the encoder (pair top-k, "
                          "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
+    ap.add_argument("--enc-arith", default=None, choices=["f16f8", "bf16x3", "f16x3"],
+                    help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f8; bf16x3 = round 2's)")
+    ap.add_argument("--no-clips-line", action="store_true", help="skip the extra `--mode clips` measurement that a `video` run appends")
     ap.add_argument("--repeats", type=int, default=5, help="extra blocks of 20 steps after the timed region, for the spread")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="fgvc_set_option knobs for A/B runs, e.g. --set-option conv_narrow=1")
@@ -273,6 +293,9 @@ def main():
     if a.no_conv64:
         ResNet.use_conv64 = False
     model = build_tracker(wl, dev)
+    if a.enc_arith:
+        model.backbone.set_arith(a.enc_arith)
+    arith = model.backbone.arith
     model.test_cfg["pair_split_fmt"] = a.pair_fmt                    # the encoder writes the bank in the pair kernel's operand format
     cfg = model.engine_config()
     cfg.pair_precision = a.pair_precision
@@ -325,9 +348,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        assert dist.get_world_size() == a.gpus == world
     for _ in range(a.warmup):
         step(False)
     barrier()
+    fdist.reset_comm_bytes()
     probe.on = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -339,9 +365,12 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    comm = {k: v / a.steps for k, v in fdist.COMM_BYTES.items()}
     assert bool(torch.isfinite(out_coords).all())
     if ops.pair_f16x3_timed_out():
         raise SystemExit("bench.py: fgvc_pair_topk_f16x3 reported a timed-out wait of its LDS protocol: results invalid")
+    if model.backbone.check_overflow():
+        raise SystemExit("bench.py: an encoder activation left the f16 range of its calibrated scale: results invalid")
     n_frames_total = T * a.steps if a.mode == "video" else world * T * a.steps
 
     # spread: a few more short blocks (not part of `value`)
@@ -375,8 +404,12 @@ def main():
             "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f32_tf / BF16_MFMA_PEAK_TFLOPS,
             "what": "ALGORITHMIC f32 FLOPs of the convolution (2 N H W Cin Cout 9) / mean launch duration, against the dense peak of "
                     "the bf16 pipe it runs on",
-            "executed_tflops": CONV_PRODUCTS * f32_tf, "frac_executed": CONV_PRODUCTS * f32_tf / BF16_MFMA_PEAK_TFLOPS,
-            "executed_note": f"{CONV_PRODUCTS} bf16 partial products per f32-grade product (hi*hi + hi*lo + lo*hi)",
+            "arith": arith,
+            "executed_tflops": CONV_UNITS[arith] * f32_tf, "frac_executed": CONV_UNITS[arith] * f32_tf / BF16_MFMA_PEAK_TFLOPS,
+            "executed_note": {"bf16x3": "3 bf16 partial products per f32-grade product (hi*hi + hi*lo + lo*hi)",
+                              "f16x3": "3 f16 partial products per f32-grade product (h*h + h*l + l*h)",
+                              "f16f8": "2 pipe units per f32-grade product: the f16 main product + both cross sums in one K-64 fp8 MFMA "
+                                       "(twice the f16 rate)"}[arith],
             "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
             "ms_per_launch": tot_ms / n_l, "launches_timed": n_l,
             "launch_note": "HIP events on the lane's stream inside the timed region; the encoder's lanes run concurrently, so a launch "
@@ -415,8 +448,8 @@ def main():
         "value": n_frames_total / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (every f32 value as two 16-bit parts -- bf16 hi/lo in the encoder, f16 h/l in the correlation -- partial products on "
-                 "the 16-bit MFMA pipe, f32 accumulate)",
+        "dtype": "f32 (f32-grade results from 16-bit / 8-bit parts on the MFMA pipe, f32 accumulate: encoder " + arith +
+                 ", correlation f16 h/l x3)",
         "data": "synthetic",
         "config": {"workload": (f"{a.workload}: one {T}x{h}x{w} video per step = {world} clip(s) of {Tc} frames, one per rank -> {Hf}x{Wf}x{C} "
                                 f"features, top-10, radius 15, tau 0.07, P={P}" if a.mode == "video" else
@@ -429,6 +462,7 @@ def main():
         "repeat_ms_per_step": rep,
         "roofline": roofline,
         "kernels": kernels,
+        "encoder_arith": arith,
     }
     if a.mode == "video":
         rr = fdist.shard_frames(T, world, first=1)
@@ -453,12 +487,52 @@ def main():
                         "ALGORITHMIC f32 FLOPs of its convolutions / the encode phase's HIP-event time",
                 "frames": n_enc, "ms": enc_ms, "bound": "mfma", "achieved": efl / (enc_ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": efl / (enc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                "executed_tflops": CONV_PRODUCTS * efl / (enc_ms * 1e-3) / 1e12,
-                "frac_executed": CONV_PRODUCTS * efl / (enc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "executed_note": "layers 2-3 (80 % of the FLOPs) in `arith`, stem / layer 1 / stride-2 convolutions in bf16x3: priced at 3 units",
+                "executed_tflops": 3.0 * efl / (enc_ms * 1e-3) / 1e12,
+                "frac_executed": 3.0 * efl / (enc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                 "frac_of_f32_mfma_peak": efl / (enc_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
         out["sharding_note"] = ("HIP-event time per phase on rank 0's main stream (the sweep runs on a side stream and overlaps the next "
                                 "step's encoder; at N = 1 broadcast / halo / all_gather are skipped)")
 
+    if a.mode == "video":
+        # what this rank handed to the exchange steps per step, against the schedule's arithmetic (N = 1: nothing moves)
+        frame_bytes = HW * C * 4                                           # one frame of the bank (f32 or 2 x 16-bit: the same bytes)
+        list_bytes = HW * cfg.topk * 8                                      # idx int32 + weight f32 of one frame's merged list
+        rr = fdist.shard_frames(T, world, first=1)
+        exp = {"broadcast": frame_bytes if world > 1 else 0,
+               "halo_recv": (min(cfg.precede_frames, lo - 1) * frame_bytes if (world > 1 and a.halo == "exchange" and rank > 0) else 0),
+               "all_gather_send": (max(hi_ - lo_ for lo_, hi_ in rr) * list_bytes if world > 1 else 0)}
+        out["comm_bytes_per_step_rank0"] = dict(comm, expected=exp, frame_bytes=frame_bytes, list_bytes_per_frame=list_bytes)
+        for k_, v_ in exp.items():
+            assert abs(comm[k_] - v_) <= 1e-6 * max(v_, 1), (k_, comm[k_], v_)
+    if a.mode == "video" and not a.no_clips_line:
+        # the reference's own data parallelism on the same clips (`--mode clips`: independent 8-frame clips per rank, no data-path
+        # collective), measured right here: separates "cost of the exchange steps" from "a longer video has more pairs per frame"
+        x_c = torch.randn(Tc, 3, h, w, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)      # this rank's own clip
+
+        def step_clips():
+            feats, Hf_, Wf_ = model.get_feats_hwc(x_c, split=True)
+            pl = engine.run_pairs(feats, Hf_, Wf_, plan1, cfg)
+            if tail_stream is None:
+                return engine.run_propagation(engine.merge_pairs(pl, cfg), 0, pts, Hf_, Wf_, h, w, cfg)[1]
+            return engine.run_propagation_async(pl, 0, pts, Hf_, Wf_, h, w, cfg, tail_stream)[1]
+        for _ in range(5):
+            step_clips()
+        barrier()
+        t1 = time.perf_counter()
+        n_c = max(20, a.steps // 2)
+        for _ in range(n_c):
+            step_clips()
+        barrier()
+        el_c = time.perf_counter() - t1
+        if world > 1:
+            tc_ = torch.tensor([el_c], device=dev, dtype=torch.float64)
+            dist.all_reduce(tc_, op=dist.ReduceOp.MAX)
+            el_c = float(tc_.item())
+        out["clips_mode"] = {"what": "the same ranks running INDEPENDENT 8-frame clips (the reference's video-level data parallelism: no broadcast, "
+                                     "no halo, no all_gather), timed the same way right after the sharded-video steps",
+                             "value": world * Tc * n_c / el_c, "unit": "frames/s", "ms_per_step": el_c / n_c * 1e3, "steps": n_c,
+                             "pairs_per_rank": n_pairs_clip}
     if rank == 0 and not a.no_corr_volume:
         gq = torch.Generator(device=dev).manual_seed(5)
         feats2 = torch.nn.functional.normalize(torch.randn(2, HW, C, generator=gq, device=dev), dim=2)

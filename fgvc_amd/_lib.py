@@ -35,8 +35,10 @@ SIGNATURES = {
     "fgvc_pair_topk_f16x3_probe": (_i, [_p]),
     "fgvc_nchw_to_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_conv_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_conv64_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_s2_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_conv_s2_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_stem7_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_nhwc_to_split_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

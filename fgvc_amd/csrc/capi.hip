@@ -39,9 +39,9 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
                       int, float, float*, int32_t*, float*, hipStream_t);
 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
-                      int, int, int, int, hipStream_t);
+                      int, int, int, int, int, int, int, int, int*, hipStream_t);
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
-                   int, int, hipStream_t);
+                   int, int, int, int, int*, hipStream_t);
 int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
@@ -530,7 +530,18 @@ int fgvc_nchw_to_split_nhwc_f32(const float* in, uint16_t* out, float* out_f32, 
 int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                         float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu,
                         void* stream) {
+  return fgvc_conv_split_fmt_f32(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, FGVC_ACT_BF16X2, 0,
+                                 FGVC_ACT_BF16X2, 0, nullptr, stream);
+}
+
+int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
+                            float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu, int in_fmt,
+                            int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, void* stream) {
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: null pointer");
+  FGVC_REQUIRE(in_fmt >= 0 && in_fmt <= 2 && out_fmt >= 0 && out_fmt <= 2, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_fmt_f32: unknown format %d / %d", in_fmt, out_fmt);
+  FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || !y_split || overflow, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_fmt_f32: an f16-format output needs the overflow word");
+  FGVC_REQUIRE(in_scale_log2 > -100 && in_scale_log2 < 100 && out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG,
+               "fgvc_conv_split_fmt_f32: scale exponent out of range");
   FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: bad shape");
   FGVC_REQUIRE(KS == 1 || KS == 3, FGVC_ERR_UNSUPPORTED, "fgvc_conv_split_f32: kernel size %d (1 or 3, stride 1)", KS);
   FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 64 == 0, FGVC_ERR_UNSUPPORTED,
@@ -540,7 +551,8 @@ int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias,
                FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: 16-byte alignment required");
   FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
-  return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, (hipStream_t)stream);
+  return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, in_fmt, in_scale_log2, out_fmt,
+                           out_scale_log2, overflow, (hipStream_t)stream);
 }
 
 int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
@@ -557,7 +569,15 @@ int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bia
 
 int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
                            int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu, void* stream) {
+  return fgvc_conv_s2_split_fmt_f32(x, w, bias, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, Hop, Wop, relu, FGVC_ACT_BF16X2, 0, nullptr, stream);
+}
+
+int fgvc_conv_s2_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
+                               int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu, int out_fmt,
+                               int out_scale_log2, int* overflow, void* stream) {
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: null pointer");
+  FGVC_REQUIRE(out_fmt >= 0 && out_fmt <= 2 && out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_fmt_f32: bad output format / scale");
+  FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || !y_split || overflow, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_fmt_f32: an f16-format output needs the overflow word");
   FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: bad shape");
   FGVC_REQUIRE(KS == 1 || KS == 3, FGVC_ERR_UNSUPPORTED, "fgvc_conv_s2_split_f32: kernel size %d (1 or 3, stride 2)", KS);
   FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, FGVC_ERR_UNSUPPORTED,
@@ -570,7 +590,8 @@ int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bi
                FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: 16-byte alignment required");
   FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
-  return conv_s2_launch(x, w, bias, y_split, y_f32, N, Hp, Wp, Cin, Cout, KS, Ho, Wo, Hop, Wop, relu, (hipStream_t)stream);
+  return conv_s2_launch(x, w, bias, y_split, y_f32, N, Hp, Wp, Cin, Cout, KS, Ho, Wo, Hop, Wop, relu, out_fmt, out_scale_log2, overflow,
+                        (hipStream_t)stream);
 }
 
 int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H,

@@ -246,6 +246,42 @@ __device__ __forceinline__ void split_bf16_4(const f32x4& x, ushort4& hv, ushort
   lv = __builtin_bit_cast(ushort4, ll);
 }
 
+// ---- the f16 forms of the encoder's split activation tensors (conv_split.hip has the arithmetic) ----
+typedef _Float16 fgvc_f16x8 __attribute__((ext_vector_type(8)));
+typedef int fgvc_i32x8 __attribute__((ext_vector_type(8)));
+typedef int fgvc_i32x4 __attribute__((ext_vector_type(4)));
+
+// f16f8 operand scales (powers of two; mirrored by fgvc_amd/ops.py): h8 = e4m3(h 2^-A), l8 = e4m3(l 2^B)
+constexpr int F8_AX = 7, F8_BX = 3;     // activations: |h| <= 65504 -> 512 (the top half-binade saturates at 448: flagged as overflow anyway), |l| <= 32 -> 256
+constexpr int F8_AW = 2, F8_BW = 9;     // weights (|h| <= 2^10): h -> 2^8, l (<= 2^-1) -> 2^8
+
+// four f32 -> the words of a split tensor.  FMT 1: h (4 f16), l8, h8 (4 e4m3 each);  FMT 2: h, l (4 f16 each).  `ovf` is raised when
+// |s x| leaves the f16 range.
+__device__ __forceinline__ void split_f16_4(const f32x4& x, float s, uint2& hw, uint32_t& l8, uint32_t& h8, uint2& lw, bool& ovf) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 h, l;
+  float hf[4], lf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xs = x[i] * s;
+    ovf |= fabsf(xs) > 65504.f;
+    const float c = __builtin_amdgcn_fmed3f(xs, -65504.f, 65504.f);
+    h[i] = (_Float16)c;
+    hf[i] = (float)h[i];
+    lf[i] = c - hf[i];
+    l[i] = (_Float16)lf[i];
+  }
+  hw = __builtin_bit_cast(uint2, h);
+  lw = __builtin_bit_cast(uint2, l);
+  constexpr float SA = 1.0f / (float)(1 << F8_AX), SB = (float)(1 << F8_BX);
+  int a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(hf[0] * SA, -448.f, 448.f), __builtin_amdgcn_fmed3f(hf[1] * SA, -448.f, 448.f), 0, false);
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(hf[2] * SA, -448.f, 448.f), __builtin_amdgcn_fmed3f(hf[3] * SA, -448.f, 448.f), a, true);
+  int b = __builtin_amdgcn_cvt_pk_fp8_f32(lf[0] * SB, lf[1] * SB, 0, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(lf[2] * SB, lf[3] * SB, b, true);
+  h8 = (uint32_t)a;
+  l8 = (uint32_t)b;
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }

@@ -30,7 +30,11 @@ struct ConvS2Params {
   int N, Hp, Wp, Cin, Cout, Ho, Wo, Hop, Wop, relu;
   int n_ty, n_tx;
   int debug;               // profiling ablations (results WRONG): 1 = no staging, 2 = no MFMA, 4 = no epilogue, 8 = no A loads
+  float out_scale;         // out_fmt != 0: the split output stores s_out * y (conv_split.hip: the f16 forms)
+  int out_fmt;             // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16
+  int* overflow;           // out_fmt != 0: raised when |s_out * y| leaves the f16 range
 };
+
 
 __device__ __forceinline__ void s2_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_uniform) : "memory");
@@ -187,14 +191,33 @@ __global__ __launch_bounds__(64 * S2_NW, 2) void conv_s2_kernel(ConvS2Params p) 
       wave_sync();
     }
     if (p.y_split) {
+      if (p.out_fmt == 0) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 x = v[g];
-        ushort4 hv, lv;
-        split_bf16_4(x, hv, lv);
-        unsigned char* o = tile + n * S2_RS + (8 * g + 4 * h) * 2;
-        *reinterpret_cast<ushort4*>(o) = hv;
-        *reinterpret_cast<ushort4*>(o + 64) = lv;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 x = v[g];
+          ushort4 hv, lv;
+          split_bf16_4(x, hv, lv);
+          unsigned char* o = tile + n * S2_RS + (8 * g + 4 * h) * 2;
+          *reinterpret_cast<ushort4*>(o) = hv;
+          *reinterpret_cast<ushort4*>(o + 64) = lv;
+        }
+      } else {                                                // the f16 forms (conv_split.hip): [h 64 B | l8 32 B | h8 32 B] or [h 64 B | l 64 B]
+        bool ovf = false;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 hw, lw;
+          uint32_t l8, h8;
+          split_f16_4(v[g], p.out_scale, hw, l8, h8, lw, ovf);
+          unsigned char* o = tile + n * S2_RS;
+          *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw;
+          if (p.out_fmt == 1) {
+            *reinterpret_cast<uint32_t*>(o + 64 + 8 * g + 4 * h) = l8;
+            *reinterpret_cast<uint32_t*>(o + 96 + 8 * g + 4 * h) = h8;
+          } else {
+            *reinterpret_cast<uint2*>(o + 64 + (8 * g + 4 * h) * 2) = lw;
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.Wo) != 0ull && lane == 0) atomicOr(p.overflow, 1);
       }
       wave_sync();
       const size_t pix0 = ((size_t)nimg * p.Hop + (y + 1)) * p.Wop + (x0 + 1);
@@ -215,8 +238,10 @@ static int g_conv_s2_debug = 0;
 void set_conv_s2_debug(int v) { g_conv_s2_debug = v; }
 
 int conv_s2_launch(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int Hp,
-                   int Wp, int Cin, int Cout, int KS, int Ho, int Wo, int Hop, int Wop, int relu, hipStream_t s) {
+                   int Wp, int Cin, int Cout, int KS, int Ho, int Wo, int Hop, int Wop, int relu, int out_fmt, int out_scale_log2,
+                   int* overflow, hipStream_t s) {
   ConvS2Params p;
+  p.out_fmt = out_fmt; p.out_scale = ldexpf(1.0f, out_scale_log2); p.overflow = overflow;
   p.x = x; p.w = w; p.bias = bias; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.Ho = Ho; p.Wo = Wo; p.Hop = Hop; p.Wop = Wop; p.relu = relu;
   p.n_ty = cdiv(Ho, S2_TR); p.n_tx = cdiv(Wo, 32);

@@ -10,6 +10,21 @@
 //   weights      w[tap][Cin/32][Cout][hi 32 ci | lo 32 ci] bf16, BatchNorm folded in on the host;
 //   f32 side outputs / residuals: dense NHWC f32 [n][H][W][C] (= a channels_last NCHW tensor: MIOpen reads and writes it
 //                without any layout conversion).
+// Arithmetic forms (template parameter ARITH = format of the INPUT tensor and of the weights; all accumulate in f32):
+//   0  bf16x3: (hi, lo) bf16 operands, hi*hi + hi*lo + lo*hi: three pipe units per product, ~2^-17 per term (above).
+//   1  f16f8 : x -> h = f16(s x) (s a per-tensor power of two), l = s x - h (|l| <= 2^-11 |h|), h8 = e4m3(h 2^-a), l8 = e4m3(l 2^b).
+//              The main product h*h runs on v_mfma_f32_32x32x16_f16 (exact products); BOTH cross sums of a 32-channel chunk run in ONE
+//              v_mfma_scale_f32_32x32x64_f8f6f4: K = 64 = [h8_w . l8_x (32 channels) | l8_w . h8_x (the same 32 channels)], the two
+//              32-element scale blocks carrying their own E8M0 scales -- two pipe units per product, ~2^-15.5 per term
+//              (tools/sim_conv_formats.py: 1.0-1.7e-5 of max|y| per layer on real activations against 0.7-1.0e-5 for bf16x3; 1e-4 logit
+//              on the final features).  Where the instruction takes a block's scale from was probed (tools/micro/probe_fp8_scaled.hip,
+//              exact integers): lane (r, hh) holds 32 bytes; its FIRST 16 (registers 0-3) belong to scale block 0, whose scale is read
+//              from lane (r, 0), its LAST 16 (registers 4-7) to block 1, scale from lane (r, 1) -- a block is 16 bytes of each lane half,
+//              not one lane half's 32.  So registers 0-3 carry the first cross term and registers 4-7 the second:
+//              rows keep their 128 bytes per (pixel | output channel, 32-channel chunk), activations [h 64 B | l8 32 B | h8 32 B],
+//              weights [h 64 B | h8 32 B | l8 32 B], and lane half hh of either operand reads the 16-byte slots 4 + hh and 6 + hh.
+//   2  f16x3 : h = f16(s x), l = f16(s x - h): h*h + h*l + l*h on the f16 pipe, three units, ~2^-22 per term.
+// The epilogue writes the split output in the format the NEXT layer reads (out_fmt, out_scale), whatever this layer's own arithmetic.
 // Work split (widest form): a 512-thread workgroup owns 8 rows x 32 columns of output pixels x 256 output channels; wave (pr, ch) owns
 // pixel rows 2pr, 2pr+1 (two 32-pixel MFMA B operands) x channels ch*128..+128 (four 32-channel A operands): 8 accumulator
 // tiles.  K loop: for every 32-channel input chunk the (8+2) x 40 pixel patch is staged once (swizzled 128-byte pixel
@@ -29,7 +44,15 @@ struct ConvSplitParams {
   int N, H, W, Hp, Wp, Cin, Cout, relu;
   int n_ty, n_tx;
   int debug;   // profiling ablations (results WRONG): 1 = patch staged once, 2 = no epilogue, 4 = no MFMA, 8 = s_memtime probe
+  float acc_scale;   // accumulator -> convolution value: 1 / (s_x s_w) for the f16 forms, 1 for bf16x3
+  float out_scale;   // out_fmt != 0: the split output stores s_out * y
+  int out_fmt;       // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16
+  int* overflow;     // out_fmt != 0: *overflow |= 1 when |s_out * y| leaves the f16 range (the scale must be re-calibrated)
 };
+
+typedef fgvc_f16x8 f16x8;
+typedef fgvc_i32x8 i32x8;
+typedef fgvc_i32x4 i32x4;
 
 __device__ __forceinline__ void conv_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_uniform) : "memory");
@@ -54,8 +77,9 @@ __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^
 // NWR = waves along the pixel rows (4: an 8-row tile, 512 threads, one workgroup per CU; 2: a 4-row tile, 256 threads,
 // small enough in LDS and registers for TWO workgroups per CU -- for the narrow layers, whose short main loop cannot hide
 // its own prologue and epilogue, the second workgroup does).
-template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false>
+template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0>
 __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel(ConvSplitParams p) {
+  static_assert(!PINNED || ARITH == 0, "the hand-scheduled stage is the bf16x3 form");
   constexpr int T = KS * KS;
   constexpr int PADK = KS / 2;                  // 1 for 3x3, 0 for 1x1
   constexpr int NW = NWR * 2;                   // waves per workgroup
@@ -259,6 +283,73 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       }
 #undef CVR
 #undef CVM
+    } else if constexpr (ARITH == 1 || ARITH == 3) {
+      // ---- f16f8: per tap two K-16 steps of the f16 main product, then ONE K-64 fp8 MFMA per tile for both cross sums
+      // E8M0 scales of this lane half (byte value 127 + log2; unsigned: 129 * 0x01010101 does not fit an int), in all four bytes
+      const uint32_t sa_ = h ? (uint32_t)(127 - F8_BW) : (uint32_t)(127 + F8_AW), sb_ = h ? (uint32_t)(127 + F8_AX) : (uint32_t)(127 - F8_BX);
+      const int scale_a = (int)(sa_ * 0x01010101u), scale_b = (int)(sb_ * 0x01010101u);
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg) {
+        const int tap = sg * TG + tg;
+        if (tap >= T) break;                          // wave-uniform: short last tap group
+        const int dy = tap / KS, dx = tap - dy * KS;
+        const unsigned char* wt = wslot + tg * COT * 128;
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+          if (ph < 2) {
+            f16x8 ah[NA], bh[2];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) ah[a] = *reinterpret_cast<const f16x8*>(wt + cv_swz(ch * (COT / 2) + a * 32 + n, 2 * ph + h));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bh[b] = *reinterpret_cast<const f16x8*>(patch + cv_swz((2 * pr + b + dy) * CV_PW + n + dx, 2 * ph + h));
+            if ((p.debug & 4) == 0) {
+#pragma unroll
+              for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+          } else {
+            i32x8 a8[NA], b8[2];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+              const int co = ch * (COT / 2) + a * 32 + n;
+              const i32x4 u = *reinterpret_cast<const i32x4*>(wt + cv_swz(co, 4 + h)), v = *reinterpret_cast<const i32x4*>(wt + cv_swz(co, 6 + h));
+              a8[a] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int P = (2 * pr + b + dy) * CV_PW + n + dx;
+              const i32x4 u = *reinterpret_cast<const i32x4*>(patch + cv_swz(P, 4 + h)), v = *reinterpret_cast<const i32x4*>(patch + cv_swz(P, 6 + h));
+              b8[b] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            }
+            if ((p.debug & 4) == 0) {
+#pragma unroll
+              for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                  if constexpr (ARITH == 3) {
+                    // A/B form (conv_debug & 128): the cross sums go through a ZERO accumulator and are added by the vector unit -- to see
+                    // whether adding 64 products of ~2^-17 of a large running sum inside the scaled MFMA costs accuracy (it does not:
+                    // same error as the direct form, 1.7x the time)
+                    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[a][b] += __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[a], b8[b], z, 0, 0, 0, scale_a, 0, scale_b);
+                  } else {
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[a], b8[b], acc[a][b], 0, 0, 0, scale_a, 0, scale_b);
+                  }
+                }
+            }
+          }
+          if (stage_more) {                           // this phase's share of the PPW weight pieces, behind its MFMAs
+            constexpr int NIT = TG * 3;
+            const int it = tg * 3 + ph;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < PPW; ++j)
+              if (j * NIT / PPW == it) stage_weight_piece(q + LA, j);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
     } else
 #pragma unroll
     for (int tg = 0; tg < TG; ++tg) {
@@ -285,9 +376,15 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
           for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+              if constexpr (ARITH == 2) {             // (h, l) f16 operands: the same three products on the f16 form
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[a]), __builtin_bit_cast(f16x8, bh[b]), acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[a]), __builtin_bit_cast(f16x8, bl[b]), acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[a]), __builtin_bit_cast(f16x8, bh[b]), acc[a][b], 0, 0, 0);
+              } else {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+              }
             }
         }
         if (stage_more) {                           // this iteration's share of the PPW weight pieces, behind its MFMAs
@@ -370,8 +467,12 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       for (int g = 0; g < 4; ++g) {
         const int cw = a * 32 + 8 * g + 4 * h;    // channel within the wave's CW: rows (r&3) + 8 (r>>2) + 4 h of the tile
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
-        v[a][g] = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z,
-                   acc[a][b][4 * g + 3] + bv.w};
+        if constexpr (ARITH == 0)
+          v[a][g] = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z,
+                     acc[a][b][4 * g + 3] + bv.w};
+        else          // the accumulator holds s_x s_w times the convolution (powers of two: the product below is exact)
+          v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
+                     fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
         if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
         if (p.relu) {
           v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
@@ -396,17 +497,38 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     }
     if (p.y_split) {
       wave_sync();
+      if (p.out_fmt == 0) {
 #pragma unroll
-      for (int a = 0; a < NA; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 x = v[a][g];
-          ushort4 hv, lv;
-          split_bf16_4(x, hv, lv);
-          unsigned char* o = tile + n * RS + a * 128 + (8 * g + 4 * h) * 2;    // [chunk a][hi 64 B | lo 64 B]
-          *reinterpret_cast<ushort4*>(o) = hv;
-          *reinterpret_cast<ushort4*>(o + 64) = lv;
-        }
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 x = v[a][g];
+            ushort4 hv, lv;
+            split_bf16_4(x, hv, lv);
+            unsigned char* o = tile + n * RS + a * 128 + (8 * g + 4 * h) * 2;    // [chunk a][hi 64 B | lo 64 B]
+            *reinterpret_cast<ushort4*>(o) = hv;
+            *reinterpret_cast<ushort4*>(o + 64) = lv;
+          }
+      } else {                                      // the f16 forms the next layer reads: [h 64 B | l8 32 B | h8 32 B] or [h 64 B | l 64 B]
+        bool ovf = false;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hw, lw;
+            uint32_t l8, h8;
+            split_f16_4(v[a][g], p.out_scale, hw, l8, h8, lw, ovf);
+            unsigned char* o = tile + n * RS + a * 128;
+            *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw;
+            if (p.out_fmt == 1) {
+              *reinterpret_cast<uint32_t*>(o + 64 + 8 * g + 4 * h) = l8;
+              *reinterpret_cast<uint32_t*>(o + 96 + 8 * g + 4 * h) = h8;
+            } else {
+              *reinterpret_cast<uint2*>(o + 64 + (8 * g + 4 * h) * 2) = lw;
+            }
+          }
+        if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.W) != 0ull && lane == 0) atomicOr(p.overflow, 1);
+      }
       wave_sync();
       // in global memory the wave's CW channels of a pixel are CW/32 consecutive 128-byte chunks = RB contiguous bytes
       unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * (p.Cout / 32) + (co_w >> 5)) * 128;
@@ -761,32 +883,43 @@ void set_conv_narrow(int v) { g_conv_narrow = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
 void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 
+template <int ARITH>
+static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int cot_eff, bool narrow, hipStream_t s) {
+  if (KS == 3) {
+    if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
+    else if (cot_eff == 128 && narrow) conv_split_kernel<3, 128, 1, 3, 2, false, ARITH><<<grid, 256, 0, s>>>(p);
+    else if (cot_eff == 128) conv_split_kernel<3, 128, 3, 2, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
+    else if (narrow) conv_split_kernel<3, 64, 3, 2, 2, false, ARITH><<<grid, 256, 0, s>>>(p);
+    else conv_split_kernel<3, 64, 3, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
+  } else {
+    if (cot_eff == 256) conv_split_kernel<1, 256, 1, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
+    else if (cot_eff == 128) conv_split_kernel<1, 128, 1, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
+    else if (narrow) conv_split_kernel<1, 64, 1, 3, 2, false, ARITH><<<grid, 256, 0, s>>>(p);
+    else conv_split_kernel<1, 64, 1, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
+  }
+}
+
+// in_fmt / out_fmt: FGVC_ACT_* (0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16); in_scale_log2 = log2(s_x s_w) of the operands (0 for bf16),
+// out_scale_log2 = log2(s_out) of the split output (ignored for bf16); overflow: device word, required when out_fmt != 0
 int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
-                      float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu,
-                      hipStream_t s) {
+                      float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu, int in_fmt,
+                      int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, hipStream_t s) {
   ConvSplitParams p;
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+  p.acc_scale = ldexpf(1.0f, -in_scale_log2); p.out_scale = ldexpf(1.0f, out_scale_log2); p.out_fmt = out_fmt; p.overflow = overflow;
   const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
   const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap) ? g_conv_cot_cap : cot;
   const bool narrow = (cot_eff == 64 && (g_conv_narrow & 1)) || (cot_eff == 128 && KS == 3 && (g_conv_narrow & 2));   // 4-row tiles, two workgroups per CU
   p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
-  if (KS == 3) {
-    if (cot_eff == 256 && (g_conv_debug & 32)) conv_split_kernel_4x4<<<grid, 256, 0, s>>>(p);                   // A/B: one wave per SIMD, 4 x 4 register tile
-    else if (cot_eff == 256 && (g_conv_debug & 16)) conv_split_kernel<3, 256, 1, 3, 4><<<grid, 512, 0, s>>>(p);   // A/B: the compiler's operand schedule
-    else if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);             // hand-placed operand reads
-    else if (cot_eff == 128 && narrow) conv_split_kernel<3, 128, 1, 3, 2><<<grid, 256, 0, s>>>(p);
-    else if (cot_eff == 128) conv_split_kernel<3, 128, 3, 2, 4><<<grid, 512, 0, s>>>(p);
-    else if (narrow) conv_split_kernel<3, 64, 3, 2, 2><<<grid, 256, 0, s>>>(p);
-    else conv_split_kernel<3, 64, 3, 3, 4><<<grid, 512, 0, s>>>(p);
-  } else {
-    if (cot_eff == 256) conv_split_kernel<1, 256, 1, 3, 4><<<grid, 512, 0, s>>>(p);
-    else if (cot_eff == 128) conv_split_kernel<1, 128, 1, 3, 4><<<grid, 512, 0, s>>>(p);
-    else if (narrow) conv_split_kernel<1, 64, 1, 3, 2><<<grid, 256, 0, s>>>(p);
-    else conv_split_kernel<1, 64, 1, 3, 4><<<grid, 512, 0, s>>>(p);
-  }
+  if (in_fmt == 1 && (g_conv_debug & 128)) conv_split_dispatch<3>(p, grid, KS, cot_eff, narrow, s);    // A/B: cross sums through a zero accumulator + vector adds
+  else if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
+  else if (in_fmt == 2) conv_split_dispatch<2>(p, grid, KS, cot_eff, narrow, s);
+  else if (KS == 3 && cot_eff == 256 && out_fmt == 0 && (g_conv_debug & 32)) conv_split_kernel_4x4<<<grid, 256, 0, s>>>(p);   // A/B: one wave per SIMD, 4 x 4 register tile
+  else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16)) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads
+  else conv_split_dispatch<0>(p, grid, KS, cot_eff, narrow, s);                                                                  // (16: the compiler's operand schedule)
   FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
   return FGVC_OK;
 }

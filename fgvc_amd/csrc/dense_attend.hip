@@ -81,7 +81,7 @@ __global__ __launch_bounds__(DA_THREADS) void dense_attend_kernel(const float* _
     const float* lab = labels + (size_t)j * P;        // uniform address: scalar loads
     if (cosine) {                                      // 1: clamp(min=0)^2, no normalisation (local_attention.py:379-380)
       float w = a > 0.f ? a * a : 0.f;
-      if (mode == 2) w = a;                            // 2: the entry itself (propagate, affinity_utils.py:45-49)
+      if (mode == 2) w = a == -INFINITY ? 0.f : a;     // 2: the entry itself (propagate, affinity_utils.py:45-49); masked-out keys carry no weight
       if (mode == 3) {                                 // 3: max(a - k-th largest of the column, 0) (:36-44); s = their sum
         w = fmaxf(a - th, 0.f);
         s += w;

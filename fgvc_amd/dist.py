@@ -99,6 +99,15 @@ def halo_messages(ranges: List[Tuple[int, int]], own: List[Tuple[int, int]], s_m
     return msgs
 
 
+# bytes this rank handed to each exchange step since the last reset (bench.py checks them against the schedule's arithmetic)
+COMM_BYTES = {"broadcast": 0, "halo_send": 0, "halo_recv": 0, "all_gather_send": 0}
+
+
+def reset_comm_bytes():
+    for k in COMM_BYTES:
+        COMM_BYTES[k] = 0
+
+
 def _host_staged(t: torch.Tensor, group) -> bool:
     """gloo moves host memory only (its CUDA support covers broadcast / all_reduce): device tensors are staged through the host.
     That is how the HIP backend is exercised with two ranks on ONE GPU in tests (RCCL refuses two ranks on a device)."""
@@ -120,6 +129,7 @@ def _broadcast(buf: torch.Tensor, src: int, group) -> None:
     """`src`: rank within `group`."""
     buf = _wire(buf)
     src = _global_rank(group, src)
+    COMM_BYTES["broadcast"] += buf.numel() * buf.element_size()
     if _host_staged(buf, group):
         tmp = buf.cpu()
         dist.broadcast(tmp, src=src, group=group)
@@ -129,6 +139,7 @@ def _broadcast(buf: torch.Tensor, src: int, group) -> None:
 
 
 def _all_gather(outs: List[torch.Tensor], t: torch.Tensor, group) -> None:
+    COMM_BYTES["all_gather_send"] += t.numel() * t.element_size()
     if _host_staged(t, group):
         tmp = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
         dist.all_gather(tmp, t.cpu(), group=group)
@@ -147,6 +158,7 @@ class _Messages:
 
     def send(self, t: torch.Tensor, dst: int):            # dst / src: ranks within the group
         t = _wire(t.contiguous())
+        COMM_BYTES["halo_send"] += t.numel() * t.element_size()
         if _host_staged(t, self.group):
             t = t.cpu()
         self.keep.append(t)
@@ -155,6 +167,7 @@ class _Messages:
     def recv(self, into: torch.Tensor, src: int):
         assert into.is_contiguous()
         into = _wire(into)
+        COMM_BYTES["halo_recv"] += into.numel() * into.element_size()
         if _host_staged(into, self.group):
             tmp = torch.empty(into.shape, dtype=into.dtype)
             self.land.append((into, tmp))

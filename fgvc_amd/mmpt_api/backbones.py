@@ -146,6 +146,95 @@ class ResNet(nn.Module):
     use_stem7 = True               # 7x7 stride-2 stem on fgvc_stem7_split_f32 (False: MIOpen f32 + ReLU/split pass)
     use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
+    arith = "f16f8"                # arithmetic of the stride-1 convolutions behind layer 1: see set_arith()
+
+    @staticmethod
+    def supported_arith():
+        return ("f16f8", "bf16x3", "f16x3")
+
+    def set_arith(self, arith: str):
+        """Arithmetic of the stride-1 convolutions of fgvc_conv_split_f32 (layers 2 and 3 of ResNet-18: 80 % of the trunk's FLOPs) on the
+        16-bit matrix pipe; every form accumulates in f32 (csrc/conv_split.hip):
+          "bf16x3"  (hi, lo) bf16 operands, hi*hi + hi*lo + lo*hi: three pipe units per product, ~2^-17 per term (round 2);
+          "f16f8"   h = f16(s x) + e4m3 forms of h and of its residual: the main product on the f16 form, both cross sums in one K-64
+                    fp8 MFMA: two units, ~2^-15.5 per term (default: 1e-4 logit on the final features, tools/sim_conv_formats.py);
+          "f16x3"   (h, l) f16 operands, three units, ~2^-22 per term.
+        The f16 forms store s x with a per-tensor power-of-two scale s, calibrated on the first batch a set of weights sees
+        (`calibrate`), with 2^7-2^8 of headroom; a value beyond the f16 range raises a device flag that `check_overflow` turns into an
+        error (and a re-calibration).  The stem, layer 1 and the stride-2 convolutions keep the bf16 form (they are bound by bytes)."""
+        if arith not in self.supported_arith():
+            raise ValueError(f"arith={arith!r}: one of {self.supported_arith()}")
+        if arith != self.arith:
+            self.arith = arith
+            self.reset_split_cache()
+
+    # ---- formats and scales of the split activation tensors ------------------------------------------------------------------------
+    def _generic_s1(self, cb) -> bool:
+        """Does this ConvBN run on fgvc_conv_split_f32 (stride 1, not the register-resident 64 -> 64 kernel)?"""
+        c = cb.conv
+        return c.stride == (1, 1) and not (self.use_conv64 and tuple(c.weight.shape) == (64, 64, 3, 3))
+
+    def _block_formats(self, si: int, bi: int, last: int):
+        """(format of the block's input, of conv1's output `a`, of the block's split output `y`) as ops.ACT_* codes.  A tensor takes the
+        trunk's f16 form iff its producer can write it (fgvc_conv_split_f32, fgvc_conv_s2_split_f32) and every convolution that reads
+        it runs on fgvc_conv_split_f32; a convolution computes in the format of its input (its weights are laid out to match)."""
+        from .. import ops
+        fmt, bf = ops.ACT_FMT[self.arith], ops.ACT_BF16X2
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = ("fmt_plan", self.arith, last, self.use_conv64, self.use_s2_conv)
+        if key not in cache:
+            blocks = [(s_i, b_i, blk) for s_i in range(last + 1) for b_i, blk in enumerate(getattr(self, self.res_layers[s_i]))]
+            wants = lambda blk: fmt if (self._generic_s1(blk.conv1) and (blk.downsample is None or self._generic_s1(blk.downsample))) else bf
+            can_write = lambda cb: self._generic_s1(cb) or (cb.conv.stride == (2, 2) and self.use_s2_conv)
+            plan, f_in = {}, bf                                   # the stem writes the bf16 form
+            for i, (s_i, b_i, blk) in enumerate(blocks):
+                f_a = fmt if (self._generic_s1(blk.conv2) and can_write(blk.conv1)) else bf
+                nxt = blocks[i + 1][2] if i + 1 < len(blocks) else None
+                f_y = wants(nxt) if (nxt is not None and self._generic_s1(blk.conv2)) else bf
+                plan[(s_i, b_i)] = (f_in, f_a, f_y)
+                f_in = f_y
+            cache[key] = plan
+        return cache[key][(si, bi)]
+
+    def _scales(self, dev):
+        cache = self.__dict__.setdefault("_split_cache", {})
+        return cache.get(("scales", dev))
+
+    def calibrate(self, x, last=None):
+        """Per-tensor scales of the f16-format activation tensors from one batch: the trunk runs once in the bf16 form (which needs no
+        scales), the largest magnitude of every split tensor is read back, and s = 2^(8 - ceil(log2(max))).  Called by the first
+        forward of a set of weights; call it yourself with representative frames to fix the scales."""
+        from .. import ops
+        cache = self.__dict__.setdefault("_split_cache", {})
+        dev = x.device
+        saved = (self.arith, self.split_lanes)
+        rec = {}
+        self.__dict__["_calib"] = rec
+        try:
+            self.arith, self.split_lanes = "bf16x3", 1
+            self._trunk(x, max(self.out_indices) if last is None else last)
+            torch.cuda.synchronize(dev)
+        finally:
+            self.arith, self.split_lanes = saved
+            self.__dict__.pop("_calib", None)
+        scales = {k: ops.act_scale_log2(float(v)) for k, v in rec.items()}
+        cache[("scales", dev)] = scales
+        if ("overflow", dev) not in cache:
+            cache[("overflow", dev)] = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._cache_filled(dev)
+        return scales
+
+    def check_overflow(self):
+        """True iff a value left the f16 range of its calibrated tensor since the last check (the results since then are invalid):
+        reads and clears the device flag (a synchronisation) and drops the scales, so that the next forward re-calibrates."""
+        cache = self.__dict__.get("_split_cache", {})
+        hit = False
+        for k in [k for k in cache if isinstance(k, tuple) and k and k[0] == "overflow"]:
+            if int(cache[k].item()) != 0:
+                hit = True
+                cache[k].zero_()
+                cache.pop(("scales", k[1]), None)
+        return hit
 
     def _load_from_state_dict(self, *args, **kwargs):
         # called for this module by ANY load_state_dict (its own or a parent model's): folded / split weights are derived
@@ -252,26 +341,50 @@ class ResNet(nn.Module):
         cache = self.__dict__.setdefault("_split_cache", {})
         dev = cur["split"].device
         lo, hi, N = cur["lo"], cur["hi"], cur["N"]
-        wkey = ("w", si, dev)
+        from ..ops import ACT_BF16X2
+        last_stage = call["last"]
+        fmts = [self._block_formats(si, bi, last_stage) for bi in range(len(stage))]
+        calib = self.__dict__.get("_calib")
+        scales = self._scales(dev) or {}
+        ovf = cache.get(("overflow", dev))
+        wkey = ("w", si, dev, self.arith)
         if wkey not in cache:
-            def prep_s1(w, bn):      # 64 -> 64 3x3: the register-resident-weights kernel (its own weight order)
-                return ops.prepare_conv64(w, bn) if (self.use_conv64 and tuple(w.shape) == (64, 64, 3, 3)) else ops.prepare_conv_split(w, bn)
-            prep = {(1, 1): prep_s1, (2, 2): ops.prepare_conv_s2}
-            cache[wkey] = [dict(c1=None if b.conv1.conv.stride not in prep else
-                                prep[b.conv1.conv.stride](b.conv1.conv.weight.detach(), b.conv1.bn),
-                                c2=prep_s1(b.conv2.conv.weight.detach(), b.conv2.bn),
-                                ds=None if (b.downsample is None or b.downsample.conv.stride not in prep) else
-                                prep[b.downsample.conv.stride](b.downsample.conv.weight.detach(), b.downsample.bn))
-                           for b in stage]
+            def prep_s1(w, bn, fmt):      # 64 -> 64 3x3: the register-resident-weights kernel (its own weight order, bf16 only)
+                if self.use_conv64 and tuple(w.shape) == (64, 64, 3, 3):
+                    return ops.prepare_conv64(w, bn) + (0,)
+                if fmt == ACT_BF16X2:
+                    return ops.prepare_conv_split(w, bn) + (0,)
+                return ops.prepare_conv_split_f16(w, bn, fmt)
+
+            def prep(cb, fmt):            # -> (weights, bias, log2 s_w) or None (MIOpen)
+                st = cb.conv.stride
+                if st == (1, 1):
+                    return prep_s1(cb.conv.weight.detach(), cb.bn, fmt)
+                if st == (2, 2):
+                    return ops.prepare_conv_s2(cb.conv.weight.detach(), cb.bn) + (0,)
+                return None
+            cache[wkey] = [dict(c1=prep(b.conv1, f[0]), c2=prep(b.conv2, f[1]),
+                                ds=None if b.downsample is None else prep(b.downsample, f[0]))
+                           for b, f in zip(stage, fmts)]
             self._cache_filled(dev)
         full = None
         for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
             Cout = blk.conv2.conv.out_channels
             H, W = cur["H"], cur["W"]
+            f_in, f_a, f_y = fmts[bi]
+            s_in = cur.get("scale", 0)
+            s_a = scales.get((si, bi, "a"), 0) if f_a != ACT_BF16X2 else 0
+            s_y = scales.get((si, bi, "y"), 0) if f_y != ACT_BF16X2 else 0
+            assert cur.get("fmt", ACT_BF16X2) == f_in, "split activation format mismatch between producer and consumer"
 
-            def conv_s1(x_split, wb, **kw):       # stride-1 convolution by whichever kernel the weights were laid out for
-                fn = ops.conv64_split if wb[0].dim() == 7 else ops.conv_split
-                fn(x_split, wb[0], wb[1], H, W, **kw)
+            def conv_s1(x_split, wb, in_fmt=ACT_BF16X2, in_scale=0, out_fmt=ACT_BF16X2, out_scale=0, **kw):
+                """stride-1 convolution by whichever kernel the weights were laid out for"""
+                if wb[0].dim() == 7:
+                    assert in_fmt == ACT_BF16X2 and (out_fmt == ACT_BF16X2 or kw.get("out_split") is None)
+                    ops.conv64_split(x_split, wb[0], wb[1], H, W, **kw)
+                else:
+                    ops.conv_split(x_split, wb[0], wb[1], H, W, in_fmt=in_fmt, in_scale_log2=in_scale + wb[2], out_fmt=out_fmt,
+                                   out_scale_log2=out_scale, overflow=ovf, **kw)
 
             last_conv = bi == len(stage) - 1 and not cur["need_split"]        # nobody reads the split form of the trunk output
             if blk.conv1.conv.stride == (2, 2) and self.use_s2_conv:
@@ -282,7 +395,8 @@ class ResNet(nn.Module):
                 buf = {k: v[lo:hi] for k, v in bufs.items()}
                 ops.conv_s2_split(cur["split"], wt["ds"][0], wt["ds"][1], Hi, Wi, relu=False, out_f32=buf["f_idt"])
                 idt = buf["f_idt"]
-                ops.conv_s2_split(cur["split"], wt["c1"][0], wt["c1"][1], Hi, Wi, relu=True, out_split=buf["s_a"])
+                ops.conv_s2_split(cur["split"], wt["c1"][0], wt["c1"][1], Hi, Wi, relu=True, out_split=buf["s_a"], out_fmt=f_a,
+                                  out_scale_log2=s_a, overflow=ovf)
             elif blk.conv1.conv.stride != (1, 1):
                 # other strides: strided 3x3 and strided projection in MIOpen, NHWC in and out (the dense f32 tensors ARE
                 # channels_last tensors), then back onto the bf16 pipe: ReLU + split in one pass
@@ -292,16 +406,20 @@ class ResNet(nn.Module):
                 _, H, W, _ = t1.shape
                 bufs = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y"))
                 buf = {k: v[lo:hi] for k, v in bufs.items()}
+                assert f_a == ACT_BF16X2                                   # (fgvc_nhwc_to_split_f32 writes the bf16 form)
                 ops.nhwc_to_split(t1, buf["s_a"], relu=True)
             else:
                 bufs = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
                 buf = {k: v[lo:hi] for k, v in bufs.items()}
                 if blk.downsample is not None:
-                    ops.conv_split(cur["split"], wt["ds"][0], wt["ds"][1], H, W, relu=False, out_f32=buf["f_idt"])
+                    conv_s1(cur["split"], wt["ds"], f_in, s_in, relu=False, out_f32=buf["f_idt"])
                     idt = buf["f_idt"]
                 else:
                     idt = cur["f32"]
-                conv_s1(cur["split"], wt["c1"], relu=True, out_split=buf["s_a"])
+                conv_s1(cur["split"], wt["c1"], f_in, s_in, f_a, s_a, relu=True, out_split=buf["s_a"])
+            if calib is not None:
+                calib[(si, bi, "a")] = torch.maximum(calib.get((si, bi, "a"), torch.zeros((), device=dev)),
+                                                     buf["s_a"].view(torch.bfloat16)[..., :32].abs().amax().float())
             full = bufs["f_y"]
             if bi == len(stage) - 1 and si in call["fresh"]:
                 if si not in call["out"]:
@@ -311,11 +429,14 @@ class ResNet(nn.Module):
                         if st is not call["main"]:
                             st.wait_stream(call["main"])                 # the block's previous life ended on that stream
                 full = call["out"][si]
-            f_y = full[lo:hi]
+            f_y_ = full[lo:hi]
             skip_f32 = bi == len(stage) - 1 and not cur["need_f32"]       # nobody reads the f32 form of this stage's output
-            conv_s1(buf["s_a"], wt["c2"], relu=True, residual=idt,
-                    out_split=None if last_conv else buf["s_y"], out_f32=None if skip_f32 else f_y)
-            cur = dict(cur, split=buf["s_y"], f32=f_y, H=H, W=W)
+            conv_s1(buf["s_a"], wt["c2"], f_a, s_a, f_y, s_y, relu=True, residual=idt,
+                    out_split=None if last_conv else buf["s_y"], out_f32=None if skip_f32 else f_y_)
+            if calib is not None and not last_conv:
+                calib[(si, bi, "y")] = torch.maximum(calib.get((si, bi, "y"), torch.zeros((), device=dev)),
+                                                     buf["s_y"].view(torch.bfloat16)[..., :32].abs().amax().float())
+            cur = dict(cur, split=buf["s_y"], f32=f_y_, H=H, W=W, fmt=f_y, scale=s_y)
         cur["full"] = full
         return cur
 
@@ -336,6 +457,8 @@ class ResNet(nn.Module):
                 and all(self._split_stage_ok(st, probe) for st in stages)):
             N, dev = x.shape[0], x.device
             cache = self.__dict__.setdefault("_split_cache", {})
+            if self.arith != "bf16x3" and self._scales(dev) is None and "_calib" not in self.__dict__:
+                self.calibrate(x, last)               # first batch of these weights: one pass in the bf16 form fixes the f16 scales
             self._touch_workspace_shape((N, x.shape[2], x.shape[3], dev))
             n_lanes = max(1, min(int(self.split_lanes), N))
             main = torch.cuda.current_stream(dev)
@@ -375,7 +498,7 @@ class ResNet(nn.Module):
                         ops.nhwc_to_split(t, sb["s_x"][lo:hi], relu=True)          # ReLU in place on t + split
                 lanes.append(dict(split=sb["s_x"][lo:hi], f32=t, H=H, W=W, lo=lo, hi=hi, N=N, need_split=True))
             fulls = []
-            call = dict(main=main, streams=streams, fresh=tuple(fresh), out={})
+            call = dict(main=main, streams=streams, fresh=tuple(fresh), out={}, last=last)
             for i in range(last + 1):
                 need_f32 = True           # the stage output in f32: returned, or the next block's identity / MIOpen input
                 if i < last and i not in call["fresh"]:

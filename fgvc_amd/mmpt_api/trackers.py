@@ -120,8 +120,14 @@ class VanillaTracker(BaseTracker):
         poison lists (NaN trajectories downstream) and raises a device flag.  The flag is read -- and cleared -- here, at the point
         where the reference synchronises anyway (`.cpu().numpy()` of the label maps, vanilla_tracker.py:404).  `check_kernels=False`
         in test_cfg (an extension key) skips the device synchronisation; the poison still marks the results."""
-        if self.test_cfg.get("check_kernels", True) and ops.pair_f16x3_timed_out():
+        if not self.test_cfg.get("check_kernels", True):
+            return
+        if ops.pair_f16x3_timed_out():
             raise RuntimeError("fgvc_pair_topk_f16x3: a bounded wait of the kernel's LDS protocol timed out; this video's results are invalid")
+        if hasattr(self.backbone, "check_overflow") and self.backbone.check_overflow():
+            raise RuntimeError("fgvc_amd ResNet: an activation left the f16 range of its calibrated scale (f16 arithmetic of the encoder); "
+                               "this video's results are invalid -- the scales were dropped and the next call re-calibrates on its own "
+                               "frames (or call backbone.calibrate(frames), or backbone.set_arith('bf16x3'))")
 
     # ---- A10: regrouping by query time ----------------------------------------------------------
     @torch.no_grad()

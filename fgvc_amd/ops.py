@@ -519,6 +519,42 @@ def prepare_conv_split(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tupl
     return packed, bias
 
 
+# formats of the encoder's split activation / weight tensors (include/fgvc_hip.h: FGVC_ACT_*) and the fixed power-of-two scales of the
+# e4m3 parts of the F16F8 form (csrc/common.hpp: F8_AX ...): h8 = e4m3(h 2^-A), l8 = e4m3(l 2^B)
+ACT_BF16X2, ACT_F16F8, ACT_F16X2 = 0, 1, 2
+ACT_FMT = {"bf16x3": ACT_BF16X2, "f16f8": ACT_F16F8, "f16x3": ACT_F16X2}
+F8_AX, F8_BX, F8_AW, F8_BW = 7, 3, 2, 9
+F16_TARGET_LOG2 = 8            # a calibrated tensor's largest value sits at ~2^8 of the f16 range (top 2^16): 2^7-2^8 of headroom
+
+
+def act_scale_log2(amax: float) -> int:
+    """log2 of the power-of-two scale that puts a tensor whose largest magnitude is `amax` at (2^7, 2^8] in f16."""
+    return F16_TARGET_LOG2 - int(math.ceil(math.log2(max(float(amax), 1e-30))))
+
+
+def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """prepare_conv_split for the f16 operand forms: returns (w int16 [KS*KS][Cin/32][Cout][64] -- 128-byte rows in format `fmt` --,
+    bias f32 [Cout], log2 of the weights' scale s_w).  ACT_F16F8 rows: [h = f16(s_w w) 32 | h8 = e4m3(h / 4) 32 B | l8 = e4m3(512 (s_w w - h))
+    32 B]; ACT_F16X2 rows: [h 32 | l = f16(s_w w - h) 32]; s_w = the power of two that puts max|w| at (2^9, 2^10]."""
+    assert fmt in (ACT_F16F8, ACT_F16X2)
+    Cout, Cin, KS, _ = weight.shape
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+    w = weight.detach().float() * scale.view(-1, 1, 1, 1)
+    bias = (bn.bias - bn.running_mean * scale).detach().float().contiguous()
+    w = w.permute(2, 3, 1, 0).reshape(KS * KS, Cin // 32, 32, Cout).permute(0, 1, 3, 2).contiguous()   # [tap][chunk][co][32 ci]
+    e = 10 - int(math.ceil(math.log2(max(float(w.abs().max()), 1e-30))))
+    ws = w * (2.0 ** e)
+    h = ws.to(torch.float16)
+    l = ws - h.float()                                                  # exact in f32
+    if fmt == ACT_F16X2:
+        packed = torch.cat([h, l.to(torch.float16)], dim=-1).contiguous().view(torch.int16)
+        return packed, bias, e
+    h8 = (h.float() * 2.0 ** -F8_AW).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    l8 = (l * 2.0 ** F8_BW).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    packed = torch.cat([h.contiguous().view(torch.uint8), h8.view(torch.uint8), l8.view(torch.uint8)], dim=-1).contiguous()   # 64 + 32 + 32 B
+    return packed.view(torch.int16), bias, e
+
+
 def prepare_conv64(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor]:
     """Folded weights (64, 64, 3, 3) for fgvc_conv64_split_f32: prepare_conv_split's values in MFMA-operand order
     [2 output tiles][9 taps][2 chunks][2 k-steps][hi | lo][lane][8]; returns (w int16, bias f32 [64])."""
@@ -598,8 +634,12 @@ def nchw_to_split_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_
 
 def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
                residual: Optional[torch.Tensor] = None, out_split: Optional[torch.Tensor] = None,
-               out_f32: Optional[torch.Tensor] = None) -> None:
-    """fgvc_conv_split_f32: y = conv(x, w) + bias [+ residual] [ReLU] into out_split and/or out_f32 (interiors only)."""
+               out_f32: Optional[torch.Tensor] = None, in_fmt: int = ACT_BF16X2, in_scale_log2: int = 0,
+               out_fmt: int = ACT_BF16X2, out_scale_log2: int = 0, overflow: Optional[torch.Tensor] = None) -> None:
+    """fgvc_conv_split_fmt_f32: y = conv(x, w) + bias [+ residual] [ReLU] into out_split and/or out_f32 (interiors only).
+    in_fmt: ACT_* format of x_split AND w (prepare_conv_split / prepare_conv_split_f16), in_scale_log2 = log2(s_x s_w);
+    out_fmt / out_scale_log2: format and scale of out_split; overflow: int32 device word OR-ed with 1 when an f16-format output
+    leaves the f16 range."""
     x_split, w = _chk(x_split, torch.int16, "x_split"), _chk(w, torch.int16, "w")
     bias = _chk(bias, torch.float32, "bias")
     N, Hp, Wp, nch, _ = x_split.shape
@@ -609,8 +649,11 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
                          (out_split, torch.int16, (N, Hp, Wp, Cout // 32, 64))):
         if t is not None:
             assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv_split buffer"
-    _lib.call("fgvc_conv_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
-              N, H, W, Hp, Wp, nch * 32, Cout, 3 if taps == 9 else 1, int(relu), _stream(x_split))
+    if out_fmt != ACT_BF16X2 and out_split is not None:
+        assert overflow is not None and overflow.dtype == torch.int32 and overflow.device == x_split.device
+    _lib.call("fgvc_conv_split_fmt_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
+              N, H, W, Hp, Wp, nch * 32, Cout, 3 if taps == 9 else 1, int(relu), int(in_fmt), int(in_scale_log2), int(out_fmt),
+              int(out_scale_log2), _ptr(overflow), _stream(x_split))
 
 
 def conv64_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
@@ -629,7 +672,8 @@ def conv64_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: 
 
 
 def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
-                  out_split: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None) -> None:
+                  out_split: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None, out_fmt: int = ACT_BF16X2,
+                  out_scale_log2: int = 0, overflow: Optional[torch.Tensor] = None) -> None:
     """3x3 / stride 2 / pad 1 or 1x1 / stride 2 convolution + bias (+ ReLU) on the bf16 pipe (fgvc_conv_s2_split_f32).
     x_split: padded split NHWC of the (N, H, W) input; w, bias from prepare_conv_s2; outputs for the
     ((H-1)//2+1, (W-1)//2+1) result: out_split (padded split NHWC) and / or out_f32 (dense NHWC f32)."""
@@ -644,8 +688,11 @@ def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H:
         assert out_split.dtype == torch.int16 and tuple(out_split.shape) == (N, Hop, Wop, Cout // 32, 64) and out_split.is_contiguous()
     if out_f32 is not None:
         assert out_f32.dtype == torch.float32 and tuple(out_f32.shape) == (N, Ho, Wo, Cout) and out_f32.is_contiguous()
-    _lib.call("fgvc_conv_s2_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(out_split), _ptr(out_f32), N, H, W, Hp, Wp,
-              nch * 32, Cout, 3 if taps == 9 else 1, Hop, Wop, int(relu), _stream(x_split))
+    if out_fmt != ACT_BF16X2 and out_split is not None:
+        assert overflow is not None and overflow.dtype == torch.int32 and overflow.device == x_split.device
+    _lib.call("fgvc_conv_s2_split_fmt_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(out_split), _ptr(out_f32), N, H, W, Hp, Wp,
+              nch * 32, Cout, 3 if taps == 9 else 1, Hop, Wop, int(relu), int(out_fmt), int(out_scale_log2), _ptr(overflow),
+              _stream(x_split))
 
 
 def stem7_split(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, relu: bool = True,
@@ -687,6 +734,21 @@ def unsplit_f16x2(split: torch.Tensor) -> torch.Tensor:
     """(…, 2, C) int16 split_f16x2() features -> (…, C) f32 = (h + l) / 2^14 (2^-22-relative approximation of the rows)."""
     v = split.view(torch.float16).float()
     return (v[..., 0, :] + v[..., 1, :]) * (1.0 / 16384.0)
+
+
+def unsplit_act(split: torch.Tensor, fmt: int, scale_log2: int = 0) -> torch.Tensor:
+    """A padded split NHWC activation tensor (N, Hp, Wp, C/32, 64) int16 in format `fmt` -> (N, Hp, Wp, C) f32 (tests, calibration)."""
+    n5 = split.shape
+    if fmt == ACT_BF16X2:
+        v = split.view(torch.bfloat16).float()
+        return (v[..., :32] + v[..., 32:]).reshape(*n5[:3], -1)
+    b = split.contiguous().view(torch.uint8).reshape(*n5[:4], 128)
+    h = b[..., :64].contiguous().view(torch.float16).float()
+    if fmt == ACT_F16X2:
+        l = b[..., 64:].contiguous().view(torch.float16).float()
+    else:
+        l = b[..., 64:96].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -F8_BX
+    return ((h + l) * 2.0 ** -scale_log2).reshape(*n5[:3], -1)
 
 
 def unsplit_bf16(split: torch.Tensor) -> torch.Tensor:

@@ -292,6 +292,22 @@ int fgvc_nhwc_to_split_f32(float* x, uint16_t* out_split, int N, int C, int H, i
 int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                         uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
                         int KS, int relu, void* stream);
+/* The same convolution with the operand format spelled out (round 3).  A split activation tensor keeps its shape and its 128 bytes
+ * per (pixel, 32-channel chunk) in every format; FGVC_ACT_*:
+ *   BF16X2  [hi 32 x bf16 | lo 32 x bf16], x = hi + lo                                      3 bf16 products per f32-grade product
+ *   F16F8   [h 32 x f16 | l8 32 x e4m3 | h8 32 x e4m3]: h = f16(s x), l8 = e4m3(8 (s x - h)), h8 = e4m3(h / 128), s a per-tensor
+ *           power of two (`*_scale_log2`) that puts the tensor's largest values around 2^8           2 products (f16 + one K-64 fp8 MFMA)
+ *   F16X2   [h 32 x f16 | l 32 x f16], l = f16(s x - h)                                     3 f16 products, ~2^-22 per term
+ * `in_fmt` is the format of x AND of w (weights: ops.prepare_conv_split(fmt=...): F16F8 rows are [h | h8 = e4m3(h / 4) | l8 =
+ * e4m3(512 l)] with h = f16(s_w w)); in_scale_log2 = log2(s_x s_w); out_fmt / out_scale_log2 describe y_split (what the NEXT
+ * layer reads); *overflow (device word, required for an f16-format output) is OR-ed with 1 when |s_out y| exceeds 65504. */
+#define FGVC_ACT_BF16X2 0
+#define FGVC_ACT_F16F8 1
+#define FGVC_ACT_F16X2 2
+int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
+                            uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
+                            int KS, int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow,
+                            void* stream);
 /* fgvc_conv_split_f32 for Cin = Cout = 64, 3x3 (ResNet layer 1: the largest activations of the trunk), as persistent
  * workgroups that keep the folded weights in registers instead of re-streaming them per tile.  Same tensors and epilogue;
  * weights in MFMA-operand order:
@@ -309,6 +325,10 @@ int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bia
 int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
                            int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu,
                            void* stream);
+/* ... with y_split in any FGVC_ACT_* format (x and w stay BF16X2: these layers read layer 1's output) */
+int fgvc_conv_s2_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
+                               int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu, int out_fmt,
+                               int out_scale_log2, int* overflow, void* stream);
 /* The stem: 7x7 / stride 2 / zero padding 3 convolution of 3-channel frames to 64 channels, BatchNorm folded, + bias
  * (+ ReLU) (resnet.py:457-466 with pool_type 'none'), from the f32 NCHW frames x[N][3][H][W] to y_f32 (dense NHWC f32
  * [N][Ho][Wo][64]) and / or y_split (padded split NHWC, Hop x Wop); Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1).

@@ -156,19 +156,23 @@ def test_vanilla_tracker_five_tuple_vs_reference_golden(dev, golden):
     cfg = dict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512, with_first=True, with_first_neighbor=True)
     model = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), cfg, int(g["seed"]))
     rgbs, qp, traj, vis = (T(g[n]).to(dev) for n in ("rgbs", "query_points", "trajectories", "visibilities"))
-    outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
-    assert torch.equal(outs[0].cpu(), T(g["out_trajectories"]))
-    assert torch.equal(outs[1].cpu(), T(g["out_visibilities"]))
-    assert torch.equal(outs[4].cpu(), T(g["out_query_points"]))
-    assert torch.equal(outs[3].cpu(), T(g["out_vis_pred"]))
-    assert outs[2].shape == g["out_traj_pred"].shape and outs[2].dtype == traj.dtype
-    d = (outs[2].cpu().double() - T(g["out_traj_pred"]).double()).abs()
-    d[0, 1, 2, 0] = 0          # the one read-out whose top-5 boundary is an exact tie in the reference (see test_oracle.py)
-    assert float(d.max()) < 5e-3, float(d.max())
+    # every arithmetic of the encoder's wide layers: bf16x3 / f16x3 within 5e-3 px of the reference's trajectories (round 2's bound),
+    # f16f8 (two pipe units per product instead of three, ~2x the feature noise) within 3e-2 px; last = the default, kept for what follows
+    for arith, tol_px in (("bf16x3", 5e-3), ("f16x3", 5e-3), ("f16f8", 3e-2)):
+        model.backbone.set_arith(arith)
+        outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
+        assert torch.equal(outs[0].cpu(), T(g["out_trajectories"]))
+        assert torch.equal(outs[1].cpu(), T(g["out_visibilities"]))
+        assert torch.equal(outs[4].cpu(), T(g["out_query_points"]))
+        assert torch.equal(outs[3].cpu(), T(g["out_vis_pred"]))
+        assert outs[2].shape == g["out_traj_pred"].shape and outs[2].dtype == traj.dtype
+        d = (outs[2].cpu().double() - T(g["out_traj_pred"]).double()).abs()
+        d[0, 1, 2, 0] = 0          # the one read-out whose top-5 boundary is an exact tie in the reference (see test_oracle.py)
+        assert float(d.max()) < tol_px, (arith, float(d.max()))
     # the un-regrouped main path (all points from frame 0), float64 like torch.from_numpy(...) in the reference
     main = model.forward_test_main(rgbs, qp[:, [0, 2]], torch.zeros(1, 4, 2, 2, device=dev), torch.zeros(1, 4, 2, device=dev))
     assert main[2].dtype == torch.float64
-    assert float((main[2].cpu() - T(g["main_traj_pred"]).double()).abs().max()) < 5e-3
+    assert float((main[2].cpu() - T(g["main_traj_pred"]).double()).abs().max()) < 3e-2          # (the default arithmetic, f16f8, from here on)
     # test_mode='v2' (masked_attention_efficient_v2): same disc, same result; a config WITHOUT with_first: one group from frame 0
     m2 = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), dict(cfg, test_mode="v2"), int(g["seed"]))
     o2 = m2(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
@@ -181,7 +185,7 @@ def test_vanilla_tracker_five_tuple_vs_reference_golden(dev, golden):
     net.load_state_dict(O.seeded_resnet_state(int(g["seed"]), (1, 1, 1, 4), "none"))
     with torch.no_grad():
         want = O.forward_test_main(net.eval()(T(g["rgbs"])[0]), T(g["query_points"])[0, :, 1:], 64, 64)
-    assert float((o3[2].cpu() - want).abs().max()) < 5e-3
+    assert float((o3[2].cpu() - want).abs().max()) < 3e-2
 
 
 def test_dense_api_operators_vs_reference_golden(dev, common, golden):
@@ -249,8 +253,12 @@ def test_tracker_cfg0_geometry_indices_through_the_encoder(dev, golden):
         n_clear, err = _cfg0_compare_topk(g, tk.idx[0][sample].cpu().numpy(), tk.logit[0][sample].cpu().numpy(), gap=1e-3, score_tol=1e-3)
         assert n_clear > 450
         # tighter, informative: how far the two encoders' scores are apart, and how many queries agree at a 1e-4 gap
-        report[arith] = dict(traj_err_px=d, clear_at_1e-3=n_clear, max_score_err=err)
+        report[arith] = dict(traj_err_px=d, clear_queries=n_clear, max_score_err=err)
     print("cfg0 through the encoder:", report)
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/r03_cfg0_report.json", "w") as f:
+        json.dump(report, f, indent=1)
 
 
 def test_tracker_refuses_what_it_does_not_honour(dev):
