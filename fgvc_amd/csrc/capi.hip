@@ -49,6 +49,7 @@ int normalize_nhwc_launch(const float*, float*, uint16_t*, int, int, int, int, i
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
 
 void set_conv_cot_cap(int);
+void set_conv_tall(int);
 void set_conv_narrow(int);
 void set_conv_debug(int);
 void set_corr6_skew(int);
@@ -127,6 +128,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "conv_narrow") == 0) {   // fgvc_conv_split_f32 with 64 output channels per workgroup: 1 (default) = 4-row tiles,
     set_conv_narrow(value);                 // two workgroups per CU;  0 = 8-row tiles, one workgroup per CU;  +2 = the same for 128
+    return FGVC_OK;
+  }
+  if (strcmp(name, "conv_tall") == 0) {   // fgvc_conv_split_fmt_f32, f16f8 3x3: 1 (default) = 16 x 32 x 128 tiles, 0 = the 8-row tilings
+    set_conv_tall(value);
     return FGVC_OK;
   }
   if (strcmp(name, "conv_cot_cap") == 0) {   // fgvc_conv_split_f32: at most this many output channels per workgroup (0, 64, 128)

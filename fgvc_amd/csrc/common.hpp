@@ -264,7 +264,7 @@ __device__ __forceinline__ void split_f16_4(const f32x4& x, float s, uint2& hw, 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float xs = x[i] * s;
-    ovf |= fabsf(xs) > 65504.f;
+    ovf |= fabsf(xs) > 57344.f;                       // 448 * 2^F8_AX: beyond it the e4m3 form of h would have to saturate
     const float c = __builtin_amdgcn_fmed3f(xs, -65504.f, 65504.f);
     h[i] = (_Float16)c;
     hf[i] = (float)h[i];

@@ -77,13 +77,21 @@ __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^
 // NWR = waves along the pixel rows (4: an 8-row tile, 512 threads, one workgroup per CU; 2: a 4-row tile, 256 threads,
 // small enough in LDS and registers for TWO workgroups per CU -- for the narrow layers, whose short main loop cannot hide
 // its own prologue and epilogue, the second workgroup does).
-template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0>
+// RPW = pixel rows per wave (2, or 4: the "tall" tile of the f16f8 form).  These kernels are paced by what the L2 can deliver into
+// the LDS (every workgroup streams the whole weight tensor for its tile: 2 GB per 256 -> 256 launch of an 8-frame 480p clip, 4-5 TB/s
+// of LDS-DMA against the ~6.4 TB/s the chip sustains, whatever the arithmetic).  Weight bytes per MAC fall with the PIXELS of a tile,
+// patch bytes with its output channels, and pixels x channels is bounded by the accumulators (half the register file): 16 x 32 pixels
+// x 128 channels moves 31 % fewer bytes per MAC than 8 x 32 x 256.
+template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0, int RPW = 2>
 __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel(ConvSplitParams p) {
-  static_assert(!PINNED || ARITH == 0, "the hand-scheduled stage is the bf16x3 form");
+  static_assert(RPW == 2 || RPW == 4, "pixel rows per wave");
+  static_assert(!PINNED || RPW == 2, "the all-assembly stage has two pixel rows per wave");
+  static_assert(!PINNED || ARITH == 0, "the all-assembly stage is the bf16x3 form");
+  static_assert(ARITH >= 0 && ARITH <= 2, "ARITH");
   constexpr int T = KS * KS;
   constexpr int PADK = KS / 2;                  // 1 for 3x3, 0 for 1x1
   constexpr int NW = NWR * 2;                   // waves per workgroup
-  constexpr int TROWS = NWR * 2;                // output rows per workgroup tile
+  constexpr int TROWS = NWR * RPW;              // output rows per workgroup tile
   constexpr int CV_PATCHB = (TROWS + 2) * CV_PW * 128;
   constexpr int NA = COT / 64;                  // A operands (32 output channels each) per wave
   constexpr int SPC = (T + TG - 1) / TG;        // stages per input chunk
@@ -117,7 +125,8 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       const int prow = i / PPR, pc0 = (i - prow * PPR) * 8;
       const int P = prow * CV_PW + pc0 + d_row;                       // patch pixel of this lane
       const int sl = d_slot ^ ((P >> 1) & 7);                         // logical slot that lives at this physical slot
-      const size_t gpix = ((size_t)nimg * p.Hp + (y0 + 1 - PADK + prow)) * p.Wp + (x0 + 1 - PADK + pc0 + d_row);
+      // (rows below the buffer -- a 16-row tile over a buffer padded for 8-row tiles -- read its last row: zero border)
+      const size_t gpix = ((size_t)nimg * p.Hp + imin(y0 + 1 - PADK + prow, p.Hp - 1)) * p.Wp + (x0 + 1 - PADK + pc0 + d_row);
       conv_lds_dma_16(xb + gpix * pix_bytes_in + sl * 16, lds_addr(patch + (prow * CV_PW + pc0) * 128));
     }
   };
@@ -125,30 +134,38 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   // lands while that stage multiplies; at the boundary only ds_writes remain (an LDS-DMA there exposed the whole memory
   // latency once per chunk, 15 % of the kernel; a second LDS patch buffer does not fit beside the weight ring).
   constexpr int NPIECE = (TROWS + 2 * PADK) * (4 + PADK), MAXP = (NPIECE + NW - 1) / NW;
-  static_assert(MAXP <= 8, "patch pieces per wave");
+  static_assert(MAXP <= 12, "patch pieces per wave");
   // seven named registers, not an array (as `uint4 pre[7]` touched from two lambdas hipcc left it in scratch memory), and
   // loaded by inline assembly: for loads it knows about, hipcc's own vmcnt wait before the ds_writes is computed without
   // the inline-assembly DMAs and comes out as vmcnt(0) -- draining the weight DMAs issued a moment before, i.e. exactly
   // the memory latency this was meant to hide.  The explicit counted wait below leaves those DMAs in flight.
-  uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {}, pre6 = {}, pre7 = {};
+  uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {}, pre5 = {}, pre6 = {}, pre7 = {}, pre8 = {}, pre9 = {}, pre10 = {}, pre11 = {};
   const unsigned char* xb0 = reinterpret_cast<const unsigned char*>(p.x);
 #define CV_PIECE_GEOM(J)                                                                              \
   const int pi_ = imin(wave + NW * (J), NPIECE - 1);                                                   \
   const int prow_ = pi_ / (4 + PADK), pc0_ = (pi_ - prow_ * (4 + PADK)) * 8;
+  // piece J of this wave = 8 pixels of patch row prow_: a wave-uniform base (scalar) + one lane offset.  The swizzle key of the lane's
+  // patch pixel, ((prow_ * 40 + pc0_ + d_row) >> 1) & 7, is (d_row >> 1) ^ 4 * ((prow_ + pc0_ / 8) & 1): one lane constant, XORed with 64
+  // bytes for every other piece -- no per-piece 64-bit lane addresses (hipcc hoisted twelve of them out of the stage loop and spilled them)
+  const uint32_t pf_lane_off = (uint32_t)(d_row * (int)pix_bytes_in + ((d_slot ^ (d_row >> 1)) << 4));
 #define CV_PREFETCH(J, CHUNK)                                                                         \
   if ((J) < MAXP) {                                                                                   \
     CV_PIECE_GEOM(J)                                                                                  \
-    const int P_ = prow_ * CV_PW + pc0_ + d_row;                                                      \
-    const int sl_ = d_slot ^ ((P_ >> 1) & 7);                                                         \
-    const size_t g_ = ((size_t)nimg * p.Hp + (y0 + 1 - PADK + prow_)) * p.Wp + (x0 + 1 - PADK + pc0_ + d_row); \
-    const unsigned char* a_ = xb0 + (size_t)(CHUNK) * 128 + g_ * pix_bytes_in + sl_ * 16;                      \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre##J) : "v"(a_) : "memory");                       \
+    const size_t g_ = ((size_t)nimg * p.Hp + imin(y0 + 1 - PADK + prow_, p.Hp - 1)) * p.Wp + (x0 + 1 - PADK + pc0_); \
+    const unsigned char* b_ = xb0 + (size_t)(CHUNK) * 128 + g_ * pix_bytes_in;                       \
+    const uint32_t o_ = pf_lane_off ^ (uint32_t)(((prow_ + (pc0_ >> 3)) & 1) << 6);                   \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pre##J) : "v"(o_), "s"(b_) : "memory");   \
   }
 #define CV_COMMIT(J)                                                                                  \
   if ((J) < MAXP && wave + NW * (J) < NPIECE) {                                                        \
     CV_PIECE_GEOM(J)                                                                                  \
-    *reinterpret_cast<uint4*>(patch + (prow_ * CV_PW + pc0_) * 128 + lane * 16) = pre##J;             \
+    /* the address is formed HERE (volatile): as loop-invariant C++ hipcc kept one address register per piece across the stage loop */ \
+    uint32_t a_;                                                                                      \
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(a_) : "s"(lds_addr(patch) + (uint32_t)((prow_ * CV_PW + pc0_) * 128)), "v"(lane16)); \
+    const i32x4 t_ = __builtin_bit_cast(i32x4, pre##J);                                               \
+    asm volatile("ds_write_b128 %0, %1" ::"v"(a_), "v"(t_) : "memory");                               \
   }
+  const uint32_t lane16 = (uint32_t)lane * 16u;
   const uint32_t w_lane_off = (uint32_t)(d_row * 128 + ((d_slot ^ (d_row >> 1)) << 4));
   // one 1-KiB piece (8 output channels of one tap) of the weight slab of stage q = chunk * SPC + tap group
   auto stage_weight_piece = [&](int q, int j) {
@@ -162,18 +179,20 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     // for every other piece
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
                               ((((size_t)tap * nchunk + chunk) * p.Cout + co_base) + c0) * 128;
-    conv_lds_dma_16s(w_lane_off ^ (uint32_t)((c0 & 8) << 3), wb, lds_addr(dst + (tg * COT + c0) * 128));
+    uint32_t wo_;                                                    // (volatile: not another lane constant held across the stage loop)
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(wo_) : "s"((uint32_t)((c0 & 8) << 3)), "v"(w_lane_off));
+    conv_lds_dma_16s(wo_, wb, lds_addr(dst + (tg * COT + c0) * 128));
   };
   auto stage_weights = [&](int q) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) stage_weight_piece(q, j);
   };
 
-  f32x16 acc[NA][2];
+  f32x16 acc[NA][RPW];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < RPW; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -203,6 +222,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       // inline-assembly DMAs and would otherwise wait for the ones issued a moment ago
       CV_PREFETCH(0, chunk + 1) CV_PREFETCH(1, chunk + 1) CV_PREFETCH(2, chunk + 1) CV_PREFETCH(3, chunk + 1)
       CV_PREFETCH(4, chunk + 1) CV_PREFETCH(5, chunk + 1) CV_PREFETCH(6, chunk + 1) CV_PREFETCH(7, chunk + 1)
+      CV_PREFETCH(8, chunk + 1) CV_PREFETCH(9, chunk + 1) CV_PREFETCH(10, chunk + 1) CV_PREFETCH(11, chunk + 1)
       __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of this stage's MFMAs
     }
     // the weight DMAs of stage q+LA (its slot held stage q-1, which every wave has finished) are issued between the MFMA
@@ -283,73 +303,94 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       }
 #undef CVR
 #undef CVM
-    } else if constexpr (ARITH == 1 || ARITH == 3) {
-      // ---- f16f8: per tap two K-16 steps of the f16 main product, then ONE K-64 fp8 MFMA per tile for both cross sums
-      // E8M0 scales of this lane half (byte value 127 + log2; unsigned: 129 * 0x01010101 does not fit an int), in all four bytes
+    } else if constexpr (ARITH == 1) {
+      // ---- f16f8.  Per tap and wave: NA "F" blocks (output-channel tile a: the two K-16 steps of the f16 main product against both
+      // pixel rows, 4 MFMAs = 128 pipe cycles) and NA "X" blocks (the K-64 fp8 MFMA of both cross sums against both pixel rows, 2 MFMAs
+      // = 128 cycles).  Left to itself hipcc keeps ONE set of weight-fragment registers and waits for every read right in front of the
+      // MFMAs that use it (ds_read, s_waitcnt lgkmcnt(0), two MFMAs, ds_read, ...): the whole LDS round trip of every block lies open
+      // and only the SIMD's other wave covers it (0.50 ms for the 256 -> 256 layer of an 8-frame 480p clip).  Here the blocks of a
+      // stage are software-pipelined by hand: the fragments of block g + 2 are read right after block g's MFMAs have issued, the pixel
+      // fragments of a phase during the phase before, and scheduling fences keep hipcc from folding the order back; its own counted
+      // lgkmcnt waits then come out right (the LDS returns a wave's reads in order).
+      static_assert(T % TG == 0, "whole tap groups");
       const uint32_t sa_ = h ? (uint32_t)(127 - F8_BW) : (uint32_t)(127 + F8_AW), sb_ = h ? (uint32_t)(127 + F8_AX) : (uint32_t)(127 - F8_BX);
-      const int scale_a = (int)(sa_ * 0x01010101u), scale_b = (int)(sb_ * 0x01010101u);
+      const int scale_a = (int)(sa_ * 0x01010101u), scale_b = (int)(sb_ * 0x01010101u);   // E8M0 scales of this lane's block (127 + log2), every byte
+      constexpr int NRP = RPW / 2;                    // pixel-row pairs of this wave: a tap's blocks run pair by pair (the weight fragments
+                                                      // are read once per pair, the pixel fragments of ONE pair are live at a time)
+      constexpr int NB = 2 * NA;                      // blocks per (tap, row pair)
+      constexpr int NBLK = TG * NRP * NB;             // blocks per stage
+      constexpr int LOOK = RPW == 4 ? 1 : 2;          // weight fragments are read LOOK blocks ahead, into LOOK buffers (the tall tile's
+                                                      // twelve patch-prefetch pieces leave registers for one buffer only)
+      f16x8 af[LOOK][2];                              // [buffer][K-16 step]: F block g lives in buffer g % LOOK
+      i32x8 ax[LOOK];                                 // X block g lives in buffer g % LOOK
+      f16x8 bf[2][2];                                 // [pixel row][K-16 step] of the current tap
+      i32x8 bx[2];                                    // [pixel row] fp8 operand of the current tap
+      auto w_row = [&](int g) {                       // LDS row of block g's weight fragment for this lane
+        const int tg = g / (NRP * NB), a = (g % NB) % NA;
+        return wslot + tg * COT * 128 + (ch * (COT / 2) + a * 32 + n) * 128;
+      };
+      auto kx = [&](int g) { return ((ch * (COT / 2) + ((g % NB) % NA) * 32 + n) >> 1) & 7; };
+      auto load_block = [&](int g) {
+        if (g >= NBLK) return;
+        const unsigned char* r = w_row(g);
+        const int k = kx(g);
+        if ((g % NB) < NA) {
+          af[g % LOOK][0] = *reinterpret_cast<const f16x8*>(r + (((0 + h) ^ k) << 4));
+          af[g % LOOK][1] = *reinterpret_cast<const f16x8*>(r + (((2 + h) ^ k) << 4));
+        } else {
+          const i32x4 u = *reinterpret_cast<const i32x4*>(r + (((4 + h) ^ k) << 4)), v = *reinterpret_cast<const i32x4*>(r + (((6 + h) ^ k) << 4));
+          ax[g % LOOK] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        }
+      };
+      auto load_bf = [&](int u_) {                    // u_ = tg * NRP + row pair
+        const int tg = u_ / NRP, rp = u_ % NRP;
+        const int tap = sg * TG + tg, dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
-      for (int tg = 0; tg < TG; ++tg) {
-        const int tap = sg * TG + tg;
-        if (tap >= T) break;                          // wave-uniform: short last tap group
-        const int dy = tap / KS, dx = tap - dy * KS;
-        const unsigned char* wt = wslot + tg * COT * 128;
+        for (int b = 0; b < 2; ++b) {
+          const int P = (RPW * pr + 2 * rp + b + dy) * CV_PW + n + dx;
+          bf[b][0] = *reinterpret_cast<const f16x8*>(patch + cv_swz(P, 0 + h));
+          bf[b][1] = *reinterpret_cast<const f16x8*>(patch + cv_swz(P, 2 + h));
+        }
+      };
+      auto load_bx = [&](int u_) {
+        const int tg = u_ / NRP, rp = u_ % NRP;
+        const int tap = sg * TG + tg, dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
-        for (int ph = 0; ph < 3; ++ph) {
-          if (ph < 2) {
-            f16x8 ah[NA], bh[2];
+        for (int b = 0; b < 2; ++b) {
+          const int P = (RPW * pr + 2 * rp + b + dy) * CV_PW + n + dx;
+          const i32x4 u = *reinterpret_cast<const i32x4*>(patch + cv_swz(P, 4 + h)), v = *reinterpret_cast<const i32x4*>(patch + cv_swz(P, 6 + h));
+          bx[b] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        }
+      };
+      load_bf(0);
 #pragma unroll
-            for (int a = 0; a < NA; ++a) ah[a] = *reinterpret_cast<const f16x8*>(wt + cv_swz(ch * (COT / 2) + a * 32 + n, 2 * ph + h));
+      for (int g = 0; g < LOOK; ++g) load_block(g);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bh[b] = *reinterpret_cast<const f16x8*>(patch + cv_swz((2 * pr + b + dy) * CV_PW + n + dx, 2 * ph + h));
-            if ((p.debug & 4) == 0) {
+      for (int g = 0; g < NBLK; ++g) {
+        const int u_ = g / NB, kb = g % NB, a = kb % NA, r0 = 2 * (u_ % NRP);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb < NA) {
 #pragma unroll
-              for (int a = 0; a < NA; ++a)
+          for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-            }
-          } else {
-            i32x8 a8[NA], b8[2];
+            for (int b = 0; b < 2; ++b) acc[a][r0 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g % LOOK][s_], bf[b][s_], acc[a][r0 + b], 0, 0, 0);
+        } else {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-              const int co = ch * (COT / 2) + a * 32 + n;
-              const i32x4 u = *reinterpret_cast<const i32x4*>(wt + cv_swz(co, 4 + h)), v = *reinterpret_cast<const i32x4*>(wt + cv_swz(co, 6 + h));
-              a8[a] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-            }
+          for (int b = 0; b < 2; ++b)
+            acc[a][r0 + b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[g % LOOK], bx[b], acc[a][r0 + b], 0, 0, 0, scale_a, 0, scale_b);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_block(g + LOOK);                         // into the buffer block g just left
+        if (kb == (NA > 1 ? 1 : 0)) load_bx(u_);      // the pair's fp8 pixel operands: needed NA - 1 blocks from here
+        if (kb == NB - 2 + (NA > 1 ? 0 : 1) && u_ + 1 < TG * NRP) load_bf(u_ + 1);   // the next (tap, pair)'s f16 pixel operands, during this one's X phase
+        if (stage_more) {                             // this block's share of the PPW weight pieces, behind its MFMAs
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              const int P = (2 * pr + b + dy) * CV_PW + n + dx;
-              const i32x4 u = *reinterpret_cast<const i32x4*>(patch + cv_swz(P, 4 + h)), v = *reinterpret_cast<const i32x4*>(patch + cv_swz(P, 6 + h));
-              b8[b] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-            }
-            if ((p.debug & 4) == 0) {
-#pragma unroll
-              for (int a = 0; a < NA; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                  if constexpr (ARITH == 3) {
-                    // A/B form (conv_debug & 128): the cross sums go through a ZERO accumulator and are added by the vector unit -- to see
-                    // whether adding 64 products of ~2^-17 of a large running sum inside the scaled MFMA costs accuracy (it does not:
-                    // same error as the direct form, 1.7x the time)
-                    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    acc[a][b] += __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[a], b8[b], z, 0, 0, 0, scale_a, 0, scale_b);
-                  } else {
-                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[a], b8[b], acc[a][b], 0, 0, 0, scale_a, 0, scale_b);
-                  }
-                }
-            }
-          }
-          if (stage_more) {                           // this phase's share of the PPW weight pieces, behind its MFMAs
-            constexpr int NIT = TG * 3;
-            const int it = tg * 3 + ph;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < PPW; ++j)
-              if (j * NIT / PPW == it) stage_weight_piece(q + LA, j);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          for (int j = 0; j < PPW; ++j)
+            if (j * NBLK / PPW == g) stage_weight_piece(q + LA, j);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     } else
 #pragma unroll
     for (int tg = 0; tg < TG; ++tg) {
@@ -358,7 +399,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       const int dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {                 // two k16 steps per 32-channel chunk
-        bf16x8 ah[NA], al[NA], bh[2], bl[2];
+        bf16x8 ah[NA], al[NA], bh[RPW], bl[RPW];
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
           const int co = ch * (COT / 2) + a * 32 + n;
@@ -366,8 +407,8 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
           al[a] = *reinterpret_cast<const bf16x8*>(wslot + tg * COT * 128 + cv_swz(co, 4 + 2 * s + h));
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int P = (2 * pr + b + dy) * CV_PW + n + dx;
+        for (int b = 0; b < RPW; ++b) {
+          const int P = (RPW * pr + b + dy) * CV_PW + n + dx;
           bh[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 2 * s + h));
           bl[b] = *reinterpret_cast<const bf16x8*>(patch + cv_swz(P, 4 + 2 * s + h));
         }
@@ -375,7 +416,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
 #pragma unroll
           for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < RPW; ++b) {
               if constexpr (ARITH == 2) {             // (h, l) f16 operands: the same three products on the f16 form
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[a]), __builtin_bit_cast(f16x8, bh[b]), acc[a][b], 0, 0, 0);
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[a]), __builtin_bit_cast(f16x8, bl[b]), acc[a][b], 0, 0, 0);
@@ -399,7 +440,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       }
     }
     if (timing) {
-      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[NA - 1][1][15]));
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[NA - 1][RPW - 1][15]));
       c3 = __builtin_amdgcn_s_memtime();
       t_wait += c1 - c0; t_issue += c2 - c1; t_mma += c3 - c2;
     }
@@ -408,6 +449,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // weight DMAs stay in flight
       lds_barrier();                                // everyone is done reading this chunk's patch
       CV_COMMIT(0) CV_COMMIT(1) CV_COMMIT(2) CV_COMMIT(3) CV_COMMIT(4) CV_COMMIT(5) CV_COMMIT(6) CV_COMMIT(7)   // visible after the
+      CV_COMMIT(8) CV_COMMIT(9) CV_COMMIT(10) CV_COMMIT(11)
                                                                                                   // next stage's barrier
       if (timing) t_bound += __builtin_amdgcn_s_memtime() - c3;
     }
@@ -444,8 +486,8 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int y = y0 + 2 * pr + b;
+  for (int b = 0; b < RPW; ++b) {
+    const int y = y0 + RPW * pr + b;
     if (y >= p.H) continue;                       // wave-uniform
     const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);   // pixel of lane n = 0 in the padded split tensor
     const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;                 // ... and in the dense f32 tensors
@@ -882,6 +924,8 @@ static int g_conv_narrow = 1;       // bit 0: 64-channel layers, bit 1: 128-chan
 void set_conv_narrow(int v) { g_conv_narrow = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
 void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
+static int g_conv_tall = 0;        // f16f8, 3x3, Cout % 128 == 0: 1 = 16 x 32 pixels x 128 channels per workgroup (experiment: 68 bytes of scratch)
+void set_conv_tall(int v) { g_conv_tall = v; }
 
 template <int ARITH>
 static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int cot_eff, bool narrow, hipStream_t s) {
@@ -914,8 +958,11 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
-  if (in_fmt == 1 && (g_conv_debug & 128)) conv_split_dispatch<3>(p, grid, KS, cot_eff, narrow, s);    // A/B: cross sums through a zero accumulator + vector adds
-  else if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
+  if (in_fmt == 1 && KS == 3 && Cout % 128 == 0 && g_conv_tall && !g_conv_cot_cap) {
+    // the tall tile: 4 pixel rows per wave, 128 output channels per workgroup, a 4-slot weight ring (157.7 KB of LDS)
+    p.n_ty = cdiv(H, 16);
+    conv_split_kernel<3, 128, 1, 4, 4, false, 1, 4><<<dim3(p.n_ty * p.n_tx * N, Cout / 128), 512, 0, s>>>(p);
+  } else if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 2) conv_split_dispatch<2>(p, grid, KS, cot_eff, narrow, s);
   else if (KS == 3 && cot_eff == 256 && out_fmt == 0 && (g_conv_debug & 32)) conv_split_kernel_4x4<<<grid, 256, 0, s>>>(p);   // A/B: one wave per SIMD, 4 x 4 register tile
   else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16)) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads

@@ -56,6 +56,14 @@ for Cin, Cout, KS, H, W in [(256, 256, 3, 120, 214), (128, 256, 3, 120, 214), (1
         forms["f16f8 cot128"] = (with_opts(base[0], 128, 1), with_opts(base[1], 128, 1))
         forms["f16f8 cot128 4-row"] = (with_opts(base[0], 128, 3), with_opts(base[1], 128, 3))
         forms["f16f8 cot64 4-row"] = (with_opts(base[0], 64, 1), with_opts(base[1], 64, 1))
+
+        def tall(fn):
+            def run():
+                ops.set_option("conv_tall", 1)
+                fn()
+                ops.set_option("conv_tall", 0)
+            return run
+        forms["f16f8 tall 16x32x128"] = (tall(base[0]), tall(base[1]))
     times = {k: [[], []] for k in forms}
     for r in range(a.rounds + 1):
         for k, fns in forms.items():
