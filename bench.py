@@ -46,6 +46,7 @@ SPLIT_PRODUCTS = 4                # partial products per f32-grade product in fg
 # f16f8 = one f16 product + both cross sums in one K-64 fp8 MFMA (half a unit each)
 CONV_UNITS = {"bf16x3": 3.0, "f16x3": 3.0, "f16f8": 2.0}
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+STORE_CEILING_GBPS = 5680.0       # measured: plain dword stores over a 2.64 GB footprint (profiles/r03_store_footprint.log)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: 8 x 480x854 -> stride-4 features 120x214x256
@@ -545,8 +546,8 @@ def main():
                "f32": lambda: ops.corr_volume(feats2[1], feats2[0], 0.07, "f32", out=vol),
                "bf16": lambda: ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol)}
         res = {k: [] for k in fns}
-        for rnd in range(4):                                           # round-robin: the first kernel timed in a process runs slow
-            for name, fn in fns.items():
+        for rnd in range(7):                                           # round-robin: the first kernel timed in a process runs slow;
+            for name, fn in fns.items():                               # round 0 is dropped, the MEDIAN of the other six is reported
                 fn()
                 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
                 for e0, e1 in evs:
@@ -554,8 +555,9 @@ def main():
                 torch.cuda.synchronize()
                 if rnd:
                     res[name].append(sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs))
-        var = {k: {"ms": sum(v) / len(v), "ms_min": min(v), "achieved": gbytes / (sum(v) / len(v) * 1e-3),
-                   "frac": gbytes / (sum(v) / len(v) * 1e-3) / HBM_PEAK_GBPS} for k, v in res.items()}
+        med = lambda v: sorted(v)[len(v) // 2]
+        var = {k: {"ms": med(v), "ms_min": min(v), "ms_max": max(v), "rounds": len(v), "achieved": gbytes / (med(v) * 1e-3),
+                   "frac": gbytes / (med(v) * 1e-3) / HBM_PEAK_GBPS} for k, v in res.items()}
         var["f16f6"]["max_abs_err_bound"] = "1e-3 logit (tests); measured 6e-5 on Gaussian rows, 8e-5 against bf16x3 at 720p"
         var["f16f8"]["max_abs_err_bound"] = "1e-3 logit (tests); measured 4e-5 on Gaussian rows, 8e-5 against bf16x3 at 720p"
         var["bf16x3"]["max_abs_err_bound"] = "1e-3 logit (tests); measured 2e-5"
@@ -567,11 +569,13 @@ def main():
             "ms_per_corr_volume": var["f16f6"]["ms"],
             "roofline": {"kernel": "fgvc_corr_volume_f16f6", "bound": "hbm", "achieved": var["f16f6"]["achieved"],
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": var["f16f6"]["frac"],
-                         "write_rate_ceiling_note": "pure-store kernels of any shape write this volume at 5.2-5.4 TB/s on MI355X "
-                                                    "(tools/micro/store_rate.hip): 0.65-0.67 of the 8 TB/s the fraction is priced against",
+                         "ceiling_gbps": STORE_CEILING_GBPS, "ceiling_frac": var["f16f6"]["achieved"] / STORE_CEILING_GBPS,
+                         "write_rate_ceiling_note": "pure stores over a 2.64 GB footprint run at 5.43 (nt) - 5.68 (plain) TB/s on MI355X, 7.2-7.4 "
+                                                    "TB/s while the footprint fits the 256 MB Infinity Cache (tools/micro/store_footprint.hip, "
+                                                    "profiles/r03_store_footprint.log): 0.68-0.71 of the 8 TB/s `frac` is priced against",
                          "traffic": pm.get("hbm_bytes_per_launch"), "mfma_util": pm.get("mfma_util"),
                          "bytes_per_launch": gbytes * 1e9,
-                         "note": "mean of 3 rounds x 10 launches (HIP events), round-robin with the other variants"},
+                         "note": "median of 6 rounds x 10 launches (HIP events), round-robin with the other variants, first round dropped"},
             "variants": var,
         }
         del vol

@@ -252,8 +252,11 @@ def test_tracker_cfg0_geometry_indices_through_the_encoder(dev, golden):
         assert not ops.pair_f16x3_timed_out()
         n_clear, err = _cfg0_compare_topk(g, tk.idx[0][sample].cpu().numpy(), tk.logit[0][sample].cpu().numpy(), gap=1e-3, score_tol=1e-3)
         assert n_clear > 450
-        # tighter, informative: how far the two encoders' scores are apart, and how many queries agree at a 1e-4 gap
-        report[arith] = dict(traj_err_px=d, clear_queries=n_clear, max_score_err=err)
+        # ten times tighter than the north_star asks: measured score errors are 2-4e-5 logit in every arithmetic, so the indices must
+        # also agree on every query whose ranks are 1e-4 apart (510 of the 512), and the scores within 1e-4
+        n_tight, _ = _cfg0_compare_topk(g, tk.idx[0][sample].cpu().numpy(), tk.logit[0][sample].cpu().numpy(), gap=1e-4, score_tol=1e-4)
+        assert n_tight >= 505
+        report[arith] = dict(traj_err_px=d, clear_queries_gap_1e_3=n_clear, clear_queries_gap_1e_4=n_tight, max_score_err=err)
     print("cfg0 through the encoder:", report)
     import json, os
     os.makedirs("gpurun_out", exist_ok=True)

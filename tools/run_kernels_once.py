@@ -1,5 +1,5 @@
 """A few launches each of the roofline kernels at the bench shapes (cfg2: 8 x 480x854 -> 120x214x256), for rocprofv3 --pmc passes
-(tools/pmc_report.py turns the result directories into profiles/r02_pmc.json).  Run the interpreter directly after `--`."""
+(tools/pmc_report.py turns the result directories into profiles/r03_pmc.json).  Run the interpreter directly after `--`."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,14 +26,17 @@ for _ in range(3):
     ops.corr_volume(hl[1], hl[0], 0.07, "bf16", out=vol)
     ops.corr_volume(feats[1], feats[0], 0.07, "f32", out=vol)
 torch.cuda.synchronize()
-# one 256 -> 256 3x3 split-bf16 convolution at the layer-3 size
+# one 256 -> 256 3x3 convolution at the layer-3 size: the f16f8 form (round 3's default: ARITH 1 in the kernel's name) and the bf16x3 form
 wt = torch.randn(256, 256, 3, 3, device=dev) * 0.02
 bn = torch.nn.BatchNorm2d(256).eval().to(dev)
 wp, bs = ops.prepare_conv_split(wt, bn)
 xs = ops.nchw_to_split_nhwc(torch.relu(torch.randn(T, 256, H, W, device=dev)))
 ys = ops.alloc_split_nhwc(T, 256, H, W, dev)
+wp8, bs8, sw8 = ops.prepare_conv_split_f16(wt, bn, ops.ACT_F16F8)
+ovf = torch.zeros(1, dtype=torch.int32, device=dev)
 for _ in range(3):
     ops.conv_split(xs, wp, bs, H, W, True, out_split=ys)
+    ops.conv_split(xs, wp8, bs8, H, W, True, out_split=ys, in_fmt=ops.ACT_F16F8, in_scale_log2=sw8, out_fmt=ops.ACT_F16F8, out_scale_log2=0, overflow=ovf)
 torch.cuda.synchronize()
 # layer 1 (64 -> 64, register-resident weights), the stem and the stride-2 block of layer 2 at the 480p clip's sizes
 frames = torch.randn(T, 3, 480, 854, device=dev)
