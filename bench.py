@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak (no sparsity)
-SPLIT_PRODUCTS = 4                # partial products per f32-grade product in fgvc_pair_topk_bf16x4 (hi*hi, hi*lo, lo*hi, lo*lo)
+SPLIT_PRODUCTS = 3                # partial products per f32-grade product in fgvc_pair_topk_f16x3 (h*h, l*h, h*l)
 # pipe units (16-bit MFMA times) per f32-grade product of fgvc_conv_split_f32, by arithmetic: bf16x3 / f16x3 = three 16-bit products,
 # f16f8 = one f16 product + both cross sums in one K-64 fp8 MFMA (half a unit each)
 CONV_UNITS = {"bf16x3": 3.0, "f16x3": 3.0, "f16f8": 2.0}
@@ -236,10 +236,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr-volume", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="MIOpen immediate mode (clean profiles)")
-    ap.add_argument("--pair-fmt", default="f16", choices=["f16", "bf16"],
-                    help="operands of the split pair kernel: f16 = fgvc_pair_topk_f16x3 (default), bf16 = fgvc_pair_topk_bf16x4 (A/B)")
     ap.add_argument("--pair-precision", default="auto", choices=["auto", "f32", "split"],
-                    help="pair top-k kernel: split = fgvc_pair_topk_bf16x4 (default where it applies), f32 = fgvc_pair_topk_f32")
+                    help="pair top-k kernel: split = fgvc_pair_topk_f16x3 (default where it applies), f32 = fgvc_pair_topk_f32")
     ap.add_argument("--encoder-lanes", type=int, default=None,
                     help="batch slices of the encoder run on this many HIP streams at once (default: ResNet.split_lanes)")
     ap.add_argument("--sync-tail", action="store_true",
@@ -249,6 +247,7 @@ def main():
                     help="what runs on the side stream: the label sweep + read-out only, or everything after the encoder (pair top-k, "
                          "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
+    ap.add_argument("--no-res-split", action="store_true", help="layer-1 identities as dense f32 copies instead of the split form (A/B)")
     ap.add_argument("--enc-arith", default=None, choices=["f16f8", "bf16x3", "f16x3"],
                     help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f8; bf16x3 = round 2's)")
     ap.add_argument("--no-clips-line", action="store_true", help="skip the extra `--mode clips` measurement that a `video` run appends")
@@ -293,11 +292,12 @@ def main():
         ResNet.split_lanes = a.encoder_lanes
     if a.no_conv64:
         ResNet.use_conv64 = False
+    if a.no_res_split:
+        ResNet.res_from_split = False
     model = build_tracker(wl, dev)
     if a.enc_arith:
         model.backbone.set_arith(a.enc_arith)
     arith = model.backbone.arith
-    model.test_cfg["pair_split_fmt"] = a.pair_fmt                    # the encoder writes the bank in the pair kernel's operand format
     cfg = model.engine_config()
     cfg.pair_precision = a.pair_precision
     cfg.regroup = False                                              # all points are given at frame 0 of the video
@@ -424,8 +424,8 @@ def main():
         fl = 2.0 * HW * n_disc * C * pair_tag[1]                       # windowed FLOPs of the launch's pairs
         f32_tf = fl / (pair_ms * 1e-3) / 1e12
         split = pair_tag[0] == "pair_split"
-        name = ("fgvc_pair_topk_f16x3" if cfg.pair_split_fmt == "f16" else "fgvc_pair_topk_bf16x4") if split else "fgvc_pair_topk_f32"
-        n_prod = (3 if cfg.pair_split_fmt == "f16" else SPLIT_PRODUCTS) if split else 1
+        name = "fgvc_pair_topk_f16x3" if split else "fgvc_pair_topk_f32"
+        n_prod = SPLIT_PRODUCTS if split else 1
         pm = pmc(name)
         kernels["pair_topk"] = {
             "kernel": name, "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS,

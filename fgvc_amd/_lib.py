@@ -27,7 +27,6 @@ SIGNATURES = {
     "fgvc_r2max_for_radius": (_i, [_f]),
     "fgvc_normalize_chw_to_hwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_pair_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
-    "fgvc_pair_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "fgvc_pair_topk_f16x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "fgvc_pair_topk_f16x3_runs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "fgvc_split_f16x2": (_i, [_p, _p, C.c_int64, _i, _p]),
@@ -37,6 +36,7 @@ SIGNATURES = {
     "fgvc_conv_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_conv64_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_conv64_split_res_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_s2_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_s2_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_stem7_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -60,7 +60,6 @@ SIGNATURES = {
     "fgvc_dense_kth_f32": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "fgvc_dense_propagate_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "fgvc_local_corr_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
-    "fgvc_local_corr_topk_bf16x4": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "fgvc_local_corr_topk_f16x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "fgvc_topk_coord_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_c2f_refine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p]),

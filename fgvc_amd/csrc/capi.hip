@@ -42,26 +42,21 @@ int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const floa
                       int, int, int, int, int, int, int, int, int*, hipStream_t);
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
                    int, int, int, int, int*, hipStream_t);
-int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
+int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, const uint16_t*, uint16_t*, float*, int, int, int, int, int, int,
+                  hipStream_t);
 int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int normalize_nhwc_launch(const float*, float*, uint16_t*, int, int, int, int, int, int, hipStream_t);
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
 
 void set_conv_cot_cap(int);
-void set_conv_tall(int);
 void set_conv_narrow(int);
 void set_conv_debug(int);
 void set_corr6_skew(int);
 void set_corr6_sdma(int);
-void set_pair_kernel(int);
 void set_pair_debug(int);
-void set_pair_v4_debug(int);
 void set_readout_prune(int);
 void set_conv_s2_debug(int);
-void set_pair_v4_products(int);
-int pair_topk_v4_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, int32_t*,
-                        float*, hipStream_t);
 int split_f16x2_launch(const float*, uint16_t*, long long, int, hipStream_t);
 int pair_topk_v5_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, const int32_t*,
                         int, int32_t*, float*, hipStream_t);
@@ -93,11 +88,6 @@ const char* fgvc_last_error(void) { return g_err; }
 
 int fgvc_set_option(const char* name, int value) {
   FGVC_REQUIRE(name != nullptr, FGVC_ERR_INVALID_ARG, "fgvc_set_option: null name");
-  if (strcmp(name, "pair_kernel") == 0) {
-    FGVC_REQUIRE(value >= 1 && value <= 3, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_kernel must be 1, 2 or 3");
-    set_pair_kernel(value);
-    return FGVC_OK;
-  }
   if (strcmp(name, "corr_debug") == 0) {   // profiling ablation: 1 = bf16 volume kernels skip their stores
     set_corr_debug(value);
     return FGVC_OK;
@@ -130,27 +120,13 @@ int fgvc_set_option(const char* name, int value) {
     set_conv_narrow(value);                 // two workgroups per CU;  0 = 8-row tiles, one workgroup per CU;  +2 = the same for 128
     return FGVC_OK;
   }
-  if (strcmp(name, "conv_tall") == 0) {   // fgvc_conv_split_fmt_f32, f16f8 3x3: 1 (default) = 16 x 32 x 128 tiles, 0 = the 8-row tilings
-    set_conv_tall(value);
-    return FGVC_OK;
-  }
   if (strcmp(name, "conv_cot_cap") == 0) {   // fgvc_conv_split_f32: at most this many output channels per workgroup (0, 64, 128)
     FGVC_REQUIRE(value == 0 || value == 64 || value == 128, FGVC_ERR_INVALID_ARG, "fgvc_set_option: conv_cot_cap must be 0, 64 or 128");
     set_conv_cot_cap(value);
     return FGVC_OK;
   }
-  if (strcmp(name, "pair_bf16_products") == 0) {   // 4 (default): hi*hi + hi*lo + lo*hi + lo*lo.  3 drops lo*lo: 12 % faster, but
-                                                   // for similar vectors that term is a one-signed ~4e-6, not noise
-    FGVC_REQUIRE(value == 3 || value == 4, FGVC_ERR_INVALID_ARG, "fgvc_set_option: pair_bf16_products must be 3 or 4");
-    set_pair_v4_products(value);
-    return FGVC_OK;
-  }
   if (strcmp(name, "pair_f16_debug") == 0) {   // fgvc_pair_topk_f16x3 ablations (results wrong): 1 = no selection, 2 = no MFMA, 4 = no staging,
     set_pair_v5_debug(value);                  // 16 = prologue only, 32 = no epilogue, 64 = no main loop
-    return FGVC_OK;
-  }
-  if (strcmp(name, "pair_bf16_debug") == 0) {   // same for fgvc_pair_topk_bf16x4: 1 = no selection, 2 = no MFMA, 4 = no staging
-    set_pair_v4_debug(value);
     return FGVC_OK;
   }
   if (strcmp(name, "conv_s2_debug") == 0) {   // profiling ablations of fgvc_conv_s2_split_f32; results are wrong when non-zero
@@ -207,29 +183,6 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
                           score_out, (hipStream_t)stream);
 }
 
-int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq,
-                          int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
-                          float* score_out, void* stream) {
-  FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_bf16x4: null pointer");
-  FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
-               "fgvc_pair_topk_bf16x4: qsplit/ksplit/pairs must be 16-byte aligned");
-  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: C=%d unsupported (256 only; use fgvc_pair_topk_f32)", C);
-  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && n_pairs >= 0, FGVC_ERR_INVALID_ARG,
-               "fgvc_pair_topk_bf16x4: bad shape Hq=%d Wq=%d Hk=%d Wk=%d n_pairs=%d", Hq, Wq, Hk, Wk, n_pairs);
-  FGVC_REQUIRE(topk >= 1 && topk <= 10, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: topk=%d outside 1..10", topk);
-  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_bf16x4: negative mask parameter");
-  FGVC_REQUIRE(n_pairs <= 65535, FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: n_pairs=%d > 65535 per call", n_pairs);
-  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
-  FGVC_REQUIRE(!any_limit || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG,
-               "fgvc_pair_topk_bf16x4: a spatial mask needs equal query/key grids (local_attention.py:331)");
-  FGVC_REQUIRE(Hk < 32768 && Wk < 32768 && Hq < 32768 && Wq < 32768 && (long long)Hk * Wk < (1ll << 30) &&
-                   (long long)Hq * Wq < (1ll << 30),
-               FGVC_ERR_UNSUPPORTED, "fgvc_pair_topk_bf16x4: grid too large");
-  if (n_pairs == 0) return FGVC_OK;
-  return pair_topk_v4_launch(qsplit, ksplit, pairs, n_pairs, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked != 0 && any_limit,
-                             idx_out, score_out, (hipStream_t)stream);
-}
-
 int fgvc_split_f16x2(const float* feat, uint16_t* h_l, int64_t n_pixels, int C, void* stream) {
   FGVC_REQUIRE(feat && h_l, FGVC_ERR_INVALID_ARG, "fgvc_split_f16x2: null pointer");
   FGVC_REQUIRE(n_pixels >= 0 && C > 0 && C % 4 == 0, FGVC_ERR_INVALID_ARG, "fgvc_split_f16x2: C must be a multiple of 4");
@@ -278,7 +231,7 @@ int fgvc_pair_topk_f16x3_runs(const uint16_t* qsplit, const uint16_t* ksplit, co
                            runs, n_runs, idx_out, score_out, stream);
 }
 
-/* debug: the 32 s_memtime words one workgroup leaves with fgvc_set_option("pair_f16_debug", 256) (tools/time_pair_v5.py) */
+/* debug: the 32 s_memtime words one workgroup leaves with fgvc_set_option("pair_f16_debug", 256) (tools/experiments/time_pair_v5.py) */
 int fgvc_pair_topk_f16x3_probe(int64_t* out32) {
   if (!out32 || hipDeviceSynchronize() != hipSuccess) return FGVC_ERR_INVALID_ARG;
   return pair_v5_probe_read(reinterpret_cast<long long*>(out32)) == 0 ? FGVC_OK : FGVC_ERR_LAUNCH;
@@ -452,23 +405,6 @@ int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32
                             weight_out, (hipStream_t)stream);
 }
 
-int fgvc_local_corr_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_slots, int C,
-                                int H, int W, int R, int topk, float temperature, int32_t* pair_idx_ws,
-                                float* pair_score_ws, int32_t* idx_out, float* logit_out, float* weight_out,
-                                void* stream) {
-  FGVC_REQUIRE(pair_idx_ws && pair_score_ws && idx_out && logit_out && weight_out, FGVC_ERR_INVALID_ARG,
-               "fgvc_local_corr_topk_bf16x4: null pointer");
-  FGVC_REQUIRE(R >= 0 && n_slots >= 1 && temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_local_corr_topk_bf16x4: bad R/n_slots/temperature");
-  FGVC_REQUIRE((long long)n_slots * (2 * R + 1) * (2 * R + 1) < (1ll << 31), FGVC_ERR_UNSUPPORTED,
-               "fgvc_local_corr_topk_bf16x4: index overflow");
-  // every slot of a local window is a masked pair (the window IS the mask): all_masked = 1
-  int rc = fgvc_pair_topk_bf16x4(qsplit, ksplit, pairs, n_slots, C, H, W, H, W, FGVC_NO_LIMIT, R, R, topk, 1, pair_idx_ws,
-                                 pair_score_ws, stream);
-  if (rc != FGVC_OK) return rc;
-  return local_merge_launch(pair_idx_ws, pair_score_ws, n_slots, H, W, R, topk, temperature, idx_out, logit_out,
-                            weight_out, (hipStream_t)stream);
-}
-
 int fgvc_local_corr_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_slots, int C,
                                int H, int W, int R, int topk, float temperature, int32_t* pair_idx_ws,
                                float* pair_score_ws, int32_t* idx_out, float* logit_out, float* weight_out,
@@ -562,14 +498,23 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
 
 int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                           float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, void* stream) {
+  return fgvc_conv64_split_res_f32(x, w, bias, residual, nullptr, y_split, y_f32, N, H, W, Hp, Wp, relu, stream);
+}
+
+int fgvc_conv64_split_res_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
+                              const uint16_t* residual_split, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp,
+                              int relu, void* stream) {
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: null pointer");
+  FGVC_REQUIRE(!(residual && residual_split), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_res_f32: one residual, f32 or split, not both");
   FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: bad shape");
   FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
-  FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(y_split) && aligned16(y_f32),
+  FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(residual_split) && aligned16(y_split) &&
+                   aligned16(y_f32),
                FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: 16-byte alignment required");
-  FGVC_REQUIRE((const void*)x != (const void*)y_split, FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: in-place not supported");
+  FGVC_REQUIRE((const void*)x != (const void*)y_split && (const void*)residual_split != (const void*)y_split, FGVC_ERR_INVALID_ARG,
+               "fgvc_conv64_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
-  return conv64_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, relu, (hipStream_t)stream);
+  return conv64_launch(x, w, bias, residual, residual_split, y_split, y_f32, N, H, W, Hp, Wp, relu, (hipStream_t)stream);
 }
 
 int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,

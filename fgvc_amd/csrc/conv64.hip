@@ -11,15 +11,20 @@
 
 namespace fgvc {
 
+int conv_debug_flags();
+
 struct Conv64Params {
   const uint16_t* x;       // padded split NHWC [N][Hp][Wp][2][64]
   const uint16_t* w;       // [2 cout tiles][9 taps][2 chunks][2 k-steps][hi | lo][64 lanes][8]: MFMA-operand order (ops.prepare_conv64)
   const float* bias;       // [64]
   const float* residual;   // optional, dense NHWC f32 [N][H][W][64]
+  const uint16_t* res_split;   // optional (instead of `residual`): the residual as a padded split NHWC tensor of x's geometry; hi + lo
+                               // is the value the next convolution sees anyway, and the producer need not write an f32 copy
   uint16_t* y_split;       // optional, padded split NHWC
   float* y_f32;            // optional, dense NHWC f32
   int N, H, W, Hp, Wp, relu;
   int n_ty, n_tx, n_tiles;
+  int debug;               // 128 ("conv_debug"): plain b + k G tile order (A/B of the XCD-aware order)
 };
 
 __device__ __forceinline__ void c64_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
@@ -77,30 +82,37 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
     const uint32_t dst = c64_lds_addr(patches + buf * C64_PATCHB + chunk * C64_CHUNKB + (prow * C64_PW + pc0) * 128);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
   };
+  // Tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and the 32 workgroups of an XCD share its L2: iteration k of
+  // XCD x takes the 32 CONSECUTIVE tiles of chunk 8 k + x, and consecutive tiles run DOWN a 32-pixel column of the image (ty
+  // fastest), so that the two patch rows a tile shares with the tile above / below it are read from HBM once per XCD instead of
+  // once per tile (4-row tiles: 2 of the 6 staged rows).  Grids that are not a multiple of 8 workgroups (tiny inputs) keep b + k G.
+  const int G = gridDim.x, per_xcd = G >> 3;
+  const bool xcd_order = (G & 7) == 0 && !(p.debug & 128);
+  auto tile_at = [&](int k) {
+    return xcd_order ? (k * 8 + ((int)blockIdx.x & 7)) * per_xcd + ((int)blockIdx.x >> 3) : k * G + (int)blockIdx.x;
+  };
   auto tile_origin = [&](int tile, int& nimg, int& y0, int& x0) {
     nimg = tile / (p.n_ty * p.n_tx);
     const int rem = tile - nimg * p.n_ty * p.n_tx;
-    const int ty = rem / p.n_tx;
-    y0 = ty * C64_TR;
-    x0 = (rem - ty * p.n_tx) * 32;
+    const int tx = rem / p.n_ty;
+    y0 = (rem - tx * p.n_ty) * C64_TR;
+    x0 = tx * 32;
   };
 
-  int tile = blockIdx.x, buf = 0;
+  int it = 0, tile = tile_at(0), buf = 0;
   if (tile < p.n_tiles) {
     int ni, ya, xa;
     tile_origin(tile, ni, ya, xa);
     for (int i = wave; i < C64_PIECES; i += 4) stage_piece(ni, ya, xa, 0, i);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (; tile < p.n_tiles; tile += gridDim.x, buf ^= 1) {
-    const int nimg = tile / (p.n_ty * p.n_tx);
-    const int rem = tile - nimg * p.n_ty * p.n_tx;
-    const int ty = rem / p.n_tx, tx = rem - ty * p.n_tx;
-    const int y0 = ty * C64_TR, x0 = tx * 32;
+  for (; tile < p.n_tiles; tile = tile_at(++it), buf ^= 1) {       // tile_at(k) grows with k: the first tile beyond the end is the last
+    int nimg, y0, x0;
+    tile_origin(tile, nimg, y0, x0);
     lds_barrier();                                          // patch `buf` complete (every wave waited for its DMAs), buffer buf^1 free
     // the next tile's patch goes into the other buffer while this one multiplies: its 15 DMA pieces per wave are issued
     // BETWEEN the MFMA groups (a wave owns its SIMD: whatever it issues outside the MFMA stream is exposed)
-    const int next = tile + gridDim.x;
+    const int next = tile_at(it + 1);
     const bool has_next = next < p.n_tiles;
     int nimg_n = 0, y0_n = 0, x0_n = 0;
     if (has_next) tile_origin(next, nimg_n, y0_n, x0_n);
@@ -140,6 +152,23 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
           for (int q = 0; q < 4; ++q) res[b][q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
         }
       }
+      if (g == 24 && p.res_split) {  // the same from the split form: channel c of a pixel's 32-channel chunk is hi at byte 2 c, lo at 64 + 2 c
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int y = imin(y0 + 2 * rg + b, p.H - 1), x = imin(x0 + n, p.W - 1);
+          const unsigned char* rp = reinterpret_cast<const unsigned char*>(p.res_split) +
+                                    ((((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x + 1)) * 2 + ct) * 128 + 8 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint2 hv = *reinterpret_cast<const uint2*>(rp + 16 * q);
+            const uint2 lv = *reinterpret_cast<const uint2*>(rp + 64 + 16 * q);
+            res[b][q] = {__builtin_bit_cast(float, hv.x << 16) + __builtin_bit_cast(float, lv.x << 16),
+                         __builtin_bit_cast(float, hv.x & 0xffff0000u) + __builtin_bit_cast(float, lv.x & 0xffff0000u),
+                         __builtin_bit_cast(float, hv.y << 16) + __builtin_bit_cast(float, lv.y << 16),
+                         __builtin_bit_cast(float, hv.y & 0xffff0000u) + __builtin_bit_cast(float, lv.y & 0xffff0000u)};
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -168,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
       for (int g = 0; g < 4; ++g) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + ct * 32 + 8 * g + 4 * h);
         v[g] = {acc[b][4 * g + 0] + bv.x, acc[b][4 * g + 1] + bv.y, acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w};
-        if (p.residual) v[g] += res[b][g];
+        if (p.residual || p.res_split) v[g] += res[b][g];
         if (p.relu) {
           v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f);
         }
@@ -211,10 +240,10 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
   }
 }
 
-int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split, float* y_f32,
-                  int N, int H, int W, int Hp, int Wp, int relu, hipStream_t s) {
+int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, const uint16_t* res_split,
+                  uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, hipStream_t s) {
   Conv64Params p;
-  p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
+  p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.res_split = res_split; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.relu = relu;
   p.n_ty = cdiv(H, C64_TR); p.n_tx = cdiv(W, 32);
   const long long tiles = (long long)p.n_ty * p.n_tx * N;
@@ -223,6 +252,7 @@ int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const
     return FGVC_ERR_UNSUPPORTED;
   }
   p.n_tiles = (int)tiles;
+  p.debug = conv_debug_flags();
   const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
   conv64_kernel<<<grid, 256, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32");

@@ -77,11 +77,9 @@ __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^
 // NWR = waves along the pixel rows (4: an 8-row tile, 512 threads, one workgroup per CU; 2: a 4-row tile, 256 threads,
 // small enough in LDS and registers for TWO workgroups per CU -- for the narrow layers, whose short main loop cannot hide
 // its own prologue and epilogue, the second workgroup does).
-// RPW = pixel rows per wave (2, or 4: the "tall" tile of the f16f8 form).  These kernels are paced by what the L2 can deliver into
-// the LDS (every workgroup streams the whole weight tensor for its tile: 2 GB per 256 -> 256 launch of an 8-frame 480p clip, 4-5 TB/s
-// of LDS-DMA against the ~6.4 TB/s the chip sustains, whatever the arithmetic).  Weight bytes per MAC fall with the PIXELS of a tile,
-// patch bytes with its output channels, and pixels x channels is bounded by the accumulators (half the register file): 16 x 32 pixels
-// x 128 channels moves 31 % fewer bytes per MAC than 8 x 32 x 256.
+// RPW = pixel rows per wave: 2 in every launched form.  (4 = a "tall" 16 x 32 x 128-channel tile of the f16f8 form, which moves 31 %
+// fewer weight + patch bytes per MAC than 8 x 32 x 256; measured 0.67 against 0.49 ms on the 256 -> 256 layer -- register spills in
+// the stage loop -- and not instantiated: docs/LAB_NOTES.md, round 3.)
 template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0, int RPW = 2>
 __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel(ConvSplitParams p) {
   static_assert(RPW == 2 || RPW == 4, "pixel rows per wave");
@@ -106,10 +104,12 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pr = wave % NWR, ch = wave / NWR;
   const int n = lane & 31, h = lane >> 5;
-  int bid = blockIdx.x;
+  // workgroups are dealt round-robin over the 8 XCDs: every XCD takes a contiguous run of tiles, and consecutive tiles run down a
+  // 32-pixel column, so the patch rows / columns neighbouring tiles share meet in ONE L2 (8 frames of 120 x 214: a frame per XCD)
+  int bid = (p.debug & 128) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int nimg = bid / (p.n_ty * p.n_tx);
   bid -= nimg * p.n_ty * p.n_tx;
-  const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
+  const int tx = bid / p.n_ty, ty = bid - tx * p.n_ty;
   const int y0 = ty * TROWS, x0 = tx * 32;
   const int co_base = blockIdx.y * COT;
   const int nchunk = p.Cin / 32;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       // of channel block a + 2 right after block a's six MFMAs have issued: a block of cover for every read, 48 fragment registers --
       // which fit since the weight DMAs take a scalar base and one lane-offset register instead of 64-bit address pairs.  The LDS
       // returns a wave's reads in order, so the waits are counted: when a fragment is needed, only the reads issued after it may still
-      // be in flight.  Bit-identical results; -1.6 % stand-alone, -0.7 % of the encoder (tools/try_conv_pinned.py): the partner wave
+      // be in flight.  Bit-identical results; -1.6 % stand-alone, -0.7 % of the encoder (tools/experiments/try_conv_pinned.py): the partner wave
       // already hid most of the latency.
       const int tap = sg;
       const int dy = tap / KS, dx = tap - dy * KS;
@@ -586,259 +586,6 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   }
 }
 
-// ---- The widest form once more, with ONE wave per SIMD and a 4 x 4 register tile (fgvc_conv_split_f32, Cout a multiple of 256, 3x3).
-// Why: in the 8-wave form above a wave owns 4 x 2 accumulator tiles and has 48 registers for operand fragments; a fragment is read
-// one block (6 MFMAs, 192 pipe cycles) ahead of its use, and under load an LDS round trip takes 200-250 cycles
-// (tools/micro/lds_read_rate.hip): the pair of waves of a SIMD retires one MFMA per 40 cycles, alone or together.  Here a wave owns
-// 4 pixel rows x 128 output channels = 16 tiles (256 accumulation registers, the whole second half of its SIMD's file), both K-16
-// steps of a stage have their own fragment registers (2 x 64), and the second step's fragments are read under the first step's 48
-// MFMAs: one exposed round trip per stage (the first step's reads, behind the stage barrier) instead of one per block.  The stage is
-// volatile inline assembly in a fixed order; the accumulators are "+a" operands.  Same tensors, same accumulation order per output
-// (chunk, tap, K-16 step, hi*hi / hi*lo / lo*hi): bit-identical to the 8-wave form.
-__global__ __launch_bounds__(256, 1) void conv_split_kernel_4x4(ConvSplitParams p) {
-  constexpr int KS = 3, T = 9, COT = 256, NSLOT = 3, NW = 4, TROWS = 8;
-  constexpr int PATCHB = (TROWS + 2) * CV_PW * 128;
-  constexpr int WSLOTB = COT * 128;
-  constexpr int PPW = COT / 8 / NW;                // 1-KiB DMA pieces per wave per stage (8)
-  constexpr int LA = NSLOT - 1;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PATCHB + NSLOT * WSLOTB];
-  unsigned char* patch = smem;
-  unsigned char* wring = smem + PATCHB;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pr = wave & 1, ch = wave >> 1;         // pixel rows 4 pr .. 4 pr + 3, output channels 128 ch .. + 127
-  const int n = lane & 31, h = lane >> 5;
-  int bid = blockIdx.x;
-  const int nimg = bid / (p.n_ty * p.n_tx);
-  bid -= nimg * p.n_ty * p.n_tx;
-  const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
-  const int y0 = ty * TROWS, x0 = tx * 32;
-  const int co_base = blockIdx.y * COT;
-  const int nchunk = p.Cin / 32;
-  const size_t pix_bytes_in = (size_t)nchunk * 128;
-  const int d_row = lane >> 3, d_slot = lane & 7;
-
-  // ---- staging (as in the 8-wave form, divided among 4 waves)
-  auto stage_patch0 = [&]() {
-    constexpr int ROWS = TROWS + 2, PPR = 5;
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x);
-    for (int i = wave; i < ROWS * PPR; i += NW) {
-      const int prow = i / PPR, pc0 = (i - prow * PPR) * 8;
-      const int P = prow * CV_PW + pc0 + d_row;
-      const int sl = d_slot ^ ((P >> 1) & 7);
-      const size_t gpix = ((size_t)nimg * p.Hp + (y0 + prow)) * p.Wp + (x0 + pc0 + d_row);
-      conv_lds_dma_16(xb + gpix * pix_bytes_in + sl * 16, lds_addr(patch + (prow * CV_PW + pc0) * 128));
-    }
-  };
-  constexpr int NPIECE = (TROWS + 2) * 5, MAXP = (NPIECE + NW - 1) / NW;      // 50 pieces, 13 per wave
-  static_assert(MAXP == 13, "patch pieces per wave");
-  uint4 q0 = {}, q1 = {}, q2 = {}, q3 = {}, q4 = {}, q5 = {}, q6 = {}, q7 = {}, q8 = {}, q9 = {}, q10 = {}, q11 = {}, q12 = {};
-  const unsigned char* xb0 = reinterpret_cast<const unsigned char*>(p.x);
-#define C4_GEOM(J)                                                                                    \
-  const int pi_ = imin(wave + NW * (J), NPIECE - 1);                                                   \
-  const int prow_ = pi_ / 5, pc0_ = (pi_ - prow_ * 5) * 8;
-#define C4_PREFETCH(J, CHUNK)                                                                         \
-  {                                                                                                   \
-    C4_GEOM(J)                                                                                        \
-    const int P_ = prow_ * CV_PW + pc0_ + d_row;                                                      \
-    const int sl_ = d_slot ^ ((P_ >> 1) & 7);                                                         \
-    const size_t g_ = ((size_t)nimg * p.Hp + (y0 + prow_)) * p.Wp + (x0 + pc0_ + d_row);            \
-    const unsigned char* a_ = xb0 + (size_t)(CHUNK) * 128 + g_ * pix_bytes_in + sl_ * 16;            \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q##J) : "v"(a_) : "memory");               \
-  }
-#define C4_COMMIT(J)                                                                                  \
-  if (wave + NW * (J) < NPIECE) {                                                                      \
-    C4_GEOM(J)                                                                                        \
-    *reinterpret_cast<uint4*>(patch + (prow_ * CV_PW + pc0_) * 128 + lane * 16) = q##J;               \
-  }
-  const uint32_t w_lane_off = (uint32_t)(d_row * 128 + ((d_slot ^ (d_row >> 1)) << 4));
-  auto stage_weight_piece = [&](int q, int j) {
-    const int chunk = q / T, tap = q - chunk * T;
-    unsigned char* dst = wring + (q % NSLOT) * WSLOTB;
-    const int c0 = (wave * PPW + j) * 8;
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
-                              ((((size_t)tap * nchunk + chunk) * p.Cout + co_base) + c0) * 128;
-    conv_lds_dma_16s(w_lane_off ^ (uint32_t)((c0 & 8) << 3), wb, lds_addr(dst + c0 * 128));
-  };
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int n_stage = nchunk * T;
-  stage_patch0();
-#pragma unroll
-  for (int i = 0; i < LA; ++i)
-    if (i < n_stage)
-#pragma unroll
-      for (int j = 0; j < PPW; ++j) stage_weight_piece(i, j);
-
-  const int ka = (n >> 1) & 7;
-  for (int q = 0; q < n_stage; ++q) {
-    const int chunk = q / T, tap = q - chunk * T;
-    if (q + LA - 1 < n_stage) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * PPW) : "memory");   // all but the stages after q have landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    lds_barrier();
-    const bool last_of_chunk = tap == T - 1 && chunk + 1 < nchunk;
-    if (last_of_chunk) {                            // next chunk's patch: lands while this stage multiplies
-      C4_PREFETCH(0, chunk + 1) C4_PREFETCH(1, chunk + 1) C4_PREFETCH(2, chunk + 1) C4_PREFETCH(3, chunk + 1)
-      C4_PREFETCH(4, chunk + 1) C4_PREFETCH(5, chunk + 1) C4_PREFETCH(6, chunk + 1) C4_PREFETCH(7, chunk + 1)
-      C4_PREFETCH(8, chunk + 1) C4_PREFETCH(9, chunk + 1) C4_PREFETCH(10, chunk + 1) C4_PREFETCH(11, chunk + 1)
-      C4_PREFETCH(12, chunk + 1)
-    }
-    const bool stage_more = q + LA < n_stage && (p.debug & 64) == 0;     // 64: ablation (results wrong): no weight DMAs in the loop
-    const int dy = tap / KS, dx = tap - dy * KS;
-    const uint32_t wbase = lds_addr(wring + (q % NSLOT) * WSLOTB) + (uint32_t)((ch * 128 + n) * 128);
-    uint32_t pb[4], kb[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int P = (4 * pr + b + dy) * CV_PW + n + dx;
-      pb[b] = lds_addr(patch) + (uint32_t)(P * 128);
-      kb[b] = (uint32_t)((P >> 1) & 7);
-    }
-    bf16x8 A_h[2][4], A_l[2][4], B_h[2][4], B_l[2][4];     // [K-16 step][channel block | pixel row]
-#define C4R(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
-#define C4M(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-    auto read_A = [&](int st) {
-      const uint32_t ah_ = wbase + (uint32_t)(((2 * st + h) ^ ka) << 4), al_ = wbase + (uint32_t)(((4 + 2 * st + h) ^ ka) << 4);
-      C4R(A_h[st][0], ah_, 0);     C4R(A_l[st][0], al_, 0);
-      C4R(A_h[st][1], ah_, 4096);  C4R(A_l[st][1], al_, 4096);
-      C4R(A_h[st][2], ah_, 8192);  C4R(A_l[st][2], al_, 8192);
-      C4R(A_h[st][3], ah_, 12288); C4R(A_l[st][3], al_, 12288);
-    };
-    auto read_B = [&](int st) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        C4R(B_h[st][b], pb[b] + (((uint32_t)(2 * st + h) ^ kb[b]) << 4), 0);
-        C4R(B_l[st][b], pb[b] + (((uint32_t)(4 + 2 * st + h) ^ kb[b]) << 4), 0);
-      }
-    };
-    read_A(0);
-    read_B(0);                                      // 16 reads of step 0 ...
-    read_A(1);                                      // ... 8 of step 1 behind them
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // step 0 has landed
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      if (st == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int prod = 0; prod < 3; ++prod) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            if (prod == 0) C4M(acc[a][b], A_h[st][a], B_h[st][b]);
-            else if (prod == 1) C4M(acc[a][b], A_h[st][a], B_l[st][b]);
-            else C4M(acc[a][b], A_l[st][a], B_h[st][b]);
-          }
-          if (st == 0 && prod == 0 && a == 0) read_B(1);      // the rest of step 1's reads, under step 0's multiplies
-          if (stage_more && a == 3) {               // this stage's weight DMAs: 8 per wave, one or two after every product pass
-            const int it = st * 3 + prod;           // 0..5
-#pragma unroll
-            for (int j = 0; j < PPW; ++j)
-              if (j * 6 / PPW == it) stage_weight_piece(q + LA, j);
-          }
-        }
-      }
-    }
-#undef C4R
-#undef C4M
-    if (last_of_chunk) {
-      if (q + LA < n_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // prefetch landed; this stage's DMAs stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();                                // everyone is done reading this chunk's patch
-      C4_COMMIT(0) C4_COMMIT(1) C4_COMMIT(2) C4_COMMIT(3) C4_COMMIT(4) C4_COMMIT(5) C4_COMMIT(6) C4_COMMIT(7)
-      C4_COMMIT(8) C4_COMMIT(9) C4_COMMIT(10) C4_COMMIT(11) C4_COMMIT(12)
-    }
-  }
-
-  // ---- epilogue (as in the 8-wave form: each wave transposes its 32-pixel x 128-channel rows through a private LDS region)
-  constexpr int CW = COT / 2, RB = CW * 4, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;
-  static_assert(NW * 32 * RS <= PATCHB + NSLOT * WSLOTB, "epilogue staging");
-  __syncthreads();
-  unsigned char* tile = smem + wave * (32 * RS);
-  const int co_w = co_base + ch * CW;
-  const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
-  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int y = y0 + 4 * pr + b;
-    if (y >= p.H) continue;                         // wave-uniform
-    const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
-    const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;
-    if (p.residual) {
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int row = i * RPI + mv_row;
-        if (x0 + row < p.W)
-          *reinterpret_cast<uint4*>(tile + row * RS + mv_col) = *reinterpret_cast<const uint4*>(src + (size_t)row * p.Cout * 4 + mv_col);
-      }
-      wave_sync();
-    }
-    f32x4 v[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cw = a * 32 + 8 * g + 4 * h;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
-        v[a][g] = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z, acc[a][b][4 * g + 3] + bv.w};
-        if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
-        if (p.relu) {
-          v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
-          v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
-        }
-      }
-    if (p.y_f32) {
-      wave_sync();
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(tile + n * RS + (a * 32 + 8 * g + 4 * h) * 4) = v[a][g];
-      wave_sync();
-      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_f32 + fpix0 * p.Cout + co_w);
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int row = i * RPI + mv_row;
-        if (x0 + row < p.W)
-          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) = *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
-      }
-    }
-    if (p.y_split) {
-      wave_sync();
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          ushort4 hv, lv;
-          split_bf16_4(v[a][g], hv, lv);
-          unsigned char* o = tile + n * RS + a * 128 + (8 * g + 4 * h) * 2;
-          *reinterpret_cast<ushort4*>(o) = hv;
-          *reinterpret_cast<ushort4*>(o + 64) = lv;
-        }
-      wave_sync();
-      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * (p.Cout / 32) + (co_w >> 5)) * 128;
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int row = i * RPI + mv_row;
-        if (x0 + row < p.W)
-          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) = *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
-      }
-    }
-    wave_sync();
-  }
-}
-#undef C4_GEOM
-#undef C4_PREFETCH
-#undef C4_COMMIT
-
 // f32 NCHW -> padded split NHWC (interior only; the border must already be zero) and/or dense NHWC f32
 __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
                                                                   float* __restrict__ out_f32, int C, int H, int W, int Hp,
@@ -875,7 +622,7 @@ __global__ __launch_bounds__(256) void nchw_to_split_nhwc_kernel(const float* __
 }
 
 // dense NHWC f32 -> L2-normalised rows: [n][H*W][C] f32 (the layout of fgvc_normalize_chw_to_hwc_f32's output) and / or their
-// (hi, lo) bf16 split [n][H*W][hi C | lo C] (fgvc_split_bf16's output: what fgvc_pair_topk_bf16x4 reads); one wave per pixel
+// (hi, lo) bf16 split [n][H*W][hi C | lo C] (fgvc_split_bf16's output: what fgvc_corr_volume_bf16x3 reads); one wave per pixel
 template <int FMT>   // split format: 0 = (hi, lo) bf16 (fgvc_split_bf16), 1 = (h, l) f16 at scale 2^14 (fgvc_split_f16x2)
 __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               uint16_t* __restrict__ out_split, int C, int normalize,
@@ -920,12 +667,11 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
 
 static int g_conv_debug = 0;
 void set_conv_debug(int v) { g_conv_debug = v; }
+int conv_debug_flags() { return g_conv_debug; }
 static int g_conv_narrow = 1;       // bit 0: 64-channel layers, bit 1: 128-channel 3x3 layers (no gain measured) -- 4-row tiles, two workgroups per CU (0: 8-row tiles)
 void set_conv_narrow(int v) { g_conv_narrow = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
 void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
-static int g_conv_tall = 0;        // f16f8, 3x3, Cout % 128 == 0: 1 = 16 x 32 pixels x 128 channels per workgroup (experiment: 68 bytes of scratch)
-void set_conv_tall(int v) { g_conv_tall = v; }
 
 template <int ARITH>
 static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int cot_eff, bool narrow, hipStream_t s) {
@@ -958,13 +704,8 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
-  if (in_fmt == 1 && KS == 3 && Cout % 128 == 0 && g_conv_tall && !g_conv_cot_cap) {
-    // the tall tile: 4 pixel rows per wave, 128 output channels per workgroup, a 4-slot weight ring (157.7 KB of LDS)
-    p.n_ty = cdiv(H, 16);
-    conv_split_kernel<3, 128, 1, 4, 4, false, 1, 4><<<dim3(p.n_ty * p.n_tx * N, Cout / 128), 512, 0, s>>>(p);
-  } else if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
+  if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 2) conv_split_dispatch<2>(p, grid, KS, cot_eff, narrow, s);
-  else if (KS == 3 && cot_eff == 256 && out_fmt == 0 && (g_conv_debug & 32)) conv_split_kernel_4x4<<<grid, 256, 0, s>>>(p);   // A/B: one wave per SIMD, 4 x 4 register tile
   else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16)) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads
   else conv_split_dispatch<0>(p, grid, KS, cot_eff, narrow, s);                                                                  // (16: the compiler's operand schedule)
   FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");

@@ -339,7 +339,7 @@ int corr_volume_bf16_launch(const uint16_t* q, const uint16_t* k, int C, int HWq
     const int chunks = imax(1, 1024 / n_q);
     int kchunk = imax(16, cdiv(n_kb, chunks));
     kchunk += kchunk & 1;                                 // whole 64-key stages
-    if (g_corr_debug >> 8) kchunk = g_corr_debug >> 8;    // tools/ablate_corr.py sweeps it
+    if (g_corr_debug >> 8) kchunk = g_corr_debug >> 8;    // tools/experiments/ablate_corr.py sweeps it
     dim3 grid(n_q, cdiv(n_kb, kchunk));
     if (nseg == 3)
       corr_volume_bf16_kernel<256, 3, 8, 2><<<grid, 512, 0, s>>>(q, k, HWq, HWk, temperature, vol, g_corr_debug & 255, kchunk);

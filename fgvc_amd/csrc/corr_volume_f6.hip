@@ -504,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   }
   if (defer && pend_v >= 0) store_tile(pend_v);
   if (probe && lane == 0 && (wave & 3) == 0) {
-    // 48-byte records over the first floats of vol (tools/time_corr6.py); row 0 is only written by the first stage of the
+    // 48-byte records over the first floats of vol (tools/experiments/time_corr6.py); row 0 is only written by the first stage of the
     // class-0 workgroups of the first key chunk, long before any workgroup ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int wg = blockIdx.x;
@@ -529,9 +529,9 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
 static int g_corr6_debug = 0;
 static int g_corr6_sdma = 1;
 void set_corr6_sdma(int v) { g_corr6_sdma = v; }
-static int g_corr6_skew = 0;   // stages moved from the two-segment piece to the others: -0.8 % / 0 / +0.7 % on three boxes at 2 (tools/try_corr6_skew.py): off
+static int g_corr6_skew = 0;   // stages moved from the two-segment piece to the others: -0.8 % / 0 / +0.7 % on three boxes at 2 (tools/experiments/try_corr6_skew.py): off
 void set_corr6_skew(int v) { g_corr6_skew = v; }
-static int g_corr6_cost_pro = 20000, g_corr6_cost_stage = 5700;      // cycles, tools/time_corr6.py
+static int g_corr6_cost_pro = 20000, g_corr6_cost_stage = 5700;      // cycles, tools/experiments/time_corr6.py
 void set_corr6_debug(int v) { g_corr6_debug = v; }
 
 int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int HWq, int HWk, float temperature, float* vol,

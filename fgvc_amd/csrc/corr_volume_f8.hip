@@ -246,13 +246,13 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_kernel(const uns
 //     16 kt + 8 + i | 16 kt + 4 + i and 16 kt + 12 + i): the same 2 x 128-byte store shape as the 32 x 32 accumulator.
 //   * stagger (corr8_debug bit 8 switches it off): waves 4-7 (the SIMD partners of waves 0-3) hold a finished tile in its
 //     accumulators and store it at the start of their NEXT tile (across the stage barrier too), so that a stage opens with one wave
-//     of each SIMD multiplying and the other in the store queue: -1.5 % (round-robin timing, tools/try_f16f8.py).
+//     of each SIMD multiplying and the other in the store queue: -1.5 % (round-robin timing, tools/experiments/try_f16f8.py).
 //   * the natural fp8 element order (bytes [32 g, 32 g + 32) of a K-128 block) costs a 2-way bank conflict on the P reads; the
 //     conflict-free order (two 16-byte pieces 64 bytes apart) needs a shufflevector of two reads, which makes hipcc wait for
 //     BOTH reads at once (s_waitcnt lgkmcnt(0) right behind them) instead of counting: measured slower.
 // ------------------------------------------------------------------------------------------
 template <int NW, int DEBUG>   // DEBUG: 1 = no volume stores, 2 = no MFMAs (results wrong), 8 = no wave stagger (results right),
-                               // 32 = s_memtime probe of one workgroup, written over the first floats of vol (tools/time_corr8.py)
+                               // 32 = s_memtime probe of one workgroup, written over the first floats of vol (tools/experiments/time_corr8.py)
 __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const unsigned char* __restrict__ q_sp,
                                                                          const unsigned char* __restrict__ k_sp, int HWq, int HWk,
                                                                          float out_scale, float* __restrict__ vol, int kchunk,
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f8_v2_kernel(const 
   };
   // Staging the NEXT stage costs the issuing wave ~125 cycles per LDS-DMA instruction (64 of them per stage).  The older wave of a
   // SIMD wins the issue arbitration, finishes its multiplies first and then sits ~2000 cycles at the stage barrier (s_memtime
-  // probe: tools/time_corr8.py), while its partner is the critical path.  So waves 0-3 stage ALL 64 rows, two per multiply
+  // probe: tools/experiments/time_corr8.py), while its partner is the critical path.  So waves 0-3 stage ALL 64 rows, two per multiply
   // part, and waves 4-7 none (as a burst behind the barrier, or spread over every wave, the matrix pipe idled ~1000 cycles per stage).
   const bool stager = wave < NW / 2;
   auto stage_row = [&](int kb, int buf, int i) {
@@ -499,7 +499,7 @@ int corr_volume_f16f8_launch(const unsigned char* q, const unsigned char* k, int
   const int n_q = cdiv(HWq + (period > 1 ? 31 : 0), 256);  // shifted classes start up to 31 queries early
   const int n_vb = cdiv(cdiv(HWk, period), 32);            // 32-row blocks of virtual rows per class
   // key blocks per workgroup.  One workgroup per CU (135 KB of LDS), ~20 000 cycles of prologue each (query fragments + first
-  // stage) and ~5 800 per 64-key stage (s_memtime probe, tools/time_corr8.py): take the number of key chunks that minimises
+  // stage) and ~5 800 per 64-key stage (s_memtime probe, tools/experiments/time_corr8.py): take the number of key chunks that minimises
   //   rounds over the 256 CUs x (prologue + stages per chunk)
   // (480p: 5 chunks = 1020 workgroups = 3.98 rounds; 720p: 9 chunks = 2025 workgroups = 7.9 rounds -- 4 chunks would leave half of
   // the fourth round empty).

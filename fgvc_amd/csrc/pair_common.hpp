@@ -80,9 +80,9 @@ struct HalfCursor {
   }
 };
 
-// ---- shared by the split-operand kernels (pair_topk_v4.hip: bf16 x 4 products, pair_topk_v5.hip: f16 x 3 products)
+// ---- the split-operand kernels (pair_topk_v5.hip: f16 x 3 products)
 struct PairParamsB {
-  const uint16_t* q_hl;   // [frame][pixel][2][256] bf16 bit patterns (hi part, lo part)
+  const uint16_t* q_hl;   // [frame][pixel][2][256] f16 bit patterns (h part, l part: fgvc_split_f16x2)
   const uint16_t* k_hl;
   const int4* pairs;
   int Hq, Wq, Hk, Wk;
@@ -94,7 +94,7 @@ struct PairParamsB {
                           // 16 = prologue only, 32 = no epilogue, 64 = no main loop, 128 = no s_setprio around the MFMA chain
   int32_t* idx_out;
   float* score_out;
-  const int2* groups;     // pair_topk_v5 only: optional [n_groups] (first pair, count) -- runs of pairs with one query frame and one
+  const int2* groups;     // optional [n_groups] (first pair, count) -- runs of pairs with one query frame and one
                           // mask flag that a workgroup takes in one go (query prologue once, the ring never drains); null: each pair alone
 };
 
@@ -108,7 +108,7 @@ struct ReachTest {
   }
 };
 
-constexpr int V4_LIST_CAP = 4096;   // key blocks a super-tile may have to visit (host-checked)
+constexpr int PAIR_LIST_CAP = 4096;   // key blocks a super-tile may have to visit (host-checked)
 
 constexpr int KEY_EMPTY = (int)0x80000000;
 
@@ -120,13 +120,5 @@ __device__ __forceinline__ void lds_dma_16(const void* src_lane, const void* lds
   const uint32_t lds = (uint32_t)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst_uniform;
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory");
 }
-
-#define FGVC_V4_DESC(a, I, J)                  \
-  {                                            \
-    const int hi_ = max(a[I], a[J]);           \
-    const int lo_ = min(a[I], a[J]);           \
-    a[I] = hi_;                                \
-    a[J] = lo_;                                \
-  }
 
 }  // namespace fgvc

@@ -1,13 +1,13 @@
 // fgvc_pair_topk_f16x3: the windowed correlation + top-k of fgvc_pair_topk_f32 on the f16 matrix pipe, f32-grade, with the
 // matrix chain and the selection in ONE instruction stream and a ring of key blocks without workgroup barriers.
 //
-// What fgvc_pair_topk_bf16x4 (pair_topk_v4.hip) left on the table, by its own ablations (tools/run_pair_v4.py): the two waves of a
-// SIMD alternate between a 64-MFMA chain (~2900 cycles for 2048 pipe cycles) and the selection of their previous tile (~2000), one
-// barrier per two key blocks, and every wave steps through the UNION of the key blocks its 2 x 2 query blocks reach (56 entries
-// where a block reaches 41: 27 % of the multiply slots empty).  Here:
+// What its predecessor (a bf16 hi/lo four-product kernel with a barrier per two key blocks, retired in round 3; docs/LAB_NOTES.md)
+// left on the table, by its own ablations: the two waves of a SIMD alternated between a 64-MFMA chain (~2900 cycles for 2048 pipe
+// cycles) and the selection of their previous tile (~2000), and every wave stepped through the UNION of the key blocks its 2 x 2
+// query blocks reach (56 entries where a block reaches 41: 27 % of the multiply slots empty).  Here:
 //   * Arithmetic: x -> h = f16(2^14 x), l = f16(2^14 x - h) (fgvc_split_f16x2): 22 significand bits per element (bf16 hi + lo:
 //     16), products of f16 are exact in f32, and  2^28 <k, q> = sum h h + sum l h + sum h l  (sum l l = 2^-22, dropped) on
-//     v_mfma_f32_32x32x16_f16: 48 MFMAs = 1536 pipe cycles per 32 x 32 tile (bf16x4: 64 = 2048).  The scale makes the accumulator
+//     v_mfma_f32_32x32x16_f16: 48 MFMAs = 1536 pipe cycles per 32 x 32 tile (bf16 hi/lo with four products: 64 = 2048).  The scale makes the accumulator
 //     the score in 2^-28 fixed point as it stands; rows must be L2-normalised (|x| <= 1: 2^14 x fits f16).
 //   * Roles: waves 0-3 = consumers, one 4 x 8 query block each (B operands resident); waves 4-7 = producers, one pixel row of
 //     every key block each, by LDS-DMA.  A consumer multiplies key block e and, IN THE SAME STREAM, selects the candidates of the
@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 }
 
 __device__ int g_pair_v5_timeout = 0;
-__device__ long long g_pair_v5_probe[32];      // debug & 256: s_memtime stamps of one workgroup (tools/time_pair_v5.py)
+__device__ long long g_pair_v5_probe[32];      // debug & 256: s_memtime stamps of one workgroup (tools/experiments/time_pair_v5.py)
 
 // bounded spin on an LDS word (wave-uniform): true = the word reached `target`.  A wave that has given up once (`dead`) never
 // waits again: a broken protocol costs milliseconds, not a hung GPU.
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
   constexpr int NSLOT = 4;
   constexpr int KS = C / 16;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * BUFB];
-  __shared__ uint32_t blist[V4_LIST_CAP];      // by | bx << 12 | (query blocks that reach it) << 24
+  __shared__ uint32_t blist[PAIR_LIST_CAP];      // by | bx << 12 | (query blocks that reach it) << 24
   __shared__ int blist_n;
   __shared__ int filled[NSLOT], done[NSLOT];
   __shared__ int wg_dead;                        // a wave of this workgroup gave up waiting: the lists written from here on are poison
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
     const int nall = (by_hi - by_lo + 1) * nbx;
     // the host has checked that a MASKED pair's reach fits the list; an unmasked pair on a larger key grid than the list holds
     // (the caller promised there was none: `all_masked`) gets EMPTY lists (-1 / -inf), never truncated ones
-    const int ncand = nall > V4_LIST_CAP ? 0 : nall;
+    const int ncand = nall > PAIR_LIST_CAP ? 0 : nall;
     auto reach_bits = [&](int c) -> uint32_t {
       const int by = by_lo + c / nbx, bx = bxl + c % nbx;
       uint32_t m = 0;
@@ -909,9 +909,9 @@ int pair_topk_v5_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_
     const long long whole = (long long)cdiv(Hk, QBH) * cdiv(Wk, QBW);
     const long long need = all_masked ? nby * nbx : whole;
     need_blocks = need;
-    if (need > V4_LIST_CAP || Hk >= 4096 * QBH || Wk >= 4096 * QBW) {
+    if (need > PAIR_LIST_CAP || Hk >= 4096 * QBH || Wk >= 4096 * QBW) {
       set_error("fgvc_pair_topk_f16x3: key grid %dx%d needs %lld > %d key blocks per query tile (%s); use fgvc_pair_topk_f32",
-                Hk, Wk, need, V4_LIST_CAP, all_masked ? "mask reach" : "a pair without FGVC_PAIR_MASKED scans the frame");
+                Hk, Wk, need, PAIR_LIST_CAP, all_masked ? "mask reach" : "a pair without FGVC_PAIR_MASKED scans the frame");
       return FGVC_ERR_UNSUPPORTED;
     }
   }

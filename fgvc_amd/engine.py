@@ -49,7 +49,7 @@ class TrackerConfig:
     test_mode: str = "v1"              # anything else = masked_attention_efficient_v2 (:379-392)
     sigma: float = 6.0
     pair_precision: str = "auto"   # ops.pair_topk_auto: "auto" | "f32" | "split" (not a reference key)
-    pair_split_fmt: str = "f16"    # operand format of the split pair kernel: "f16" (fgvc_pair_topk_f16x3) | "bf16" (fgvc_pair_topk_bf16x4)
+    pair_split_fmt: str = "f16"    # operand format of the split pair kernel (fgvc_pair_topk_f16x3): "f16" is the only one
 
     @staticmethod
     def from_test_cfg(cfg) -> "TrackerConfig":
@@ -235,7 +235,9 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
         raise ValueError("run_pairs: sim_mode='l2-distance' needs channels= (the encoder's un-padded channel count)")
     if use_split:      # 16-bit matrix pipe on the two-part split of the (normalised) features, f32-grade scores
         fmt = cfg.pair_split_fmt
-        split = feats_hwc if pre_split else (ops.split_f16x2 if fmt == "f16" else ops.split_bf16)(feats_hwc)
+        if fmt != "f16":
+            raise ValueError(f"pair_split_fmt={fmt!r}: the split pair kernel reads split_f16x2 operands ('f16') only")
+        split = feats_hwc if pre_split else ops.split_f16x2(feats_hwc)
         pair_fn = lambda prs: ops.pair_topk_split(split, split, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False, all_masked=all_masked,
                                                   fmt=fmt)
     else:

@@ -145,6 +145,7 @@ class ResNet(nn.Module):
     use_conv64 = True              # 64 -> 64 3x3 layers on fgvc_conv64_split_f32 (register-resident weights)
     use_stem7 = True               # 7x7 stride-2 stem on fgvc_stem7_split_f32 (False: MIOpen f32 + ReLU/split pass)
     use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
+    res_from_split = True          # layer 1: identities read from the split form (False: dense f32 copies, rounds 1-2)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
     arith = "f16f8"                # arithmetic of the stride-1 convolutions behind layer 1: see set_arith()
 
@@ -195,6 +196,15 @@ class ResNet(nn.Module):
                 f_in = f_y
             cache[key] = plan
         return cache[key][(si, bi)]
+
+    def _identity_from_split(self, blk) -> bool:
+        """Whether `blk` adds its identity from the SPLIT form of its input (hi + lo, the value its first convolution multiplies)
+        instead of a dense f32 copy: the 64-channel blocks of layer 1 on fgvc_conv64_split_res_f32 -- their kernels are bound by the
+        bytes they move, and the producer of the input then writes 4 bytes per value instead of 8."""
+        c2 = getattr(blk, "conv2", None)
+        return bool(self.use_conv64 and self.res_from_split and isinstance(blk, BasicBlock) and blk.downsample is None
+                    and c2 is not None and tuple(c2.conv.weight.shape) == (64, 64, 3, 3) and c2.conv.stride == (1, 1)
+                    and tuple(blk.conv1.conv.weight.shape) == (64, 64, 3, 3) and blk.conv1.conv.stride == (1, 1))
 
     def _scales(self, dev):
         cache = self.__dict__.setdefault("_split_cache", {})
@@ -370,6 +380,7 @@ class ResNet(nn.Module):
         full = None
         for bi, (blk, wt) in enumerate(zip(stage, cache[wkey])):
             Cout = blk.conv2.conv.out_channels
+            idt_split = None
             H, W = cur["H"], cur["W"]
             f_in, f_a, f_y = fmts[bi]
             s_in = cur.get("scale", 0)
@@ -414,8 +425,11 @@ class ResNet(nn.Module):
                 if blk.downsample is not None:
                     conv_s1(cur["split"], wt["ds"], f_in, s_in, relu=False, out_f32=buf["f_idt"])
                     idt = buf["f_idt"]
+                elif self._identity_from_split(blk):
+                    idt, idt_split = None, cur["split"]                    # hi + lo of the block's input: no f32 copy of it exists
                 else:
                     idt = cur["f32"]
+                    assert idt is not None
                 conv_s1(cur["split"], wt["c1"], f_in, s_in, f_a, s_a, relu=True, out_split=buf["s_a"])
             if calib is not None:
                 calib[(si, bi, "a")] = torch.maximum(calib.get((si, bi, "a"), torch.zeros((), device=dev)),
@@ -430,9 +444,13 @@ class ResNet(nn.Module):
                             st.wait_stream(call["main"])                 # the block's previous life ended on that stream
                 full = call["out"][si]
             f_y_ = full[lo:hi]
-            skip_f32 = bi == len(stage) - 1 and not cur["need_f32"]       # nobody reads the f32 form of this stage's output
-            conv_s1(buf["s_a"], wt["c2"], f_a, s_a, f_y, s_y, relu=True, residual=idt,
-                    out_split=None if last_conv else buf["s_y"], out_f32=None if skip_f32 else f_y_)
+            # nobody reads the f32 form of this output: the stage's last block when the next stage takes the split form, any other
+            # block whose successor takes its identity from the split form
+            skip_f32 = (not cur["need_f32"]) if bi == len(stage) - 1 else self._identity_from_split(stage[bi + 1])
+            if skip_f32:
+                f_y_ = None
+            kw_res = dict(residual_split=idt_split) if idt_split is not None else dict(residual=idt)
+            conv_s1(buf["s_a"], wt["c2"], f_a, s_a, f_y, s_y, relu=True, out_split=None if last_conv else buf["s_y"], out_f32=f_y_, **kw_res)
             if calib is not None and not last_conv:
                 calib[(si, bi, "y")] = torch.maximum(calib.get((si, bi, "y"), torch.zeros((), device=dev)),
                                                      buf["s_y"].view(torch.bfloat16)[..., :32].abs().amax().float())
@@ -488,8 +506,12 @@ class ResNet(nn.Module):
                 with torch.cuda.stream(s):
                     if stem7:                                                   # stem on the bf16 pipe, from the NCHW frames
                         H, W, C0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1, 64
-                        sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x", "f_x"))
-                        t = sb["f_x"][lo:hi]
+                        if self._identity_from_split(stages[0][0]):             # nobody reads an f32 copy of the stem's output
+                            sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x",))
+                            t = None
+                        else:
+                            sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x", "f_x"))
+                            t = sb["f_x"][lo:hi]
                         ops.stem7_split(x[lo:hi], stem7[0], stem7[1], True, out_split=sb["s_x"][lo:hi], out_f32=t)
                     else:
                         t = self._miopen_nhwc(("stem",), self.conv1, x_cl[lo:hi])   # (n,H,W,64)

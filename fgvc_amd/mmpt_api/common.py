@@ -294,7 +294,7 @@ def local_square_attention(query, key, value, kernel_size, temperature=1, topk=N
 def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask, temperature=1, topk=None,
                                    normalize=True, step=32, non_mask_len=0, mode="softmax",
                                    sim_mode="dot_product", radius_fine=12):
-    """local_attention.py:721-880.  Coarse stage = fgvc_pair_topk_bf16x4 / fgvc_pair_topk_f32 with topk=1 per key slot (arg-max of
+    """local_attention.py:721-880.  Coarse stage = fgvc_pair_topk_f16x3 / fgvc_pair_topk_f32 with topk=1 per key slot (arg-max of
     the per-frame softmax, :835-837); fine stage = fgvc_c2f_refine_f32."""
     _check_common(query, key, value, mode, sim_mode, normalize)
     if topk is None:

@@ -180,7 +180,7 @@ class VanillaTracker(BaseTracker):
 @MODELS.register_module()
 class HRVanillaTracker(VanillaTracker):
     """Single-scale local-window variant (vanilla_tracker.py:417-660): mmcv.ops.Correlation(max_displacement=R)
-    + F.unfold + top-k is one call to fgvc_local_corr_topk_{bf16x4,f32} per frame.
+    + F.unfold + top-k is one call to fgvc_local_corr_topk_{f16x3,f32} per frame.
 
     Keys read here exactly as the reference reads them: `neighbor_range` (default 24, -> R), `withnorm` (sic, :437; NOT
     `with_norm`), `topk` (10), `temperature` (default 1, :563), `precede_frames`, `with_first` (slot 0, default True, :534;

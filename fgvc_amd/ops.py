@@ -57,7 +57,7 @@ class MaskSpec:
 
 
 def set_option(name: str, value: int) -> None:
-    """fgvc_set_option: e.g. set_option("pair_kernel", 1) selects the non-specialised pair kernel."""
+    """fgvc_set_option: process-wide tuning / ablation knobs (include/fgvc_hip.h lists them), e.g. set_option("readout_prune", 0)."""
     _lib.call("fgvc_set_option", name.encode(), int(value))
 
 
@@ -159,12 +159,13 @@ def pair_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq:
 
 def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int,
                     Wk: int, mask: MaskSpec, topk: int, validate: bool = True,
-                    all_masked: bool = False, fmt: str = "bf16", use_runs: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
-    """pair_topk() on the 16-bit matrix pipe: qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256) int16 = the split of
-    L2-NORMALISED features, fmt "bf16": split_bf16() -> fgvc_pair_topk_bf16x4; fmt "f16": split_f16x2() -> fgvc_pair_topk_f16x3
-    (the faster one).  Same outputs as pair_topk().  all_masked=True: the caller built `pairs` with PAIR_MASKED on every row
-    (then only the mask's reach, not the whole key grid, must fit the kernel's block list)."""
-    assert fmt in ("bf16", "f16")
+                    all_masked: bool = False, fmt: str = "f16", use_runs: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pair_topk() on the 16-bit matrix pipe (fgvc_pair_topk_f16x3): qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256) int16 =
+    split_f16x2() of L2-NORMALISED features.  Same outputs as pair_topk().  all_masked=True: the caller built `pairs` with
+    PAIR_MASKED on every row (then only the mask's reach, not the whole key grid, must fit the kernel's block list).
+    `fmt` names the operand format; "f16" is the only one (the bf16 four-product kernel of rounds 1-2 is retired)."""
+    if fmt != "f16":
+        raise ValueError(f"pair_topk_split: fmt={fmt!r} (only 'f16': split_f16x2 operands)")
     qsplit, ksplit = _chk(qsplit, torch.int16, "qsplit"), _chk(ksplit, torch.int16, "ksplit")
     pairs = _chk(pairs, torch.int32, "pairs")
     assert qsplit.dim() == 4 and ksplit.dim() == 4 and qsplit.shape[2] == 2 and ksplit.shape[2] == 2
@@ -176,13 +177,13 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
         assert not all_masked or bool((pairs[:, 2] & PAIR_MASKED).all()), "all_masked=True but a pair is not masked"
     idx = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.int32)
     score = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.float32)
-    runs = pair_runs(pairs) if (fmt == "f16" and use_runs and n) else None
+    runs = pair_runs(pairs) if (use_runs and n) else None
     if runs is not None:            # a query frame's pairs in one workgroup (query prologue once, the key-block ring never drains)
         _lib.call("fgvc_pair_topk_f16x3_runs", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n, qsplit.shape[3], Hq, Wq, Hk, Wk,
                   mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(runs), runs.shape[0], _ptr(idx), _ptr(score),
                   _stream(qsplit))
         return idx, score
-    _lib.call("fgvc_pair_topk_bf16x4" if fmt == "bf16" else "fgvc_pair_topk_f16x3", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n,
+    _lib.call("fgvc_pair_topk_f16x3", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n,
               qsplit.shape[3], Hq, Wq, Hk, Wk, mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(idx), _ptr(score),
               _stream(qsplit))
     return idx, score
@@ -195,11 +196,11 @@ def pair_f16x3_timed_out() -> bool:
     return _lib.load().fgvc_pair_topk_f16x3_timed_out() != 0
 
 
-V4_LIST_CAP = 4096   # key blocks (4x8 pixels) one query tile may visit in fgvc_pair_topk_bf16x4 (csrc/pair_topk_v4.hip)
+PAIR_LIST_CAP = 4096   # key blocks (4x8 pixels) one query tile may visit in fgvc_pair_topk_f16x3 (csrc/pair_topk_v5.hip)
 
 
-def v4_blocks_needed(Hk: int, Wk: int, mask: Optional[MaskSpec] = None, all_masked: bool = False) -> int:
-    """Key blocks a 8x16-pixel query tile of fgvc_pair_topk_bf16x4 may have to list (pair_topk_v4_launch's own check):
+def pair_blocks_needed(Hk: int, Wk: int, mask: Optional[MaskSpec] = None, all_masked: bool = False) -> int:
+    """Key blocks a 8x16-pixel query tile of fgvc_pair_topk_f16x3 may have to list (pair_topk_v5_launch's own check):
     the blocks within the mask's reach when every pair is masked, the whole key grid otherwise."""
     whole = -(-Hk // 4) * -(-Wk // 8)
     if not all_masked or mask is None or mask.is_none:
@@ -211,10 +212,10 @@ def v4_blocks_needed(Hk: int, Wk: int, mask: Optional[MaskSpec] = None, all_mask
 
 def split_path_ok(C: int, Hk: int, Wk: int, topk: int, normalized: bool, dense_mask=None, mask: Optional[MaskSpec] = None,
                   all_masked: bool = False) -> bool:
-    """Whether fgvc_pair_topk_bf16x4 applies: 256 channels, top-k <= 10, analytic mask, L2-normalised rows (its
-    fixed-point keys assume |q.k| <= 1) and at most 4096 key blocks per query tile (v4_blocks_needed)."""
+    """Whether fgvc_pair_topk_f16x3 applies: 256 channels, top-k <= 10, analytic mask, L2-normalised rows (its
+    fixed-point keys assume |q.k| <= 1) and at most 4096 key blocks per query tile (pair_blocks_needed)."""
     return (normalized and C == 256 and 1 <= topk <= 10 and dense_mask is None
-            and v4_blocks_needed(Hk, Wk, mask, all_masked) <= V4_LIST_CAP and Hk < 16384 and Wk < 32768)
+            and pair_blocks_needed(Hk, Wk, mask, all_masked) <= PAIR_LIST_CAP and Hk < 16384 and Wk < 32768)
 
 
 def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int,
@@ -223,8 +224,7 @@ def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor
                    split_fmt: str = "f16") -> Tuple[torch.Tensor, torch.Tensor]:
     """pair_topk() with the kernel chosen by `precision`:
       "f32"   fgvc_pair_topk_f32 (f32 MFMA);
-      "split" fgvc_pair_topk_f16x3 on split_f16x2() of the features (split_fmt "bf16": fgvc_pair_topk_bf16x4 on split_bf16());
-              raises when it does not apply;
+      "split" fgvc_pair_topk_f16x3 on split_f16x2() of the features; raises when it does not apply;
       "auto"  "split" where split_path_ok(), else "f32".
     qfeat/kfeat are the f32 channels-last features either way (the split costs one extra pass over them)."""
     if precision not in ("auto", "f32", "split"):
@@ -235,10 +235,9 @@ def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor
         return pair_topk(qfeat, kfeat, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, dense_mask)
     if not ok:
         raise ValueError("the split pair kernels need C == 256, topk <= 10, an analytic mask, normalised features and "
-                         f"<= {V4_LIST_CAP} key blocks per query tile")
-    split = split_f16x2 if split_fmt == "f16" else split_bf16
-    ks = split(kfeat)
-    qs = ks if qfeat is kfeat else split(qfeat)
+                         f"<= {PAIR_LIST_CAP} key blocks per query tile")
+    ks = split_f16x2(kfeat)
+    qs = ks if qfeat is kfeat else split_f16x2(qfeat)
     return pair_topk_split(qs, ks, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, all_masked, fmt=split_fmt)
 
 
@@ -423,22 +422,21 @@ def dense_propagate(aff: torch.Tensor, labels: torch.Tensor, topk: Optional[int]
 def local_corr_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, H: int, W: int, R: int, topk: int,
                     temperature: float, normalized: bool = False, split_fmt: str = "f16"):
     """A7: qfeat (1, HW, C), kfeat (K, HW, C) -> idx (HW,k) int32 = slot*(2R+1)^2 + tap, logit, weight.
-    normalized=True (rows are L2-normalised) lets C == 256 / k <= 10 run on the 16-bit matrix pipe: fgvc_local_corr_topk_f16x3
-    (split_fmt="f16", default) or fgvc_local_corr_topk_bf16x4 (split_fmt="bf16")."""
+    normalized=True (rows are L2-normalised) lets C == 256 / k <= 10 run on the 16-bit matrix pipe (fgvc_local_corr_topk_f16x3)."""
     qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
     K = kfeat.shape[0]
     dev = qfeat.device
-    if split_fmt not in ("f16", "bf16"):
-        raise ValueError(f"split_fmt={split_fmt!r}")
+    if split_fmt != "f16":
+        raise ValueError(f"split_fmt={split_fmt!r} (only 'f16')")
     if split_path_ok(qfeat.shape[-1], H, W, topk, normalized, None, MaskSpec(ry=R, rx=R), True):
-        qs, ks = (split_f16x2(qfeat), split_f16x2(kfeat)) if split_fmt == "f16" else (split_bf16(qfeat), split_bf16(kfeat))
+        qs, ks = split_f16x2(qfeat), split_f16x2(kfeat)
         pairs = make_pairs([(0, t) for t in range(K)], dev)
         ws_i = torch.empty((K, H * W, topk), device=dev, dtype=torch.int32)
         ws_s = torch.empty((K, H * W, topk), device=dev, dtype=torch.float32)
         idx = torch.empty((H * W, topk), device=dev, dtype=torch.int32)
         logit = torch.empty((H * W, topk), device=dev, dtype=torch.float32)
         weight = torch.empty_like(logit)
-        _lib.call("fgvc_local_corr_topk_f16x3" if split_fmt == "f16" else "fgvc_local_corr_topk_bf16x4", _ptr(qs), _ptr(ks), _ptr(pairs), K, qfeat.shape[-1], H, W, R, topk,
+        _lib.call("fgvc_local_corr_topk_f16x3", _ptr(qs), _ptr(ks), _ptr(pairs), K, qfeat.shape[-1], H, W, R, topk,
                   float(temperature), _ptr(ws_i), _ptr(ws_s), _ptr(idx), _ptr(logit), _ptr(weight), _stream(qfeat))
         return idx, logit, weight
     pairs = make_pairs([(0, t) for t in range(K)], dev)
@@ -529,7 +527,19 @@ F16_TARGET_LOG2 = 8            # a calibrated tensor's largest value sits at ~2^
 
 def act_scale_log2(amax: float) -> int:
     """log2 of the power-of-two scale that puts a tensor whose largest magnitude is `amax` at (2^7, 2^8] in f16."""
-    return F16_TARGET_LOG2 - int(math.ceil(math.log2(max(float(amax), 1e-30))))
+    return _pow2_exponent(amax, F16_TARGET_LOG2)
+
+
+def _pow2_exponent(amax: float, target_log2: int) -> int:
+    """e with amax * 2^e in (2^(target-1), 2^target]; 0 for an all-zero tensor (a zero-initialised residual branch: any scale
+    represents it exactly); clamped to +-45 so that the combined exponents stay inside the C ABI's range; a tensor holding inf /
+    NaN is an error, not a scale."""
+    amax = float(amax)
+    if not math.isfinite(amax):
+        raise ValueError("a tensor with inf / NaN values has no f16 scale")
+    if amax <= 0.0:
+        return 0
+    return max(-45, min(45, target_log2 - int(math.ceil(math.log2(amax)))))
 
 
 def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
@@ -542,7 +552,7 @@ def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt
     w = weight.detach().float() * scale.view(-1, 1, 1, 1)
     bias = (bn.bias - bn.running_mean * scale).detach().float().contiguous()
     w = w.permute(2, 3, 1, 0).reshape(KS * KS, Cin // 32, 32, Cout).permute(0, 1, 3, 2).contiguous()   # [tap][chunk][co][32 ci]
-    e = 10 - int(math.ceil(math.log2(max(float(w.abs().max()), 1e-30))))
+    e = _pow2_exponent(float(w.abs().max()), 10)
     ws = w * (2.0 ** e)
     h = ws.to(torch.float16)
     l = ws - h.float()                                                  # exact in f32
@@ -658,17 +668,19 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
 
 def conv64_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
                  residual: Optional[torch.Tensor] = None, out_split: Optional[torch.Tensor] = None,
-                 out_f32: Optional[torch.Tensor] = None) -> None:
-    """conv_split for Cin = Cout = 64, 3x3, with register-resident weights (fgvc_conv64_split_f32; w, bias from prepare_conv64)."""
+                 out_f32: Optional[torch.Tensor] = None, residual_split: Optional[torch.Tensor] = None) -> None:
+    """conv_split for Cin = Cout = 64, 3x3, with register-resident weights (fgvc_conv64_split_res_f32; w, bias from prepare_conv64).
+    The residual is dense NHWC f32 (`residual`) or a padded split NHWC tensor of x_split's shape (`residual_split`: hi + lo is added)."""
     x_split = _chk(x_split, torch.int16, "x_split")
     N, Hp, Wp, nch, _ = x_split.shape
     assert nch == 2 and tuple(w.shape) == (2, 9, 2, 2, 2, 64, 8) and bias.shape == (64,)
+    assert residual is None or residual_split is None, "one residual, f32 or split"
     for t, dt, shape in ((residual, torch.float32, (N, H, W, 64)), (out_f32, torch.float32, (N, H, W, 64)),
-                         (out_split, torch.int16, (N, Hp, Wp, 2, 64))):
+                         (out_split, torch.int16, (N, Hp, Wp, 2, 64)), (residual_split, torch.int16, (N, Hp, Wp, 2, 64))):
         if t is not None:
             assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv64_split buffer"
-    _lib.call("fgvc_conv64_split_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
-              N, H, W, Hp, Wp, int(relu), _stream(x_split))
+    _lib.call("fgvc_conv64_split_res_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(residual_split), _ptr(out_split),
+              _ptr(out_f32), N, H, W, Hp, Wp, int(relu), _stream(x_split))
 
 
 def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,

@@ -55,17 +55,13 @@ const char* fgvc_version(void);
 const char* fgvc_last_error(void);
 
 /* Process-wide tuning knobs (host only, not thread-safe against concurrent launches).
- *   "pair_kernel"        fgvc_pair_topk_f32 variant: 3 (default; C = 256, 2 <= topk <= 10, analytic mask) = wave-specialised
- *                        kernel with the sorting network in the MFMA shadow, 2 = wave-specialised, 1 = plain 4-wave kernel.
- *                        Identical results up to the last bit of the scores.
- *   "pair_bf16_products" fgvc_pair_topk_bf16x4: 4 (default) = hi*hi + hi*lo + lo*hi + lo*lo, 3 = without lo*lo.
  *   "conv_cot_cap"       fgvc_conv_split_f32: at most this many output channels per workgroup (0 = widest, 64, 128).
  *   "conv_narrow"        fgvc_conv_split_f32: 4-row tiles with two workgroups per CU for the 64-channel layers (bit 0, default) /
  *                        the 128-channel 3x3 layers (bit 1).
  *   "readout_prune"      fgvc_softargmax_top5_f32: 1 (default) = pruned read-out, full scan only for the maps it hands back;
  *                        0 = full scan of every map.  Identical results.
- *   "pair_debug", "pair_bf16_debug", "corr_debug", "conv_debug", "conv_s2_debug": profiling ablations (skip selection / MFMA / staging /
- *                        epilogue, s_memtime probes); results are WRONG when non-zero -- tools/ablate_*.py, tools/time_*.py. */
+ *   "pair_debug", "pair_f16_debug", "corr_debug", "conv_debug", "conv_s2_debug": profiling ablations (skip selection / MFMA / staging /
+ *                        epilogue, s_memtime probes); results are WRONG when non-zero -- tools/experiments/ablate_*.py, tools/experiments/time_*.py. */
 int fgvc_set_option(const char* name, int value);
 
 /* Largest integer d2 such that sqrtf((float)d2) < radius, -1 if none (host helper). */
@@ -98,12 +94,13 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
                        int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk,
                        const uint8_t* dense_mask, int32_t* idx_out, float* score_out, void* stream);
 
-/* Same operator and outputs as fgvc_pair_topk_f32 on the bf16 matrix pipe, f32-grade: the features are the
- * [pixel][hi C | lo C] bf16 split that fgvc_split_bf16 writes (x = hi + lo up to 2^-18 |x|); all four partial
- * products hi*hi + hi*lo + lo*hi + lo*lo are accumulated in f32 (v_mfma_f32_32x32x16_bf16), so a score differs from
- * the f32 dot product by ~1e-7 (the size of f32 summation-order noise); selection runs on fixed-point keys with 24 fractional bits
- * (scores closer than 6e-8 tie and are ordered by pixel index, like equal f32 scores).
- * The default pair kernel of the engine for C == 256.
+/* Same operator and outputs as fgvc_pair_topk_f32 on the 16-bit matrix pipe, f32-grade (replaces local_attention.py:331-371 like
+ * fgvc_pair_topk_f32; the default pair kernel of the engine for C == 256): f16 operands h = f16(2^14 x), l = f16(2^14 x - h) as
+ * fgvc_split_f16x2 writes them ([pixel][h C | l C]), three products h h + l h + h l on v_mfma_f32_32x32x16_f16 accumulated in f32
+ * (22 significand bits per element; a score differs from the f32 dot product by ~1e-7, the size of f32 summation-order noise);
+ * selection runs on fixed-point keys with 24 fractional bits (scores closer than 6e-8 tie and are ordered by pixel index, like
+ * equal f32 scores), in waves of their own beside the multiplying ones; key blocks travel through a producer / consumer ring
+ * without workgroup barriers.
  *   Precondition: feature rows L2-normalised (|q.k| <= 1), as fgvc_normalize_chw_to_hwc_f32(normalize=1) makes them.
  *   C == 256; 1 <= topk <= 10; analytic mask only (a dense mask tensor needs fgvc_pair_topk_f32).
  *   A query tile walks a list of at most 4096 key blocks (4x8 pixels): the key blocks within the mask's reach for a pair with
@@ -111,15 +108,6 @@ int fgvc_pair_topk_f32(const float* qfeat, const float* kfeat, const int32_t* pa
  *   all_masked != 0 that EVERY pair carries FGVC_PAIR_MASKED; then only the reach is checked against the list (a 480x854 grid
  *   with a radius-6 window is fine), otherwise the whole grid must fit (FGVC_ERR_UNSUPPORTED beyond 4096 blocks).  A pair
  *   that breaks the promise on such a grid gets empty lists (-1 / -inf), never truncated ones. */
-int fgvc_pair_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs,
-                          int C, int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked,
-                          int32_t* idx_out, float* score_out, void* stream);
-
-/* The same operator, faster (replaces local_attention.py:331-371 like fgvc_pair_topk_f32): f16 operands h = f16(2^14 x),
- * l = f16(2^14 x - h) as fgvc_split_f16x2 writes them ([pixel][h C | l C], the container of fgvc_split_bf16), three products
- * h h + l h + h l on v_mfma_f32_32x32x16_f16 (22 significand bits per element; scores within ~1e-7 of the f32 dot product), the
- * selection of a tile in the instruction stream of the next tile's MFMAs, and a producer / consumer ring of key blocks without
- * workgroup barriers.  Same arguments, outputs and tie order as fgvc_pair_topk_bf16x4; rows must be L2-normalised. */
 int fgvc_split_f16x2(const float* feat, uint16_t* h_l /* [n][2][C] f16: h then l */, int64_t n_pixels, int C, void* stream);
 int fgvc_pair_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
                          int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out,
@@ -232,14 +220,8 @@ int fgvc_local_corr_topk_f32(const float* qfeat, const float* kfeat, const int32
                              int C, int H, int W, int R, int topk, float temperature,
                              int32_t* pair_idx_ws, float* pair_score_ws,
                              int32_t* idx_out, float* logit_out, float* weight_out, void* stream);
-/* the same on the bf16 matrix pipe: features as written by fgvc_split_bf16 from L2-NORMALISED rows, C == 256, topk <= 10
- * (fgvc_pair_topk_bf16x4 with the square window, then the same merge) */
-int fgvc_local_corr_topk_bf16x4(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_slots,
-                                int C, int H, int W, int R, int topk, float temperature,
-                                int32_t* pair_idx_ws, float* pair_score_ws,
-                                int32_t* idx_out, float* logit_out, float* weight_out, void* stream);
-/* ... and on the f16 pipe: features as written by fgvc_split_f16x2 (fgvc_pair_topk_f16x3 with the square window, then the same
- * merge): three products instead of four, 22-bit operands instead of 16 -- the default of the HR driver for C == 256 */
+/* the same on the f16 matrix pipe: features as written by fgvc_split_f16x2 from L2-NORMALISED rows, C == 256, topk <= 10
+ * (fgvc_pair_topk_f16x3 with the square window, then the same merge) -- the default of the HR driver for C == 256 */
 int fgvc_local_corr_topk_f16x3(const uint16_t* qsplit, const uint16_t* ksplit, const int32_t* pairs, int n_slots,
                                int C, int H, int W, int R, int topk, float temperature,
                                int32_t* pair_idx_ws, float* pair_score_ws,
@@ -314,6 +296,12 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
  *   w[2 output tiles][9 taps][2 chunks][2 k-steps][hi | lo][lane = 32 * (k >> 3 & 1) + cout % 32][k & 7]   (ops.prepare_conv64). */
 int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                           float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, void* stream);
+/* ... with the residual (resnet.py:96-106 `identity = x ... out += identity`) given EITHER as dense NHWC f32 (`residual`) OR as a padded split NHWC
+ * tensor of x's geometry (`residual_split`: the identity is then hi + lo, the value the block's first convolution multiplied;
+ * the producer of the identity need not write an f32 copy of it).  At most one of the two. */
+int fgvc_conv64_split_res_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
+                              const uint16_t* residual_split, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp,
+                              int relu, void* stream);
 /* The stride-2 members of the same family: the 3x3 / stride 2 / zero padding 1 convolution that opens a down-sampling
  * stage and its 1x1 / stride 2 projection (resnet.py:54-76 conv1 of the first BasicBlock, :288-296 downsample), BatchNorm
  * folded, + bias (+ ReLU).  x: padded split NHWC of the H x W input; outputs for the Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1)
@@ -341,7 +329,7 @@ int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, u
  * fgvc_normalize_chw_to_hwc_f32) */
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream);
 /* the same rows and / or their (hi, lo) bf16 split [n][H*W][hi C | lo C] (= fgvc_split_bf16 of them, what
- * fgvc_pair_topk_bf16x4 reads) in ONE pass over the trunk output; either output may be NULL */
+ * fgvc_corr_volume_bf16x3 reads) in ONE pass over the trunk output; either output may be NULL */
 int fgvc_normalize_split_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
                                   int normalize, void* stream);
 /* the same with the split in the (h, l) f16 form of fgvc_split_f16x2 (what fgvc_pair_topk_f16x3 reads) */

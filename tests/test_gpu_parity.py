@@ -379,28 +379,11 @@ def test_split_feature_bank_equals_f32_bank(dev):
     cfg32 = engine.TrackerConfig(**{**cfg.__dict__, "pair_precision": "f32"})
     with pytest.raises(ValueError):
         engine.run_affinity(bank_s, Hf, Wf, plan, cfg32)
-    # the (hi, lo) bf16 form and its kernel stay selectable and give the same lists
+    # the retired bf16 operand format is refused, not silently replaced
     model.test_cfg["pair_split_fmt"] = "bf16"
-    cfgb = model.engine_config()
-    bank_b, _, _ = model.get_feats_hwc(frames, split=True)
-    assert torch.equal(ops.split_bf16(bank_f), bank_b)
-    c = engine.run_affinity(bank_b, Hf, Wf, plan, cfgb)
-    # rows may differ only where two of the scores involved are within rounding of each other: every row that differs must hold,
-    # two neighbouring ranks closer than the two kernels' combined rounding (bf16x4 is within 5e-5 logit of float64, f16x3 within
-    # 4e-6: bound 1e-4, the same bound the score sequences are held to), inside the list or across its k-th place
-    assert float((c.logit - a.logit).abs().max()) < 1e-4
-    differ = ~(c.idx == a.idx).all(-1)
-    if bool(differ.any()):
-        assert float(differ.float().mean()) < 0.01
-        ai, ci, al, cl = a.idx[differ], c.idx[differ], a.logit[differ], c.logit[differ]
-        common = (ai.unsqueeze(-1) == ci.unsqueeze(-2)).any(-1).sum(-1)
-        kk = ai.shape[-1]
-        assert int(common.min()) >= kk - 1                               # the same candidates, or one swapped at the k-th place
-        perm = common == kk                                              # same set, two neighbours in the other order: a near-tie inside the list
-        if bool(perm.any()):
-            assert float((al[perm][..., :-1] - al[perm][..., 1:]).min(-1).values.max()) < 1e-4, "a differing row without a near-tie"
-        if bool((~perm).any()):                                          # k-th and (k+1)-th candidates tied: the two k-th scores coincide
-            assert float((al[~perm][..., -1] - cl[~perm][..., -1]).abs().max()) < 1e-4, "a swapped candidate without a near-tie"
+    with pytest.raises(ValueError):
+        engine.run_affinity(bank_f, Hf, Wf, plan, model.engine_config())
+    model.test_cfg["pair_split_fmt"] = "f16"
     assert not ops.pair_f16x3_timed_out()
 
 
@@ -530,32 +513,22 @@ def test_engine_vs_oracle_tracker(dev):
     assert order.tolist() == [0, 1, 2, 3, 4]
 
 
-def test_pair_kernel_variants_agree(dev):
-    """v1 (4-wave) and v2 (wave-specialised) kernels must produce bit-identical lists."""
+def test_pair_f32_kernel_is_prefix_consistent_and_deterministic(dev):
+    """The exact-f32 pair kernel (the fallback of the 16-bit one and its reference in these tests): a shorter list is the prefix of
+    a longer one (the list length is a compile-time register array: 1 / 5 / 10 / 16), and two launches give identical bits."""
     from fgvc_amd import ops
     g = torch.Generator().manual_seed(77)
     for (C, H, W, nr) in [(256, 37, 53, 30), (64, 9, 70, 12), (128, 20, 20, None)]:
         f = ops.normalize_to_hwc(torch.randn(3, C, H, W, generator=g).to(dev))
         mask = ops.MaskSpec.from_neighbor_range(nr)
         pairs = ops.make_pairs([(2, 0, nr is not None), (2, 1, nr is not None), (1, 0, nr is not None)], dev)
-        try:
-            ops.set_option("pair_kernel", 1)
-            i1, s1 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
-            ops.set_option("pair_kernel", 2)
-            i2, s2 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
-            ops.set_option("pair_kernel", 3)
-            i3, s3 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
-            i3b, s3b = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 4)
-        finally:
-            ops.set_option("pair_kernel", 3)
-        # v2 sums the channels in four interleaved chains: last-bit differences in the scores are expected
-        assert torch.allclose(s1, s2, atol=2e-6) and (i1 == i2).float().mean() > 0.999
-        # v3 uses one chain like v1 (for C=256; other C fall back to v2): identical bits
-        if C == 256:
-            assert torch.equal(i1, i3) and torch.equal(s1, s3)
-            assert torch.equal(i3[..., :4], i3b) and torch.equal(s3[..., :4], s3b)
-        else:
-            assert torch.equal(i2, i3) and torch.equal(s2, s3)
+        i10, s10 = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+        i10b, s10b = ops.pair_topk(f, f, pairs, H, W, H, W, mask, 10)
+        assert torch.equal(i10, i10b) and torch.equal(s10, s10b)
+        for k in (1, 4, 16):
+            ik, sk = ops.pair_topk(f, f, pairs, H, W, H, W, mask, k)
+            kk = min(k, 10)
+            assert torch.equal(ik[..., :kk], i10[..., :kk]) and torch.equal(sk[..., :kk], s10[..., :kk])
 
 
 def test_tracker_end_to_end_on_synthetic_tapvid(dev):
@@ -640,9 +613,9 @@ def test_get_coord_vs_oracle(dev):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# fgvc_pair_topk_bf16x4: the same operator on the bf16 matrix pipe (hi/lo split features, fixed-point selection keys)
+# fgvc_pair_topk_f16x3: the same operator on the f16 matrix pipe (h/l split features, fixed-point selection keys)
 # ---------------------------------------------------------------------------------------------------------------
-def split_affinity(dev, q, key, topk, temperature, neighbor_range, mask_mode="circle", products=3):
+def split_affinity(dev, q, key, topk, temperature, neighbor_range, mask_mode="circle"):
     from fgvc_amd import ops
     C, H, W = q.shape
     Tn = key.shape[1]
@@ -650,40 +623,25 @@ def split_affinity(dev, q, key, topk, temperature, neighbor_range, mask_mode="ci
     feats = ops.normalize_to_hwc(frames)
     mask = ops.MaskSpec.from_neighbor_range(neighbor_range, mask_mode)
     pairs = ops.make_pairs([(0, 1 + t, not mask.is_none) for t in range(Tn)], dev)
-    if products == "f16":                          # fgvc_pair_topk_f16x3 (the engine's default)
-        h16 = ops.split_f16x2(feats)
-        pidx, pscore = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, topk, fmt="f16")
-        assert not ops.pair_f16x3_timed_out()
-    else:
-        hl = ops.split_bf16(feats)
-        ops.set_option("pair_bf16_products", products)
-        try:
-            pidx, pscore = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, topk)
-        finally:
-            ops.set_option("pair_bf16_products", 4)
+    h16 = ops.split_f16x2(feats)                   # fgvc_pair_topk_f16x3 (the engine's default)
+    pidx, pscore = ops.pair_topk_split(h16, h16, pairs, H, W, H, W, mask, topk)
+    assert not ops.pair_f16x3_timed_out()
     fidx, fscore = ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, topk)
     slot_pair = torch.arange(Tn, dtype=torch.int32, device=dev).view(1, Tn)
     idx, logit, weight = ops.merge_topk(pidx, pscore, slot_pair, H * W, topk, temperature, "softmax")
     return (pidx, pscore, fidx, fscore), idx[0], logit[0], weight[0]
 
 
-@pytest.mark.parametrize("shape", [(3, 30, 44, 30, "circle", 10, 3), (3, 30, 44, 30, "circle", 10, 4),
-                                   (2, 17, 23, 9, "square", 10, 3), (1, 33, 70, 30, "circle", 5, 3),
-                                   (2, 5, 3, 4, "circle", 5, 3), (2, 20, 20, None, "circle", 10, 3),
-                                   (1, 9, 130, 12, "circle", 3, 4), (6, 8, 8, 30, "circle", 10, 3),
-                                   (3, 30, 44, 30, "circle", 10, "f16"), (2, 17, 23, 9, "square", 10, "f16"),
-                                   (1, 33, 70, 30, "circle", 5, "f16"), (2, 5, 3, 4, "circle", 5, "f16"),
-                                   (2, 20, 20, None, "circle", 10, "f16"), (1, 9, 130, 12, "circle", 3, "f16"),
-                                   (6, 8, 8, 30, "circle", 10, "f16"), (2, 37, 53, 30, "circle", 10, "f16"),
-                                   (1, 61, 47, 14, "square", 7, "f16")])
+@pytest.mark.parametrize("shape", [(3, 30, 44, 30, "circle", 10), (2, 17, 23, 9, "square", 10), (1, 33, 70, 30, "circle", 5),
+                                   (2, 5, 3, 4, "circle", 5), (2, 20, 20, None, "circle", 10), (1, 9, 130, 12, "circle", 3),
+                                   (6, 8, 8, 30, "circle", 10), (2, 37, 53, 30, "circle", 10), (1, 61, 47, 14, "square", 7)])
 def test_split_pair_topk_vs_oracle(dev, shape):
-    """Ragged grids, both mask modes, no mask, k in {3,5,7,10}; fgvc_pair_topk_bf16x4 with 3 and 4 partial products and
-    fgvc_pair_topk_f16x3 ("f16"): indices exact wherever the f64 ranks are clear, scores within the north_star bar (and within
-    1e-5 of the f32-MFMA kernel)."""
-    Tn, H, W, nr, mm, topk, products = shape
+    """Ragged grids, both mask modes, no mask, k in {3,5,7,10}; fgvc_pair_topk_f16x3: indices exact wherever the f64 ranks are
+    clear, scores within the north_star bar (and within 1e-5 of the f32-MFMA kernel)."""
+    Tn, H, W, nr, mm, topk = shape
     g = torch.Generator().manual_seed(sum(v for v in shape if isinstance(v, int)))
     q, key = torch.randn(256, H, W, generator=g), torch.randn(256, Tn, H, W, generator=g)
-    (pidx, pscore, fidx, fscore), idx, logit, weight = split_affinity(dev, q, key, topk, 0.07, nr, mm, products)
+    (pidx, pscore, fidx, fscore), idx, logit, weight = split_affinity(dev, q, key, topk, 0.07, nr, mm)
     stats = O.check_topk(dense64(q, key, 0.07, nr, mm), idx.cpu().long(), logit.cpu(), topk, tol=TOL)
     assert stats["exact"] >= stats["clear"]
     assert stats["max_score_err"] < 5e-5                       # logit units (score / 0.07)
@@ -707,7 +665,7 @@ def test_split_pair_topk_exact_ties_and_identical_frames(dev):
     const = torch.ones(1, 256, H, W)
     fc = ops.normalize_to_hwc(const.to(dev))
     qy, qx = torch.arange(H * W) // W, torch.arange(H * W) % W
-    for fmt, split in (("bf16", ops.split_bf16), ("f16", ops.split_f16x2)):
+    for fmt, split in (("f16", ops.split_f16x2),):
         hl = split(f)
         idx, score = ops.pair_topk_split(hl, hl, pairs, H, W, H, W, mask, 10, fmt=fmt)
         assert torch.equal(idx[0, :, 0].cpu(), torch.arange(H * W, dtype=torch.int32))
@@ -754,9 +712,8 @@ def test_pair_f16x3_runs_of_pairs_equal_pair_by_pair(dev):
 
 
 def test_conv256_forms_are_bit_identical(dev):
-    """The three builds of the 256-channel-tile convolution -- hand-ordered assembly stage (default), the compiler's schedule
-    (conv_debug = 16), one wave per SIMD with a 4 x 4 register tile (conv_debug = 32) -- accumulate in the same order and must
-    agree bit for bit, with residual + ReLU + both outputs, on a ragged grid (edge tiles) and two input widths."""
+    """The two builds of the 256-channel-tile bf16x3 convolution -- hand-ordered assembly stage (default) and the compiler's
+    schedule (conv_debug = 16) -- accumulate in the same order and must agree bit for bit, with residual + ReLU + both outputs, on a ragged grid (edge tiles) and two input widths."""
     from fgvc_amd import ops
     g = torch.Generator().manual_seed(9)
     for Cin, H, W in ((128, 19, 45), (256, 24, 70)):
@@ -769,7 +726,7 @@ def test_conv256_forms_are_bit_identical(dev):
         res = ops.alloc_nhwc(3, 256, H, W, dev)
         res.copy_(torch.randn(res.shape, generator=g).to(dev))
         outs = []
-        for dbg in (0, 16, 32):
+        for dbg in (0, 16):
             ys, yf = ops.alloc_split_nhwc(3, 256, H, W, dev), ops.alloc_nhwc(3, 256, H, W, dev)
             ops.set_option("conv_debug", dbg)
             try:
@@ -1105,6 +1062,18 @@ def test_conv64_split_vs_torch(dev, case):
     only_s = ops.alloc_split_nhwc(N, 64, H, W, dev)
     ops.conv64_split(xs, wp, bias, H, W, relu, residual=resp, out_split=only_s)
     assert torch.equal(only_s, out_s)
+    if with_res:
+        # the identity given as a split tensor (what the encoder does in layer 1): bit-identical to the f32 identity hi + lo
+        rs = ops.nchw_to_split_nhwc(res.to(dev))
+        r32 = ops.unsplit_act(rs, ops.ACT_BF16X2)[:, 1:H + 1, 1:W + 1].contiguous()
+        assert float((r32 - resp).abs().max()) <= 2.0 ** -16 * float(resp.abs().max())
+        a_s, a_f = ops.alloc_split_nhwc(N, 64, H, W, dev), ops.alloc_nhwc(N, 64, H, W, dev)
+        b_s, b_f = ops.alloc_split_nhwc(N, 64, H, W, dev), ops.alloc_nhwc(N, 64, H, W, dev)
+        ops.conv64_split(xs, wp, bias, H, W, relu, residual=r32, out_split=a_s, out_f32=a_f)
+        ops.conv64_split(xs, wp, bias, H, W, relu, residual_split=rs, out_split=b_s, out_f32=b_f)
+        assert torch.equal(a_s, b_s) and torch.equal(a_f, b_f)
+        with pytest.raises(Exception):
+            ops.conv64_split(xs, wp, bias, H, W, relu, residual=r32, residual_split=rs, out_split=b_s)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 96, True), (1, 37, 131, True), (3, 9, 5, False), (1, 480, 854, True)])
@@ -1143,6 +1112,33 @@ def test_stem7_split_vs_torch(dev, case):
     only_f = ops.alloc_nhwc(N, 64, Ho, Wo, dev)
     ops.stem7_split(x.to(dev), wp, bias, relu, out_f32=only_f)
     assert torch.equal(only_f, out_f)
+
+
+@pytest.mark.gpu
+def test_encoder_zero_initialised_residual_branch(dev):
+    """init_weights() of the reference's ResNet zeroes bn2.weight of every block (zero_init_residual, mmpt/models/backbones/resnet.py
+    :596-601): folded conv2 weights are all zero, so is a block's pre-residual tensor.  The f16 forms take a scale from the largest
+    magnitude of a tensor: an all-zero one must get a finite scale and the trunk must equal the MIOpen path."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    torch.manual_seed(21)
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none"))
+    net.init_weights()
+    assert all(float(b.conv2.bn.weight.abs().max()) == 0.0 for b in net.layer3)
+    net = net.to(dev).eval()
+    x = torch.randn(2, 3, 64, 96, device=dev)
+    with torch.no_grad():
+        try:
+            ResNet.use_split_conv = False
+            ref = net(x).cpu()
+        finally:
+            ResNet.use_split_conv = True
+        for arith in net.supported_arith():
+            net.set_arith(arith)
+            a = net(x).cpu()
+            net.check_overflow()
+            assert torch.isfinite(a).all()
+            assert float((a - ref).abs().max()) <= 5e-5 * float(ref.abs().max()) + 1e-6, (arith, float((a - ref).abs().max()), float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("arith", ["f16f8", "bf16x3", "f16x3"])
@@ -1253,7 +1249,7 @@ def test_sharded_tracker_hip_backend_single_rank(dev):
 
 
 def test_local_corr_split_path_vs_oracle(dev):
-    """A7 local window on the bf16 pipe (C = 256, normalised): against the oracle and against the f32-MFMA path."""
+    """A7 local window on the f16 pipe (C = 256, normalised): against the oracle and against the f32-MFMA path."""
     from fgvc_amd import ops
     g = torch.Generator().manual_seed(31)
     C, K, H, W, R, topk = 256, 3, 14, 19, 4, 10
@@ -1263,8 +1259,8 @@ def test_local_corr_split_path_vs_oracle(dev):
     qf = ops.normalize_to_hwc(q[None].to(dev))
     kf = ops.normalize_to_hwc(key.permute(1, 0, 2, 3).contiguous().to(dev))
     i1, l1, w1 = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07, normalized=True)                       # fgvc_local_corr_topk_f16x3
-    ib, lb, wb = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07, normalized=True, split_fmt="bf16")   # fgvc_local_corr_topk_bf16x4
-    assert torch.allclose(lb, l1, atol=1e-4) and (ib == i1).all(1).float().mean() > 0.98 and torch.allclose(wb, w1, atol=1e-4)
+    with pytest.raises(ValueError):
+        ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07, normalized=True, split_fmt="bf16")             # retired operand format
     i0, l0, w0 = ops.local_corr_topk(qf, kf, H, W, R, topk, 0.07)
     o_out, o_idx, o_logit = O.local_corr_topk(q, key.transpose(0, 1), v.transpose(0, 1), R, topk, 0.07)
     assert torch.allclose(l1.cpu(), o_logit, atol=TOL) and torch.allclose(l1, l0, atol=1e-4)

@@ -364,3 +364,19 @@ def test_bench_encoder_flops_matches_hand_count():
     want += 2.0 * h2 * w2 * 128 * 256 * 9 + 3 * 2.0 * h2 * w2 * 256 * 256 * 9 + 2.0 * h2 * w2 * 128 * 256    # stage 3 (+ 1x1 projection)
     got = bench.encoder_flops(bench.WORKLOADS["cfg2_480p_8f"], 8)
     assert abs(got - 8 * want) < 1e-6 * got
+
+
+def test_f16_scale_exponents_of_degenerate_tensors():
+    """The f16 operand forms scale a tensor by a power of two taken from its largest magnitude.  A zero tensor (zero-initialised
+    residual branch, reference resnet.py:596-601) gets exponent 0, tiny / huge tensors are clamped so that activation + weight
+    exponents stay inside the C ABI's +-100, inf / NaN raise."""
+    import math
+    import pytest
+    from fgvc_amd import ops
+    assert ops.act_scale_log2(0.0) == 0
+    assert ops.act_scale_log2(200.0) == 0 and ops.act_scale_log2(256.0) == 0 and ops.act_scale_log2(257.0) == -1
+    assert ops.act_scale_log2(1.0) == 8
+    assert ops.act_scale_log2(1e-40) == 45 and ops.act_scale_log2(1e30) == -45
+    for bad in (math.inf, math.nan):
+        with pytest.raises(ValueError):
+            ops.act_scale_log2(bad)

@@ -39,9 +39,8 @@ lw = ops.normalize_to_hwc(torch.randn(T + 1, C, H, W, device=dev))
 for R in (6, 12):
     t_f32 = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07))
     t_split = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07, normalized=True))
-    t_b = timeit(lambda: ops.local_corr_topk(lw[:1], lw[1:], H, W, R, k, 0.07, normalized=True, split_fmt="bf16"))
     print(f"local window (A7) radius {R}, {T} key slots at {H}x{W}x{C}: f32-MFMA kernel {t_f32:.3f} ms, f16x3 kernel "
-          f"{t_split:.3f} ms, bf16x4 kernel {t_b:.3f} ms per query frame (the 16-bit forms include their split pass)")
+          f"{t_split:.3f} ms per query frame (the 16-bit form includes its split pass)")
 
 # ---- the configuration as BASELINE.json states it: the single-scale local window on the stride-1 grid (480 x 854 x 256, radius 6, 6
 #      key slots): 409 920 queries x 6 x 169 candidates x 256 channels = 2.13e11 FLOP, 7 frames x 420 MB of f32 features

@@ -1,9 +1,12 @@
+# A/B runs of bench.py on ONE box (boxes differ by up to 8 %): each line is a variant against the default, interleaved twice.
 set -e
-for args in "" "--encoder-lanes 1" "--encoder-lanes 4" "--tail-from pairs"; do
+for round in 1 2; do
+for args in "" "--set-option conv_debug=128" "--no-res-split" "--no-res-split --set-option conv_debug=128"; do
   python bench.py --steps 60 --repeats 2 --no-cpu-baseline --no-corr-volume --no-clips-line $args > gpurun_out/bv.json 2>/dev/null
   python - "$args" <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/bv.json').read().strip().splitlines()[-1])
-print(sys.argv[1] or "default", round(d["value"],1), "fps", round(d["ms_per_step"],3), "ms", {k:round(v,2) for k,v in d["sharding_ms_per_step"].items() if v>0.05})
+print(sys.argv[1] or "default", round(d["value"],1), "fps", round(d["ms_per_step"],3), "ms", {k:round(v,2) for k,v in d["sharding_ms_per_step"].items() if v>0.05}, flush=True)
 PY
+done
 done

@@ -1,7 +1,7 @@
 """Ablations of fgvc_conv_split_f32 (256->256 3x3 on 8x120x214) through the conv_debug option."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 shapes = {"256": (8, 256, 120, 214), "128": (8, 128, 120, 214), "64": (8, 64, 240, 427)}

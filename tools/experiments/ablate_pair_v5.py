@@ -2,7 +2,7 @@
 whose consumers only multiply could reach."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import engine, ops
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 H, W, C, T = 120, 214, 256, 8

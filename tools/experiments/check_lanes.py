@@ -1,6 +1,6 @@
 """Encoder lanes (ResNet.split_lanes) A/B: outputs of the multi-stream trunk against the single-stream one, repeated."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fgvc_amd.mmpt_api as api
 from fgvc_amd.mmpt_api.backbones import ResNet
 dev = torch.device("cuda")

@@ -1,6 +1,6 @@
 """Host time per bench step (how far the CPU runs ahead of the GPU): enqueue K steps without synchronising, then synchronise."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from fgvc_amd import _lib, engine
 dev = torch.device("cuda", 0)

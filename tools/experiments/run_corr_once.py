@@ -1,6 +1,6 @@
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 H, W, C = 120, 214, 256; HW = H * W

@@ -2,7 +2,7 @@
 timed round-robin (the first kernel timed in a process runs slow): HIP-event ms per launch, every form with the same epilogue
 (split output in its own format; "+f32" adds the dense f32 output and a residual).
 
-    python tools/time_conv_arith.py [--rounds 5] [--reps 10]
+    python tools/experiments/time_conv_arith.py [--rounds 5] [--reps 10]
 """
 import argparse
 import json
@@ -11,7 +11,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -57,13 +57,6 @@ for Cin, Cout, KS, H, W in [(256, 256, 3, 120, 214), (128, 256, 3, 120, 214), (1
         forms["f16f8 cot128 4-row"] = (with_opts(base[0], 128, 3), with_opts(base[1], 128, 3))
         forms["f16f8 cot64 4-row"] = (with_opts(base[0], 64, 1), with_opts(base[1], 64, 1))
 
-        def tall(fn):
-            def run():
-                ops.set_option("conv_tall", 1)
-                fn()
-                ops.set_option("conv_tall", 0)
-            return run
-        forms["f16f8 tall 16x32x128"] = (tall(base[0]), tall(base[1]))
     times = {k: [[], []] for k in forms}
     for r in range(a.rounds + 1):
         for k, fns in forms.items():

@@ -2,7 +2,7 @@
 and per 64-key stage in the two multiply phases, the two store bursts and wait + barrier."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 HW = 120 * 214

@@ -2,7 +2,7 @@
 wave the cycles of its loop, of its waits for key blocks and of its chains; per producer wave its loop and its waits for free slots."""
 import os, sys, ctypes
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import engine, ops, _lib
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 H, W, C, T = 120, 214, 256, 8

@@ -1,6 +1,6 @@
 """256->256 3x3 at 8x120x214 under the tiling options of fgvc_conv_split_f32 (conv_cot_cap, conv_narrow)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 N, C, H, W = 8, 256, 120, 214

@@ -1,9 +1,9 @@
 """fgvc_corr_volume_f16f6: split-format check, correctness against f64 / bf16x3 and round-robin timing next to f16f8 / bf16x3 / bf16
 (GPU box).  Every configuration is timed in turn, several rounds; minimum and last round are printed (the first configuration
 timed in a process runs slow -- never compare a first measurement with a later one).
-    python tools/try_f16f6.py [HxW ...] [--quick]"""
+    python tools/experiments/try_f16f6.py [HxW ...] [--quick]"""
 import sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from fgvc_amd import ops

@@ -2,7 +2,7 @@
 Timing: every configuration is timed in turn, several rounds; the minimum and the last round are printed (the first
 configuration timed in a process runs up to 15 % slow -- never compare a first measurement with a later one)."""
 import sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fgvc_amd import ops
 dev = torch.device("cuda:0")

@@ -52,13 +52,6 @@ def main():
     n_pairs = len(plan.pairs)
     pairs = ops.make_pairs(plan.pairs, dev)
     mask = cfg.mask
-    ops.set_option("pair_kernel", 1)
-    med, best = timeit(lambda: ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, 10, validate=False), a.reps)
-    res["pair_topk_v1_ms"] = med
-    i1, s1 = ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, 10, validate=False)
-    ops.set_option("pair_kernel", 3)
-    i2, s2 = ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, 10, validate=False)
-    res["v1_v3_identical"] = bool(torch.equal(i1, i2) and torch.equal(s1, s2))
     med, best = timeit(lambda: ops.pair_topk(feats, feats, pairs, H, W, H, W, mask, 10, validate=False), a.reps)
     # algorithmic windowed FLOPs: 2 * HW * N_disc * C per pair (interior disc count)
     ndisc = sum(1 for dy in range(-15, 16) for dx in range(-15, 16) if dy * dy + dx * dx <= mask.r2max)

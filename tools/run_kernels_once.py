@@ -10,15 +10,13 @@ feats = ops.normalize_to_hwc(torch.randn(T, C, H, W, device=dev))
 cfg = engine.TrackerConfig()
 plan = engine.plan_clip(T, [0], cfg)
 pairs = ops.make_pairs(plan.pairs, dev)
-hl_all = ops.split_bf16(feats)
 h16_all = ops.split_f16x2(feats)
-hl = hl_all[:2]
+hl = ops.split_bf16(feats[:2])
 sp = ops.split_f16f8(feats[:2])
 sp6 = ops.split_f16f6(feats[:2])
 vol = torch.empty((HW, HW), device=dev)
 for _ in range(3):
     ops.pair_topk_split(h16_all, h16_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16")
-    ops.pair_topk_split(hl_all, hl_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True)
     ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False)
     ops.corr_volume(sp6[1], sp6[0], 0.07, "f16f6", out=vol)
     ops.corr_volume(sp[1], sp[0], 0.07, "f16f8", out=vol)
