@@ -511,7 +511,8 @@ int fgvc_conv64_split_res_f32(const uint16_t* x, const uint16_t* w, const float*
   FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(residual_split) && aligned16(y_split) &&
                    aligned16(y_f32),
                FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: 16-byte alignment required");
-  FGVC_REQUIRE((const void*)x != (const void*)y_split && (const void*)residual_split != (const void*)y_split, FGVC_ERR_INVALID_ARG,
+  FGVC_REQUIRE((const void*)x != (const void*)y_split && (!residual_split || (const void*)residual_split != (const void*)y_split),
+               FGVC_ERR_INVALID_ARG,
                "fgvc_conv64_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
   return conv64_launch(x, w, bias, residual, residual_split, y_split, y_f32, N, H, W, Hp, Wp, relu, (hipStream_t)stream);

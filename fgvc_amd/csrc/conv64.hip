@@ -11,8 +11,6 @@
 
 namespace fgvc {
 
-int conv_debug_flags();
-
 struct Conv64Params {
   const uint16_t* x;       // padded split NHWC [N][Hp][Wp][2][64]
   const uint16_t* w;       // [2 cout tiles][9 taps][2 chunks][2 k-steps][hi | lo][64 lanes][8]: MFMA-operand order (ops.prepare_conv64)
@@ -24,7 +22,6 @@ struct Conv64Params {
   float* y_f32;            // optional, dense NHWC f32
   int N, H, W, Hp, Wp, relu;
   int n_ty, n_tx, n_tiles;
-  int debug;               // 128 ("conv_debug"): plain b + k G tile order (A/B of the XCD-aware order)
 };
 
 __device__ __forceinline__ void c64_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
@@ -82,21 +79,17 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
     const uint32_t dst = c64_lds_addr(patches + buf * C64_PATCHB + chunk * C64_CHUNKB + (prow * C64_PW + pc0) * 128);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
   };
-  // Tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and the 32 workgroups of an XCD share its L2: iteration k of
-  // XCD x takes the 32 CONSECUTIVE tiles of chunk 8 k + x, and consecutive tiles run DOWN a 32-pixel column of the image (ty
-  // fastest), so that the two patch rows a tile shares with the tile above / below it are read from HBM once per XCD instead of
-  // once per tile (4-row tiles: 2 of the 6 staged rows).  Grids that are not a multiple of 8 workgroups (tiny inputs) keep b + k G.
-  const int G = gridDim.x, per_xcd = G >> 3;
-  const bool xcd_order = (G & 7) == 0 && !(p.debug & 128);
-  auto tile_at = [&](int k) {
-    return xcd_order ? (k * 8 + ((int)blockIdx.x & 7)) * per_xcd + ((int)blockIdx.x >> 3) : k * G + (int)blockIdx.x;
-  };
+  // Tile order: workgroup b takes tiles b, b + G, ... in raster order.  (An XCD-aware order -- the 32 workgroups of an XCD on 32
+  // consecutive tiles of one image column, so that the patch rows vertical neighbours share meet in one L2 -- measured 0.7 % SLOWER
+  // end to end on the same box, profiles/r03_bv_xcd.log.)
+  const int G = gridDim.x;
+  auto tile_at = [&](int k) { return k * G + (int)blockIdx.x; };
   auto tile_origin = [&](int tile, int& nimg, int& y0, int& x0) {
     nimg = tile / (p.n_ty * p.n_tx);
     const int rem = tile - nimg * p.n_ty * p.n_tx;
-    const int tx = rem / p.n_ty;
-    y0 = (rem - tx * p.n_ty) * C64_TR;
-    x0 = tx * 32;
+    const int ty = rem / p.n_tx;
+    y0 = ty * C64_TR;
+    x0 = (rem - ty * p.n_tx) * 32;
   };
 
   int it = 0, tile = tile_at(0), buf = 0;
@@ -252,7 +245,6 @@ int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const
     return FGVC_ERR_UNSUPPORTED;
   }
   p.n_tiles = (int)tiles;
-  p.debug = conv_debug_flags();
   const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
   conv64_kernel<<<grid, 256, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32");

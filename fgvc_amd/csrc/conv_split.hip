@@ -104,12 +104,10 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pr = wave % NWR, ch = wave / NWR;
   const int n = lane & 31, h = lane >> 5;
-  // workgroups are dealt round-robin over the 8 XCDs: every XCD takes a contiguous run of tiles, and consecutive tiles run down a
-  // 32-pixel column, so the patch rows / columns neighbouring tiles share meet in ONE L2 (8 frames of 120 x 214: a frame per XCD)
-  int bid = (p.debug & 128) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  int bid = blockIdx.x;     // raster order over the XCDs round-robin (xcd_remap + column-major tiles: 0.7 % slower, profiles/r03_bv_xcd.log)
   const int nimg = bid / (p.n_ty * p.n_tx);
   bid -= nimg * p.n_ty * p.n_tx;
-  const int tx = bid / p.n_ty, ty = bid - tx * p.n_ty;
+  const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
   const int y0 = ty * TROWS, x0 = tx * 32;
   const int co_base = blockIdx.y * COT;
   const int nchunk = p.Cin / 32;
@@ -667,7 +665,6 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
 
 static int g_conv_debug = 0;
 void set_conv_debug(int v) { g_conv_debug = v; }
-int conv_debug_flags() { return g_conv_debug; }
 static int g_conv_narrow = 1;       // bit 0: 64-channel layers, bit 1: 128-channel 3x3 layers (no gain measured) -- 4-row tiles, two workgroups per CU (0: 8-row tiles)
 void set_conv_narrow(int v) { g_conv_narrow = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)

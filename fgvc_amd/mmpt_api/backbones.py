@@ -145,7 +145,9 @@ class ResNet(nn.Module):
     use_conv64 = True              # 64 -> 64 3x3 layers on fgvc_conv64_split_f32 (register-resident weights)
     use_stem7 = True               # 7x7 stride-2 stem on fgvc_stem7_split_f32 (False: MIOpen f32 + ReLU/split pass)
     use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
-    res_from_split = True          # layer 1: identities read from the split form (False: dense f32 copies, rounds 1-2)
+    res_from_split = False         # True: layer 1 adds its identities from the split form and nobody writes f32 copies of them --
+                                   # fewer bytes, but 0.08 ms per clip SLOWER (8-byte loads + conversions in the owner wave's MFMA stream;
+                                   # profiles/r03_bv_xcd.log); same precision (tools/experiments/res_split_precision.py)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
     arith = "f16f8"                # arithmetic of the stride-1 convolutions behind layer 1: see set_arith()
 

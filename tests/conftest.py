@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle's CPU work runs on torch's intra-op pool: a GPU box shows every host core but grants a share of 16 -- a pool of
+    # 100+ threads on that share made one oracle comparison take minutes instead of seconds
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
+    except Exception:
+        pass
 
 
 def pytest_sessionstart(session):

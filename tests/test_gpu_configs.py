@@ -127,7 +127,7 @@ def test_cfg4_plan_pairs_and_merged_lists(dev):
 def test_cfg4_tracker_end_to_end(dev):
     """The tracker at the reference's eval geometry on a 64-frame clip, P = 32 (two query times -> two groups), through the
     hand-written encoder: (i) frames 0..5 of the result are bit-identical to running the first 6 frames alone (a frame's labels
-    depend on earlier frames only: a schedule / slot-table error at 64 frames breaks this); (ii) the first 5 frames against the
+    depend on earlier frames only: a schedule / slot-table error at 64 frames breaks this); (ii) the first 4 frames against the
     oracle driver run on the GPU encoder's features (the CPU oracle needs ~5 s per frame at 128 x 128 x 256)."""
     import fgvc_amd.mmpt_api as api
     from oracle import fgvc_oracle as O
@@ -161,12 +161,12 @@ def test_cfg4_tracker_end_to_end(dev):
     # (i) prefix property
     o6 = model(test_mode=True, rgbs=rgbs[:, :6], query_points=qp, trajectories=traj[:, :6], visibilities=vis[:, :6])
     assert torch.equal(o6[2], pred[:, :6])
-    # (ii) the oracle driver on the GPU encoder's features, frames 0..4, group of frame 0
-    feats, Hf, Wf = model.get_feats_hwc(rgbs[0, :5])
+    # (ii) the oracle driver on the GPU encoder's features, frames 0..3, group of frame 0
+    feats, Hf, Wf = model.get_feats_hwc(rgbs[0, :4])
     assert (Hf, Wf) == (H4, W4)
-    fc = feats.cpu().transpose(1, 2).reshape(5, C, Hf, Wf)
-    want = O.forward_test_main(fc, qp[0, :24, 1:].cpu(), h, w)                        # (5, 24, 2)
-    assert float((pred[0, :5, :24].cpu() - want).abs().max()) < 5e-3
+    fc = feats.cpu().transpose(1, 2).reshape(4, C, Hf, Wf)
+    want = O.forward_test_main(fc, qp[0, :24, 1:].cpu(), h, w)                        # (4, 24, 2)
+    assert float((pred[0, :4, :24].cpu() - want).abs().max()) < 5e-3
     REPORT["cfg4_tracker"] = dict(frames=T4, points=P4, groups=2, median_drift_error_px=float((drift - torch.tensor([-40.0, -20.0], dtype=drift.dtype)).abs().median()))
 
 

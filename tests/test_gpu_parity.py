@@ -1114,6 +1114,30 @@ def test_stem7_split_vs_torch(dev, case):
     assert torch.equal(only_f, out_f)
 
 
+def test_encoder_identities_from_the_split_form(dev):
+    """ResNet.res_from_split (off by default: measured slower): layer 1 adds its identities as hi + lo of the split tensor its
+    first convolution reads, and neither the stem nor the first block writes an f32 copy.  Same trunk within the split's 2^-17."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    torch.manual_seed(22)
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")).to(dev).eval()
+    x = torch.randn(3, 3, 72, 100, device=dev)
+    with torch.no_grad():
+        for arith in net.supported_arith():
+            net.set_arith(arith)
+            ref = net(x).clone()
+            try:
+                ResNet.res_from_split = True
+                net.reset_split_cache()
+                got = net(x).clone()
+            finally:
+                ResNet.res_from_split = False
+                net.reset_split_cache()
+            net.check_overflow()
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (arith, float((got - ref).abs().max()), float(ref.abs().max()))
+            assert not torch.equal(got, ref)                       # (the option did change the arithmetic)
+
+
 @pytest.mark.gpu
 def test_encoder_zero_initialised_residual_branch(dev):
     """init_weights() of the reference's ResNet zeroes bn2.weight of every block (zero_init_residual, mmpt/models/backbones/resnet.py
@@ -1146,7 +1170,8 @@ def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev, arith):
     """A1: the ResNet-18 trunk on the hand-written kernels (the default on the GPU), in each arithmetic of the wide layers, against
     the same network with every convolution in MIOpen (f32), against the CPU oracle network, and through the tracker's forward_hwc
     fast path.  Whole-trunk bounds relative to the largest feature: bf16x3 / f16x3 2e-5 (round 2's bound), f16f8 (two pipe units
-    instead of three) 5e-5; normalised features 5e-6 / 1.5e-5."""
+    instead of three) 5e-5; normalised features 8e-6 / 1.5e-5 (measured against a float64 network: 4-6e-6 / 1.0-1.3e-5,
+    tools/experiments/res_split_precision.py; layer 1 adds its identities from the split form, which changes none of these)."""
     import fgvc_amd.mmpt_api as api
     from fgvc_amd.mmpt_api.backbones import ResNet
     g = torch.Generator().manual_seed(14)
@@ -1164,7 +1189,7 @@ def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev, arith):
     ora.load_state_dict(sd)
     net = net.to(dev).eval()
     net.set_arith(arith)
-    tol, tol_n = (5e-5, 1.5e-5) if arith == "f16f8" else (2e-5, 5e-6)
+    tol, tol_n = (5e-5, 1.5e-5) if arith == "f16f8" else (2e-5, 8e-6)
     x = torch.randn(3, 3, 76, 132, generator=g)              # features 19 x 33: ragged against the 8 x 32 tiles
     with torch.no_grad():
         assert net._split_stage_ok(net.layer3, torch.empty(1, 128, 4, 4, device=dev))
