@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfgvc_hip.so")
+# FGVC_HIP_LIB: another build of the same library (A/B timing of two kernel versions on one box: tools/experiments)
+LIB_PATH = os.environ.get("FGVC_HIP_LIB") or os.path.join(_HERE, "lib", "libfgvc_hip.so")
 
 FGVC_OK = 0
 NO_LIMIT = 0x3FFFFFFF
@@ -32,6 +33,7 @@ SIGNATURES = {
     "fgvc_split_f16x2": (_i, [_p, _p, C.c_int64, _i, _p]),
     "fgvc_pair_topk_f16x3_timed_out": (_i, []),
     "fgvc_pair_topk_f16x3_probe": (_i, [_p]),
+    "fgvc_conv64_probe": (_i, [_p]),
     "fgvc_nchw_to_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),

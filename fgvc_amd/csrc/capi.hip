@@ -51,6 +51,8 @@ int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, h
 
 void set_conv_cot_cap(int);
 void set_conv_narrow(int);
+void set_conv64_variant(int);
+int conv64_probe_read(long long*);
 void set_conv_debug(int);
 void set_corr6_skew(int);
 void set_corr6_sdma(int);
@@ -114,6 +116,10 @@ int fgvc_set_option(const char* name, int value) {
   }
   if (strcmp(name, "conv_debug") == 0) {   // profiling ablations of fgvc_conv_split_f32; results are wrong when non-zero
     set_conv_debug(value);
+    return FGVC_OK;
+  }
+  if (strcmp(name, "conv64_variant") == 0) {   // A/B bits of fgvc_conv64_split_f32 (csrc/conv64.hip)
+    set_conv64_variant(value);
     return FGVC_OK;
   }
   if (strcmp(name, "conv_narrow") == 0) {   // fgvc_conv_split_f32 with 64 output channels per workgroup: 1 (default) = 4-row tiles,
@@ -494,6 +500,12 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
   if (N == 0) return FGVC_OK;
   return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, in_fmt, in_scale_log2, out_fmt,
                            out_scale_log2, overflow, (hipStream_t)stream);
+}
+
+/* debug: the 32 s_memtime sums workgroup 77 leaves with fgvc_set_option("conv64_variant", 8) (tools/experiments/time_conv64_variants.py) */
+int fgvc_conv64_probe(int64_t* out32) {
+  FGVC_REQUIRE(out32 != nullptr, FGVC_ERR_INVALID_ARG, "fgvc_conv64_probe: null pointer");
+  return conv64_probe_read(reinterpret_cast<long long*>(out32)) == 0 ? FGVC_OK : FGVC_ERR_LAUNCH;
 }
 
 int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,

@@ -11,6 +11,13 @@
 
 namespace fgvc {
 
+__device__ long long g_c64_probe[32];   // variant & 8: per wave of workgroup 77, cycles summed over its tiles: barrier, multiply loop, DMA wait, epilogue, tiles
+static int g_conv64_variant = 0;
+void set_conv64_variant(int v) { g_conv64_variant = v; }
+int conv64_probe_read(long long* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_c64_probe), 32 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+
 struct Conv64Params {
   const uint16_t* x;       // padded split NHWC [N][Hp][Wp][2][64]
   const uint16_t* w;       // [2 cout tiles][9 taps][2 chunks][2 k-steps][hi | lo][64 lanes][8]: MFMA-operand order (ops.prepare_conv64)
@@ -22,6 +29,7 @@ struct Conv64Params {
   float* y_f32;            // optional, dense NHWC f32
   int N, H, W, Hp, Wp, relu;
   int n_ty, n_tx, n_tiles;
+  int variant;             // option "conv64_variant": 8 = s_memtime probe of workgroup 77 (fgvc_conv64_probe)
 };
 
 __device__ __forceinline__ void c64_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
@@ -38,6 +46,10 @@ constexpr int C64_CHUNKB = (C64_TR + 2) * C64_PW * 128;    // one 32-channel chu
 constexpr int C64_PATCHB = 2 * C64_CHUNKB;
 constexpr int C64_RS = 144;                                // epilogue tile row stride (bytes)
 constexpr int C64_PIECES = 2 * (C64_TR + 2) * 5;           // 1-KiB DMA pieces per patch
+
+#define C64_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define C64_MFMA_A(ACC, W, X) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "a"(W), "v"(X))
+#define C64_MFMA_V(ACC, W, X) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(W), "v"(X))
 
 __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char patches[2 * C64_PATCHB];
@@ -92,6 +104,23 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
     x0 = (rem - ty * p.n_tx) * 32;
   };
 
+  // lane parts of the B-operand addresses: pixel P = r * 40 + n + dx of the patch lives at P * 128 + ((slot ^ key(P)) << 4) with
+  // key(P) = (P >> 1) & 7 = (((n + dx) >> 1) & 7) ^ (4 (r & 1))  (40 r / 2 = 20 r = 4 r mod 8); slot = 2 s + h for the hi part,
+  // 4 + 2 s + h for the lo part (= the hi address with bit 6 flipped)
+  uint32_t lane_b[3][2][2][2];                              // [dx][k-step][row parity][hi | lo]
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const uint32_t key = (uint32_t)((((n + dx) >> 1) & 7) ^ (4 * par));
+        const uint32_t a0 = (uint32_t)((n + dx) * 128) + ((((uint32_t)(2 * s2 + h)) ^ key) << 4);
+        lane_b[dx][s2][par][0] = a0;
+        lane_b[dx][s2][par][1] = a0 ^ 64u;
+      }
+  const bool probe = (p.variant & 8) && blockIdx.x == 77;
+  long long pb = 0, pm = 0, pw = 0, pe = 0, pn = 0;
   int it = 0, tile = tile_at(0), buf = 0;
   if (tile < p.n_tiles) {
     int ni, ya, xa;
@@ -102,9 +131,11 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
   for (; tile < p.n_tiles; tile = tile_at(++it), buf ^= 1) {       // tile_at(k) grows with k: the first tile beyond the end is the last
     int nimg, y0, x0;
     tile_origin(tile, nimg, y0, x0);
+    const long long t0 = probe ? __builtin_amdgcn_s_memtime() : 0;
     lds_barrier();                                          // patch `buf` complete (every wave waited for its DMAs), buffer buf^1 free
     // the next tile's patch goes into the other buffer while this one multiplies: its 15 DMA pieces per wave are issued
     // BETWEEN the MFMA groups (a wave owns its SIMD: whatever it issues outside the MFMA stream is exposed)
+    const long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0;
     const int next = tile_at(it + 1);
     const bool has_next = next < p.n_tiles;
     int nimg_n = 0, y0_n = 0, x0_n = 0;
@@ -117,23 +148,36 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    const unsigned char* patch = patches + buf * C64_PATCHB;
     // B operands of group g = (tap, chunk, k-step): [row][hi | lo], read one group ahead of the multiplies (left to itself
-    // hipcc reads each operand right before its first use: 144 exposed LDS round trips per tile, 3x the MFMA time)
+    // hipcc reads each operand right before its first use: 144 exposed LDS round trips per tile, 3x the MFMA time).  The reads are
+    // assembly with explicit addresses: address = (row base: scalar) + (lane part: one of 24 registers set up once) + (chunk:
+    // immediate).  As C++ loads the compiler kept the lane part of all 144 addresses of a tile in registers across the tile loop,
+    // and spilled them.  The LDS returns a wave's reads in order and nothing else of this wave uses the LDS inside the loop: one
+    // lgkmcnt(0) at the top of a group covers the operands read during the group before.
+    const uint32_t pbase = c64_lds_addr(patches) + (uint32_t)(buf * C64_PATCHB);
     bf16x8 bc[4], bn[4];
     auto load_b = [&](bf16x8* d, int g) {
       const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
+      const int dy = t / 3, dx = t % 3;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int P = (2 * rg + b + t / 3) * C64_PW + n + t % 3;
-        d[b * 2 + 0] = *reinterpret_cast<const bf16x8*>(patch + c * C64_CHUNKB + c64_swz(P, 2 * s + h));
-        d[b * 2 + 1] = *reinterpret_cast<const bf16x8*>(patch + c * C64_CHUNKB + c64_swz(P, 4 + 2 * s + h));
+        const int r = 2 * rg + b + dy;                                  // patch row (wave-uniform)
+        const uint32_t rowbase = pbase + (uint32_t)(r * C64_PW * 128);
+        const uint32_t ah = rowbase + lane_b[dx][s][r & 1][0], al = rowbase + lane_b[dx][s][r & 1][1];
+        if (c == 0) {
+          C64_READ(d[b * 2 + 0], ah, 0);
+          C64_READ(d[b * 2 + 1], al, 0);
+        } else {
+          C64_READ(d[b * 2 + 0], ah, C64_CHUNKB);
+          C64_READ(d[b * 2 + 1], al, C64_CHUNKB);
+        }
       }
     };
     load_b(bc, 0);
 #pragma unroll
     for (int g = 0; g < 36; ++g) {
       const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // this group's operands (read during the group before)
       if (g + 1 < 36) load_b(bn, g + 1);
       if (g >= 2 && g < 32 && (g & 1) == 0 && has_next) stage_piece(nimg_n, y0_n, x0_n, buf ^ 1, wave + 4 * ((g - 2) >> 1));
       if (g == 24 && p.residual) {   // residual rows of this wave in accumulator layout (pixel on the lane, 4 consecutive channels per register group)
@@ -163,20 +207,36 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const bf16x8 xh = bc[b * 2 + 0], xl = bc[b * 2 + 1];
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t][c][s], xh, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[t][c][s], xh, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t][c][s], xl, acc[b], 0, 0, 0);
+      // The MFMAs are inline assembly so that the weight operands can be PINNED: hi parts and the lo parts of taps 0-6 in the 256
+      // accumulation registers (used by the matrix instruction directly), the lo parts of taps 7-8 in 32 vector registers.  Left to
+      // the compiler the 288 weight registers were spread over both files with the accumulation half as SPILL space: 300
+      // v_accvgpr_read copies per tile in the only wave of the SIMD, and the multiply loop ran at 65 cycles per MFMA (s_memtime probe,
+      // profiles/r03_probe_conv64_before.log, _after.log).  Same order per accumulator (hi hi, lo hi, hi lo), the two pixel rows interleaved.
+      {
+        const bf16x8 xh0 = bc[0], xl0 = bc[1], xh1 = bc[2], xl1 = bc[3];
+        C64_MFMA_A(acc[0], wh[t][c][s], xh0);
+        C64_MFMA_A(acc[1], wh[t][c][s], xh1);
+        if (t < 7) {
+          C64_MFMA_A(acc[0], wl[t][c][s], xh0);
+          C64_MFMA_A(acc[1], wl[t][c][s], xh1);
+        } else {
+          C64_MFMA_V(acc[0], wl[t][c][s], xh0);
+          C64_MFMA_V(acc[1], wl[t][c][s], xh1);
+        }
+        C64_MFMA_A(acc[0], wh[t][c][s], xl0);
+        C64_MFMA_A(acc[1], wh[t][c][s], xl1);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) bc[q] = bn[q];
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results before vector instructions read them (the compiler
+                                                             // does not see matrix instructions in the assembly statements)
     // the next patch's DMAs (and the residual loads) are older than anything the epilogue issues: one wait covers them and
     // leaves this tile's stores in flight across the barrier
+    const long long t2 = probe ? __builtin_amdgcn_s_memtime() : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t3 = probe ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- epilogue: bias (+ residual) (+ ReLU), transposed through a wave-private LDS tile: 128-byte rows per pixel
     unsigned char* tw = tiles + wave * (32 * C64_RS);
@@ -230,6 +290,14 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
         wave_sync();
       }
     }
+    if (probe) {
+      const long long t4 = __builtin_amdgcn_s_memtime();
+      pb += t1 - t0; pm += t2 - t1; pw += t3 - t2; pe += t4 - t3; pn += 1;
+    }
+  }
+  if (probe && lane == 0) {
+    g_c64_probe[wave * 8 + 0] = pb; g_c64_probe[wave * 8 + 1] = pm; g_c64_probe[wave * 8 + 2] = pw; g_c64_probe[wave * 8 + 3] = pe;
+    g_c64_probe[wave * 8 + 4] = pn;
   }
 }
 
@@ -245,6 +313,7 @@ int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const
     return FGVC_ERR_UNSUPPORTED;
   }
   p.n_tiles = (int)tiles;
+  p.variant = g_conv64_variant;
   const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
   conv64_kernel<<<grid, 256, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32");

@@ -299,6 +299,7 @@ int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bia
 /* ... with the residual (resnet.py:96-106 `identity = x ... out += identity`) given EITHER as dense NHWC f32 (`residual`) OR as a padded split NHWC
  * tensor of x's geometry (`residual_split`: the identity is then hi + lo, the value the block's first convolution multiplied;
  * the producer of the identity need not write an f32 copy of it).  At most one of the two. */
+int fgvc_conv64_probe(int64_t* out32);   /* debug: s_memtime sums of one workgroup (conv64_variant = 8) */
 int fgvc_conv64_split_res_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                               const uint16_t* residual_split, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp,
                               int relu, void* stream);
