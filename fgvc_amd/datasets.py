@@ -259,3 +259,97 @@ def jhmdb_evaluate(model, dataset: "JhmdbPoses"):
         preds.append(dataset.pose_prediction(meta, pred))
         gts.append(meta["gt_poses"])
     return metrics.jhmdb_pck(preds, gts)
+
+
+# SMAL joints BADJA annotates (badja_dataset.py:71-82 `SMALJointInfo.annotated_classes`): 20 of the 37 per frame
+BADJA_ANNOTATED = (8, 9, 10, 12, 13, 14, 15, 18, 19, 20, 22, 23, 24, 25, 28, 31, 32, 33, 35, 36)
+
+
+class BadjaPoses:
+    """BADJA animal videos in the sample format VanillaTracker.forward_test consumes.  Like the reference's JHMDB dataset, its
+    BadjaDataset yields `imgs` / `ref_seg_map` (badja_dataset.py:355-410), which the released tracker does not accept (SURVEY.md
+    section 8b): the joints of the FIRST frame become query points at t = 0.
+
+    Files as the reference reads them (:152-229): `<list_path>/joint_annotations/*.json`, each a list of records with `image_path`,
+    `segmentation_path` (their first 6 characters are dropped and the rest joined to `root`), `joints` (37 x (y, x)) and `visibility`;
+    a video = the frames `JPEGImages/Full-Resolution/<animal>/%05d.jpg` from the first to the last annotated number, silhouettes
+    `Annotations/Full-Resolution/<animal>/%05d.png`; frames without a record have no joints (:206-211).  Videos under `extra_videos`
+    are skipped (:177); the reference's IGNORE_ANIMALS list is ONE string by a missing comma (:38-41) and ignores nothing -- same here.
+    Frames are resized to `size` = (320, 512) (:355-362; the released pipeline's Resize(-1, 320) then changes nothing) and go through
+    the RGB->Lab contract; joints are scaled the same way (:364-366, :489-494).  Image resizing is PIL's here, OpenCV's there: the
+    adapter is restated from the file, "parity unpinned" (no BADJA data or mmcv offline)."""
+
+    def __init__(self, root: str, list_path: str = None, size=(320, 512), length: int = -1, device="cpu"):
+        import json
+        self.root, self.size, self.length, self.device = root, tuple(size), int(length), device
+        self.videos = []
+        adir = os.path.join(list_path or root, "joint_annotations")
+        for name in sorted(os.listdir(adir)):
+            with open(os.path.join(adir, name)) as f:
+                records = json.load(f)
+            first, last = records[0]["segmentation_path"], records[-1]["segmentation_path"]
+            if "extra_videos" in first:
+                continue
+            animal = first.split("/")[-2]
+            lo, hi = int(first.split("/")[-1].split(".")[0]), int(last.split("/")[-1].split(".")[0])
+            by_file = {os.path.join(root, r["image_path"][6:]): r for r in records}
+            frames, segs, joints, vis = [], [], [], []
+            for fr in range(lo, hi + 1):
+                img = os.path.join(root, "JPEGImages/Full-Resolution/%s/%05d.jpg" % (animal, fr))
+                r = by_file.get(img)
+                frames.append(img)
+                segs.append(os.path.join(root, r["segmentation_path"][6:]) if r else
+                            os.path.join(root, "Annotations/Full-Resolution/%s/%05d.png" % (animal, fr)))
+                joints.append(np.asarray(r["joints"], dtype=np.float64)[list(BADJA_ANNOTATED)] if r else None)
+                vis.append(np.asarray(r["visibility"])[list(BADJA_ANNOTATED)] if r else None)
+            if frames:
+                self.videos.append(dict(name=animal, frames=frames, segs=segs, joints=joints, visibles=vis))
+
+    def __len__(self):
+        return len(self.videos)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        v = self.videos[i]
+        n = len(v["frames"]) if self.length == -1 else min(self.length, len(v["frames"]))
+        imgs = [Image.open(p).convert("RGB") for p in v["frames"][:n]]
+        w0, h0 = imgs[0].size
+        h, w = self.size
+        sy, sx = h / h0, w / w0
+        frames = torch.from_numpy(np.stack([np.asarray(im) for im in imgs]))                       # (T,h0,w0,3)
+        segs = [np.asarray(Image.open(p).resize((w0, h0), Image.NEAREST).resize((w, h), Image.NEAREST)) for p in v["segs"][:n]]
+        joints = [None if j is None else j * np.array([sy, sx]) for j in v["joints"][:n]]          # (J,2) = (y,x) at the network size
+        visibles = list(v["visibles"][:n])
+        assert joints[0] is not None, "BADJA: the first frame of a video carries the query joints (badja_dataset.py:364)"
+        J = joints[0].shape[0]
+        traj = torch.zeros(n, J, 2)
+        vis = torch.zeros(n, J)
+        for t in range(n):
+            if joints[t] is not None:
+                traj[t] = torch.from_numpy(joints[t][:, ::-1].copy()).float()                      # (x,y)
+                vis[t] = torch.from_numpy((np.asarray(visibles[t]) > 0).astype(np.float32))
+        qp = torch.cat([torch.zeros(J, 1), traj[0]], 1)                                            # (J,3) = (0,x,y)
+        rgbs = preprocess_tapvid_frames(frames.to(self.device), self.size)
+        d = self.device
+        return (dict(rgbs=rgbs, query_points=qp.unsqueeze(0).to(d), trajectories=traj.unsqueeze(0).to(d), visibilities=vis.unsqueeze(0).to(d)),
+                dict(joints=joints, visibles=visibles, segs=segs, original_shape=(h0, w0), name=v["name"]))
+
+    @staticmethod
+    def pose_prediction(traj_pred) -> np.ndarray:
+        """traj_pred (1,T,J,2) = (x,y) at the network size -> (2,J,T), the layout pck_evaluate reads (:526-527)."""
+        p = np.asarray(traj_pred.cpu() if hasattr(traj_pred, "cpu") else traj_pred, dtype=np.float64)[0]
+        return p.transpose(2, 1, 0)
+
+
+def badja_evaluate(model, dataset: "BadjaPoses"):
+    """Run the tracker over a BadjaPoses dataset and score PCK@0.1..0.4 as the reference's pck_evaluate does (BASELINE.md quotes its
+    PCK@0.2)."""
+    from . import metrics
+    preds, js, vs, ss = [], [], [], []
+    for i in range(len(dataset)):
+        sample, meta = dataset[i]
+        out = model(test_mode=True, **sample)
+        assert torch.equal(out[4], sample["query_points"])              # every query is at t = 0: one group, order kept
+        preds.append(dataset.pose_prediction(out[2]))
+        js.append(meta["joints"]); vs.append(meta["visibles"]); ss.append(meta["segs"])
+    return metrics.badja_pck(preds, js, vs, ss)

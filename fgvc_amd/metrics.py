@@ -11,7 +11,8 @@
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, Sequence
+import math
+from typing import Dict, Iterable, Optional, Sequence
 
 import numpy as np
 
@@ -175,4 +176,37 @@ def jhmdb_pck(pred_poses: Sequence[np.ndarray], gt_poses: Sequence[np.ndarray],
     for a in alphas:
         per_joint = [100.0 * np.mean(np.asarray(dj) <= a) for dj in dists if len(dj)]
         out[f"PCK@{a}"] = float(np.mean(per_joint))
+    return out
+
+
+def badja_pck(pred_poses: Sequence[np.ndarray], joints: Sequence[Sequence[Optional[np.ndarray]]],
+              visibles: Sequence[Sequence[Optional[np.ndarray]]], segs: Sequence[Sequence[np.ndarray]],
+              ratios: Sequence[float] = (0.1, 0.2, 0.3, 0.4)) -> Dict[str, float]:
+    """BADJA PCK as BadjaDataset.pck_evaluate computes it (badja_dataset.py:451-571).  Per video: pred_poses (2, J, T) = (x; y) at
+    the evaluation size; joints[t] (J, 2) = (y, x) at that size or None for an unlabelled frame (then nothing is counted, :504-508);
+    visibles[t] (J,); segs[t] the silhouette at that size.  A VISIBLE joint is correct at ratio r when its distance to the ground
+    truth is < r * sqrt(number of silhouette pixels of that frame) (:541-546, strict).  Returns PCK@r over all counted joints of all
+    videos (%), and "PCK@0.2 per-video mean": the mean of the per-video PCK@0.2 values (the number :552-557 / :578 write out --
+    under the label 'PCK@0.1 AVG')."""
+    counts = {r: [] for r in ratios}
+    per_video = []
+    for pred, js, vs, ss in zip(pred_poses, joints, visibles, segs):
+        mine = {r: [] for r in ratios}
+        T = min(pred.shape[-1], len(js))
+        for t in range(T):
+            if js[t] is None:
+                continue
+            thr0 = math.sqrt(float((np.asarray(ss[t]) > 0).sum()))
+            for j in range(js[t].shape[0]):
+                if not vs[t][j] > 0:
+                    continue
+                d = math.sqrt((float(js[t][j, 1]) - float(pred[0, j, t])) ** 2 + (float(js[t][j, 0]) - float(pred[1, j, t])) ** 2)
+                for r in ratios:
+                    ok = d < r * thr0
+                    counts[r].append(ok)
+                    mine[r].append(ok)
+        if 0.2 in mine and mine[0.2]:
+            per_video.append(100.0 * float(np.mean(mine[0.2])))
+    out = {f"PCK@{r}": (100.0 * float(np.mean(counts[r])) if counts[r] else float("nan")) for r in ratios}
+    out["PCK@0.2 per-video mean"] = float(np.mean(per_video)) if per_video else float("nan")
     return out

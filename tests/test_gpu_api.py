@@ -335,6 +335,27 @@ def test_jhmdb_adapter_end_to_end(dev, tmp_path):
     assert pck["PCK@0.2"] > 80.0 and pck["PCK@0.1"] <= pck["PCK@0.2"] <= pck["PCK@0.5"], pck
 
 
+def test_badja_adapter_end_to_end(dev, tmp_path):
+    """BADJA-format files -> BadjaPoses -> VanillaTracker -> PCK as the reference's pck_evaluate computes it (badja_dataset.py:451-571)
+    on rigidly translating textures with joints that move along (adapter + metric plumbing, not an accuracy claim); also through
+    tools/test.py's --task badja driver code path (evaluate function)."""
+    from fgvc_amd import datasets
+    from tests.test_metrics import _write_fake_badja
+    _write_fake_badja(str(tmp_path), n_videos=2, T=6, size=(120, 160))
+    ds = datasets.BadjaPoses(str(tmp_path), size=(128, 160), device=dev)
+    import fgvc_amd.mmpt_api as api
+    model = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4), out_indices=(2,),
+                                                                       pool_type="none", zero_init_residual=False)),
+                            train_cfg=None, test_cfg=api.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30,
+                                                                    with_first=True, with_first_neighbor=True))
+    torch.manual_seed(0)
+    model.init_weights()
+    model = model.to(dev).eval()
+    pck = datasets.badja_evaluate(model, ds)
+    assert set(pck) == {"PCK@0.1", "PCK@0.2", "PCK@0.3", "PCK@0.4", "PCK@0.2 per-video mean"}
+    assert pck["PCK@0.2"] > 80.0 and pck["PCK@0.1"] <= pck["PCK@0.2"] <= pck["PCK@0.4"], pck
+
+
 def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
     """World size 2 with the PRODUCT backend: tools/two_ranks_one_gpu.py (started by conftest before this process touched the
     GPU) runs fgvc_amd.dist.track_points_sharded(HipBackend) in two processes on this GPU -- over gloo with host staging, RCCL

@@ -135,3 +135,79 @@ def test_summaries_and_result_files(tmp_path):
     df = pd.read_csv(paths["results_df"], index_col=0)
     assert list(df.columns) == list(summaries[0].keys()) and len(df) == 6
     assert len(pickle.load(open(paths["results_list"], "rb"))) == 6
+
+
+def _write_fake_badja(root, n_videos=2, T=6, size=(120, 160), seed=0, skip_label=3):
+    """A BADJA-format tree (joint_annotations/*.json, JPEG frames, PNG silhouettes) of rigidly translating textures whose 37 'SMAL
+    joints' move with the texture; frame `skip_label` of every video has no annotation record (as most BADJA frames have none)."""
+    import json
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    h, w = size
+    os.makedirs(os.path.join(root, "joint_annotations"), exist_ok=True)
+    for v in range(n_videos):
+        pad = 3 * T
+        base = rng.integers(0, 255, ((h + 2 * pad) // 6, (w + 2 * pad) // 6, 3)).astype(np.uint8)
+        base = np.asarray(Image.fromarray(base).resize((w + 2 * pad, h + 2 * pad), Image.BICUBIC))
+        vx, vy = int(rng.integers(-2, 3)), int(rng.integers(-2, 3))
+        animal = f"animal{v}"
+        os.makedirs(os.path.join(root, "JPEGImages/Full-Resolution", animal), exist_ok=True)
+        os.makedirs(os.path.join(root, "Annotations/Full-Resolution", animal), exist_ok=True)
+        x0, y0 = rng.uniform(20, w - 20, 37), rng.uniform(20, h - 20, 37)
+        records = []
+        for t in range(T):
+            fr = 7 + t                                                   # frame numbers need not start at 0
+            Image.fromarray(base[pad - vy * t: pad - vy * t + h, pad - vx * t: pad - vx * t + w]).save(
+                os.path.join(root, "JPEGImages/Full-Resolution", animal, f"{fr:05d}.jpg"), quality=97)
+            sil = np.zeros((h, w), np.uint8)
+            sil[h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 255             # area = h w / 4
+            Image.fromarray(sil).save(os.path.join(root, "Annotations/Full-Resolution", animal, f"{fr:05d}.png"))
+            if t == skip_label:
+                continue
+            vis = np.ones(37, int)
+            vis[9] = 0                                                   # SMAL joint 9 (the 2nd annotated one) is never visible
+            records.append(dict(image_path=f"BADJA/JPEGImages/Full-Resolution/{animal}/{fr:05d}.jpg",
+                                segmentation_path=f"BADJA/Annotations/Full-Resolution/{animal}/{fr:05d}.png",
+                                joints=np.stack([y0 + vy * t, x0 + vx * t], 1).tolist(), visibility=vis.tolist()))
+        with open(os.path.join(root, "joint_annotations", f"{animal}.json"), "w") as f:
+            json.dump(records, f)
+
+
+def test_badja_adapter_sample_format_and_pck(tmp_path):
+    """BADJA files -> (rgbs, query_points, trajectories, visibilities) + what the metric needs; PCK as badja_dataset.py:451-571:
+    visible joints of labelled frames only, distance < ratio * sqrt(silhouette area), strict; the per-video PCK@0.2 mean beside it."""
+    from fgvc_amd import datasets, metrics
+    _write_fake_badja(str(tmp_path))
+    ds = datasets.BadjaPoses(str(tmp_path), size=(60, 80))
+    assert len(ds) == 2
+    sample, meta = ds[0]
+    J = len(datasets.BADJA_ANNOTATED)
+    assert J == 20 and sample["rgbs"].shape == (1, 6, 3, 60, 80) and sample["query_points"].shape == (1, J, 3)
+    assert sample["trajectories"].shape == (1, 6, J, 2) and sample["visibilities"].shape == (1, 6, J)
+    assert float(sample["query_points"][0, :, 0].abs().max()) == 0.0
+    assert torch.allclose(sample["query_points"][0, :, 1:], sample["trajectories"][0, 0])
+    assert meta["joints"][3] is None and float(sample["visibilities"][0, 3].sum()) == 0.0          # the unlabelled frame
+    assert float(sample["visibilities"][0, 0, 1]) == 0.0 and float(sample["visibilities"][0, 0].sum()) == J - 1
+    assert meta["segs"][0].shape == (60, 80) and int((meta["segs"][0] > 0).sum()) == 30 * 40
+    # a perfect prediction: every visible joint of every labelled frame is correct at every ratio
+    perfect = ds.pose_prediction(sample["trajectories"])
+    assert perfect.shape == (2, J, 6)
+    r = metrics.badja_pck([perfect], [meta["joints"]], [meta["visibles"]], [meta["segs"]])
+    assert r["PCK@0.1"] == r["PCK@0.4"] == r["PCK@0.2 per-video mean"] == 100.0
+    # shifted in x by 0.25 * sqrt(area): wrong at 0.1 and 0.2, right at 0.3 and 0.4; exactly AT the threshold is wrong (strict <)
+    thr = np.sqrt(30 * 40)
+    shifted = perfect.copy(); shifted[0] += 0.25 * thr
+    r = metrics.badja_pck([shifted], [meta["joints"]], [meta["visibles"]], [meta["segs"]])
+    assert r["PCK@0.1"] == r["PCK@0.2"] == 0.0 and r["PCK@0.3"] == r["PCK@0.4"] == 100.0
+    # the invisible joint and the unlabelled frame are not counted: moving them far away changes nothing
+    far = perfect.copy(); far[:, 1, :] += 1000.0; far[:, :, 3] -= 1000.0
+    assert metrics.badja_pck([far], [meta["joints"]], [meta["visibles"]], [meta["segs"]])["PCK@0.1"] == 100.0
+    # two videos: overall PCK pools the joints, the per-video number averages the videos
+    s1, m1 = ds[1]
+    p1 = ds.pose_prediction(s1["trajectories"]); p1[0, :10] += 0.25 * thr                            # half of video 1's joints off at 0.2
+    r = metrics.badja_pck([perfect, p1], [meta["joints"], m1["joints"]], [meta["visibles"], m1["visibles"]], [meta["segs"], m1["segs"]])
+    n_vis = 5 * (J - 1)                                                                              # counted joints per video
+    wrong = 5 * 9                                                                                    # joints 0..9 minus the invisible one, 5 frames
+    assert abs(r["PCK@0.2"] - 100.0 * (2 * n_vis - wrong) / (2 * n_vis)) < 1e-9
+    assert abs(r["PCK@0.2 per-video mean"] - 0.5 * (100.0 + 100.0 * (n_vis - wrong) / n_vis)) < 1e-9

@@ -22,7 +22,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fgvc_amd.mmpt_api as api  # noqa: E402
 from fgvc_amd import apis, metrics  # noqa: E402
-from fgvc_amd.datasets import JhmdbPoses, StridedLoader, SyntheticTapVid, TapVidPickles, jhmdb_evaluate  # noqa: E402
+from fgvc_amd.datasets import BadjaPoses, JhmdbPoses, StridedLoader, SyntheticTapVid, TapVidPickles, badja_evaluate, jhmdb_evaluate  # noqa: E402
 
 DEFAULT_CFG = dict(
     model=dict(type="VanillaTracker",
@@ -59,9 +59,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         rank, world = dist.get_rank(), dist.get_world_size()
 
-    if a.task == "jhmdb":
+    if a.task in ("jhmdb", "badja"):
         if not a.data_root:
-            raise SystemExit("--task jhmdb needs --data-root (JHMDB frames + joint_positions + val_list.txt)")
+            raise SystemExit("--task jhmdb needs --data-root (JHMDB frames + joint_positions + val_list.txt); --task badja the BADJA root "
+                             "(joint_annotations/*.json, JPEGImages/, Annotations/)")
         dataset = None
     elif a.data_root:
         dataset = TapVidPickles(a.data_root, a.query_mode, tuple(a.size), device=dev)                   # :121-122
@@ -69,7 +70,7 @@ def main():
         dataset = SyntheticTapVid(a.videos, a.frames, tuple(a.size), a.points, a.query_mode, device=dev)
     loader = StridedLoader(dataset, rank, world) if dataset is not None else None          # :124-134
     key = "test_cfg_" + a.task                                                               # :135
-    if key not in cfg and a.task == "jhmdb" and "test_cfg_davis" in cfg:
+    if key not in cfg and a.task in ("jhmdb", "badja") and "test_cfg_davis" in cfg:
         key = "test_cfg_davis"         # the pose task of DEFAULT_CFG (and of configs without a test_cfg_jhmdb) tracks with the TAP-Vid settings
     if key not in cfg:
         raise SystemExit(f"the config has no '{key}' (tasks it defines: {sorted(k[9:] for k in cfg if k.startswith('test_cfg_'))})")
@@ -84,7 +85,12 @@ def main():
         api.load_checkpoint(model, a.checkpoint)                                             # :158-159
     model = model.to(dev).eval()
 
-    if a.task == "jhmdb":      # pose tracking: the 15 joints of frame 0 are the query points (fgvc_amd.datasets.JhmdbPoses)
+    if a.task == "badja":      # animal pose tracking: the 20 annotated SMAL joints of frame 0 are the query points (datasets.BadjaPoses)
+        if rank == 0:          # (one process scores the set, as for JHMDB below; badja_dataset.py:451-571)
+            pck = badja_evaluate(model, BadjaPoses(a.data_root, size=(320, 512), device=dev))
+            print(json.dumps({k: round(v, 2) for k, v in pck.items()}))
+        outputs = None
+    elif a.task == "jhmdb":    # pose tracking: the 15 joints of frame 0 are the query points (fgvc_amd.datasets.JhmdbPoses)
         # PCK is a mean over ALL videos' joints (jhmdb_dataset.py:174-256), so the set is scored by one process: rank 0 runs it, the
         # other ranks of a `--launcher pytorch` job wait at the common teardown below
         if rank == 0:
