@@ -46,6 +46,9 @@ SPLIT_PRODUCTS = 3                # partial products per f32-grade product in fg
 # f16f8 = one f16 product + both cross sums in one K-64 fp8 MFMA (half a unit each)
 CONV_UNITS = {"bf16x3": 3.0, "f16x3": 3.0, "f16f8": 2.0}
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+# what the board SUSTAINS on matrix work alone at its 1.4 kW cap (tools/micro/mfma_sustained.hip, profiles/r03_mfma_sustained.log): the
+# 16-bit shapes do not reach the 2.4 GHz figure the roofline is priced against
+SUSTAINED_TFLOPS = {"f16": 1750.0, "bf16": 1950.0, "fp8": 4900.0, "f16f8_mix_per_f16_unit": 2375.0}
 STORE_CEILING_GBPS = 5680.0       # measured: plain dword stores over a 2.64 GB footprint (profiles/r03_store_footprint.log)
 
 WORKLOADS = {
@@ -80,7 +83,7 @@ def encoder_flops(wl, n_frames: int) -> float:
 
 
 def pmc(kernel: str):
-    """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r02_pmc.json, written by tools/pmc_report.py from
+    """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r03_pmc.json, written by tools/pmc_report.py from
     separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes); {} if absent."""
     for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
@@ -399,7 +402,7 @@ def main():
         tot_fl = sum(len(probe.ev[t]) * 2.0 * t[1] * HW * 256 * 256 * 9 for t in conv_tags)
         n_l = sum(len(probe.ev[t]) for t in conv_tags)
         f32_tf = tot_fl / (tot_ms * 1e-3) / 1e12
-        pm = pmc("fgvc_conv_split_f32")
+        pm = pmc("fgvc_conv_split_fmt_f32[f16f8]" if arith == "f16f8" else "fgvc_conv_split_f32")   # (no PMC pass of the f16x3 form)
         kernels["encoder_conv"] = {
             "kernel": "fgvc_conv_split_f32 (256 -> 256, 3x3: the time-dominant kernel, 4 launches per clip and encoder lane)",
             "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f32_tf / BF16_MFMA_PEAK_TFLOPS,
@@ -412,11 +415,18 @@ def main():
                               "f16f8": "2 pipe units per f32-grade product: the f16 main product + both cross sums in one K-64 fp8 MFMA "
                                        "(twice the f16 rate)"}[arith],
             "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
+            "sustained_peak": {"bf16x3": SUSTAINED_TFLOPS["bf16"], "f16x3": SUSTAINED_TFLOPS["f16"],
+                               "f16f8": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"]}[arith],
+            "frac_executed_of_sustained": CONV_UNITS[arith] * f32_tf / {"bf16x3": SUSTAINED_TFLOPS["bf16"], "f16x3": SUSTAINED_TFLOPS["f16"],
+                                                                        "f16f8": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"]}[arith],
+            "sustained_note": "the matrix pipe alone, whole chip, at the board's power cap (tools/micro/mfma_sustained.hip: f16 1750, bf16 1950, "
+                              "fp8 4900 TFLOP/s; the 2 f16 + 1 fp8 mix 0.95 of its nominal rate = 2375 in f16 units); the step itself "
+                              "runs at the cap (1.27-1.37 kW)",
             "ms_per_launch": tot_ms / n_l, "launches_timed": n_l,
             "launch_note": "HIP events on the lane's stream inside the timed region; the encoder's lanes run concurrently, so a launch "
                            "shares the GPU with the other lane's kernels",
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch"),
-            "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone on the GPU (profiles/r02_pmc.json)"}
+            "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone on the GPU (profiles/r03_pmc.json)"}
     pair_tag = next((t for t in probe.ev if t[0] in ("pair_split", "pair_f32")), None)
     if pair_tag:
         pair_ms, n_l = probe.mean_ms(pair_tag)
@@ -441,7 +451,7 @@ def main():
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch")}
     head = kernels.get("encoder_conv") or kernels.get("pair_topk")
     roofline = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "what", "executed_tflops",
-                                     "frac_executed", "frac_of_f32_mfma_peak", "ms_per_launch", "mfma_util", "launch_note", "pmc_note")
+                                     "frac_executed", "frac_of_f32_mfma_peak", "sustained_peak", "frac_executed_of_sustained", "sustained_note", "ms_per_launch", "mfma_util", "launch_note", "pmc_note")
                 if k in head} if head else None
 
     out = {
