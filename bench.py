@@ -250,6 +250,7 @@ def main():
                     help="what runs on the side stream: the label sweep + read-out only, or everything after the encoder (pair top-k, "
                          "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
+    ap.add_argument("--no-conv64-f16f8", action="store_true", help="layer 1 and the stem's output in the bf16 form also when the trunk computes in f16f8 (A/B)")
     ap.add_argument("--res-split", action="store_true", help="layer-1 identities from the split form instead of dense f32 copies (A/B)")
     ap.add_argument("--enc-arith", default=None, choices=["f16f8", "bf16x3", "f16x3"],
                     help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f8; bf16x3 = round 2's)")
@@ -297,6 +298,8 @@ def main():
         ResNet.use_conv64 = False
     if a.res_split:
         ResNet.res_from_split = True
+    if a.no_conv64_f16f8:
+        ResNet.conv64_f16f8 = False
     model = build_tracker(wl, dev)
     if a.enc_arith:
         model.backbone.set_arith(a.enc_arith)

@@ -39,9 +39,11 @@ SIGNATURES = {
     "fgvc_conv_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_conv64_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv64_split_res_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_conv64_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_conv_s2_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv_s2_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_stem7_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_stem7_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_nhwc_to_split_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -43,8 +43,9 @@ int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const floa
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
                    int, int, int, int, int*, hipStream_t);
 int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, const uint16_t*, uint16_t*, float*, int, int, int, int, int, int,
-                  hipStream_t);
-int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, hipStream_t);
+                  int, int, int, int, int*, hipStream_t);
+int stem7_launch(const float*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int, int, int*,
+                 hipStream_t);
 int nchw_to_split_nhwc_launch(const float*, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
 int normalize_nhwc_launch(const float*, float*, uint16_t*, int, int, int, int, int, int, hipStream_t);
 int nhwc_to_split_launch(float*, uint16_t*, int, int, int, int, int, int, int, hipStream_t);
@@ -516,18 +517,33 @@ int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bia
 int fgvc_conv64_split_res_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                               const uint16_t* residual_split, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp,
                               int relu, void* stream) {
+  return fgvc_conv64_split_fmt_f32(x, w, bias, residual, residual_split, y_split, y_f32, N, H, W, Hp, Wp, relu, FGVC_ACT_BF16X2, 0,
+                                   FGVC_ACT_BF16X2, 0, nullptr, stream);
+}
+
+int fgvc_conv64_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
+                              const uint16_t* residual_split, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp,
+                              int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, void* stream) {
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: null pointer");
+  FGVC_REQUIRE((in_fmt == FGVC_ACT_BF16X2 || in_fmt == FGVC_ACT_F16F8) && (out_fmt == FGVC_ACT_BF16X2 || out_fmt == FGVC_ACT_F16F8),
+               FGVC_ERR_UNSUPPORTED, "fgvc_conv64_split_fmt_f32: formats %d -> %d (bf16x2 or f16f8)", in_fmt, out_fmt);
+  FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || !y_split || overflow, FGVC_ERR_INVALID_ARG,
+               "fgvc_conv64_split_fmt_f32: an f16-format output needs the overflow word");
+  FGVC_REQUIRE(in_scale_log2 > -100 && in_scale_log2 < 100 && out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG,
+               "fgvc_conv64_split_fmt_f32: scale exponent out of range");
   FGVC_REQUIRE(!(residual && residual_split), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_res_f32: one residual, f32 or split, not both");
+  FGVC_REQUIRE(!residual_split || in_fmt == FGVC_ACT_BF16X2, FGVC_ERR_UNSUPPORTED,
+               "fgvc_conv64_split_fmt_f32: a split residual is read as (hi, lo) bf16: bf16x2 tensors only");
   FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: bad shape");
   FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
   FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(residual_split) && aligned16(y_split) &&
                    aligned16(y_f32),
                FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: 16-byte alignment required");
   FGVC_REQUIRE((const void*)x != (const void*)y_split && (!residual_split || (const void*)residual_split != (const void*)y_split),
-               FGVC_ERR_INVALID_ARG,
-               "fgvc_conv64_split_f32: in-place not supported");
+               FGVC_ERR_INVALID_ARG, "fgvc_conv64_split_f32: in-place not supported");
   if (N == 0) return FGVC_OK;
-  return conv64_launch(x, w, bias, residual, residual_split, y_split, y_f32, N, H, W, Hp, Wp, relu, (hipStream_t)stream);
+  return conv64_launch(x, w, bias, residual, residual_split, y_split, y_f32, N, H, W, Hp, Wp, relu, in_fmt, in_scale_log2, out_fmt,
+                       out_scale_log2, overflow, (hipStream_t)stream);
 }
 
 int fgvc_conv_s2_split_f32(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N,
@@ -559,7 +575,16 @@ int fgvc_conv_s2_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float
 
 int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H,
                          int W, int Hop, int Wop, int relu, void* stream) {
+  return fgvc_stem7_split_fmt_f32(x, w, bias, y_split, y_f32, N, H, W, Hop, Wop, relu, FGVC_ACT_BF16X2, 0, nullptr, stream);
+}
+
+int fgvc_stem7_split_fmt_f32(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H,
+                             int W, int Hop, int Wop, int relu, int out_fmt, int out_scale_log2, int* overflow, void* stream) {
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_stem7_split_f32: null pointer");
+  FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || out_fmt == FGVC_ACT_F16F8, FGVC_ERR_UNSUPPORTED, "fgvc_stem7_split_fmt_f32: output format %d", out_fmt);
+  FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || !y_split || overflow, FGVC_ERR_INVALID_ARG,
+               "fgvc_stem7_split_fmt_f32: an f16-format output needs the overflow word");
+  FGVC_REQUIRE(out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG, "fgvc_stem7_split_fmt_f32: scale exponent out of range");
   FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_stem7_split_f32: bad shape");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;     // floor((H + 6 - 7) / 2) + 1
   FGVC_REQUIRE(!y_split || conv_pad_ok(Ho, Wo, Hop, Wop), FGVC_ERR_INVALID_ARG,
@@ -567,7 +592,7 @@ int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, u
   FGVC_REQUIRE(aligned16(w) && aligned16(bias) && aligned16(y_split) && aligned16(y_f32) && ((uintptr_t)x & 3) == 0,
                FGVC_ERR_INVALID_ARG, "fgvc_stem7_split_f32: alignment (16 bytes; 4 for x)");
   if (N == 0) return FGVC_OK;
-  return stem7_launch(x, w, bias, y_split, y_f32, N, H, W, Ho, Wo, Hop, Wop, relu, (hipStream_t)stream);
+  return stem7_launch(x, w, bias, y_split, y_f32, N, H, W, Ho, Wo, Hop, Wop, relu, out_fmt, out_scale_log2, overflow, (hipStream_t)stream);
 }
 
 int fgvc_nhwc_to_split_f32(float* x, uint16_t* out, int N, int C, int H, int W, int Hp, int Wp, int relu, void* stream) {

@@ -7,6 +7,10 @@
 // 576 K x (hi, lo) are 72 MFMA operands = 288 VGPRs, so a wave owns a SIMD (4 waves per CU) and only pixels move:
 // the (4+2) x 40 pixel patch of the NEXT tile is LDS-DMA'd into the second buffer while the current one multiplies,
 // residuals are prefetched into registers, stores drain under the next tile.
+// ARITH 1 (round 3): the f16 + fp8 arithmetic of conv_split.hip's wide layers (x -> h = f16(s x), e4m3 forms of h and of its
+// residual; the main product on two K-16 f16 MFMAs, both cross sums in ONE K-64 fp8 MFMA with E8M0 block scales): 72 f16 + 36 fp8
+// MFMAs per tile = 4608 pipe cycles instead of 216 bf16 MFMAs = 6912, the same 288 weight registers (144 of f16 fragments, 144 of
+// fp8), the same 128-byte rows in the patch ([h 64 B | l8 32 B | h8 32 B] per pixel and 32-channel chunk).
 #include "common.hpp"
 
 namespace fgvc {
@@ -20,7 +24,9 @@ int conv64_probe_read(long long* out32) {
 
 struct Conv64Params {
   const uint16_t* x;       // padded split NHWC [N][Hp][Wp][2][64]
-  const uint16_t* w;       // [2 cout tiles][9 taps][2 chunks][2 k-steps][hi | lo][64 lanes][8]: MFMA-operand order (ops.prepare_conv64)
+  const uint16_t* w;       // [2 cout tiles][9 taps][2 chunks] x 4 KiB in MFMA-operand order: ARITH 0 [2 k-steps][hi | lo][64 lanes][16 B]
+                           // (ops.prepare_conv64), ARITH 1 [f16 k-step 0 | f16 k-step 1][64 lanes][16 B] then [64 lanes][h8 16 B | l8 16 B]
+                           // (ops.prepare_conv64_f16)
   const float* bias;       // [64]
   const float* residual;   // optional, dense NHWC f32 [N][H][W][64]
   const uint16_t* res_split;   // optional (instead of `residual`): the residual as a padded split NHWC tensor of x's geometry; hi + lo
@@ -29,6 +35,10 @@ struct Conv64Params {
   float* y_f32;            // optional, dense NHWC f32
   int N, H, W, Hp, Wp, relu;
   int n_ty, n_tx, n_tiles;
+  float acc_scale;         // ARITH 1: 1 / (s_x s_w), the accumulator's scale (a power of two)
+  float out_scale;         // out_fmt 1: s_y of the split output
+  int out_fmt;             // split output: 0 = (hi, lo) bf16, 1 = f16 + fp8 (FGVC_ACT_F16F8)
+  int* overflow;           // out_fmt 1: OR-ed with 1 when |s_y y| leaves the f16 range
   int variant;             // option "conv64_variant": 8 = s_memtime probe of workgroup 77 (fgvc_conv64_probe)
 };
 
@@ -48,10 +58,27 @@ constexpr int C64_RS = 144;                                // epilogue tile row 
 constexpr int C64_PIECES = 2 * (C64_TR + 2) * 5;           // 1-KiB DMA pieces per patch
 
 #define C64_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+// address = scalar row base + lane part, as an opaque instruction: left visible, the compiler computes each of a tile's 48 distinct
+// sums once and keeps them alive from their first to their last use (spills in the f16 + fp8 form)
+#define C64_ADDR(DST, SBASE, LANE) asm volatile("v_add_u32 %0, %1, %2" : "=v"(DST) : "s"(SBASE), "v"(LANE))
 #define C64_MFMA_A(ACC, W, X) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "a"(W), "v"(X))
 #define C64_MFMA_V(ACC, W, X) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(W), "v"(X))
+// first product of a tile: SrcC is the inline constant 0, the accumulator an early-clobber OUTPUT.  Zeroing it with vector moves
+// put a VALU write right in front of a matrix instruction that reads it as SrcC -- a hazard the compiler covers for its own MFMAs
+// and cannot see in an assembly statement (the first build of the f16 + fp8 form read stale operand bits that way).
+#define C64_MFMA_A0(ACC, W, X) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(ACC) : "a"(W), "v"(X))
+#define C64_MFMA_F0(ACC, W, X) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "a"(W), "v"(X))
+#define C64_MFMA_F(ACC, W, X) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "a"(W), "v"(X))
+#define C64_MFMA_XA(ACC, W, X, SA, SB) \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(ACC) : "a"(W), "v"(X), "v"(SA), "v"(SB))
+#define C64_MFMA_XV(ACC, W, X, SA, SB) \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(ACC) : "v"(W), "v"(X), "v"(SA), "v"(SB))
 
+template <int ARITH>
 __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) unsigned char patches[2 * C64_PATCHB];
   __shared__ __attribute__((aligned(16))) unsigned char tiles[4 * 32 * C64_RS];
   __shared__ __attribute__((aligned(16))) float bias_s[64];
@@ -62,18 +89,32 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
   const int n = lane & 31, h = lane >> 5;
   const int d_row = lane >> 3, d_slot = lane & 7;
 
-  // this wave's weights: 9 taps x 2 chunks x 2 k-steps x (hi, lo), registers for the whole kernel
+  // this wave's weights, registers for the whole kernel.  ARITH 0: 9 taps x 2 chunks x 2 k-steps x (hi, lo) bf16 fragments;
+  // ARITH 1: 9 x 2 x (two f16 fragments + one 8-register fp8 operand: h8 of the weights in the first scale block, l8 in the second)
   bf16x8 wh[9][2][2], wl[9][2][2];
+  f16x8 wf[9][2][2];
+  i32x8 wx[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 2; ++c) {
+      const uint16_t* wp = p.w + ((((size_t)ct * 9 + t) * 2 + c) * 4) * 512;
+      if constexpr (ARITH == 0) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const uint16_t* wp = p.w + (((((size_t)ct * 9 + t) * 2 + c) * 2 + s) * 2) * 512 + lane * 8;
-        wh[t][c][s] = *reinterpret_cast<const bf16x8*>(wp);
-        wl[t][c][s] = *reinterpret_cast<const bf16x8*>(wp + 512);
+        for (int s = 0; s < 2; ++s) {
+          wh[t][c][s] = *reinterpret_cast<const bf16x8*>(wp + (s * 2) * 512 + lane * 8);
+          wl[t][c][s] = *reinterpret_cast<const bf16x8*>(wp + (s * 2 + 1) * 512 + lane * 8);
+        }
+      } else {
+        wf[t][c][0] = *reinterpret_cast<const f16x8*>(wp + lane * 8);
+        wf[t][c][1] = *reinterpret_cast<const f16x8*>(wp + 512 + lane * 8);
+        wx[t][c] = *reinterpret_cast<const i32x8*>(wp + 1024 + lane * 16);
       }
+    }
+  // E8M0 scales of this lane half's block of the fp8 operands (127 + log2, every byte): lanes 0-31 carry the first 32 K elements
+  // (weights h8 = h / 2^AW against activations l8 = l 2^BX), lanes 32-63 the second (l8 = l 2^BW against h8 = h / 2^AX)
+  const uint32_t sa_ = h ? (uint32_t)(127 - F8_BW) : (uint32_t)(127 + F8_AW), sb_ = h ? (uint32_t)(127 + F8_AX) : (uint32_t)(127 - F8_BX);
+  const int scale_a = (int)(sa_ * 0x01010101u), scale_b = (int)(sb_ * 0x01010101u);
   if (tid < 64) bias_s[tid] = p.bias[tid];                 // read back per tile (registers are for the weights)
 
   // pieces i, i + 4, ... of a patch belong to this wave; piece -> (chunk, patch row, 8-pixel column group).  Scalar base +
@@ -143,11 +184,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
 
     f32x4 res[2][4];
 
-    f32x16 acc[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    f32x16 acc[2];                                          // (written first by the zero-SrcC products of group 0)
     // B operands of group g = (tap, chunk, k-step): [row][hi | lo], read one group ahead of the multiplies (left to itself
     // hipcc reads each operand right before its first use: 144 exposed LDS round trips per tile, 3x the MFMA time).  The reads are
     // assembly with explicit addresses: address = (row base: scalar) + (lane part: one of 24 registers set up once) + (chunk:
@@ -155,32 +192,9 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
     // and spilled them.  The LDS returns a wave's reads in order and nothing else of this wave uses the LDS inside the loop: one
     // lgkmcnt(0) at the top of a group covers the operands read during the group before.
     const uint32_t pbase = c64_lds_addr(patches) + (uint32_t)(buf * C64_PATCHB);
-    bf16x8 bc[4], bn[4];
-    auto load_b = [&](bf16x8* d, int g) {
-      const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
-      const int dy = t / 3, dx = t % 3;
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int r = 2 * rg + b + dy;                                  // patch row (wave-uniform)
-        const uint32_t rowbase = pbase + (uint32_t)(r * C64_PW * 128);
-        const uint32_t ah = rowbase + lane_b[dx][s][r & 1][0], al = rowbase + lane_b[dx][s][r & 1][1];
-        if (c == 0) {
-          C64_READ(d[b * 2 + 0], ah, 0);
-          C64_READ(d[b * 2 + 1], al, 0);
-        } else {
-          C64_READ(d[b * 2 + 0], ah, C64_CHUNKB);
-          C64_READ(d[b * 2 + 1], al, C64_CHUNKB);
-        }
-      }
-    };
-    load_b(bc, 0);
-#pragma unroll
-    for (int g = 0; g < 36; ++g) {
-      const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // this group's operands (read during the group before)
-      if (g + 1 < 36) load_b(bn, g + 1);
-      if (g >= 2 && g < 32 && (g & 1) == 0 && has_next) stage_piece(nimg_n, y0_n, x0_n, buf ^ 1, wave + 4 * ((g - 2) >> 1));
-      if (g == 24 && p.residual) {   // residual rows of this wave in accumulator layout (pixel on the lane, 4 consecutive channels per register group)
+    auto side_work = [&](int k, int k_res) {    // what rides between the MFMA groups: DMA piece k - 1 of the next patch (k = 1..15), the residual loads
+      if (k >= 1 && k <= 15 && has_next) stage_piece(nimg_n, y0_n, x0_n, buf ^ 1, wave + 4 * (k - 1));
+      if (k == k_res && p.residual) {   // residual rows of this wave in accumulator layout (pixel on the lane, 4 consecutive channels per register group)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int y = imin(y0 + 2 * rg + b, p.H - 1), x = imin(x0 + n, p.W - 1);
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
           for (int q = 0; q < 4; ++q) res[b][q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
         }
       }
-      if (g == 24 && p.res_split) {  // the same from the split form: channel c of a pixel's 32-channel chunk is hi at byte 2 c, lo at 64 + 2 c
+      if (k == k_res && p.res_split) {  // the same from the bf16 split form: channel c of a pixel's 32-channel chunk is hi at byte 2 c, lo at 64 + 2 c
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int y = imin(y0 + 2 * rg + b, p.H - 1), x = imin(x0 + n, p.W - 1);
@@ -206,29 +220,124 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // The MFMAs are inline assembly so that the weight operands can be PINNED: hi parts and the lo parts of taps 0-6 in the 256
-      // accumulation registers (used by the matrix instruction directly), the lo parts of taps 7-8 in 32 vector registers.  Left to
-      // the compiler the 288 weight registers were spread over both files with the accumulation half as SPILL space: 300
-      // v_accvgpr_read copies per tile in the only wave of the SIMD, and the multiply loop ran at 65 cycles per MFMA (s_memtime probe,
-      // profiles/r03_probe_conv64_before.log, _after.log).  Same order per accumulator (hi hi, lo hi, hi lo), the two pixel rows interleaved.
-      {
-        const bf16x8 xh0 = bc[0], xl0 = bc[1], xh1 = bc[2], xl1 = bc[3];
-        C64_MFMA_A(acc[0], wh[t][c][s], xh0);
-        C64_MFMA_A(acc[1], wh[t][c][s], xh1);
-        if (t < 7) {
-          C64_MFMA_A(acc[0], wl[t][c][s], xh0);
-          C64_MFMA_A(acc[1], wl[t][c][s], xh1);
-        } else {
-          C64_MFMA_V(acc[0], wl[t][c][s], xh0);
-          C64_MFMA_V(acc[1], wl[t][c][s], xh1);
-        }
-        C64_MFMA_A(acc[0], wh[t][c][s], xl0);
-        C64_MFMA_A(acc[1], wh[t][c][s], xl1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    // The MFMAs are inline assembly so that the weight operands can be PINNED: 256 of the 288 weight registers in the accumulation
+    // registers (used by the matrix instruction directly), 32 in vector registers.  Left to the compiler the weights were spread
+    // over both files with the accumulation half as SPILL space: 300 v_accvgpr_read copies per tile in the only wave of the SIMD,
+    // and the multiply loop ran at 65 cycles per MFMA (s_memtime probe, profiles/r03_probe_conv64_before.log, _after.log).
+    if constexpr (ARITH == 0) {
+      bf16x8 bc[4], bn[4];
+      auto load_b = [&](bf16x8* d, int g) {
+        const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
+        const int dy = t / 3, dx = t % 3;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bc[q] = bn[q];
+        for (int b = 0; b < 2; ++b) {
+          const int r = 2 * rg + b + dy;                                  // patch row (wave-uniform)
+          const uint32_t rowbase = pbase + (uint32_t)(r * C64_PW * 128);
+          uint32_t ah, al;
+          C64_ADDR(ah, rowbase, lane_b[dx][s][r & 1][0]);
+          C64_ADDR(al, rowbase, lane_b[dx][s][r & 1][1]);
+          if (c == 0) {
+            C64_READ(d[b * 2 + 0], ah, 0);
+            C64_READ(d[b * 2 + 1], al, 0);
+          } else {
+            C64_READ(d[b * 2 + 0], ah, C64_CHUNKB);
+            C64_READ(d[b * 2 + 1], al, C64_CHUNKB);
+          }
+        }
+      };
+      load_b(bc, 0);
+#pragma unroll
+      for (int g = 0; g < 36; ++g) {
+        const int t = g >> 2, c = (g >> 1) & 1, s = g & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // this group's operands (read during the group before)
+        if (g + 1 < 36) load_b(bn, g + 1);
+        side_work((g & 1) == 0 ? g / 2 : -1, 12);                         // pieces in groups 2, 4, .., 30; residual in group 24
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        {   // same order per accumulator as ever (hi hi, lo hi, hi lo), the two pixel rows interleaved; lo parts of taps 7-8 from vector registers
+          const bf16x8 xh0 = bc[0], xl0 = bc[1], xh1 = bc[2], xl1 = bc[3];
+          if (g == 0) {
+            C64_MFMA_A0(acc[0], wh[t][c][s], xh0);
+            C64_MFMA_A0(acc[1], wh[t][c][s], xh1);
+          } else {
+            C64_MFMA_A(acc[0], wh[t][c][s], xh0);
+            C64_MFMA_A(acc[1], wh[t][c][s], xh1);
+          }
+          if (t < 7) {
+            C64_MFMA_A(acc[0], wl[t][c][s], xh0);
+            C64_MFMA_A(acc[1], wl[t][c][s], xh1);
+          } else {
+            C64_MFMA_V(acc[0], wl[t][c][s], xh0);
+            C64_MFMA_V(acc[1], wl[t][c][s], xh1);
+          }
+          C64_MFMA_A(acc[0], wh[t][c][s], xl0);
+          C64_MFMA_A(acc[1], wh[t][c][s], xl1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bc[q] = bn[q];
+      }
+    } else {
+      // group g = (tap, chunk): per pixel row the two f16 fragments (slots h, 2 + h of the row) and the fp8 operand (slot 4 + h: l8 of
+      // the activations, first scale block; slot 6 + h: h8, second block).  fp8 operands of taps 7-8 from vector registers.
+      f16x8 fc[2][2], fn[2][2];
+      i32x4 xc[2][2], xn[2][2];
+      auto load_b = [&](f16x8 (*df)[2], i32x4 (*dxp)[2], int g) {
+        const int t = g >> 1, c = g & 1;
+        const int dy = t / 3, dx = t % 3;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int r = 2 * rg + b + dy;
+          const uint32_t rowbase = pbase + (uint32_t)(r * C64_PW * 128);
+          uint32_t a0, a1, a2, a3;
+          C64_ADDR(a0, rowbase, lane_b[dx][0][r & 1][0]);
+          C64_ADDR(a1, rowbase, lane_b[dx][1][r & 1][0]);
+          C64_ADDR(a2, rowbase, lane_b[dx][0][r & 1][1]);
+          C64_ADDR(a3, rowbase, lane_b[dx][1][r & 1][1]);
+          if (c == 0) {
+            C64_READ(df[b][0], a0, 0); C64_READ(df[b][1], a1, 0); C64_READ(dxp[b][0], a2, 0); C64_READ(dxp[b][1], a3, 0);
+          } else {
+            C64_READ(df[b][0], a0, C64_CHUNKB); C64_READ(df[b][1], a1, C64_CHUNKB);
+            C64_READ(dxp[b][0], a2, C64_CHUNKB); C64_READ(dxp[b][1], a3, C64_CHUNKB);
+          }
+        }
+      };
+      load_b(fc, xc, 0);
+#pragma unroll
+      for (int g = 0; g < 18; ++g) {
+        const int t = g >> 1, c = g & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (g + 1 < 18) load_b(fn, xn, g + 1);
+        side_work(g, 12);                                                 // pieces in groups 1..15, residual in group 12
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        {
+          const i32x8 x0v = __builtin_shufflevector(xc[0][0], xc[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          const i32x8 x1v = __builtin_shufflevector(xc[1][0], xc[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          if (g == 0) {
+            C64_MFMA_F0(acc[0], wf[t][c][0], fc[0][0]);
+            C64_MFMA_F0(acc[1], wf[t][c][0], fc[1][0]);
+          } else {
+            C64_MFMA_F(acc[0], wf[t][c][0], fc[0][0]);
+            C64_MFMA_F(acc[1], wf[t][c][0], fc[1][0]);
+          }
+          C64_MFMA_F(acc[0], wf[t][c][1], fc[0][1]);
+          C64_MFMA_F(acc[1], wf[t][c][1], fc[1][1]);
+          if (t < 7) {
+            C64_MFMA_XA(acc[0], wx[t][c], x0v, scale_a, scale_b);
+            C64_MFMA_XA(acc[1], wx[t][c], x1v, scale_a, scale_b);
+          } else {
+            C64_MFMA_XV(acc[0], wx[t][c], x0v, scale_a, scale_b);
+            C64_MFMA_XV(acc[1], wx[t][c], x1v, scale_a, scale_b);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) { fc[b][q] = fn[b][q]; xc[b][q] = xn[b][q]; }
+      }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results before vector instructions read them (the compiler
                                                              // does not see matrix instructions in the assembly statements)
@@ -249,7 +358,11 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + ct * 32 + 8 * g + 4 * h);
-        v[g] = {acc[b][4 * g + 0] + bv.x, acc[b][4 * g + 1] + bv.y, acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w};
+        if constexpr (ARITH == 0)
+          v[g] = {acc[b][4 * g + 0] + bv.x, acc[b][4 * g + 1] + bv.y, acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w};
+        else          // the accumulator holds s_x s_w times the convolution (powers of two: the product below is exact)
+          v[g] = {fmaf(acc[b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[b][4 * g + 1], p.acc_scale, bv.y),
+                  fmaf(acc[b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[b][4 * g + 3], p.acc_scale, bv.w)};
         if (p.residual || p.res_split) v[g] += res[b][g];
         if (p.relu) {
           v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f);
@@ -269,14 +382,29 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
         wave_sync();
       }
       if (p.y_split) {
+        if (p.out_fmt == 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 x = v[g];
-          ushort4 hv, lv;
-          split_bf16_4(x, hv, lv);
-          unsigned char* o = tw + n * C64_RS + (8 * g + 4 * h) * 2;
-          *reinterpret_cast<ushort4*>(o) = hv;
-          *reinterpret_cast<ushort4*>(o + 64) = lv;
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 x = v[g];
+            ushort4 hv, lv;
+            split_bf16_4(x, hv, lv);
+            unsigned char* o = tw + n * C64_RS + (8 * g + 4 * h) * 2;
+            *reinterpret_cast<ushort4*>(o) = hv;
+            *reinterpret_cast<ushort4*>(o + 64) = lv;
+          }
+        } else {                                    // the f16 + fp8 form the next layer reads: [h 64 B | l8 32 B | h8 32 B]
+          bool ovf = false;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hw, lw;
+            uint32_t l8, h8;
+            split_f16_4(v[g], p.out_scale, hw, l8, h8, lw, ovf);
+            unsigned char* o = tw + n * C64_RS;
+            *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw;
+            *reinterpret_cast<uint32_t*>(o + 64 + 8 * g + 4 * h) = l8;
+            *reinterpret_cast<uint32_t*>(o + 96 + 8 * g + 4 * h) = h8;
+          }
+          if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.W) != 0ull && lane == 0) atomicOr(p.overflow, 1);
         }
         wave_sync();
         const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
@@ -302,10 +430,12 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
 }
 
 int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, const uint16_t* res_split,
-                  uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, hipStream_t s) {
+                  uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, int in_fmt, int in_scale_log2,
+                  int out_fmt, int out_scale_log2, int* overflow, hipStream_t s) {
   Conv64Params p;
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.res_split = res_split; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.relu = relu;
+  p.acc_scale = ldexpf(1.0f, -in_scale_log2); p.out_scale = ldexpf(1.0f, out_scale_log2); p.out_fmt = out_fmt; p.overflow = overflow;
   p.n_ty = cdiv(H, C64_TR); p.n_tx = cdiv(W, 32);
   const long long tiles = (long long)p.n_ty * p.n_tx * N;
   if (tiles >= (1ll << 31)) {
@@ -315,7 +445,8 @@ int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const
   p.n_tiles = (int)tiles;
   p.variant = g_conv64_variant;
   const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
-  conv64_kernel<<<grid, 256, 0, s>>>(p);
+  if (in_fmt == 1) conv64_kernel<1><<<grid, 256, 0, s>>>(p);
+  else conv64_kernel<0><<<grid, 256, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32");
   return FGVC_OK;
 }

@@ -22,6 +22,9 @@ struct Stem7Params {
   float* y_f32;            // optional, dense NHWC f32 [N][Ho][Wo][64]
   int N, H, W, Ho, Wo, Hop, Wop, relu;
   int n_ty, n_tx, n_tiles;
+  float out_scale;         // out_fmt 1: s_y of the split output
+  int out_fmt;             // split output: 0 = (hi, lo) bf16, 1 = f16 + fp8 rows [h 64 B | l8 32 B | h8 32 B] (FGVC_ACT_F16F8)
+  int* overflow;           // out_fmt 1: OR-ed with 1 when |s_y y| leaves the f16 range
 };
 
 constexpr int ST_TR = 4;                         // output rows per tile
@@ -153,14 +156,29 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(Stem7Params p) {
         wave_sync();
       }
       if (p.y_split) {
+        if (p.out_fmt == 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 x = v[g];
-          ushort4 hv, lv;
-          split_bf16_4(x, hv, lv);
-          unsigned char* o = tw + n * ST_RS + (8 * g + 4 * h) * 2;
-          *reinterpret_cast<ushort4*>(o) = hv;
-          *reinterpret_cast<ushort4*>(o + 64) = lv;
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 x = v[g];
+            ushort4 hv, lv;
+            split_bf16_4(x, hv, lv);
+            unsigned char* o = tw + n * ST_RS + (8 * g + 4 * h) * 2;
+            *reinterpret_cast<ushort4*>(o) = hv;
+            *reinterpret_cast<ushort4*>(o + 64) = lv;
+          }
+        } else {
+          bool ovf = false;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hw, lw;
+            uint32_t l8, h8;
+            split_f16_4(v[g], p.out_scale, hw, l8, h8, lw, ovf);
+            unsigned char* o = tw + n * ST_RS;
+            *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw;
+            *reinterpret_cast<uint32_t*>(o + 64 + 8 * g + 4 * h) = l8;
+            *reinterpret_cast<uint32_t*>(o + 96 + 8 * g + 4 * h) = h8;
+          }
+          if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.Wo) != 0ull && lane == 0) atomicOr(p.overflow, 1);
         }
         wave_sync();
         const size_t pix0 = ((size_t)nimg * p.Hop + (y + 1)) * p.Wop + (x0 + 1);
@@ -178,8 +196,9 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(Stem7Params p) {
 }
 
 int stem7_launch(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H, int W,
-                 int Ho, int Wo, int Hop, int Wop, int relu, hipStream_t s) {
+                 int Ho, int Wo, int Hop, int Wop, int relu, int out_fmt, int out_scale_log2, int* overflow, hipStream_t s) {
   Stem7Params p;
+  p.out_fmt = out_fmt; p.out_scale = ldexpf(1.0f, out_scale_log2); p.overflow = overflow;
   p.x = x; p.w = w; p.bias = bias; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Hop = Hop; p.Wop = Wop; p.relu = relu;
   p.n_ty = cdiv(Ho, ST_TR); p.n_tx = cdiv(Wo, 32);

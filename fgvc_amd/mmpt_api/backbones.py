@@ -145,6 +145,10 @@ class ResNet(nn.Module):
     use_conv64 = True              # 64 -> 64 3x3 layers on fgvc_conv64_split_f32 (register-resident weights)
     use_stem7 = True               # 7x7 stride-2 stem on fgvc_stem7_split_f32 (False: MIOpen f32 + ReLU/split pass)
     use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
+    conv64_f16f8 = False           # True: with arith "f16f8" layer 1 (fgvc_conv64_split_fmt_f32) computes in the f16 + fp8 form too and the stem
+                                   # writes it.  Stand-alone those launches are 4-11 % faster (profiles/r03_time_conv64_arith.log); in the step
+                                   # nothing (4.99-5.01 against 4.95-5.00 ms on one box, profiles/r03_bv_conv64_f16f8.log) at 15 % more trunk
+                                   # error (rms 3.6e-6 -> 4.2e-6 of the largest feature): off
     res_from_split = False         # True: layer 1 adds its identities from the split form and nobody writes f32 copies of them --
                                    # fewer bytes, but 0.08 ms per clip SLOWER (8-byte loads + conversions in the owner wave's MFMA stream;
                                    # profiles/r03_bv_xcd.log); same precision (tools/experiments/res_split_precision.py)
@@ -164,7 +168,8 @@ class ResNet(nn.Module):
           "f16x3"   (h, l) f16 operands, three units, ~2^-22 per term.
         The f16 forms store s x with a per-tensor power-of-two scale s, calibrated on the first batch a set of weights sees
         (`calibrate`), with 2^7-2^8 of headroom; a value beyond the f16 range raises a device flag that `check_overflow` turns into an
-        error (and a re-calibration).  The stem, layer 1 and the stride-2 convolutions keep the bf16 form (they are bound by bytes)."""
+        error (and a re-calibration).  The stem, layer 1 and the stride-2 convolutions keep the bf16 form (`conv64_f16f8 = True` moves layer 1
+        and the stem's output to the f16 + fp8 form as well: measured, no gain end to end)."""
         if arith not in self.supported_arith():
             raise ValueError(f"arith={arith!r}: one of {self.supported_arith()}")
         if arith != self.arith:
@@ -177,34 +182,71 @@ class ResNet(nn.Module):
         c = cb.conv
         return c.stride == (1, 1) and not (self.use_conv64 and tuple(c.weight.shape) == (64, 64, 3, 3))
 
-    def _block_formats(self, si: int, bi: int, last: int):
-        """(format of the block's input, of conv1's output `a`, of the block's split output `y`) as ops.ACT_* codes.  A tensor takes the
-        trunk's f16 form iff its producer can write it (fgvc_conv_split_f32, fgvc_conv_s2_split_f32) and every convolution that reads
-        it runs on fgvc_conv_split_f32; a convolution computes in the format of its input (its weights are laid out to match)."""
+    def _is_conv64(self, cb) -> bool:
+        c = cb.conv
+        return bool(self.use_conv64 and c.stride == (1, 1) and tuple(c.weight.shape) == (64, 64, 3, 3))
+
+    def _stem7_ok(self) -> bool:
+        """The stem runs on fgvc_stem7_split_fmt_f32 (7x7 / stride 2 / pad 3, 3 -> 64 channels, ReLU) rather than in MIOpen."""
+        c1 = self.conv1.conv
+        return bool(self.use_stem7 and c1.kernel_size == (7, 7) and c1.stride == (2, 2) and c1.padding == (3, 3) and c1.in_channels == 3
+                    and c1.out_channels == 64 and c1.dilation == (1, 1) and self.conv1.relu)
+
+    def _format_plan(self, last: int):
+        """{(stage, block): (format of the block's input, of conv1's output `a`, of the block's split output `y`), "stem": format of the
+        stem's split output} as ops.ACT_* codes.  A tensor takes an f16 form iff every convolution that reads it can (the stride-1
+        kernel fgvc_conv_split_fmt_f32: the trunk's arithmetic; the register-resident 64 -> 64 kernel fgvc_conv64_split_fmt_f32: the
+        f16 + fp8 form only; the stride-2 kernels and MIOpen: bf16) and its producer can write it (the stride-1 and stride-2 kernels
+        and the stem: any form; the 64 -> 64 kernel: bf16 or f16 + fp8).  A convolution computes in the format of its input (its
+        weights are laid out to match)."""
         from .. import ops
         fmt, bf = ops.ACT_FMT[self.arith], ops.ACT_BF16X2
         cache = self.__dict__.setdefault("_split_cache", {})
-        key = ("fmt_plan", self.arith, last, self.use_conv64, self.use_s2_conv)
+        key = ("fmt_plan", self.arith, last, self.use_conv64, self.use_s2_conv, self.use_stem7, self.conv64_f16f8)
         if key not in cache:
             blocks = [(s_i, b_i, blk) for s_i in range(last + 1) for b_i, blk in enumerate(getattr(self, self.res_layers[s_i]))]
-            wants = lambda blk: fmt if (self._generic_s1(blk.conv1) and (blk.downsample is None or self._generic_s1(blk.downsample))) else bf
-            can_write = lambda cb: self._generic_s1(cb) or (cb.conv.stride == (2, 2) and self.use_s2_conv)
-            plan, f_in = {}, bf                                   # the stem writes the bf16 form
+            f64 = ops.ACT_F16F8 if (fmt == ops.ACT_F16F8 and self.conv64_f16f8) else bf
+
+            def reads(cb):                 # the format this convolution takes its input in
+                if self._is_conv64(cb):
+                    return f64
+                return fmt if self._generic_s1(cb) else bf
+
+            def can_write(cb, f):
+                if f == bf:
+                    return True
+                if self._is_conv64(cb):
+                    return f == ops.ACT_F16F8
+                return self._generic_s1(cb) or (cb.conv.stride == (2, 2) and self.use_s2_conv)
+
+            def wants(blk):
+                f = reads(blk.conv1)
+                return f if (blk.downsample is None or reads(blk.downsample) == f) else bf
+            plan = {}
+            f_in = wants(blocks[0][2]) if blocks else bf
+            if f_in != bf and not (self._stem7_ok() and f_in == ops.ACT_F16F8):   # (MIOpen stem + fgvc_nhwc_to_split_f32: the bf16 form)
+                f_in = bf
+            plan["stem"] = f_in
             for i, (s_i, b_i, blk) in enumerate(blocks):
-                f_a = fmt if (self._generic_s1(blk.conv2) and can_write(blk.conv1)) else bf
+                f_a = reads(blk.conv2) if can_write(blk.conv1, reads(blk.conv2)) else bf
                 nxt = blocks[i + 1][2] if i + 1 < len(blocks) else None
-                f_y = wants(nxt) if (nxt is not None and self._generic_s1(blk.conv2)) else bf
+                f_y = wants(nxt) if (nxt is not None and can_write(blk.conv2, wants(nxt))) else bf
                 plan[(s_i, b_i)] = (f_in, f_a, f_y)
                 f_in = f_y
             cache[key] = plan
-        return cache[key][(si, bi)]
+        return cache[key]
+
+    def _block_formats(self, si: int, bi: int, last: int):
+        return self._format_plan(last)[(si, bi)]
+
 
     def _identity_from_split(self, blk) -> bool:
         """Whether `blk` adds its identity from the SPLIT form of its input (hi + lo, the value its first convolution multiplies)
         instead of a dense f32 copy: the 64-channel blocks of layer 1 on fgvc_conv64_split_res_f32 -- their kernels are bound by the
         bytes they move, and the producer of the input then writes 4 bytes per value instead of 8."""
         c2 = getattr(blk, "conv2", None)
-        return bool(self.use_conv64 and self.res_from_split and isinstance(blk, BasicBlock) and blk.downsample is None
+        return bool(self.use_conv64 and self.res_from_split and not (self.arith == "f16f8" and self.conv64_f16f8)      # (hi, lo) bf16 tensors only
+                    and isinstance(blk, BasicBlock) and blk.downsample is None
                     and c2 is not None and tuple(c2.conv.weight.shape) == (64, 64, 3, 3) and c2.conv.stride == (1, 1)
                     and tuple(blk.conv1.conv.weight.shape) == (64, 64, 3, 3) and blk.conv1.conv.stride == (1, 1))
 
@@ -287,9 +329,13 @@ class ResNet(nn.Module):
         from .. import ops
         cache = self.__dict__.setdefault("_split_cache", {})
         k = ("b", self.__dict__.get("_ws_sig")) + key + (N, C, H, W, device)
+        mk = {"s": ops.alloc_split_nhwc, "f": ops.alloc_nhwc}
         if k not in cache:
-            mk = {"s": ops.alloc_split_nhwc, "f": ops.alloc_nhwc}
-            cache[k] = {nm: mk[nm[0]](N, C, H, W, device) for nm in names}
+            cache[k] = {}
+        missing = [nm for nm in names if nm not in cache[k]]      # (the calibration pass and the real one may ask for different sets)
+        if missing:
+            for nm in missing:
+                cache[k][nm] = mk[nm[0]](N, C, H, W, device)
             self._cache_filled(device)
         return cache[k]
 
@@ -361,19 +407,22 @@ class ResNet(nn.Module):
         ovf = cache.get(("overflow", dev))
         wkey = ("w", si, dev, self.arith)
         if wkey not in cache:
-            def prep_s1(w, bn, fmt):      # 64 -> 64 3x3: the register-resident-weights kernel (its own weight order, bf16 only)
+            def prep_s1(w, bn, fmt):      # 64 -> 64 3x3: the register-resident-weights kernel (its own weight orders)
                 if self.use_conv64 and tuple(w.shape) == (64, 64, 3, 3):
-                    return ops.prepare_conv64(w, bn) + (0,)
+                    if fmt == ops.ACT_F16F8:
+                        return ops.prepare_conv64_f16(w, bn) + ("conv64",)
+                    assert fmt == ACT_BF16X2
+                    return ops.prepare_conv64(w, bn) + (0, "conv64")
                 if fmt == ACT_BF16X2:
-                    return ops.prepare_conv_split(w, bn) + (0,)
-                return ops.prepare_conv_split_f16(w, bn, fmt)
+                    return ops.prepare_conv_split(w, bn) + (0, "s1")
+                return ops.prepare_conv_split_f16(w, bn, fmt) + ("s1",)
 
             def prep(cb, fmt):            # -> (weights, bias, log2 s_w) or None (MIOpen)
                 st = cb.conv.stride
                 if st == (1, 1):
                     return prep_s1(cb.conv.weight.detach(), cb.bn, fmt)
                 if st == (2, 2):
-                    return ops.prepare_conv_s2(cb.conv.weight.detach(), cb.bn) + (0,)
+                    return ops.prepare_conv_s2(cb.conv.weight.detach(), cb.bn) + (0, "s2")
                 return None
             cache[wkey] = [dict(c1=prep(b.conv1, f[0]), c2=prep(b.conv2, f[1]),
                                 ds=None if b.downsample is None else prep(b.downsample, f[0]))
@@ -392,9 +441,9 @@ class ResNet(nn.Module):
 
             def conv_s1(x_split, wb, in_fmt=ACT_BF16X2, in_scale=0, out_fmt=ACT_BF16X2, out_scale=0, **kw):
                 """stride-1 convolution by whichever kernel the weights were laid out for"""
-                if wb[0].dim() == 7:
-                    assert in_fmt == ACT_BF16X2 and (out_fmt == ACT_BF16X2 or kw.get("out_split") is None)
-                    ops.conv64_split(x_split, wb[0], wb[1], H, W, **kw)
+                if wb[3] == "conv64":
+                    ops.conv64_split(x_split, wb[0], wb[1], H, W, in_fmt=in_fmt, in_scale_log2=in_scale + wb[2], out_fmt=out_fmt,
+                                     out_scale_log2=out_scale, overflow=ovf, **kw)
                 else:
                     ops.conv_split(x_split, wb[0], wb[1], H, W, in_fmt=in_fmt, in_scale_log2=in_scale + wb[2], out_fmt=out_fmt,
                                    out_scale_log2=out_scale, overflow=ovf, **kw)
@@ -484,8 +533,10 @@ class ResNet(nn.Module):
             main = torch.cuda.current_stream(dev)
             c1 = self.conv1.conv
             stem7 = None
-            if (self.use_stem7 and c1.kernel_size == (7, 7) and c1.stride == (2, 2) and c1.padding == (3, 3)
-                    and c1.in_channels == 3 and c1.out_channels == 64 and c1.dilation == (1, 1) and self.conv1.relu):
+            f_stem = self._format_plan(last)["stem"]
+            s_stem = (self._scales(dev) or {}).get(("stem",), 0) if f_stem != ops.ACT_BF16X2 else 0
+            calib = self.__dict__.get("_calib")
+            if self._stem7_ok():
                 if ("stem7", dev) not in cache:
                     cache[("stem7", dev)] = ops.prepare_stem7(c1.weight.detach(), self.conv1.bn)
                     self._cache_filled(dev)
@@ -514,13 +565,18 @@ class ResNet(nn.Module):
                         else:
                             sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x", "f_x"))
                             t = sb["f_x"][lo:hi]
-                        ops.stem7_split(x[lo:hi], stem7[0], stem7[1], True, out_split=sb["s_x"][lo:hi], out_f32=t)
+                        ops.stem7_split(x[lo:hi], stem7[0], stem7[1], True, out_split=sb["s_x"][lo:hi], out_f32=t, out_fmt=f_stem,
+                                        out_scale_log2=s_stem, overflow=cache.get(("overflow", dev)))
                     else:
+                        assert f_stem == ops.ACT_BF16X2
                         t = self._miopen_nhwc(("stem",), self.conv1, x_cl[lo:hi])   # (n,H,W,64)
                         _, H, W, C0 = t.shape
                         sb = self._split_buffers(("stem",), N, C0, H, W, dev, ("s_x",))
                         ops.nhwc_to_split(t, sb["s_x"][lo:hi], relu=True)          # ReLU in place on t + split
-                lanes.append(dict(split=sb["s_x"][lo:hi], f32=t, H=H, W=W, lo=lo, hi=hi, N=N, need_split=True))
+                    if calib is not None:                                        # (the calibration pass runs in the bf16 form)
+                        calib[("stem",)] = torch.maximum(calib.get(("stem",), torch.zeros((), device=dev)),
+                                                         sb["s_x"][lo:hi].view(torch.bfloat16)[..., :32].abs().amax().float())
+                lanes.append(dict(split=sb["s_x"][lo:hi], f32=t, H=H, W=W, lo=lo, hi=hi, N=N, need_split=True, fmt=f_stem, scale=s_stem))
             fulls = []
             call = dict(main=main, streams=streams, fresh=tuple(fresh), out={}, last=last)
             for i in range(last + 1):

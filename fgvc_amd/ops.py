@@ -575,6 +575,23 @@ def prepare_conv64(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[to
     return v.view(2, 9, 2, 2, 2, 64, 8), bias
 
 
+def prepare_conv64_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """Folded weights (64, 64, 3, 3) for fgvc_conv64_split_fmt_f32 with in_fmt = ACT_F16F8: prepare_conv_split_f16's rows
+    ([h 64 B | h8 32 B | l8 32 B] per output channel and 32-channel chunk) in MFMA-operand order, per (output tile, tap, chunk) 4 KiB:
+    [f16 k-step 0][64 lanes][16 B], [f16 k-step 1][64 lanes][16 B], then [64 lanes][h8 16 B | l8 16 B] (lane = 32 * half + cout % 32;
+    a half's 16 bytes of an fp8 vector are its bytes 16 half .. 16 half + 15).  Returns (w int16 (2, 9, 2, 2048), bias, log2 s_w)."""
+    assert tuple(weight.shape) == (64, 64, 3, 3)
+    packed, bias, e = prepare_conv_split_f16(weight, bn, ACT_F16F8)      # int16 [tap 9][chunk 2][Cout 64][64]
+    rows = packed.view(torch.uint8).view(9, 2, 2, 32, 128)               # [t][c][ct][n][128 B]
+    hpart = rows[..., :64].reshape(9, 2, 2, 32, 2, 2, 16)                # [t][c][ct][n][s][half][16 B]
+    f16 = hpart.permute(2, 0, 1, 4, 5, 3, 6)                             # [ct][t][c][s][half][n][16]
+    h8 = rows[..., 64:96].reshape(9, 2, 2, 32, 2, 16)                    # [t][c][ct][n][half][16]
+    l8 = rows[..., 96:128].reshape(9, 2, 2, 32, 2, 16)
+    x = torch.stack([h8, l8], dim=-2).permute(2, 0, 1, 4, 3, 5, 6)       # [ct][t][c][half][n][h8 | l8][16]
+    out = torch.cat([f16.reshape(2, 9, 2, 2048), x.reshape(2, 9, 2, 2048)], dim=-1).contiguous()   # 2 KiB of f16 fragments + 2 KiB of fp8
+    return out.view(torch.int16), bias, e
+
+
 def prepare_conv_s2(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tuple[torch.Tensor, torch.Tensor]:
     """Folded weights for fgvc_conv_s2_split_f32: prepare_conv_split's values in MFMA-operand order
     [KS*KS][Cin/32][Cout/32][hi k0-15 | hi k16-31 | lo k0-15 | lo k16-31][lane = 32 * (k >> 3 & 1) + cout % 32][k & 7]
@@ -668,19 +685,25 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
 
 def conv64_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
                  residual: Optional[torch.Tensor] = None, out_split: Optional[torch.Tensor] = None,
-                 out_f32: Optional[torch.Tensor] = None, residual_split: Optional[torch.Tensor] = None) -> None:
-    """conv_split for Cin = Cout = 64, 3x3, with register-resident weights (fgvc_conv64_split_res_f32; w, bias from prepare_conv64).
-    The residual is dense NHWC f32 (`residual`) or a padded split NHWC tensor of x_split's shape (`residual_split`: hi + lo is added)."""
+                 out_f32: Optional[torch.Tensor] = None, residual_split: Optional[torch.Tensor] = None,
+                 in_fmt: int = ACT_BF16X2, in_scale_log2: int = 0, out_fmt: int = ACT_BF16X2, out_scale_log2: int = 0,
+                 overflow: Optional[torch.Tensor] = None) -> None:
+    """conv_split for Cin = Cout = 64, 3x3, with register-resident weights (fgvc_conv64_split_fmt_f32).  in_fmt ACT_BF16X2: w, bias
+    from prepare_conv64; ACT_F16F8: from prepare_conv64_f16, in_scale_log2 = log2(s_x) + its log2 s_w.  out_fmt / out_scale_log2 /
+    overflow as in conv_split.  The residual is dense NHWC f32 (`residual`) or, for bf16 tensors, a padded split NHWC tensor of
+    x_split's shape (`residual_split`: hi + lo is added)."""
     x_split = _chk(x_split, torch.int16, "x_split")
     N, Hp, Wp, nch, _ = x_split.shape
-    assert nch == 2 and tuple(w.shape) == (2, 9, 2, 2, 2, 64, 8) and bias.shape == (64,)
+    assert nch == 2 and bias.shape == (64,)
+    assert tuple(w.shape) == ((2, 9, 2, 2, 2, 64, 8) if in_fmt == ACT_BF16X2 else (2, 9, 2, 2048)), "conv64_split weights / in_fmt"
     assert residual is None or residual_split is None, "one residual, f32 or split"
     for t, dt, shape in ((residual, torch.float32, (N, H, W, 64)), (out_f32, torch.float32, (N, H, W, 64)),
                          (out_split, torch.int16, (N, Hp, Wp, 2, 64)), (residual_split, torch.int16, (N, Hp, Wp, 2, 64))):
         if t is not None:
             assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv64_split buffer"
-    _lib.call("fgvc_conv64_split_res_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(residual_split), _ptr(out_split),
-              _ptr(out_f32), N, H, W, Hp, Wp, int(relu), _stream(x_split))
+    _lib.call("fgvc_conv64_split_fmt_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(residual_split), _ptr(out_split),
+              _ptr(out_f32), N, H, W, Hp, Wp, int(relu), int(in_fmt), int(in_scale_log2), int(out_fmt), int(out_scale_log2),
+              _ptr(overflow), _stream(x_split))
 
 
 def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
@@ -708,9 +731,11 @@ def conv_s2_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H:
 
 
 def stem7_split(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, relu: bool = True,
-                out_split: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None) -> None:
-    """7x7 / stride 2 / pad 3 stem (3 -> 64 channels) + bias (+ ReLU) on the bf16 pipe (fgvc_stem7_split_f32): f32 NCHW
-    frames (N, 3, H, W) -> out_f32 (N, Ho, Wo, 64) dense NHWC f32 and / or out_split (padded split NHWC)."""
+                out_split: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None, out_fmt: int = ACT_BF16X2,
+                out_scale_log2: int = 0, overflow: Optional[torch.Tensor] = None) -> None:
+    """7x7 / stride 2 / pad 3 stem (3 -> 64 channels) + bias (+ ReLU) on the bf16 pipe (fgvc_stem7_split_fmt_f32): f32 NCHW
+    frames (N, 3, H, W) -> out_f32 (N, Ho, Wo, 64) dense NHWC f32 and / or out_split (padded split NHWC in `out_fmt`: ACT_BF16X2, or
+    ACT_F16F8 at scale 2^out_scale_log2 with the overflow word)."""
     x = _chk(x, torch.float32, "x")
     N, C, H, W = x.shape
     assert C == 3 and x.is_contiguous() and tuple(w.shape) == (7, 2, 2, 2, 64, 8) and bias.shape == (64,)
@@ -720,8 +745,8 @@ def stem7_split(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, relu: bool
         assert out_split.dtype == torch.int16 and tuple(out_split.shape) == (N, Hop, Wop, 2, 64) and out_split.is_contiguous()
     if out_f32 is not None:
         assert out_f32.dtype == torch.float32 and tuple(out_f32.shape) == (N, Ho, Wo, 64) and out_f32.is_contiguous()
-    _lib.call("fgvc_stem7_split_f32", _ptr(x), _ptr(w), _ptr(bias), _ptr(out_split), _ptr(out_f32), N, H, W, Hop, Wop,
-              int(relu), _stream(x))
+    _lib.call("fgvc_stem7_split_fmt_f32", _ptr(x), _ptr(w), _ptr(bias), _ptr(out_split), _ptr(out_f32), N, H, W, Hop, Wop,
+              int(relu), int(out_fmt), int(out_scale_log2), _ptr(overflow), _stream(x))
 
 
 def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split=False, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -299,6 +299,13 @@ int fgvc_conv64_split_f32(const uint16_t* x, const uint16_t* w, const float* bia
 /* ... with the residual (resnet.py:96-106 `identity = x ... out += identity`) given EITHER as dense NHWC f32 (`residual`) OR as a padded split NHWC
  * tensor of x's geometry (`residual_split`: the identity is then hi + lo, the value the block's first convolution multiplied;
  * the producer of the identity need not write an f32 copy of it).  At most one of the two. */
+/* ... and with the operand formats of fgvc_conv_split_fmt_f32: in_fmt / out_fmt FGVC_ACT_BF16X2 or FGVC_ACT_F16F8 (the f16 + fp8
+ * arithmetic of the wide layers: a third fewer matrix passes; weights from ops.prepare_conv64_f16: per (output tile, tap, chunk)
+ * 4 KiB = [f16 k-step 0 | f16 k-step 1][64 lanes][16 B] then [64 lanes][h8 16 B | l8 16 B]); in_scale_log2 = log2(s_x s_w);
+ * residual_split only with bf16x2 tensors. */
+int fgvc_conv64_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
+                              const uint16_t* residual_split, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp,
+                              int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, void* stream);
 int fgvc_conv64_probe(int64_t* out32);   /* debug: s_memtime sums of one workgroup (conv64_variant = 8) */
 int fgvc_conv64_split_res_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                               const uint16_t* residual_split, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp,
@@ -326,6 +333,9 @@ int fgvc_conv_s2_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float
  *   bias[64] = beta - mean * gamma / sqrt(var + eps). */
 int fgvc_stem7_split_f32(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H,
                          int W, int Hop, int Wop, int relu, void* stream);
+/* ... with the split output in the format the first block's kernel reads (FGVC_ACT_BF16X2 or FGVC_ACT_F16F8 at scale 2^out_scale_log2) */
+int fgvc_stem7_split_fmt_f32(const float* x, const uint16_t* w, const float* bias, uint16_t* y_split, float* y_f32, int N, int H,
+                             int W, int Hop, int Wop, int relu, int out_fmt, int out_scale_log2, int* overflow, void* stream);
 /* dense NHWC f32 -> [n][H*W][C] f32, rows L2-normalised if `normalize` (the output layout of
  * fgvc_normalize_chw_to_hwc_f32) */
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream);

@@ -1076,6 +1076,65 @@ def test_conv64_split_vs_torch(dev, case):
             ops.conv64_split(xs, wp, bias, H, W, relu, residual=r32, residual_split=rs, out_split=b_s)
 
 
+@pytest.mark.parametrize("case", [(2, 21, 50, True, True), (1, 4, 32, False, True), (1, 3, 5, True, False), (2, 120, 214, True, True)])
+def test_conv64_f16f8_vs_torch(dev, case):
+    """fgvc_conv64_split_fmt_f32 in the f16 + fp8 arithmetic (input, register-resident weights AND split output in the f16f8 format)
+    against torch in float64 of the exact f32 operands, heavy-tailed ReLU-like input: the bound (3e-5 of max|y|, the wide layers' bound)
+    covers the format's quantisation of input and weights.  Also: bf16 split output from f16f8 input (what layer 1's last block hands
+    to the stride-2 convolutions), agreement with the generic kernel in the same arithmetic, the overflow flag."""
+    import torch.nn.functional as F
+    from fgvc_amd import ops
+    N, H, W, with_res, relu = case
+    fmt = ops.ACT_F16F8
+    g = torch.Generator().manual_seed(640 + N + H + W)
+    x = torch.randn(N, 64, H, W, generator=g).abs() ** 1.5 * (torch.rand(N, 64, H, W, generator=g) > 0.4)
+    wt = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    bn = torch.nn.BatchNorm2d(64).eval()
+    bn.weight.data = torch.rand(64, generator=g) * 1.5 + 0.2
+    bn.bias.data = torch.randn(64, generator=g) * 0.1
+    bn.running_mean = torch.randn(64, generator=g) * 0.1
+    bn.running_var = torch.rand(64, generator=g) + 0.5
+    res = torch.randn(N, 64, H, W, generator=g) if with_res else None
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double().view(1, -1, 1, 1)
+    ref = (ref - bn.running_mean.double().view(1, -1, 1, 1)) * sc + bn.bias.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    ref = ref.detach()
+    scale = float(ref.abs().max())
+    sx, so = ops.act_scale_log2(float(x.abs().max())), ops.act_scale_log2(scale)
+    wp, bias, sw = ops.prepare_conv64_f16(wt.to(dev), bn.to(dev))
+    xs = _pack_act(x, fmt, sx, dev)
+    out_s, out_f = ops.alloc_split_nhwc(N, 64, H, W, dev), ops.alloc_nhwc(N, 64, H, W, dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    resp = res.permute(0, 2, 3, 1).contiguous().to(dev) if with_res else None
+    ops.conv64_split(xs, wp, bias, H, W, relu, residual=resp, out_split=out_s, out_f32=out_f, in_fmt=fmt, in_scale_log2=sx + sw, out_fmt=fmt,
+                     out_scale_log2=so, overflow=ovf)
+    got_f = _nhwc_to_nchw(out_f.cpu()).double()
+    got_s = _padded_to_nchw(ops.unsplit_act(out_s.cpu(), fmt, so), H, W).double()
+    err = float((got_f - ref).abs().max()) / scale
+    assert err < 3e-5, err
+    assert float((got_s - got_f).abs().max()) < 4e-5 * scale and int(ovf.item()) == 0
+    assert int(out_s[:, :, W + 1:].abs().max()) == 0 and int(out_s[:, H + 1:].abs().max()) == 0
+    assert int(out_s[:, 0].abs().max()) == 0 and int(out_s[:, :, 0].abs().max()) == 0
+    # the generic kernel in the same arithmetic on the same operands: same products, another accumulation order
+    wg, bg, swg = ops.prepare_conv_split_f16(wt.to(dev), bn.to(dev), fmt)
+    gen_f = ops.alloc_nhwc(N, 64, H, W, dev)
+    ops.conv_split(xs, wg, bg, H, W, relu, residual=resp, out_f32=gen_f, in_fmt=fmt, in_scale_log2=sx + swg)
+    assert swg == sw and float((gen_f - out_f).abs().max()) < 2e-6 * scale
+    # bf16 split output from the f16f8 input
+    out_b = ops.alloc_split_nhwc(N, 64, H, W, dev)
+    ops.conv64_split(xs, wp, bias, H, W, relu, residual=resp, out_split=out_b, in_fmt=fmt, in_scale_log2=sx + sw)
+    got_b = _split_to_nchw(out_b.cpu(), H, W).double()
+    assert float((got_b - got_f).abs().max()) < 1e-5 * scale
+    # the overflow flag
+    ops.conv64_split(xs, wp, bias, H, W, relu, residual=resp, out_split=out_s, in_fmt=fmt, in_scale_log2=sx + sw, out_fmt=fmt,
+                     out_scale_log2=so + 9, overflow=ovf)
+    assert int(ovf.item()) == 1
+
+
 @pytest.mark.parametrize("case", [(2, 64, 96, True), (1, 37, 131, True), (3, 9, 5, False), (1, 480, 854, True)])
 def test_stem7_split_vs_torch(dev, case):
     """7x7 / stride 2 / pad 3 stem -> BN(eval) [-> ReLU] against torch in float64: even and odd sizes, images smaller than
@@ -1112,6 +1171,16 @@ def test_stem7_split_vs_torch(dev, case):
     only_f = ops.alloc_nhwc(N, 64, Ho, Wo, dev)
     ops.stem7_split(x.to(dev), wp, bias, relu, out_f32=only_f)
     assert torch.equal(only_f, out_f)
+    # the split output in the f16 + fp8 form (what layer 1 reads when the trunk computes in f16f8), and its overflow flag
+    so = ops.act_scale_log2(scale)
+    out_8 = ops.alloc_split_nhwc(N, 64, Ho, Wo, dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.stem7_split(x.to(dev), wp, bias, relu, out_split=out_8, out_fmt=ops.ACT_F16F8, out_scale_log2=so, overflow=ovf)
+    got_8 = _padded_to_nchw(ops.unsplit_act(out_8.cpu(), ops.ACT_F16F8, so), Ho, Wo).double()
+    assert float((got_8 - got_f).abs().max()) < 4e-5 * scale and int(ovf.item()) == 0
+    assert int(out_8[:, :, Wo + 1:].abs().max()) == 0 and int(out_8[:, 0].abs().max()) == 0
+    ops.stem7_split(x.to(dev), wp, bias, relu, out_split=out_8, out_fmt=ops.ACT_F16F8, out_scale_log2=so + 9, overflow=ovf)
+    assert int(ovf.item()) == 1
 
 
 def test_encoder_identities_from_the_split_form(dev):
@@ -1136,6 +1205,39 @@ def test_encoder_identities_from_the_split_form(dev):
             net.check_overflow()
             assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (arith, float((got - ref).abs().max()), float(ref.abs().max()))
             assert not torch.equal(got, ref)                       # (the option did change the arithmetic)
+
+
+def test_encoder_layer1_in_f16f8(dev):
+    """ResNet.conv64_f16f8 (off by default: no gain end to end): with the trunk in f16f8, layer 1 runs fgvc_conv64_split_fmt_f32 in the
+    f16 + fp8 form and the stem writes that form (calibrated scales, overflow word).  Same trunk within the arithmetic's bound."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import ops
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    torch.manual_seed(23)
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")).to(dev).eval()
+    x = torch.randn(3, 3, 72, 100, device=dev)
+    with torch.no_grad():
+        try:
+            ResNet.use_split_conv = False
+            ref = net(x).clone()                                    # MIOpen f32
+        finally:
+            ResNet.use_split_conv = True
+        net.set_arith("f16f8")
+        base = net(x).clone()
+        try:
+            ResNet.conv64_f16f8 = True
+            net.reset_split_cache()
+            plan = net._format_plan(2)
+            assert plan["stem"] == ops.ACT_F16F8 and plan[(0, 0)] == (ops.ACT_F16F8,) * 3 and plan[(0, 1)][:2] == (ops.ACT_F16F8,) * 2
+            assert plan[(0, 1)][2] == ops.ACT_BF16X2                 # the stride-2 convolutions of layer 2 read the bf16 form
+            got = net(x).clone()
+            net.check_overflow()
+        finally:
+            ResNet.conv64_f16f8 = False
+            net.reset_split_cache()
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 5e-5 * scale and float((base - ref).abs().max()) <= 5e-5 * scale
+        assert not torch.equal(got, base)
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
-# A/B runs of bench.py on ONE box (boxes differ by up to 8 %): each line is a variant against the default, interleaved twice.
+# A/B runs of bench.py on ONE box (boxes differ by up to 8 %): each line is a variant against the default, interleaved three times.
 set -e
-for round in 1 2; do
-for args in "" "--set-option conv_debug=128" "--no-res-split" "--no-res-split --set-option conv_debug=128"; do
+for round in 1 2 3; do
+for args in "" "--no-conv64-f16f8"; do
   python bench.py --steps 60 --repeats 2 --no-cpu-baseline --no-corr-volume --no-clips-line $args > gpurun_out/bv.json 2>/dev/null
   python - "$args" <<'PY'
 import json,sys
