@@ -235,9 +235,10 @@ class HipBackend:
         self.tail_from = tail_from          # "pairs": everything after the encoder runs on the side stream
         self.tail_event = None
 
-    def encode(self, frames: torch.Tensor):
-        # the bank in the form the pair kernel reads ((hi, lo) bf16 split where it applies): no second pass, same bytes to ship
-        return self.model.get_feats_hwc(frames, split=True)
+    def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None):
+        # the bank in the form the pair kernel reads (the (h, l) f16 split where it applies): no second pass, same bytes to ship.
+        # `out`: rows of the caller's local bank -- the encoder writes there when shape and dtype match (returned by identity)
+        return self.model.get_feats_hwc(frames, split=True, out=out)
 
     def affinity(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig, phases=None):
         """`phases` = (plan indices of the pairs to launch first, callable to run before the others): see engine.run_pairs."""
@@ -319,9 +320,24 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
     Hf = Wf = None
     frame_shape = None
     enc_bank = None
+    # With the bank's geometry known from an earlier call (cached schedule), the local bank -- every frame this rank will hold,
+    # ascending -- exists BEFORE the encoder runs and the encoder writes its frames into their rows: no copy of the clip's features.
+    pre_bank, pre_ids = None, None
+    if world > 1 and sc["geom"] is not None and e_hi > e_lo and _takes_out(backend):
+        g_Hf, g_Wf, g_dtype, g_shape = sc["geom"]
+        mine_ = [(src, a, b) for (src, dst, a, b) in msgs if dst == rank]
+        own_ = set(range(e_lo, e_hi)) | {s for s in starts if owner_of(s, enc) == rank}
+        pre_ids = sorted(own_ | set(starts) | {f for (_, a, b) in mine_ for f in range(a, b)})
+        pre_bank = torch.empty((len(pre_ids),) + tuple(g_shape), device=dev, dtype=g_dtype)
     with _span(timing, "encode"):
         if e_hi > e_lo:
-            f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev))
+            if pre_bank is not None:
+                p0 = pre_ids.index(e_lo)
+                f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev), out=pre_bank[p0:p0 + (e_hi - e_lo)])
+                if f.data_ptr() != pre_bank[p0].data_ptr():          # the backend produced another shape / dtype: the copy path below
+                    pre_bank = None
+            else:
+                f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev))
             enc_bank = f
             frame_shape, frame_dtype = tuple(f.shape[1:]), f.dtype
             for i in range(e_hi - e_lo):
@@ -363,9 +379,13 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
             halo_frames = {f for (_, a, b) in mine for f in range(a, b)} - set(feats)
             local_ids = sorted(set(feats) | set(starts) | halo_frames)
             pos = {f: i for i, f in enumerate(local_ids)}
-            bank = torch.empty((len(local_ids),) + tuple(frame_shape), device=dev, dtype=frame_dtype)
-            if enc_bank is not None:
-                bank[pos[e_lo]:pos[e_lo] + (e_hi - e_lo)].copy_(enc_bank)          # consecutive frames = consecutive bank rows
+            if pre_bank is not None and pre_ids == local_ids and tuple(pre_bank.shape[1:]) == tuple(frame_shape) and pre_bank.dtype == frame_dtype:
+                bank = pre_bank                                                    # the encoder already wrote this rank's frames into it
+                sc["bank_in_place"] = sc.get("bank_in_place", 0) + 1               # (observability: tests / the rehearsal tool read it)
+            else:
+                bank = torch.empty((len(local_ids),) + tuple(frame_shape), device=dev, dtype=frame_dtype)
+                if enc_bank is not None:
+                    bank[pos[e_lo]:pos[e_lo] + (e_hi - e_lo)].copy_(enc_bank)      # consecutive frames = consecutive bank rows
             for f, t in feats.items():
                 if not (e_lo <= f < e_hi):
                     bank[pos[f]].copy_(t)
@@ -464,6 +484,15 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                     backend.tail_event = torch.cuda.Event()
                     backend.tail_event.record(tail)
         return traj, sc["order"]
+
+
+def _takes_out(backend) -> bool:
+    """Does backend.encode accept `out=` (rows of the caller's bank to write into)?"""
+    import inspect
+    try:
+        return "out" in inspect.signature(backend.encode).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 def _takes_phases(backend) -> bool:

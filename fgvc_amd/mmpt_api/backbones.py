@@ -617,7 +617,7 @@ class ResNet(nn.Module):
         outs = [stage_out[i] for i in want]
         return outs[0] if len(outs) == 1 else tuple(outs)
 
-    def forward_hwc(self, x, normalize: bool = True, split_if=None, split_fmt: str = "bf16"):
+    def forward_hwc(self, x, normalize: bool = True, split_if=None, split_fmt: str = "bf16", out=None):
         """The tracker's fast path: features of the single requested stage as (N, H*W, C) f32 rows, L2-normalised if
         `normalize` -- straight from the dense NHWC buffer when the stage ran on the bf16 pipe (no NCHW round trip).
         `split_if(C, H, W) -> bool`: when given and true for the stage's shape, the rows come back as their (hi, lo) bf16
@@ -630,9 +630,13 @@ class ResNet(nn.Module):
         def post(y_slice, lo, hi, C, H, W):      # each lane normalises (and splits) its own frames under the other lane's tail
             if "out" not in box:
                 as_split = bool(split_if is not None and split_if(C, H, W))
-                with torch.cuda.stream(main):                                  # the result is the caller's: its stream owns it
-                    box["out"] = torch.empty((x.shape[0], H * W, 2, C) if as_split else (x.shape[0], H * W, C), device=x.device,
-                                             dtype=torch.int16 if as_split else torch.float32)
+                shape = (x.shape[0], H * W, 2, C) if as_split else (x.shape[0], H * W, C)
+                dtype = torch.int16 if as_split else torch.float32
+                if out is not None and tuple(out.shape) == shape and out.dtype == dtype and out.is_contiguous() and out.device == x.device:
+                    box["out"] = out                                           # the caller's rows (a slice of its feature bank): no copy later
+                else:
+                    with torch.cuda.stream(main):                              # the result is the caller's: its stream owns it
+                        box["out"] = torch.empty(shape, device=x.device, dtype=dtype)
                 torch.cuda.current_stream(x.device).wait_stream(main)          # (the block's previous life ended on that stream)
                 box["split"] = as_split
             elif torch.cuda.current_stream(x.device) != main:

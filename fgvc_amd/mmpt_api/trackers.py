@@ -9,6 +9,8 @@ argsort, :404-406).
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn as nn
 
@@ -76,14 +78,18 @@ class VanillaTracker(BaseTracker):
         return x
 
     @torch.no_grad()
-    def get_feats_hwc(self, frames: torch.Tensor, split: bool = False):
+    def get_feats_hwc(self, frames: torch.Tensor, split: bool = False, out: Optional[torch.Tensor] = None):
         """frames (T,3,h,w) -> normalised channels-last (T, HfWf, C'), Hf, Wf.
         batch_step frames per encoder call (vanilla_tracker.py:135-147).  split=True: the bank comes back as its two-part 16-bit
         split (T, HfWf, 2, C') int16, in the format engine_config().pair_split_fmt names, wherever the engine's split pair kernel
-        applies (one pass less; engine.run_affinity takes either form), f32 otherwise."""
+        applies (one pass less; engine.run_affinity takes either form), f32 otherwise.
+        `out`: rows of the caller's own feature bank (T, ...) of the shape / dtype this call produces; the encoder then writes there
+        and `out` itself is returned (clip sharding: the frames a rank encodes land in its local bank without a copy).  A mismatch
+        falls back to a fresh tensor -- compare the result with `out` by identity."""
         step = int(self.test_cfg.get("batch_step", 5))
         norm = bool(self.test_cfg.get("with_norm", True))
         chunks = []
+        in_place = out is not None
         Hf = Wf = None
         if self.test_cfg.get("channels_last", False):
             # MIOpen's fastest f32 kernels on gfx950 are NHWC; feeding NHWC avoids its transposes
@@ -100,9 +106,11 @@ class VanillaTracker(BaseTracker):
                                                              cfg.with_first_neighbor or not cfg.with_first)
         for i in range(0, frames.shape[0], step):
             if fast:       # backbone writes normalised channels-last rows itself (no NCHW round trip)
-                f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm, split_if=split_if, split_fmt=split_fmt)
+                o = out[i:i + step] if out is not None else None
+                f, Hf, Wf = self.backbone.forward_hwc(frames[i:i + step], norm, split_if=split_if, split_fmt=split_fmt, out=o)
                 self.feat_channels = f.shape[-1]                      # (this path never pads)
                 chunks.append(f)
+                in_place = in_place and o is not None and f is o
                 continue
             f = self.extract_feat(frames[i:i + step])
             if isinstance(f, (tuple, list)):
@@ -110,6 +118,9 @@ class VanillaTracker(BaseTracker):
             Hf, Wf = f.shape[-2:]
             self.feat_channels = f.shape[1]                           # before the zero padding to a kernel width
             chunks.append(ops.normalize_to_hwc(f.float(), norm, pad=True))
+            in_place = False
+        if in_place and chunks:
+            return out, Hf, Wf
         return (chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)), Hf, Wf       # (cat of one tensor is a copy)
 
     def engine_config(self) -> engine.TrackerConfig:

@@ -371,6 +371,7 @@ def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
         assert set(r) == {"exchange", "exchange+tail", "exchange+tail_from_pairs", "recompute", "recompute+tail", "recompute+tail_from_pairs"}
         for v in r.values():
             assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 and "halo_wait" in v["phases"]
+            assert v["bank_in_place"] == 1          # the second (cached-schedule) call encoded straight into the rank's local bank
     # ... and at BASELINE configs[3]'s shape: 64 frames of 256 x 256 (128 x 128 x 256 features), 32 points, precede_frames 5
     c4 = two_ranks["cfg4"]
     assert c4["rc"] == 0, (c4["out"][-2000:], c4["err"][-2000:])
