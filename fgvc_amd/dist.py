@@ -323,25 +323,65 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
     # With the bank's geometry known from an earlier call (cached schedule), the local bank -- every frame this rank will hold,
     # ascending -- exists BEFORE the encoder runs and the encoder writes its frames into their rows: no copy of the clip's features.
     pre_bank, pre_ids = None, None
-    if world > 1 and sc["geom"] is not None and e_hi > e_lo and _takes_out(backend):
+    if world > 1 and sc["geom"] is not None and _takes_out(backend):      # (the same decision on every rank: it fixes the order of the collectives)
         g_Hf, g_Wf, g_dtype, g_shape = sc["geom"]
         mine_ = [(src, a, b) for (src, dst, a, b) in msgs if dst == rank]
         own_ = set(range(e_lo, e_hi)) | {s for s in starts if owner_of(s, enc) == rank}
         pre_ids = sorted(own_ | set(starts) | {f for (_, a, b) in mine_ for f in range(a, b)})
         pre_bank = torch.empty((len(pre_ids),) + tuple(g_shape), device=dev, dtype=g_dtype)
+    # Early halo (every call after the first of a cached schedule, `halo="exchange"`): a clip's halo is the LAST p frames of the clip
+    # before it, so every rank encodes its last p frames FIRST (into the bank), posts its messages -- the sends of those frames and
+    # the receives of its own halo, one batch -- and only then encodes the frames in front of them: the transfer (5 x 26 MB over one
+    # xGMI direction, ~1.7 ms) runs under the rest of the encoder instead of behind it.  Every rank posts at the same point of its
+    # schedule (also the last rank, which only receives) and before the first-frame broadcast: one order of communication calls
+    # for the whole group.
+    early_halo = pre_bank is not None and halo == "exchange" and bool(msgs) and getattr(backend, "early_halo", True)
+    pending = None
+
+    def post_halo():
+        nonlocal pending
+        ppos = {f: i for i, f in enumerate(pre_ids)}
+        pending = _Messages(group)
+        for (src, dst, a, b) in msgs:
+            if src == rank:
+                pending.send(pre_bank[ppos[a]:ppos[a] + (b - a)], dst)
+            elif dst == rank:
+                pending.recv(pre_bank[ppos[a]:ppos[a] + (b - a)], src)
+        with _span(timing, "halo_exchange"):
+            pending.post()
+
     with _span(timing, "encode"):
         if e_hi > e_lo:
             if pre_bank is not None:
                 p0 = pre_ids.index(e_lo)
-                f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev), out=pre_bank[p0:p0 + (e_hi - e_lo)])
-                if f.data_ptr() != pre_bank[p0].data_ptr():          # the backend produced another shape / dtype: the copy path below
-                    pre_bank = None
+                rows = pre_bank[p0:p0 + (e_hi - e_lo)]
+                split_at = max(e_lo, e_hi - cfg.precede_frames) if early_halo else e_lo
+                if split_at > e_lo:
+                    ft, Hf, Wf = backend.encode(rgbs[split_at:e_hi].to(dev), out=rows[split_at - e_lo:])
+                    if ft.data_ptr() != rows[split_at - e_lo].data_ptr():
+                        raise RuntimeError("track_points_sharded: the backend did not encode into the local bank (geometry changed "
+                                           "under a cached schedule?)")     # (a silent fallback would change the order of collectives on this rank only)
+                    post_halo()
+                    fh, Hf, Wf = backend.encode(rgbs[e_lo:split_at].to(dev), out=rows[:split_at - e_lo])
+                    if fh.data_ptr() != rows.data_ptr():
+                        raise RuntimeError("track_points_sharded: the backend did not encode into the local bank")
+                    f = rows
+                else:
+                    f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev), out=rows)
+                    if f.data_ptr() != rows.data_ptr():                  # the backend produced another shape / dtype
+                        if early_halo:
+                            raise RuntimeError("track_points_sharded: the backend did not encode into the local bank")
+                        pre_bank = None                                  # the copy path below
+                    elif early_halo:
+                        post_halo()
             else:
                 f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev))
             enc_bank = f
             frame_shape, frame_dtype = tuple(f.shape[1:]), f.dtype
             for i in range(e_hi - e_lo):
                 feats[e_lo + i] = f[i]
+        elif early_halo:
+            post_halo()                                                  # a rank with an empty range still takes part
         for s in starts:                       # a start frame nobody's range covers is encoded by its owner
             if owner_of(s, enc) == rank and s not in feats:
                 f, Hf, Wf = backend.encode(rgbs[s:s + 1].to(dev))
@@ -371,7 +411,7 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
         HW = Hf * Wf
         k = cfg.topk
 
-        pending, halo_frames = None, set()
+        halo_frames = set()
         if world > 1:
             # ---- the local bank: every frame this rank will hold, ascending, in ONE tensor the pair kernel reads; what arrives from
             #      other ranks lands in its slices directly
@@ -400,14 +440,18 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
 
             # ---- 3. halo: the p frames in front of this rank's clip, from the rank(s) that encoded them -- posted here, awaited in
             #      front of the first pair that reads one of them
-            with _span(timing, "halo_exchange"):
-                pending = _Messages(group)
-                for (src, dst, a, b) in msgs:
-                    if src == rank:
-                        pending.send(bank[pos[a]:pos[a] + (b - a)], dst)
-                    elif dst == rank:
-                        pending.recv(bank[pos[a]:pos[a] + (b - a)], src)
-                pending.post()
+            if pending is not None:                       # early halo: posted after this rank's last p frames were encoded
+                assert bank is pre_bank
+                sc["halo_early"] = sc.get("halo_early", 0) + 1
+            else:
+                with _span(timing, "halo_exchange"):
+                    pending = _Messages(group)
+                    for (src, dst, a, b) in msgs:
+                        if src == rank:
+                            pending.send(bank[pos[a]:pos[a] + (b - a)], dst)
+                        elif dst == rank:
+                            pending.recv(bank[pos[a]:pos[a] + (b - a)], src)
+                    pending.post()
         else:
             with _span(timing, "broadcast_first_frames"):
                 pass

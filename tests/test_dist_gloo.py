@@ -14,9 +14,13 @@ from oracle import fgvc_oracle as O
 class OracleBackend:
     """Same interface as fgvc_amd.dist.HipBackend, torch CPU arithmetic (test infrastructure)."""
 
-    def encode(self, frames):                       # "frames" are already feature maps (n,C,Hf,Wf) in this test
+    def encode(self, frames, out=None):             # "frames" are already feature maps (n,C,Hf,Wf) in this test
         n, C, Hf, Wf = frames.shape
-        return O.l2_normalize(frames, 1).flatten(2).transpose(1, 2).contiguous(), Hf, Wf
+        f = O.l2_normalize(frames, 1).flatten(2).transpose(1, 2).contiguous()
+        if out is not None and out.shape == f.shape and out.dtype == f.dtype:      # rows of the caller's local bank (HipBackend.encode(out=))
+            out.copy_(f)
+            return out, Hf, Wf
+        return f, Hf, Wf
 
     def affinity(self, bank, Hf, Wf, plan, cfg, phases=None):
         """`phases` as HipBackend.affinity: rows made only of pairs in `first` are computed BEFORE between() (= before the halo
@@ -94,7 +98,16 @@ def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5, members
     try:
         timing = D.Timing()
         be = OracleBackend()
-        traj, order = _run(D, be, feats, qp, cfg, h, w, halo=halo, timing=timing, group=group)
+        cache = {}
+        traj, order = _run(D, be, feats, qp, cfg, h, w, halo=halo, timing=timing, group=group, cache=cache)
+        # second call, cached schedule: the bank exists before the encoder runs, the encoder writes into it, and with halo="exchange"
+        # every rank posts its messages after its last `precede` frames and before the rest (one order of collectives on all ranks --
+        # a rank that decided differently would hang here); same trajectories
+        timing = D.Timing()
+        traj2, order2 = _run(D, be, feats, qp, cfg, h, w, halo=halo, timing=timing, group=group, cache=cache)
+        assert torch.equal(traj2, traj) and torch.equal(order2, order)
+        assert cache["schedule"].get("bank_in_place", 0) == 1
+        assert cache["schedule"].get("halo_early", 0) == (1 if halo == "exchange" else 0)
         rep = timing.report()
         rank = dist.get_rank(group) if group is not None else rank
         world = len(members) if members is not None else world

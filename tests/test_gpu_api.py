@@ -372,6 +372,8 @@ def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
         for v in r.values():
             assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 and "halo_wait" in v["phases"]
             assert v["bank_in_place"] == 1          # the second (cached-schedule) call encoded straight into the rank's local bank
+        for mode, v in r.items():                   # ... and posted the halo messages after its last five frames, before the rest
+            assert v["halo_early"] == (1 if mode.startswith("exchange") else 0), (mode, v)
     # ... and at BASELINE configs[3]'s shape: 64 frames of 256 x 256 (128 x 128 x 256 features), 32 points, precede_frames 5
     c4 = two_ranks["cfg4"]
     assert c4["rc"] == 0, (c4["out"][-2000:], c4["err"][-2000:])
@@ -380,4 +382,4 @@ def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
     for r in res["ranks"].values():
         assert set(r) == {"exchange", "exchange+tail", "exchange+tail_from_pairs"}
         for v in r.values():
-            assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3
+            assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 and v["halo_early"] == 1

@@ -65,7 +65,7 @@ def worker(rank, world, path, a, q):
                 out[halo + {False: "", True: "+tail", "pairs": "+tail_from_pairs"}[tail]] = dict(
                     max_abs_diff_px=float((traj_s.cpu() - traj.cpu()).abs().max()), order_equal=bool(torch.equal(order_s, order)),
                     finite=bool(torch.isfinite(traj_s).all()), phases=sorted(rep),
-                    bank_in_place=int(cache["schedule"].get("bank_in_place", 0)))     # second call: the encoder wrote into the local bank
+                    bank_in_place=int(cache["schedule"].get("bank_in_place", 0)), halo_early=int(cache["schedule"].get("halo_early", 0)))     # second call: the encoder wrote into the local bank
         q.put((rank, out))
         dist.barrier()
         dist.destroy_process_group()
