@@ -264,6 +264,40 @@ def test_cfg5_plan_pairs_and_merged_lists(dev, clip5):
     assert torch.allclose(allv.gather(1, order) / cfg.temperature, tk.logit[row], atol=1e-5)
 
 
+def test_cfg5_tracker_end_to_end(dev):
+    """BASELINE configs[4]'s shape through the whole path: 24 frames of 720 x 1280 -> 180 x 320 x 256 features (stride 4), 16 query
+    points at frame 0, hand-written encoder -> pair top-k (123 pairs) -> merge -> sweep -> read-out.  (i) finite, the tracks follow a
+    textured field that drifts by (+3, +2) pixels per frame; (ii) frames 0..7 equal the first 8 frames run alone bit for bit (a
+    frame's labels depend on earlier frames only)."""
+    import fgvc_amd.mmpt_api as api
+    from oracle import fgvc_oracle as O
+    torch.manual_seed(720)
+    cfg = dict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, with_first=True, with_first_neighbor=True, batch_step=8)
+    model = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                                                      pool_type="none")), train_cfg=None, test_cfg=api.ConfigDict(cfg))
+    model.backbone.load_state_dict(O.seeded_resnet_state(72, (1, 2, 1, 1), "none"), strict=False)
+    model = model.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(721)
+    h, w, T, P = 720, 1280, 24, 16
+    base = torch.nn.functional.interpolate(torch.randn(1, 3, 100, 170, generator=g, device=dev), size=(h + 100, w + 120), mode="bicubic",
+                                           align_corners=False)[0]
+    rgbs = torch.stack([base[:, 10 + 2 * t: 10 + 2 * t + h, 20 + 3 * t: 20 + 3 * t + w] for t in range(T)], 0) * 1.2
+    rgbs = (rgbs + 0.1 * torch.randn(rgbs.shape, generator=g, device=dev)).unsqueeze(0)
+    gq = torch.Generator().manual_seed(722)
+    qp = torch.cat([torch.zeros(P, 1), torch.rand(P, 1, generator=gq) * 800 + 300, torch.rand(P, 1, generator=gq) * 400 + 200], 1)
+    qp = qp.unsqueeze(0).to(dev)
+    traj, vis = torch.zeros(1, T, P, 2, device=dev), torch.ones(1, T, P, device=dev)
+    outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
+    pred = outs[2]
+    assert pred.shape == (1, T, P, 2) and bool(torch.isfinite(pred).all())
+    drift = (pred[0, 20] - pred[0, 0]).cpu()                       # the content moves by (-3, -2) px per frame in image coordinates
+    err = (drift - torch.tensor([-60.0, -40.0], dtype=drift.dtype)).abs()
+    assert float(err.median()) < 6.0, drift
+    o8 = model(test_mode=True, rgbs=rgbs[:, :8], query_points=qp, trajectories=traj[:, :8], visibilities=vis[:, :8])
+    assert torch.equal(o8[2], pred[:, :8])
+    REPORT["cfg5_tracker"] = dict(frames=T, size=[h, w], points=P, median_drift_error_px=float(err.median()))
+
+
 def test_cfg5_dense_volume_bf16_full_size_and_accuracy_report(dev, clip5):
     """The full 57 600 x 57 600 volume (13.3 GB) in plain bf16 (configs[4]: "MFMA bf16 correlation GEMM") and in the
     parity-grade bf16x3 form.  Stated bounds: bf16x3 within 1e-3 of float64 (the north_star's score bar); plain bf16 within
