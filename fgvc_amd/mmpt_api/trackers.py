@@ -20,6 +20,10 @@ from .config import ConfigDict
 from .registry import MODELS
 
 
+class EncoderOverflow(RuntimeError):
+    """An activation left the f16 range of its calibrated scale (ResNet.check_overflow): the pass that raised it is invalid."""
+
+
 class BaseModel(nn.Module):
     """base.py:24-60: holds train_cfg/test_cfg, dispatches on test_mode."""
 
@@ -40,7 +44,17 @@ class BaseModel(nn.Module):
         raise NotImplementedError
 
     def forward(self, test_mode=False, **kwargs):
-        return self.forward_test(**kwargs) if test_mode else self.forward_train(**kwargs)
+        if not test_mode:
+            return self.forward_train(**kwargs)
+        try:
+            return self.forward_test(**kwargs)
+        except EncoderOverflow:
+            # The f16 arithmetic of the encoder stores activations at scales calibrated on the FIRST batch these weights saw; a later
+            # video with larger activations overflows them.  The check that raised has dropped the scales: run the video once more --
+            # the encoder re-calibrates on this video's own frames.  A second overflow (a single video whose later frames exceed its
+            # first batch by more than the 2^7 of headroom) is an error: results are never returned from an overflowed pass.
+            self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
+            return self.forward_test(**kwargs)
 
 
 @MODELS.register_module()
@@ -136,7 +150,7 @@ class VanillaTracker(BaseTracker):
         if ops.pair_f16x3_timed_out():
             raise RuntimeError("fgvc_pair_topk_f16x3: a bounded wait of the kernel's LDS protocol timed out; this video's results are invalid")
         if hasattr(self.backbone, "check_overflow") and self.backbone.check_overflow():
-            raise RuntimeError("fgvc_amd ResNet: an activation left the f16 range of its calibrated scale (f16 arithmetic of the encoder); "
+            raise EncoderOverflow("fgvc_amd ResNet: an activation left the f16 range of its calibrated scale (f16 arithmetic of the encoder); "
                                "this video's results are invalid -- the scales were dropped and the next call re-calibrates on its own "
                                "frames (or call backbone.calibrate(frames), or backbone.set_arith('bf16x3'))")
 

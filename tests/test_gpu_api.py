@@ -335,6 +335,40 @@ def test_jhmdb_adapter_end_to_end(dev, tmp_path):
     assert pck["PCK@0.2"] > 80.0 and pck["PCK@0.1"] <= pck["PCK@0.2"] <= pck["PCK@0.5"], pck
 
 
+def test_tracker_recalibrates_after_an_encoder_overflow(dev):
+    """The f16 arithmetic of the encoder keeps per-tensor scales calibrated on the first batch a set of weights sees.  A later video
+    whose activations are 2^10 times larger leaves that range: the pass raises the device flag, its results are dropped
+    (EncoderOverflow inside forward), the scales are re-calibrated on the new video and the video runs once more -- the caller gets
+    the trajectories a freshly calibrated model gives, bit for bit, and `overflow_retries` counts the event.  (The reference has no
+    such failure mode; never returning numbers from an overflowed pass is the point.)"""
+    import fgvc_amd.mmpt_api as api
+    from oracle import fgvc_oracle as O
+
+    def build():
+        m = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                                                       pool_type="none")), train_cfg=None,
+                            test_cfg=api.ConfigDict(precede_frames=3, topk=10, temperature=0.07, neighbor_range=12, with_first=True,
+                                                    with_first_neighbor=True))
+        m.backbone.load_state_dict(O.seeded_resnet_state(31, (1, 2, 1, 1), "none"), strict=False)
+        return m.to(dev).eval()
+    g = torch.Generator().manual_seed(31)
+    faint = (torch.randn(1, 4, 3, 64, 96, generator=g) * 2.0 ** -6).to(dev)
+    bright = (torch.randn(1, 4, 3, 64, 96, generator=g) * 2.0 ** 4).to(dev)
+    qp = torch.tensor([[[0., 20., 17.], [0., 70.5, 40.25], [1., 33., 50.]]]).to(dev)
+    traj, vis = torch.zeros(1, 4, 3, 2, device=dev), torch.ones(1, 4, 3, device=dev)
+    model = build()
+    assert model.backbone.arith == "f16f8"
+    model(test_mode=True, rgbs=faint, query_points=qp, trajectories=traj, visibilities=vis)          # calibrates on the faint video
+    assert getattr(model, "overflow_retries", 0) == 0
+    out = model(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)   # overflows, re-calibrates, re-runs
+    assert model.overflow_retries == 1 and bool(torch.isfinite(out[2]).all())
+    fresh = build()(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)
+    assert torch.equal(out[2], fresh[2]) and torch.equal(out[4], fresh[4])
+    # ... and from then on the bright scales hold: no further retry for the same kind of video
+    model(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)
+    assert model.overflow_retries == 1
+
+
 def test_badja_adapter_end_to_end(dev, tmp_path):
     """BADJA-format files -> BadjaPoses -> VanillaTracker -> PCK as the reference's pck_evaluate computes it (badja_dataset.py:451-571)
     on rigidly translating textures with joints that move along (adapter + metric plumbing, not an accuracy claim); also through
