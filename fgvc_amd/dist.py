@@ -249,6 +249,14 @@ class HipBackend:
         tk = engine.DeviceTopk(plan, idx, None, weight, slot_frame)
         return engine.run_propagation(tk, start, pts, Hf, Wf, h, w, cfg)[1]
 
+    def failure_flags(self) -> Tuple[bool, bool]:
+        """(a bounded wait of the pair kernel's LDS protocol gave up, an activation left the encoder's calibrated f16 range) since the
+        last call -- either makes the results since then invalid (poison lists / saturated features).  Reads and clears both device
+        flags (a synchronisation); an overflow also drops the encoder's scales (the next encode re-calibrates)."""
+        from . import ops
+        bb = getattr(self.model, "backbone", None)
+        return bool(ops.pair_f16x3_timed_out()), bool(bb is not None and hasattr(bb, "check_overflow") and bb.check_overflow())
+
 
 def _span(timing: Optional[Timing], name: str):
     class _Ctx:
@@ -265,13 +273,17 @@ def _span(timing: Optional[Timing], name: str):
 
 def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor, cfg: TrackerConfig,
                          group=None, device: Optional[torch.device] = None, halo: str = "exchange",
-                         timing: Optional[Timing] = None, cache: Optional[dict] = None):
+                         timing: Optional[Timing] = None, cache: Optional[dict] = None, check: bool = False):
     """One video, all ranks.  rgbs (T,3,h,w) (every rank may hold the whole clip on the host or the device; only
     its own frames are moved/encoded), query_points (P,3)=(t,x,y).
     Returns (traj (T,P',2) f64 regrouped by query time, order (P',)) on every rank.
     `cache`: a dict the caller keeps between calls with the SAME video shape, query points, cfg and process group; the schedule
     (frame ranges, message plan, slot tables on the device, query points on the device, bank geometry) is then built once --
-    per call that is a dozen small blocking host-to-device copies and, at more than one rank, one tiny broadcast + host read."""
+    per call that is a dozen small blocking host-to-device copies and, at more than one rank, one tiny broadcast + host read.
+    `check=True`: before returning, read the backend's failure flags (`backend.failure_flags()`: pair-kernel timeout, encoder
+    overflow), agree on them across the group (one MAX all_reduce of two words, so that every rank raises or none does -- a rank
+    raising alone would leave the others in their next collective) and raise RuntimeError if any rank saw one.  Costs a device
+    synchronisation per video; drivers that pipeline videos (bench.py) check once per loop instead."""
     if halo not in ("exchange", "recompute"):
         raise ValueError(f"halo={halo!r}")
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -527,6 +539,19 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                 if tail is not None:
                     backend.tail_event = torch.cuda.Event()
                     backend.tail_event.record(tail)
+        if check and hasattr(backend, "failure_flags"):
+            tail_s = getattr(backend, "tail_stream", None)
+            if tail_s is not None:
+                tail_s.synchronize()
+            flags = torch.tensor([float(v) for v in backend.failure_flags()], device=dev if world > 1 and not _host_staged(traj, group) else "cpu")
+            if world > 1:
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+            t_out, ovf = (bool(v) for v in flags.tolist())
+            if t_out or ovf:
+                raise RuntimeError("track_points_sharded: " + " and ".join(
+                    m for m, f in (("a bounded wait of the pair kernel timed out on some rank", t_out),
+                                   ("an activation left the encoder's calibrated f16 range on some rank (scales dropped: the next "
+                                    "call re-calibrates)", ovf)) if f) + "; this video's results are invalid")
         return traj, sc["order"]
 
 

@@ -1363,8 +1363,21 @@ def test_sharded_tracker_hip_backend_single_rank(dev):
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         created = True
+    from fgvc_amd import ops
     try:
-        traj_s, order_s = fdist.track_points_sharded(fdist.HipBackend(model), rgbs, qp, cfg, device=dev)
+        be = fdist.HipBackend(model)
+        traj_s, order_s = fdist.track_points_sharded(be, rgbs, qp, cfg, device=dev, check=True)
+        # check=True: a failure flag of the backend (here the pair kernel's bounded wait, injected) is agreed on over the group
+        # (one MAX all_reduce) and raised -- the results of that video never leave the function
+        ops.set_option("pair_f16_debug", 4096)
+        try:
+            with pytest.raises(RuntimeError, match="timed out"):
+                fdist.track_points_sharded(be, rgbs, qp, cfg, device=dev, check=True)
+        finally:
+            ops.set_option("pair_f16_debug", 0)
+        assert be.failure_flags() == (False, False)                      # read and cleared by the check
+        t2, _ = fdist.track_points_sharded(be, rgbs, qp, cfg, device=dev, check=True)
+        assert torch.equal(t2, traj_s)
     finally:
         if created:
             dist.destroy_process_group()
