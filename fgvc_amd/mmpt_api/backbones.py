@@ -617,7 +617,43 @@ class ResNet(nn.Module):
         outs = [stage_out[i] for i in want]
         return outs[0] if len(outs) == 1 else tuple(outs)
 
+    use_graph = False              # True: forward_hwc replays a HIP graph of the whole NHWC trunk per input shape (captured on the second
+                                   # call of a shape).  For HOST-bound inputs: a 2-frame 256 x 256 call is 32 launches at ~25 us of Python
+                                   # each against 0.3 ms of GPU work; an 8-frame 480p clip is GPU-bound and gains nothing.
+
     def forward_hwc(self, x, normalize: bool = True, split_if=None, split_fmt: str = "bf16", out=None):
+        """forward_hwc_eager, or -- with `use_graph` on the GPU in eval mode -- the same work replayed from a HIP graph (torch.cuda.CUDAGraph
+        on ROCm).  The graph of a shape is captured on its second call (the first runs eagerly: calibration, workspaces, weight
+        layouts), reads a static copy of the input and writes a static output: the returned tensor is overwritten by the next call
+        with the same shape (the tracker consumes it before; `out` receives a copy).  Graphs live in the split cache: new weights,
+        another arithmetic or a re-calibration drop them."""
+        if not (self.use_graph and x.is_cuda and not self.training and x.dtype == torch.float32):
+            return self.forward_hwc_eager(x, normalize, split_if, split_fmt, out)
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = ("graph", tuple(x.shape), x.device, bool(normalize), split_fmt, split_if is not None)
+        ent = cache.get(key)
+        if ent is None:                                        # first call of this shape: eager (it may calibrate and allocate)
+            cache[key] = "warm"
+            return self.forward_hwc_eager(x, normalize, split_if, split_fmt, out)
+        if ent == "warm":
+            if self._scales(x.device) is None and self.arith != "bf16x3":
+                return self.forward_hwc_eager(x, normalize, split_if, split_fmt, out)      # (scales were dropped: calibrate eagerly first)
+            static_in = torch.empty_like(x)
+            static_in.copy_(x)
+            torch.cuda.synchronize(x.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                o, H, W = self.forward_hwc_eager(static_in, normalize, split_if, split_fmt, None)
+            ent = cache[key] = (g, static_in, o, H, W)
+        g, static_in, o, H, W = ent
+        static_in.copy_(x)
+        g.replay()
+        if out is not None and tuple(out.shape) == tuple(o.shape) and out.dtype == o.dtype:
+            out.copy_(o)
+            return out, H, W
+        return o, H, W
+
+    def forward_hwc_eager(self, x, normalize: bool = True, split_if=None, split_fmt: str = "bf16", out=None):
         """The tracker's fast path: features of the single requested stage as (N, H*W, C) f32 rows, L2-normalised if
         `normalize` -- straight from the dense NHWC buffer when the stage ran on the bf16 pipe (no NCHW round trip).
         `split_if(C, H, W) -> bool`: when given and true for the stage's shape, the rows come back as their (hi, lo) bf16

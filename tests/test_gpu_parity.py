@@ -1240,6 +1240,42 @@ def test_encoder_layer1_in_f16f8(dev):
         assert not torch.equal(got, base)
 
 
+def test_encoder_hip_graph_replay(dev):
+    """ResNet.use_graph: forward_hwc replays a HIP graph of the whole trunk (two stream lanes, ~32 launches, the normalise + split pass)
+    captured on the second call of an input shape.  Same bits as the eager path for new inputs, through `out=`, for a second shape;
+    new weights drop the graphs."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import ops
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    torch.manual_seed(24)
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")).to(dev).eval()
+    split_if = lambda C, H, W: True
+    xs = [torch.randn(3, 3, 72, 100, device=dev) for _ in range(4)] + [torch.randn(2, 3, 64, 64, device=dev)]
+    with torch.no_grad():
+        want = [net.forward_hwc(x, True, split_if=split_if, split_fmt="f16")[0].clone() for x in xs]
+        try:
+            ResNet.use_graph = True
+            got = []
+            for x in xs + xs[:2]:                                  # first call of a shape eager, second captures, later ones replay
+                f, H, W = net.forward_hwc(x, True, split_if=split_if, split_fmt="f16")
+                got.append(f.clone())
+            cache = net.__dict__["_split_cache"]
+            graphs = [k for k, v in cache.items() if isinstance(k, tuple) and k and k[0] == "graph" and isinstance(v, tuple)]
+            assert len(graphs) == 1                                # (the 2-frame shape was seen once: still "warm")
+            for a, b in zip(got, want + want[:2]):
+                assert torch.equal(a, b)
+            out = torch.empty_like(want[0])
+            f, H, W = net.forward_hwc(xs[3], True, split_if=split_if, split_fmt="f16", out=out)
+            assert f is out and torch.equal(out, want[3]) and (H, W) == (18, 25)
+            net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})       # any load drops the derived state, graphs included
+            assert not any(isinstance(k, tuple) and k and k[0] == "graph" for k in net.__dict__.get("_split_cache", {}))
+            f, _, _ = net.forward_hwc(xs[0], True, split_if=split_if, split_fmt="f16")
+            assert torch.equal(f, want[0])
+        finally:
+            ResNet.use_graph = False
+    assert not net.check_overflow()
+
+
 @pytest.mark.gpu
 def test_encoder_zero_initialised_residual_branch(dev):
     """init_weights() of the reference's ResNet zeroes bn2.weight of every block (zero_init_residual, mmpt/models/backbones/resnet.py
