@@ -69,6 +69,29 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const int32_t* __restri
     const int pid = slot_pair[f * T + t];
     if (pid < 0) continue;
     const size_t o = ((size_t)pid * HWq + q) * kout;
+    if constexpr ((K & 1) == 0) {
+      if (kout == K) {
+        // full lists of an even length: 8-byte loads of the whole list (a lane's list is K * 4 contiguous bytes, 8-byte aligned; read
+        // one dword at a time every load instruction of a wave touched 64 dwords K * 4 bytes apart), then the same early-out walk
+        int2 ii[K / 2];
+        float2 ss[K / 2];
+#pragma unroll
+        for (int j = 0; j < K / 2; ++j) {
+          ii[j] = reinterpret_cast<const int2*>(pair_idx + o)[j];
+          ss[j] = reinterpret_cast<const float2*>(pair_score + o)[j];
+        }
+        bool more = true;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int id = (j & 1) ? ii[j / 2].y : ii[j / 2].x;
+          const float s = (j & 1) ? ss[j / 2].y : ss[j / 2].x;
+          const int gid = t * HWk + id;
+          more = more && id >= 0 && top.accepts(s, gid);
+          if (more) top.insert(s, gid);
+        }
+        continue;
+      }
+    }
     for (int j = 0; j < kout; ++j) {
       const int id = pair_idx[o + j];
       if (id < 0) break;  // lists are sorted; -1 marks the empty tail
