@@ -211,8 +211,9 @@ class HRVanillaTracker(VanillaTracker):
     `with_norm`), `topk` (10), `temperature` (default 1, :563), `precede_frames`, `with_first` (slot 0, default True, :534;
     regrouping, default False, :246), `batch_step`.  `dilations` is passed by the reference as the dilation of the
     Correlation KERNEL (:426-428), which has a single tap (kernel_size=1): any value gives the same result, so it is accepted
-    and has no effect (mmcv arithmetic: "parity unpinned").  `save_mem=True` is refused (the reference's branch pairs one key
-    frame with several label maps, :538-545, and cannot run)."""
+    and has no effect (mmcv arithmetic: "parity unpinned").  `save_mem=True` (:432, :537-545: one key frame, the previous one, and no
+    first-frame slot) runs as in the reference for `precede_frames = 1` and is refused otherwise (the reference's branch then pairs one
+    key frame with several label maps and fails at its reshape, :552)."""
 
     def __init__(self, stride=2, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -221,8 +222,11 @@ class HRVanillaTracker(VanillaTracker):
         self.infer_radius = g("neighbor_range", 24) // 2
         self.infer_dilations = g("dilations", 1)
         self.grid_size_hr = 2 * self.infer_radius + 1
-        if g("save_mem", False):
-            raise NotImplementedError("fgvc_amd: HRVanillaTracker save_mem=True (unrunnable in the reference, vanilla_tracker.py:538-545)")
+        self.save_mem = bool(g("save_mem", False))                      # :432
+        if self.save_mem and int(g("precede_frames", 5)) != 1:
+            raise NotImplementedError("fgvc_amd: HRVanillaTracker save_mem=True needs precede_frames = 1: the reference's branch pairs ONE key "
+                                      "frame with the label maps of all preceding frames (vanilla_tracker.py:520-545) and fails at its "
+                                      "reshape (:552) for any other value")
 
     def _feats_hwc(self, frames: torch.Tensor):
         """frames (T,3,h,w) -> channels-last rows (T, HfWf, C'), L2-normalised iff `withnorm` (:437-439), Hf, Wf."""
@@ -246,7 +250,8 @@ class HRVanillaTracker(VanillaTracker):
         R, k, tau = self.infer_radius, int(g("topk", 10)), float(g("temperature", 1))
         pre, with_first = int(g("precede_frames", 5)), bool(g("with_first", True))
         for f in range(1, T):
-            ks = engine.key_slots(f, 0, pre, with_first)
+            # save_mem (:537-545): the single key frame f - 1 (features re-extracted there, the same values here), no first-frame slot
+            ks = [f - 1] if self.save_mem else engine.key_slots(f, 0, pre, with_first)
             # `normalized` must be the flag that controlled the normalisation of the bank: the bf16-pipe kernel's fixed-point
             # keys assume |q.k| <= 1 and raw ResNet dot products are not (they go through fgvc_local_corr_topk_f32)
             idx, _, weight = ops.local_corr_topk(feats[f:f + 1], feats[ks], Hf, Wf, R, k, tau, normalized=norm)

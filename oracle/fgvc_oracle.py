@@ -637,18 +637,23 @@ def forward_test(encode, rgbs: torch.Tensor, query_points: torch.Tensor, traject
 
 
 def hr_forward_test_main(feats: torch.Tensor, query_xy: torch.Tensor, h: int, w: int, *, radius: int, precede_frames=5,
-                         topk=10, temperature=1.0, with_first=True, normalize=True, return_all=False):
+                         topk=10, temperature=1.0, with_first=True, normalize=True, return_all=False, save_mem=False):
     """HRVanillaTracker.forward_test_main ("backward warping") after feature extraction (vanilla_tracker.py:492-585):
     per frame a local (2R+1)^2 window over every key slot (mmcv Correlation, :547), top-k over K*(2R+1)^2 of the RAW
     correlation (:558), temperature then softmax (:563-564), labels gathered from the unfolded label maps (:550-561).
-    `normalize` is the reference's `withnorm` key (:437).  feats (T,C,Hf,Wf), query_xy (P,2)=(x,y) at frame 0.
+    `normalize` is the reference's `withnorm` key (:437), `save_mem` its `save_mem` key (:432).  feats (T,C,Hf,Wf), query_xy (P,2)=(x,y) at frame 0.
     Returns trajectories_pred (1,T,P,2) float64 [+ internals]."""
     T, C, Hf, Wf = feats.shape
     stride = h // Hf
     full0, lab0 = gaussian_labels(query_xy, h, w, stride)
     labels, preds, idxs, logits = [lab0], [full0], [], []
     for f in range(1, T):
-        ks = key_slots(f, precede_frames, with_first)                                   # :521-536
+        if save_mem:      # :537-545: ONE key frame (frame key_start, features re-extracted; no first-frame slot, whatever with_first says)
+            ks = [max(0, f - precede_frames)]                                           # against the label maps of key_start..f-1 (:520-521):
+            if f - ks[0] != 1:                                                          # more than one map cannot be reshaped to one key frame (:552)
+                raise RuntimeError("save_mem=True pairs one key frame with frame - key_start label maps: runs only for precede_frames = 1")
+        else:
+            ks = key_slots(f, precede_frames, with_first)                               # :521-536
         out, idx, logit = local_corr_topk(feats[f], feats[ks], torch.stack([labels[k] for k in ks], 0), radius, topk,
                                           temperature, normalize)
         labels.append(out)

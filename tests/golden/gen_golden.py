@@ -236,9 +236,12 @@ def gen_hr_tracker():
     rgbs = torch.randn(1, T, 3, h, w, generator=g)
     sd = O.seeded_resnet_state(seed=11, strides=(1, 2, 1, 1), pool_type="none")
     out = {}
-    for tag, extra in (("norm", {}), ("raw", dict(withnorm=False, temperature=4.0)), ("nofirst", dict(with_first=False))):
-        cfg = ref.ConfigDict(dict(precede_frames=2, topk=6, temperature=0.07, neighbor_range=8, with_first=True,
-                                  batch_step=2), **extra)
+    # "savemem": save_mem=True pairs ONE key frame (frame key_start, features re-extracted, no first-frame slot) with the label maps
+    # of key_start..frame-1 (vanilla_tracker.py:521-545): it runs only when that is one map, i.e. precede_frames = 1
+    for tag, extra in (("norm", {}), ("raw", dict(withnorm=False, temperature=4.0)), ("nofirst", dict(with_first=False)),
+                       ("savemem", dict(save_mem=True, precede_frames=1))):
+        cfg = ref.ConfigDict({**dict(precede_frames=2, topk=6, temperature=0.07, neighbor_range=8, with_first=True,
+                                     batch_step=2), **extra})
         model = ref.builder.build_model(
             dict(type="HRVanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
                                                         pool_type="none")), train_cfg=None, test_cfg=cfg)

@@ -239,7 +239,8 @@ def test_hr_tracker(golden):
     with torch.no_grad():
         feats = net(rgbs[0])
         q0 = T(g["query_points0"])[0, :, 1:]
-        for tag, extra in (("norm", {}), ("raw", dict(normalize=False, temperature=4.0)), ("nofirst", dict(with_first=False))):
+        for tag, extra in (("norm", {}), ("raw", dict(normalize=False, temperature=4.0)), ("nofirst", dict(with_first=False)),
+                           ("savemem", dict(save_mem=True, precede_frames=1))):
             main, al = O.hr_forward_test_main(feats, q0, h, w, return_all=True, **{**base, **extra})
             d = (main - T(g[f"main_{tag}"]).double()).abs()[0]
             d[torch.from_numpy(al["ties"])] = 0          # read-outs whose 5th/6th values tie: argsort order unspecified
