@@ -103,10 +103,11 @@ def _check_common(query, key, value, mode, sim_mode, normalize=True):
         raise NotImplementedError("fgvc_amd: batch size must be 1 (as in the reference's tracker)")
     if sim_mode not in ("dot_product", "l2-distance"):
         raise NotImplementedError(f"fgvc_amd: sim_mode={sim_mode!r} (the reference knows 'dot_product' and 'l2-distance')")
-    if sim_mode == "l2-distance" and (not normalize or mode != "softmax"):
-        # (2 k.q - |k|^2) / sqrt(C): with |k| = 1 the -|k|^2 term shifts every logit alike -- same ranking as the dot product, and
-        # the softmax does not see the shift.  Un-normalised keys or the (shift-sensitive) cosine weights need another kernel.
-        raise NotImplementedError("fgvc_amd: sim_mode='l2-distance' is on the accelerated path for normalize=True, mode='softmax'")
+    if sim_mode == "l2-distance" and not normalize:
+        # (2 k.q - |k|^2) / sqrt(C): with |k| = 1 the -|k|^2 term shifts every logit alike -- same ranking as the dot product; the
+        # softmax does not see the shift, the cosine weights get it added back (_attention's logit_shift).  Un-normalised keys rank
+        # differently: another kernel.
+        raise NotImplementedError("fgvc_amd: sim_mode='l2-distance' is on the accelerated path for normalize=True")
 
 
 def _temperature(sim_mode, temperature, channels):
@@ -115,7 +116,12 @@ def _temperature(sim_mode, temperature, channels):
     return (channels ** 0.5) / 2.0 if sim_mode == "l2-distance" else temperature
 
 
-def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk, normalize, non_mask_len, mode):
+def _logit_shift(sim_mode, channels):
+    """What 'l2-distance' subtracts from every logit beside the scaled dot product: |k|^2 / sqrt(C) = 1 / sqrt(C) for unit keys."""
+    return 1.0 / (channels ** 0.5) if sim_mode == "l2-distance" else 0.0
+
+
+def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk, normalize, non_mask_len, mode, logit_shift=0.0):
     if key.ndim == 4:
         key, value = key.unsqueeze(2), value.unsqueeze(2)
     assert value.ndim == key.ndim == 5
@@ -133,6 +139,8 @@ def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk,
         assert same or dense_mask is not None
     labels = value[0].permute(1, 2, 3, 0).reshape(T, Hk * Wk, P).float().contiguous()
     if topk is None:        # weights over every unmasked key (local_attention.py:376-383)
+        if logit_shift != 0.0 and mode != "softmax":
+            raise NotImplementedError("fgvc_amd: sim_mode='l2-distance' with mode='cosine' needs topk (the dense form applies no shift)")
         out = ops.dense_attend(qf[0], kf, labels, Hq, Wq, Hk, Wk, spec, temperature, mode, non_mask_len if any_mask else T,
                                dense_mask)
         return out.t().reshape(1, P, Hq, Wq).to(query.dtype)
@@ -140,7 +148,11 @@ def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk,
     pidx, pscore = ops.pair_topk_auto(qf, kf, pairs, Hq, Wq, Hk, Wk, spec, topk, normalized=bool(normalize),
                                       validate=False, dense_mask=dense_mask, all_masked=any_mask and non_mask_len == 0)
     slot_pair = torch.arange(T, dtype=torch.int32, device=query.device).view(1, T)
-    idx, _, weight = ops.merge_topk(pidx, pscore, slot_pair, Hk * Wk, topk, temperature, mode, validate=False)
+    idx, logit, weight = ops.merge_topk(pidx, pscore, slot_pair, Hk * Wk, topk, temperature, mode, validate=False)
+    if logit_shift != 0.0 and mode == "cosine":
+        # 'l2-distance': the logit is the scaled dot product MINUS |k|^2 / sqrt(C); clamp(logit, 0)^2 sees that shift (:370-371).
+        # Empty list entries carry -inf: weight 0 either way.
+        weight = (logit - logit_shift).clamp_(min=0).square_()
     out = ops.propagate_topk(labels, torch.arange(T, dtype=torch.int32, device=query.device), idx[0], weight[0],
                              Hq, Wq, Hk, Wk)
     return out.t().reshape(1, P, Hq, Wq).to(query.dtype)
@@ -160,7 +172,7 @@ def masked_attention_efficient(query, key, value, mask, temperature=1, topk=None
         assert tuple(mask.shape[-2:]) == (hk * wk, query.shape[2] * query.shape[3])
         dense = mask.reshape(hk * wk, -1).bool()
     return _attention(query, key, value, spec, dense, _temperature(sim_mode, temperature, query.shape[1]), topk, normalize,
-                      non_mask_len, mode)
+                      non_mask_len, mode, _logit_shift(sim_mode, query.shape[1]))
 
 
 def masked_attention_efficient_v2(query, key, value, radius, temperature=1, topk=None, normalize=True, step=32,

@@ -278,7 +278,9 @@ def gen_extra_modes():
     mask = ref.spatial_neighbor(1, H, W, neighbor_range=nr, device="cpu", dtype=torch.float32)
     with TopkSpy() as spy:
         out = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=k, step=64, sim_mode="l2-distance")
-    save("mae_l2_12x16", query=q, key=key, value=v, nr=nr, topk=k, temperature=0.07, out=out,
+    # ... with the cosine weights clamp(logit, 0)^2 (:370-371): the logit is (2 k.q - |k|^2) / sqrt(C), so the -|k|^2 shift matters here
+    out_cos = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=k, step=64, sim_mode="l2-distance", mode="cosine")
+    save("mae_l2_12x16", query=q, key=key, value=v, nr=nr, topk=k, temperature=0.07, out=out, out_cos=out_cos,
          ref_topk_val=torch.cat([c[0][0] for c in spy.calls], 1).t().contiguous(),
          ref_topk_idx=torch.cat([c[1][0] for c in spy.calls], 1).t().contiguous().to(torch.int32))
     g = torch.Generator().manual_seed(901)

@@ -112,6 +112,13 @@ def test_l2_distance_branch(dev, common, golden):
     mask = common.spatial_neighbor(1, 12, 16, neighbor_range=int(g["nr"]), device=dev, dtype=torch.float32)
     out = common.masked_attention_efficient(q, k, v, mask, temperature=0.07, topk=int(g["topk"]), step=64, sim_mode="l2-distance")
     assert float((out.cpu() - T(g["out"])).abs().max()) < TOL
+    # cosine weights on that branch: clamp((2 k.q - 1) / sqrt(C), 0)^2 -- the shift the softmax cannot see (values ~1e-4 here)
+    out_c = common.masked_attention_efficient(q, k, v, mask, temperature=0.07, topk=int(g["topk"]), step=64, sim_mode="l2-distance",
+                                              mode="cosine")
+    want = T(g["out_cos"])
+    assert float(want.abs().max()) > 1e-5 and float((out_c.cpu() - want).abs().max()) < 1e-3 * float(want.abs().max())
+    with pytest.raises(NotImplementedError):
+        common.masked_attention_efficient(q, k, v, mask, topk=None, sim_mode="l2-distance", mode="cosine")
     with pytest.raises(NotImplementedError):
         common.masked_attention_efficient(q, k, v, mask, topk=4, sim_mode="l2-distance", normalize=False)
     with pytest.raises(NotImplementedError):

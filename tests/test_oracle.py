@@ -261,6 +261,9 @@ def test_l2_distance_and_dense_softmax_branches(golden):
     out = O.masked_attention_efficient(T(g["query"]), T(g["key"]), T(g["value"]), temperature=0.07, topk=int(g["topk"]),
                                        neighbor_range=int(g["nr"]), sim_mode="l2-distance")
     assert torch.allclose(out, T(g["out"]), atol=1e-5)
+    out_c = O.masked_attention_efficient(T(g["query"]), T(g["key"]), T(g["value"]), temperature=0.07, topk=int(g["topk"]),
+                                         neighbor_range=int(g["nr"]), sim_mode="l2-distance", mode="cosine")
+    assert float((out_c - T(g["out_cos"])).abs().max()) < 1e-4 * float(T(g["out_cos"]).abs().max())      # (values ~1e-4: relative bound)
     g = golden("mae_dense_softmax_10x12")
     q, k, v, nr = T(g["query"]), T(g["key"]), T(g["value"]), int(g["nr"])
     for name, kw in (("out", dict(neighbor_range=nr)), ("out_nml1", dict(neighbor_range=nr, non_mask_len=1)), ("out_nomask", {}),
