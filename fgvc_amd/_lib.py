@@ -67,6 +67,7 @@ SIGNATURES = {
     "fgvc_local_corr_topk_f16x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "fgvc_topk_coord_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_c2f_refine_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "fgvc_c2f_refine_mode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
     "fgvc_bn_act_f32": (_i, [_p, _p, _p, _p, _p, _p, _f, _i, _p, _i, _i, _i, _p]),
     "fgvc_gaussian_labels_f32": (_i, [_p, _i, _i, _i, _i, _f, _p, _p]),
     "fgvc_softargmax_workspace_bytes": (C.c_size_t, [_i, _i]),

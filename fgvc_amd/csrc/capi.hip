@@ -36,7 +36,7 @@ int local_merge_launch(const int32_t*, const float*, int, int, int, int, int, fl
                        hipStream_t);
 int topk_coord_launch(const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
 int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, int, int, int, int, int, int, int,
-                      int, float, float*, int32_t*, float*, hipStream_t);
+                      int, float, int, float*, int32_t*, float*, hipStream_t);
 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
                       int, int, int, int, int, int, int, int, int*, hipStream_t);
@@ -439,6 +439,13 @@ int fgvc_topk_coord_f32(const int32_t* idx, const float* weight, int H, int W, i
 int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const float* kfine, const float* vfine, int T,
                         int H, int W, int scale, int Cf, int P, int Rf, int topk, float temperature, float* out,
                         int32_t* idx_out, float* logit_out, void* stream) {
+  return fgvc_c2f_refine_mode_f32(coarse_arg, qfine, kfine, vfine, T, H, W, scale, Cf, P, Rf, topk, temperature, FGVC_WEIGHT_SOFTMAX,
+                                  out, idx_out, logit_out, stream);
+}
+
+int fgvc_c2f_refine_mode_f32(const int32_t* coarse_arg, const float* qfine, const float* kfine, const float* vfine, int T,
+                             int H, int W, int scale, int Cf, int P, int Rf, int topk, float temperature, int weight_mode,
+                             float* out, int32_t* idx_out, float* logit_out, void* stream) {
   FGVC_REQUIRE(coarse_arg && qfine && kfine && vfine && out && idx_out && logit_out, FGVC_ERR_INVALID_ARG,
                "fgvc_c2f_refine_f32: null pointer");
   FGVC_REQUIRE(T >= 1 && H > 0 && W > 0 && scale >= 1 && P > 0 && Rf >= 0, FGVC_ERR_INVALID_ARG, "fgvc_c2f_refine_f32: bad shape");
@@ -446,7 +453,9 @@ int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const flo
   FGVC_REQUIRE(aligned16(qfine) && aligned16(kfine), FGVC_ERR_INVALID_ARG, "fgvc_c2f_refine_f32: 16-byte alignment required");
   FGVC_REQUIRE(topk >= 1 && topk <= 16, FGVC_ERR_UNSUPPORTED, "fgvc_c2f_refine_f32: topk=%d outside 1..16", topk);
   FGVC_REQUIRE(temperature > 0.f, FGVC_ERR_INVALID_ARG, "fgvc_c2f_refine_f32: temperature must be > 0");
-  return c2f_refine_launch(coarse_arg, qfine, kfine, vfine, T, H, W, scale, Cf, P, Rf, topk, temperature, out,
+  FGVC_REQUIRE(weight_mode == FGVC_WEIGHT_SOFTMAX || weight_mode == FGVC_WEIGHT_COSINE, FGVC_ERR_INVALID_ARG,
+               "fgvc_c2f_refine_mode_f32: weight_mode %d (FGVC_WEIGHT_SOFTMAX or FGVC_WEIGHT_COSINE)", weight_mode);
+  return c2f_refine_launch(coarse_arg, qfine, kfine, vfine, T, H, W, scale, Cf, P, Rf, topk, temperature, weight_mode, out,
                            idx_out, logit_out, (hipStream_t)stream);
 }
 

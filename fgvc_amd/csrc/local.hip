@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void c2f_refine_kernel(const int32_t* __restri
                                                           const float* __restrict__ kfine,
                                                           const float* __restrict__ vfine, int T, int H, int W,
                                                           int scale, int Cf, int P, int Rf, int kout,
-                                                          float temperature, float* __restrict__ out,
+                                                          float temperature, int weight_mode, float* __restrict__ out,
                                                           int32_t* __restrict__ idx_out,
                                                           float* __restrict__ logit_out) {
   const int lane = threadIdx.x & 63;
@@ -218,10 +218,19 @@ __global__ __launch_bounds__(256) void c2f_refine_kernel(const int32_t* __restri
   }
   float w[K];
   float sum = 0.f;
+  if (weight_mode == FGVC_WEIGHT_SOFTMAX) {
 #pragma unroll
-  for (int r = 0; r < K; ++r) {
-    w[r] = (r < kout) ? expf(win_s[r] - win_s[0]) : 0.f;
-    sum += w[r];
+    for (int r = 0; r < K; ++r) {
+      w[r] = (r < kout) ? expf(win_s[r] - win_s[0]) : 0.f;
+      sum += w[r];
+    }
+  } else {                                  // 'cosine' (local_attention.py:860-861): clamp(affinity, 0)^2, not normalised
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const float c = (r < kout) ? fmaxf(win_s[r], 0.f) : 0.f;
+      w[r] = c * c;
+    }
+    sum = 1.f;
   }
   if (lane == 0) {
 #pragma unroll
@@ -248,12 +257,12 @@ __global__ __launch_bounds__(256) void c2f_refine_kernel(const int32_t* __restri
 }
 
 int c2f_refine_launch(const int32_t* coarse_arg, const float* qfine, const float* kfine, const float* vfine, int T,
-                      int H, int W, int scale, int Cf, int P, int Rf, int topk, float temperature, float* out,
+                      int H, int W, int scale, int Cf, int P, int Rf, int topk, float temperature, int weight_mode, float* out,
                       int32_t* idx_out, float* logit_out, hipStream_t s) {
   const int grid = cdiv(H * W, 4);
 #define FGVC_C2F(KK)                                                                                            \
   c2f_refine_kernel<KK><<<grid, 256, 0, s>>>(coarse_arg, qfine, kfine, vfine, T, H, W, scale, Cf, P, Rf, topk, \
-                                             temperature, out, idx_out, logit_out)
+                                             temperature, weight_mode, out, idx_out, logit_out)
   if (topk <= 1) FGVC_C2F(1);
   else if (topk <= 5) FGVC_C2F(5);
   else if (topk <= 10) FGVC_C2F(10);

@@ -308,12 +308,10 @@ def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask
                                    sim_mode="dot_product", radius_fine=12):
     """local_attention.py:721-880.  Coarse stage = fgvc_pair_topk_f16x3 / fgvc_pair_topk_f32 with topk=1 per key slot (arg-max of
     the per-frame softmax, :835-837); fine stage = fgvc_c2f_refine_f32."""
-    _check_common(query, key, value, mode, sim_mode, normalize)
+    _check_common(query, key, value, mode, "dot_product", normalize)    # `sim_mode` is accepted and never read there (:733, :805, :847)
     if topk is None:
         # the reference's own branch is `pass` followed by `output[...] = cur_output` with cur_output unbound (:866-870): it raises
         raise NotImplementedError("masked_attention_efficient_c2f: topk=None cannot run in the reference either (local_attention.py:866-870)")
-    if mode != "softmax" or sim_mode != "dot_product":
-        raise NotImplementedError("fgvc_amd c2f: mode='softmax' and sim_mode='dot_product' only")
     if key.ndim == 4:
         key, value = key.unsqueeze(2), value.unsqueeze(2)
         key_fine = key_fine.unsqueeze(2) if key_fine.ndim == 4 else key_fine
@@ -335,7 +333,7 @@ def masked_attention_efficient_c2f(query, key, query_fine, key_fine, value, mask
     qfine = ops.normalize_to_hwc(query_fine.float(), normalize)[0]
     kfine = ops.normalize_to_hwc(key_fine[0].transpose(0, 1).float().contiguous(), normalize)
     vfine = value[0].permute(1, 2, 3, 0).reshape(T, -1, P).float().contiguous()
-    out, _, _ = ops.c2f_refine(coarse, qfine, kfine, vfine, H, W, scale, radius_fine, topk, temperature)
+    out, _, _ = ops.c2f_refine(coarse, qfine, kfine, vfine, H, W, scale, radius_fine, topk, temperature, mode)
     return out.t().reshape(1, P, H, W).to(query.dtype)
 
 

@@ -468,8 +468,9 @@ def topk_coord(idx: torch.Tensor, weight: torch.Tensor, H: int, W: int, R: int, 
 
 
 def c2f_refine(coarse_arg: torch.Tensor, qfine: torch.Tensor, kfine: torch.Tensor, vfine: torch.Tensor, H: int,
-               W: int, scale: int, Rf: int, topk: int, temperature: float):
-    """A6 fine stage. coarse_arg int32 (T, HW); qfine (sHsW, Cf); kfine (T, sHsW, Cf); vfine (T, sHsW, P)."""
+               W: int, scale: int, Rf: int, topk: int, temperature: float, mode: str = "softmax"):
+    """A6 fine stage. coarse_arg int32 (T, HW); qfine (sHsW, Cf); kfine (T, sHsW, Cf); vfine (T, sHsW, P); mode "softmax" or
+    "cosine" (clamp(affinity, 0)^2, local_attention.py:858-861)."""
     coarse_arg = _chk(coarse_arg, torch.int32, "coarse_arg")
     qfine, kfine = _chk(qfine, torch.float32, "qfine"), _chk(kfine, torch.float32, "kfine")
     vfine = _chk(vfine, torch.float32, "vfine")
@@ -480,8 +481,9 @@ def c2f_refine(coarse_arg: torch.Tensor, qfine: torch.Tensor, kfine: torch.Tenso
     out = torch.empty((H * W, P), device=dev, dtype=torch.float32)
     idx = torch.empty((H * W, topk), device=dev, dtype=torch.int32)
     logit = torch.empty((H * W, topk), device=dev, dtype=torch.float32)
-    _lib.call("fgvc_c2f_refine_f32", _ptr(coarse_arg), _ptr(qfine), _ptr(kfine), _ptr(vfine), T, H, W, scale, Cf, P,
-              Rf, topk, float(temperature), _ptr(out), _ptr(idx), _ptr(logit), _stream(qfine))
+    _lib.call("fgvc_c2f_refine_mode_f32", _ptr(coarse_arg), _ptr(qfine), _ptr(kfine), _ptr(vfine), T, H, W, scale, Cf, P,
+              Rf, topk, float(temperature), {"softmax": WEIGHT_SOFTMAX, "cosine": WEIGHT_COSINE}[mode], _ptr(out), _ptr(idx), _ptr(logit),
+              _stream(qfine))
     return out, idx, logit
 
 

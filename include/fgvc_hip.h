@@ -243,6 +243,11 @@ int fgvc_c2f_refine_f32(const int32_t* coarse_arg, const float* qfine, const flo
                         const float* vfine, int T, int H, int W, int scale, int Cf, int P, int Rf,
                         int topk, float temperature, float* out, int32_t* idx_out, float* logit_out,
                         void* stream);
+/* ... with the weights of the reference's `mode`: FGVC_WEIGHT_SOFTMAX, or FGVC_WEIGHT_COSINE = clamp(affinity, 0)^2, not normalised
+ * (local_attention.py:858-861) */
+int fgvc_c2f_refine_mode_f32(const int32_t* coarse_arg, const float* qfine, const float* kfine, const float* vfine, int T,
+                             int H, int W, int scale, int Cf, int P, int Rf, int topk, float temperature, int weight_mode,
+                             float* out, int32_t* idx_out, float* logit_out, void* stream);
 
 /* ---- A1 glue: inference BatchNorm2d (+ residual) (+ ReLU) fused over an NCHW activation
  * replaces the BN / `out += identity` / ReLU modules around every convolution of the ResNet

@@ -397,7 +397,7 @@ def get_coord(query, key, radius: int, topk: int, temperature: float, scale: int
 # ----------------------------------------------------------------------------
 def c2f_attention(query, key, query_fine, key_fine, value, topk: int, temperature: float = 1.0,
                   neighbor_range=None, mask_mode="circle", normalize: bool = True,
-                  radius_fine: int = 12, non_mask_len: int = 0, step: int = 512):
+                  radius_fine: int = 12, non_mask_len: int = 0, step: int = 512, mode: str = "softmax"):
     """masked_attention_efficient_c2f (local_attention.py:721-880), N=1.
 
     query (C,H,W), key (C,T,H,W), query_fine (Cf,sH,sW), key_fine (Cf,T,sH,sW),
@@ -437,7 +437,7 @@ def c2f_attention(query, key, query_fine, key_fine, value, topk: int, temperatur
         v_sel = v_sel.permute(1, 0, 2, 3).reshape(P, T * L * L, s)               # :855
         val, idx = topk_canonical(fine, topk)                                    # :859
         g = v_sel.gather(1, idx.unsqueeze(0).expand(P, -1, -1))                  # :862
-        w = val.softmax(0)                                                       # :865
+        w = val.softmax(0) if mode == "softmax" else val.clamp(min=0) ** 2       # :858-861
         outs.append((g * w.unsqueeze(0)).sum(1))                                 # :870
         arg_all.append(am); idx_all.append(idx.t()); logit_all.append(val.t())
     out = torch.cat(outs, 1).reshape(P, H, W)

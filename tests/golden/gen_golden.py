@@ -133,8 +133,10 @@ def main():
     with TopkSpy() as spy:
         out = ref.masked_attention_efficient_c2f(q, key, qf, kf, v, mask, temperature=0.07, topk=5, step=32,
                                                  radius_fine=Rf)
+    out_cos = ref.masked_attention_efficient_c2f(q, key, qf, kf, v, mask, temperature=0.07, topk=5, step=32, radius_fine=Rf,
+                                                 mode="cosine")                      # clamp(affinity, 0)^2 weights (:860-861)
     save("c2f_8x10", query=q, key=key, query_fine=qf, key_fine=kf, value=v, nr=8, topk=5, radius_fine=Rf,
-         temperature=0.07, out=out,
+         temperature=0.07, out=out, out_cos=out_cos,
          ref_topk_val=torch.cat([c[0][0] for c in spy.calls], 1).t().contiguous(),
          ref_topk_idx=torch.cat([c[1][0] for c in spy.calls], 1).t().contiguous().to(torch.int32))
 

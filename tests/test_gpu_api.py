@@ -104,6 +104,14 @@ def test_c2f_golden_through_the_api(dev, common, golden):
     out = common.masked_attention_efficient_c2f(q, k, qf, kf, v, mask, temperature=0.07, topk=int(g["topk"]), step=32,
                                                 radius_fine=int(g["radius_fine"]))
     assert float((out.cpu() - T(g["out"])).abs().max()) < TOL
+    out_c = common.masked_attention_efficient_c2f(q, k, qf, kf, v, mask, temperature=0.07, topk=int(g["topk"]), step=32,
+                                                  radius_fine=int(g["radius_fine"]), mode="cosine")      # clamp(affinity, 0)^2 weights
+    want = T(g["out_cos"])
+    assert float((out_c.cpu() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    # `sim_mode` is accepted and never read, as in the reference (dot products on both scales, :805, :847)
+    out_l = common.masked_attention_efficient_c2f(q, k, qf, kf, v, mask, temperature=0.07, topk=int(g["topk"]), step=32,
+                                                  radius_fine=int(g["radius_fine"]), sim_mode="l2-distance")
+    assert torch.equal(out_l, out)
 
 
 def test_l2_distance_branch(dev, common, golden):

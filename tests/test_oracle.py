@@ -100,6 +100,9 @@ def test_c2f(golden):
     rv, ri = canon_ref_topk(g["ref_topk_val"], g["ref_topk_idx"])
     assert torch.allclose(logit, rv, atol=1e-5) and bool((idx == ri).all())
     assert torch.allclose(out, T(g["out"])[0], atol=2e-5)
+    out_c = O.c2f_attention(T(g["query"])[0], T(g["key"])[0], T(g["query_fine"])[0], T(g["key_fine"])[0], T(g["value"])[0],
+                            int(g["topk"]), 0.07, neighbor_range=int(g["nr"]), radius_fine=int(g["radius_fine"]), mode="cosine")[0]
+    assert torch.allclose(out_c, T(g["out_cos"])[0], atol=2e-4, rtol=1e-5)          # logits / 0.07 squared: values up to ~100
 
 
 def test_local_corr(golden):
