@@ -103,11 +103,6 @@ def _check_common(query, key, value, mode, sim_mode, normalize=True):
         raise NotImplementedError("fgvc_amd: batch size must be 1 (as in the reference's tracker)")
     if sim_mode not in ("dot_product", "l2-distance"):
         raise NotImplementedError(f"fgvc_amd: sim_mode={sim_mode!r} (the reference knows 'dot_product' and 'l2-distance')")
-    if sim_mode == "l2-distance" and not normalize:
-        # (2 k.q - |k|^2) / sqrt(C): with |k| = 1 the -|k|^2 term shifts every logit alike -- same ranking as the dot product; the
-        # softmax does not see the shift, the cosine weights get it added back (_attention's logit_shift).  Un-normalised keys rank
-        # differently: another kernel.
-        raise NotImplementedError("fgvc_amd: sim_mode='l2-distance' is on the accelerated path for normalize=True")
 
 
 def _temperature(sim_mode, temperature, channels):
@@ -116,9 +111,19 @@ def _temperature(sim_mode, temperature, channels):
     return (channels ** 0.5) / 2.0 if sim_mode == "l2-distance" else temperature
 
 
-def _logit_shift(sim_mode, channels):
-    """What 'l2-distance' subtracts from every logit beside the scaled dot product: |k|^2 / sqrt(C) = 1 / sqrt(C) for unit keys."""
-    return 1.0 / (channels ** 0.5) if sim_mode == "l2-distance" else 0.0
+def _logit_shift(sim_mode, channels, normalize=True):
+    """What 'l2-distance' subtracts from every logit beside the scaled dot product: |k|^2 / sqrt(C) = 1 / sqrt(C) for unit keys
+    (un-normalised keys carry their own |k|^2 inside the product: _l2_augment)."""
+    return 1.0 / (channels ** 0.5) if (sim_mode == "l2-distance" and normalize) else 0.0
+
+
+def _l2_augment(query, key):
+    """'l2-distance' on UN-normalised features, (2 k.q - |k|^2) / sqrt(C) (local_attention.py:324-327), as a plain dot product at
+    temperature sqrt(C) / 2: one more channel, 1 on the query side and -|k|^2 / 2 on the key side.  (With normalised features the
+    extra term is the same for every key and this is not needed.)"""
+    q1 = torch.cat([query, torch.ones_like(query[:, :1])], 1)
+    k1 = torch.cat([key, -0.5 * key.float().pow(2).sum(1, keepdim=True).to(key.dtype)], 1)
+    return q1, k1
 
 
 def _attention(query, key, value, spec: MaskSpec, dense_mask, temperature, topk, normalize, non_mask_len, mode, logit_shift=0.0):
@@ -171,8 +176,13 @@ def masked_attention_efficient(query, key, value, mask, temperature=1, topk=None
         hk, wk = key.shape[-2:]
         assert tuple(mask.shape[-2:]) == (hk * wk, query.shape[2] * query.shape[3])
         dense = mask.reshape(hk * wk, -1).bool()
-    return _attention(query, key, value, spec, dense, _temperature(sim_mode, temperature, query.shape[1]), topk, normalize,
-                      non_mask_len, mode, _logit_shift(sim_mode, query.shape[1]))
+    C = query.shape[1]
+    if sim_mode == "l2-distance" and not normalize:
+        if key.ndim == 4:
+            key, value = key.unsqueeze(2), value.unsqueeze(2)
+        query, key = _l2_augment(query, key)
+    return _attention(query, key, value, spec, dense, _temperature(sim_mode, temperature, C), topk, normalize,
+                      non_mask_len, mode, _logit_shift(sim_mode, C, normalize))
 
 
 def masked_attention_efficient_v2(query, key, value, radius, temperature=1, topk=None, normalize=True, step=32,

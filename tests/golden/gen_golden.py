@@ -282,7 +282,12 @@ def gen_extra_modes():
         out = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=k, step=64, sim_mode="l2-distance")
     # ... with the cosine weights clamp(logit, 0)^2 (:370-371): the logit is (2 k.q - |k|^2) / sqrt(C), so the -|k|^2 shift matters here
     out_cos = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=k, step=64, sim_mode="l2-distance", mode="cosine")
-    save("mae_l2_12x16", query=q, key=key, value=v, nr=nr, topk=k, temperature=0.07, out=out, out_cos=out_cos,
+    # ... and on UN-normalised features, where |k|^2 differs from key to key and changes the ranking (top-k and topk=None forms)
+    out_raw = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=k, step=64, sim_mode="l2-distance", normalize=False)
+    out_raw_dense = ref.masked_attention_efficient(q, key, v, mask, temperature=0.07, topk=None, step=64, sim_mode="l2-distance",
+                                                   normalize=False)
+    save("mae_l2_12x16", query=q, key=key, value=v, nr=nr, topk=k, temperature=0.07, out=out, out_cos=out_cos, out_raw=out_raw,
+         out_raw_dense=out_raw_dense,
          ref_topk_val=torch.cat([c[0][0] for c in spy.calls], 1).t().contiguous(),
          ref_topk_idx=torch.cat([c[1][0] for c in spy.calls], 1).t().contiguous().to(torch.int32))
     g = torch.Generator().manual_seed(901)

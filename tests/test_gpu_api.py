@@ -127,8 +127,14 @@ def test_l2_distance_branch(dev, common, golden):
     assert float(want.abs().max()) > 1e-5 and float((out_c.cpu() - want).abs().max()) < 1e-3 * float(want.abs().max())
     with pytest.raises(NotImplementedError):
         common.masked_attention_efficient(q, k, v, mask, topk=None, sim_mode="l2-distance", mode="cosine")
-    with pytest.raises(NotImplementedError):
-        common.masked_attention_efficient(q, k, v, mask, topk=4, sim_mode="l2-distance", normalize=False)
+    # un-normalised features: |k|^2 differs from key to key and changes the ranking -- one augmented channel carries it into the
+    # dot-product kernels (top-k form and topk=None)
+    out_r = common.masked_attention_efficient(q, k, v, mask, temperature=0.07, topk=int(g["topk"]), step=64, sim_mode="l2-distance",
+                                              normalize=False)
+    assert float((out_r.cpu() - T(g["out_raw"])).abs().max()) < TOL
+    out_rd = common.masked_attention_efficient(q, k, v, mask, temperature=0.07, topk=None, step=64, sim_mode="l2-distance",
+                                               normalize=False)
+    assert float((out_rd.cpu() - T(g["out_raw_dense"])).abs().max()) < TOL
     with pytest.raises(NotImplementedError):
         common.masked_attention_efficient(q, k, v, mask, topk=4, sim_mode="cosine-distance")
 

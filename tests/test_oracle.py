@@ -267,6 +267,10 @@ def test_l2_distance_and_dense_softmax_branches(golden):
     out_c = O.masked_attention_efficient(T(g["query"]), T(g["key"]), T(g["value"]), temperature=0.07, topk=int(g["topk"]),
                                          neighbor_range=int(g["nr"]), sim_mode="l2-distance", mode="cosine")
     assert float((out_c - T(g["out_cos"])).abs().max()) < 1e-4 * float(T(g["out_cos"]).abs().max())      # (values ~1e-4: relative bound)
+    for name, kw in (("out_raw", dict(topk=int(g["topk"]))), ("out_raw_dense", dict(topk=None))):
+        o = O.masked_attention_efficient(T(g["query"]), T(g["key"]), T(g["value"]), temperature=0.07, neighbor_range=int(g["nr"]),
+                                         sim_mode="l2-distance", normalize=False, **kw)
+        assert torch.allclose(o, T(g[name]), atol=1e-5), name
     g = golden("mae_dense_softmax_10x12")
     q, k, v, nr = T(g["query"]), T(g["key"]), T(g["value"]), int(g["nr"])
     for name, kw in (("out", dict(neighbor_range=nr)), ("out_nml1", dict(neighbor_range=nr, non_mask_len=1)), ("out_nomask", {}),
