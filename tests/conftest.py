@@ -49,6 +49,12 @@ def pytest_sessionstart(session):
         TWO_RANKS["cfg4"] = dict(rc=r.returncode, out=r.stdout[-6000:], err=r.stderr[-3000:])
     except Exception as e:
         TWO_RANKS["cfg4"] = dict(rc=-1, out="", err=repr(e))
+    try:   # four ranks (the two middle ones both send and receive a halo in one message batch), 26 frames, the full five-frame halo
+        r = subprocess.run([sys.executable, tool, "--world", "4", "--frames", "26", "--precede", "5", "--halos", "exchange", "--tail-stream"],
+                           capture_output=True, text=True, timeout=900)
+        TWO_RANKS["w4"] = dict(rc=r.returncode, out=r.stdout[-8000:], err=r.stderr[-3000:])
+    except Exception as e:
+        TWO_RANKS["w4"] = dict(rc=-1, out="", err=repr(e))
 
 
 @pytest.fixture(scope="session")

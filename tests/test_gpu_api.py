@@ -430,6 +430,14 @@ def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
             assert v["bank_in_place"] == 1          # the second (cached-schedule) call encoded straight into the rank's local bank
         for mode, v in r.items():                   # ... and posted the halo messages after its last five frames, before the rest
             assert v["halo_early"] == (1 if mode.startswith("exchange") else 0), (mode, v)
+    # ... at world size 4 (the middle ranks send AND receive a halo in one batch; every rank posts it after its last five frames)
+    w4 = two_ranks["w4"]
+    assert w4["rc"] == 0, (w4["out"][-2000:], w4["err"][-2000:])
+    res4 = json.loads([l for l in w4["out"].splitlines() if l.startswith("{")][-1])
+    assert res4["ok"] and res4["world"] == 4 and set(res4["ranks"]) == {"0", "1", "2", "3"}
+    for r in res4["ranks"].values():
+        for v in r.values():
+            assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 and v["bank_in_place"] == 1 and v["halo_early"] == 1
     # ... and at BASELINE configs[3]'s shape: 64 frames of 256 x 256 (128 x 128 x 256 features), 32 points, precede_frames 5
     c4 = two_ranks["cfg4"]
     assert c4["rc"] == 0, (c4["out"][-2000:], c4["err"][-2000:])
