@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the label-propagation hot path on MI355X (contract: see the task prompt / DESIGN.md section 6).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without WORLD_SIZE in the environment: bench.py starts the N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W                  # ... or the launcher does (the driver's form)
 
 A "step" = one synthetic 480x854 video of N x 8 frames (BASELINE.json configs[1]: an 8-frame 480p clip per GPU) through the
 whole path, inputs resident in HBM, SHARDED BY CLIP over the N ranks exactly as BASELINE.json's north_star describes
 (fgvc_amd.dist.track_points_sharded with the product backend): every rank encodes its own 8-frame clip (hand-written HIP ResNet-18
 trunk on the 16-bit matrix pipe; `--enc-arith`: f16 main product + fp8 cross terms by default), rank 0 broadcasts the first-frame ("query") features over RCCL/xGMI, the 5-frame halo in front
 of a clip comes from the previous rank by a point-to-point message, windowed correlation + top-10 for the clip's (query, key) frame
-pairs (features as bf16 hi + lo, four partial products on the bf16 matrix pipe: f32-grade scores), slot merge + softmax,
+pairs (fgvc_pair_topk_*: features split into 16-bit + low-precision parts on the matrix pipe, f32 accumulate; `--pair-arith`), slot merge + softmax,
 all_gather of the merged lists, then the sequential label sweep + fused upsample / top-5 soft-argmax read-out over the whole video
 (replicated; on a side stream so that the next step's encoder starts under it).  Nothing is skipped or cached across steps.
 At N = 1 the same function runs without any collective (27 pairs, 7 propagations: the single-GPU figure of configs[1]).
@@ -22,7 +22,7 @@ launches per clip and lane), priced both as algorithmic f32 FLOPs and as execute
 hand-written kernels of the step, each with its own roofline object (launch durations from HIP events inside the timed region, on
 the launch stream); `corr_volume` = the dense materialised volume kernel that BASELINE.json's "ms/corr-volume" and the
 >= 50 % HBM-roofline target refer to, timed right after the steps; `mfma_util` / `traffic` come from the committed rocprofv3 PMC
-passes of the same kernels at the same shapes (profiles/r02_pmc.json: counters cannot be read from inside this process);
+passes of the same kernels at the same shapes (profiles/r04_pmc.json, else the newest earlier one: counters cannot be read from inside this process);
 `cpu_baseline` = the oracle (CPU restatement of the reference) timed on this box's host cores.
 """
 from __future__ import annotations
@@ -41,7 +41,9 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak (no sparsity)
-SPLIT_PRODUCTS = 3                # partial products per f32-grade product in fgvc_pair_topk_f16x3 (h*h, l*h, h*l)
+# pipe units (16-bit MFMA times) per f32-grade product of the pair kernels: fgvc_pair_topk_f16x3 = three f16 products (h*h, l*h, h*l),
+# fgvc_pair_topk_f16f6 = one f16 product + both cross sums in FP6 (a quarter unit each)
+PAIR_UNITS = {"f16": 3.0, "f16f6": 1.5}
 # pipe units (16-bit MFMA times) per f32-grade product of fgvc_conv_split_f32, by arithmetic: bf16x3 / f16x3 = three 16-bit products,
 # f16f8 = one f16 product + both cross sums in one K-64 fp8 MFMA (half a unit each)
 CONV_UNITS = {"bf16x3": 3.0, "f16x3": 3.0, "f16f8": 2.0}
@@ -85,7 +87,7 @@ def encoder_flops(wl, n_frames: int) -> float:
 def pmc(kernel: str):
     """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r03_pmc.json, written by tools/pmc_report.py from
     separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes); {} if absent."""
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -186,12 +188,15 @@ def cpu_baseline(wl, runs=3):
         return dict(threads=threads, runs=n, encoder_s_per_frame=med[0], attention_s_last_frame=med[1], readout_s_per_frame=med[2],
                     mask_build_s_per_video=med[3], clip_seconds=clip_s, frames_per_s=T / clip_s)
 
-    cores = min(os.cpu_count() or 1, 32)                                  # torch CPU ops stop scaling long before 256 threads here
+    aff, quota = granted_cpus()
+    grant = max(1, int(min(aff, quota) if quota else aff))                 # the share of the host this process was given
+    cores = min(grant, 32)                                                 # torch CPU ops stop scaling long before 256 threads here
     res = [measure(cores, runs)]
-    if phys and phys > cores and phys <= (os.cpu_count() or 1):
-        res.append(measure(phys, 2))                                       # all physical cores as well (slower or equal on these hosts)
+    if cores >= 32 and grant >= 64:
+        res.append(measure(16, 2))                                         # a second thread count, for the scaling of the port
     best = max(res, key=lambda r: r["frames_per_s"])
     return dict(value=best["frames_per_s"], unit="frames/s", cores=best["threads"], kind="port", measurement="measured frame",
+                granted_cpus=dict(sched_affinity=aff, cgroup_quota=quota, used_threads=best["threads"]),
                 runs=best["runs"],
                 sample=f"1 whole frame x{best['runs']} (median): encoder, all {len(chunks)} chunks x {len(ks)} key slots, read-out",
                 host_cpu=dict(model=model, physical_cores=phys, logical_cpus=logical),
@@ -199,6 +204,45 @@ def cpu_baseline(wl, runs=3):
                 note=(f"oracle/fgvc_oracle.py (plain torch.topk, pre-built mask like the reference); the clip's {T} frames = {T} encoder + "
                       f"read-out passes and {slots} key slots of attention, the measured last frame has {len(ks)}"),
                 clip_seconds_est=best["clip_seconds"])
+
+
+def self_launch(n: int) -> int:
+    """Start `n` ranks of this script under torch.distributed.run on 127.0.0.1 (a free port), relay their output, return the launcher's
+    exit code (non-zero if any rank failed).  Runs in a parent that has made no GPU call: the ranks are fresh child processes."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL / device-tensor sharing between the ranks
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def granted_cpus():
+    """CPUs this process may actually use: its affinity mask, capped by the cgroup's CPU quota where one is set (a GPU box grants a
+    share of its host's cores; torch's default thread count = all logical CPUs oversubscribes that share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())    # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return n, quota
 
 
 class KernelProbe:
@@ -240,7 +284,11 @@ def main():
     ap.add_argument("--no-corr-volume", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="MIOpen immediate mode (clean profiles)")
     ap.add_argument("--pair-precision", default="auto", choices=["auto", "f32", "split"],
-                    help="pair top-k kernel: split = fgvc_pair_topk_f16x3 (default where it applies), f32 = fgvc_pair_topk_f32")
+                    help="pair top-k kernel: split = the 16-bit matrix pipe (default where it applies), f32 = fgvc_pair_topk_f32")
+    ap.add_argument("--pair-fmt", default="auto", choices=["auto", "f16", "f16f6"],
+                    help="arithmetic of the split pair kernel: f16 = fgvc_pair_topk_f16x3 (three f16 products, 1e-7-grade), f16f6 = "
+                         "fgvc_pair_topk_f16f6 (f16 + FP6 cross terms, ~6e-5 logit); auto = f16f6 with an f16f8 encoder, f16 otherwise")
+    ap.add_argument("--no-f16x3-line", action="store_true", help="skip the extra steps in the highest-precision arithmetic (`value_f16x3`)")
     ap.add_argument("--encoder-lanes", type=int, default=None,
                     help="batch slices of the encoder run on this many HIP streams at once (default: ResNet.split_lanes)")
     ap.add_argument("--sync-tail", action="store_true",
@@ -260,12 +308,17 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="extra blocks of 20 steps after the timed region, for the spread")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="fgvc_set_option knobs for A/B runs, e.g. --set-option conv_narrow=1")
+    ap.add_argument("--comm-timeout", type=float, default=180.0, help="seconds before a collective that does not complete aborts the job (rc != 0)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU over gloo (device tensors staged through the host by fgvc_amd.dist): exercises every "
                          "line of the multi-rank path on a one-GPU box; the number it prints is NOT a measurement (RCCL refuses two "
                          "ranks on one device, hence gloo)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process (which has not touched the GPU and never will) starts the N ranks with the
+        # reference's launcher shape (tools/dist_test.sh:10-13: torch.distributed.launch --nproc_per_node) and hands on their exit code
+        raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -278,11 +331,19 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend_name = None
     if world > 1:
+        import datetime
+        # every collective is bounded: a rank that hangs in one makes the job exit non-zero (the process group's watchdog aborts
+        # the communicator and raises) instead of sitting at the closing barrier for ever
+        tmo = datetime.timedelta(seconds=a.comm_timeout)
         if a.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # RCCL over xGMI
+        backend_name = dist.get_backend()
 
     from fgvc_amd import _lib, dist as fdist, engine, ops
     _lib.load()
@@ -308,7 +369,10 @@ def main():
     if a.enc_arith:
         model.backbone.set_arith(a.enc_arith)
     arith = model.backbone.arith
+    if a.pair_fmt != "auto":
+        model.test_cfg["pair_split_fmt"] = a.pair_fmt
     cfg = model.engine_config()
+    pair_fmt = cfg.pair_split_fmt
     cfg.pair_precision = a.pair_precision
     cfg.regroup = False                                              # all points are given at frame 0 of the video
 
@@ -336,6 +400,8 @@ def main():
 
     tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
     backend = fdist.HipBackend(model, tail_stream=tail_stream, tail_from=a.tail_from)
+    if os.environ.get("FGVC_EARLY_HALO", "1") == "0":               # escape hatch: the halo posted after the whole encoder pass (round 2's order)
+        backend.early_halo = False
     timing = fdist.Timing(dev)
     plan1 = engine.plan_clip(Tc, [0], cfg)
     state = {}
@@ -441,8 +507,8 @@ def main():
         fl = 2.0 * HW * n_disc * C * pair_tag[1]                       # windowed FLOPs of the launch's pairs
         f32_tf = fl / (pair_ms * 1e-3) / 1e12
         split = pair_tag[0] == "pair_split"
-        name = "fgvc_pair_topk_f16x3" if split else "fgvc_pair_topk_f32"
-        n_prod = SPLIT_PRODUCTS if split else 1
+        name = ("fgvc_pair_topk_f16f6" if pair_fmt == "f16f6" else "fgvc_pair_topk_f16x3") if split else "fgvc_pair_topk_f32"
+        n_prod = PAIR_UNITS[pair_fmt] if split else 1
         pm = pmc(name)
         kernels["pair_topk"] = {
             "kernel": name, "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS,
@@ -450,9 +516,11 @@ def main():
             "what": "ALGORITHMIC windowed f32 FLOPs (2 HW N_disc C per pair, N_disc = 697) / mean launch duration",
             "executed_tflops": n_prod * f32_tf,
             "frac_executed": (n_prod * f32_tf / BF16_MFMA_PEAK_TFLOPS) if split else f32_tf / F32_MFMA_PEAK_TFLOPS,
-            "executed_note": f"{n_prod} 16-bit partial products per f32-grade product (f16: h*h + l*h + h*l; bf16: + lo*lo), in-window "
-                             "candidates only (the 4x8-block tiling multiplies 1312 candidates per query for 697 in the disc)"
+            "executed_note": f"{n_prod} 16-bit pipe units per f32-grade product (f16x3: h*h + l*h + h*l; f16f6: h*h on the f16 pipe + "
+                             "h6*l6 + l6*h6 in FP6 at four times the rate), in-window candidates only (the 4x8-block tiling multiplies "
+                             "1312 candidates per query for 697 in the disc)"
                              if split else "exact f32 MFMA",
+            "pair_fmt": pair_fmt if split else "f32",
             "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
             "ms_per_launch": pair_ms, "pairs_per_launch": pair_tag[1], "launches_timed": n_l,
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch")}
@@ -466,8 +534,8 @@ def main():
         "value": n_frames_total / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (f32-grade results from 16-bit / 8-bit parts on the MFMA pipe, f32 accumulate: encoder " + arith +
-                 ", correlation f16 h/l x3)",
+        "dtype": "f32 (f32-grade results from 16-bit / 8-bit / 6-bit parts on the MFMA pipe, f32 accumulate: encoder " + arith +
+                 ", correlation " + {"f16": "f16 h/l x3", "f16f6": "f16 + FP6 cross terms"}[pair_fmt] + ")",
         "data": "synthetic",
         "config": {"workload": (f"{a.workload}: one {T}x{h}x{w} video per step = {world} clip(s) of {Tc} frames, one per rank -> {Hf}x{Wf}x{C} "
                                 f"features, top-10, radius 15, tau 0.07, P={P}" if a.mode == "video" else
@@ -481,6 +549,7 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
         "encoder_arith": arith,
+        "pair_arith": pair_fmt,
     }
     if a.mode == "video":
         rr = fdist.shard_frames(T, world, first=1)
@@ -489,6 +558,19 @@ def main():
         out["config"]["pairs_note"] = ("unique (query frame, key frame) pairs: frame t of a video has min(t, 6) key frames (frame 0 + the 5 "
                                        "before it), so every rank after the first carries 6 per frame where an 8-frame clip has 27 in all -- "
                                        "per-GPU frames are fixed as N grows (weak scaling), per-GPU pair work grows from 27 to 48")
+    if world > 1:
+        # what the communication library saw (so that a reader of the line can check it was a real N-rank RCCL job)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        devs = [None] * world
+        dist.all_gather_object(devs, (rank, local, torch.cuda.get_device_properties(dev).name, str(torch.cuda.get_device_properties(dev).uuid)
+                                      if hasattr(torch.cuda.get_device_properties(dev), "uuid") else None))
+        out["distributed"] = {"world_size": dist.get_world_size(), "backend": backend_name, "rccl_version": rccl,
+                              "ranks": [dict(rank=r_, local_rank=l_, device=n_, uuid=u_) for r_, l_, n_, u_ in devs],
+                              "distinct_devices": len({u_ for _, _, _, u_ in devs if u_}) or None,
+                              "early_halo": bool(getattr(backend, "early_halo", False)), "comm_timeout_s": a.comm_timeout}
     if a.rehearse_on_one_gpu:
         out["rehearsal"] = (f"{world} ranks on ONE GPU over gloo, device tensors staged through the host: a functional rehearsal of the "
                             "multi-rank path, not a measurement")
@@ -551,6 +633,40 @@ def main():
                                      "no halo, no all_gather), timed the same way right after the sharded-video steps",
                              "value": world * Tc * n_c / el_c, "unit": "frames/s", "ms_per_step": el_c / n_c * 1e3, "steps": n_c,
                              "pairs_per_rank": n_pairs_clip}
+    if a.mode == "video" and not a.no_f16x3_line and (arith != "f16x3" or pair_fmt != "f16"):
+        # the price of precision, on the driver's record: the same steps with every matrix product in the three-f16-product form
+        # (22 significand bits per operand: encoder f16x3 + fgvc_pair_topk_f16x3), timed the same way right here
+        model.backbone.set_arith("f16x3")
+        model.test_cfg["pair_split_fmt"] = "f16"
+        cfg3 = model.engine_config()
+        cfg3.pair_precision, cfg3.regroup = cfg.pair_precision, False
+        cache3 = {}
+
+        def step3():
+            return fdist.track_points_sharded(backend, rgbs, qp, cfg3, device=dev, halo=a.halo, timing=None, cache=cache3)[0]
+        for _ in range(5):
+            step3()
+        barrier()
+        t1 = time.perf_counter()
+        n3 = max(20, a.steps // 2)
+        for _ in range(n3):
+            out3 = step3()
+        barrier()
+        el3 = time.perf_counter() - t1
+        if world > 1:
+            t3_ = torch.tensor([el3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t3_, op=dist.ReduceOp.MAX)
+            el3 = float(t3_.item())
+        assert bool(torch.isfinite(out3).all())
+        out["value_f16x3"] = {"what": "the same sharded-video steps with the encoder in f16x3 and the pair kernel fgvc_pair_topk_f16x3 (three f16 products "
+                                      "per f32-grade product everywhere: the form closest to the reference's fp32)",
+                              "value": T * n3 / el3, "unit": "frames/s", "ms_per_step": el3 / n3 * 1e3, "steps": n3,
+                              "max_abs_traj_diff_px_vs_default": float((out3.to(torch.float64) - out_coords.to(torch.float64)).abs().max())}
+        model.backbone.set_arith(arith)
+        if a.pair_fmt != "auto":
+            model.test_cfg["pair_split_fmt"] = a.pair_fmt
+        else:
+            model.test_cfg.pop("pair_split_fmt", None)
     if rank == 0 and not a.no_corr_volume:
         gq = torch.Generator(device=dev).manual_seed(5)
         feats2 = torch.nn.functional.normalize(torch.randn(2, HW, C, generator=gq, device=dev), dim=2)

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FGVC_HIP_LIB") or os.path.join(_HERE, "lib", "libfgvc_hip.so")
 
 FGVC_OK = 0
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 1, 2, 3
 NO_LIMIT = 0x3FFFFFFF
 PAIR_MASKED = 1
 WEIGHT_SOFTMAX, WEIGHT_COSINE, WEIGHT_RAW = 0, 1, 2
@@ -31,6 +32,9 @@ SIGNATURES = {
     "fgvc_pair_topk_f16x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "fgvc_pair_topk_f16x3_runs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "fgvc_split_f16x2": (_i, [_p, _p, C.c_int64, _i, _p]),
+    "fgvc_split_f16f6p": (_i, [_p, _p, C.c_int64, _i, _p]),
+    "fgvc_pair_topk_f16f6": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "fgvc_pair_topk_f16f6_runs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "fgvc_pair_topk_f16x3_timed_out": (_i, []),
     "fgvc_pair_topk_f16x3_probe": (_i, [_p]),
     "fgvc_conv64_probe": (_i, [_p]),
@@ -48,6 +52,7 @@ SIGNATURES = {
     "fgvc_normalize_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_split_f16x2_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "fgvc_normalize_split_f16f6p_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_merge_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
     "fgvc_propagate_topk_f32": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_corr_volume_f32": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),

@@ -61,6 +61,9 @@ void set_pair_debug(int);
 void set_readout_prune(int);
 void set_conv_s2_debug(int);
 int split_f16x2_launch(const float*, uint16_t*, long long, int, hipStream_t);
+int split_f16f6p_launch(const float*, unsigned char*, long long, hipStream_t);
+int pair_topk_v7_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, const int32_t*, int,
+                        int32_t*, float*, hipStream_t);
 int pair_topk_v5_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, const int32_t*,
                         int, int32_t*, float*, hipStream_t);
 void set_pair_v5_debug(int);
@@ -235,6 +238,53 @@ int fgvc_pair_topk_f16x3_runs(const uint16_t* qsplit, const uint16_t* ksplit, co
                               int n_runs, int32_t* idx_out, float* score_out, void* stream) {
   FGVC_REQUIRE(runs, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16x3_runs: null runs");
   return pair_f16x3_common("fgvc_pair_topk_f16x3_runs", qsplit, ksplit, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
+                           runs, n_runs, idx_out, score_out, stream);
+}
+
+int fgvc_split_f16f6p(const float* feat, uint8_t* rows, int64_t n_pixels, int C, void* stream) {
+  FGVC_REQUIRE(feat && rows, FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6p: null pointer");
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_split_f16f6p: C=%d unsupported (256 only)", C);
+  FGVC_REQUIRE(n_pixels >= 0 && n_pixels < (1ll << 40), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6p: bad n_pixels");
+  FGVC_REQUIRE(aligned16(feat) && aligned16(rows), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6p: 16-byte alignment required");
+  if (n_pixels == 0) return FGVC_OK;
+  return split_f16f6p_launch(feat, rows, n_pixels, (hipStream_t)stream);
+}
+
+static int pair_f16f6_common(const char* what, const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C,
+                             int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs,
+                             int n_runs, int32_t* idx_out, float* score_out, void* stream) {
+  FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "%s: null pointer", what);
+  FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
+               "%s: qsplit/ksplit/pairs must be 16-byte aligned", what);
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "%s: C=%d unsupported (256 only; use fgvc_pair_topk_f32)", what, C);
+  FGVC_REQUIRE(Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0 && n_pairs >= 0, FGVC_ERR_INVALID_ARG,
+               "%s: bad shape Hq=%d Wq=%d Hk=%d Wk=%d n_pairs=%d", what, Hq, Wq, Hk, Wk, n_pairs);
+  FGVC_REQUIRE(topk >= 1 && topk <= 10, FGVC_ERR_UNSUPPORTED, "%s: topk=%d outside 1..10", what, topk);
+  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "%s: negative mask parameter", what);
+  FGVC_REQUIRE(n_pairs <= 65535, FGVC_ERR_UNSUPPORTED, "%s: n_pairs=%d > 65535 per call", what, n_pairs);
+  FGVC_REQUIRE(!runs || (n_runs >= 1 && n_runs <= n_pairs && (reinterpret_cast<uintptr_t>(runs) & 7u) == 0), FGVC_ERR_INVALID_ARG,
+               "%s: runs must be 8-byte aligned, 1 <= n_runs <= n_pairs", what);
+  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
+  FGVC_REQUIRE(any_limit && all_masked != 0, FGVC_ERR_UNSUPPORTED,
+               "%s: every pair must carry FGVC_PAIR_MASKED under an analytic mask (a pair that scans the whole frame needs fgvc_pair_topk_f16x3)", what);
+  FGVC_REQUIRE(Hq == Hk && Wq == Wk, FGVC_ERR_INVALID_ARG, "%s: a spatial mask needs equal query/key grids (local_attention.py:331)", what);
+  FGVC_REQUIRE(Hk < 16384 && Wk < 32768 && (long long)Hk * Wk < (1ll << 30), FGVC_ERR_UNSUPPORTED, "%s: grid too large", what);
+  if (n_pairs == 0) return FGVC_OK;
+  return pair_topk_v7_launch(reinterpret_cast<const uint16_t*>(qsplit), reinterpret_cast<const uint16_t*>(ksplit), pairs, n_pairs, Hq, Wq, Hk, Wk,
+                             r2max, ry, rx, topk, runs, n_runs, idx_out, score_out, (hipStream_t)stream);
+}
+
+int fgvc_pair_topk_f16f6(const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq, int Hk,
+                         int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out, float* score_out, void* stream) {
+  return pair_f16f6_common("fgvc_pair_topk_f16f6", qsplit, ksplit, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
+                           nullptr, 0, idx_out, score_out, stream);
+}
+
+int fgvc_pair_topk_f16f6_runs(const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
+                              int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs, int n_runs,
+                              int32_t* idx_out, float* score_out, void* stream) {
+  FGVC_REQUIRE(runs, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16f6_runs: null runs");
+  return pair_f16f6_common("fgvc_pair_topk_f16f6_runs", qsplit, ksplit, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
                            runs, n_runs, idx_out, score_out, stream);
 }
 
@@ -632,6 +682,11 @@ int fgvc_normalize_split_nhwc_f32(const float* in, float* out_f32, uint16_t* out
 int fgvc_normalize_split_f16x2_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
                                         int normalize, void* stream) {
   return normalize_split_common("fgvc_normalize_split_f16x2_nhwc_f32", in, out_f32, out_split, N, C, H, W, normalize, 1, stream);
+}
+
+int fgvc_normalize_split_f16f6p_nhwc_f32(const float* in, uint8_t* rows, int N, int C, int H, int W, int normalize, void* stream) {
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_normalize_split_f16f6p_nhwc_f32: C=%d unsupported (256 only)", C);
+  return normalize_split_common("fgvc_normalize_split_f16f6p_nhwc_f32", in, nullptr, reinterpret_cast<uint16_t*>(rows), N, C, H, W, normalize, 2, stream);
 }
 
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream) {

@@ -663,6 +663,98 @@ __global__ __launch_bounds__(256) void normalize_nhwc_kernel(const float* __rest
   }
 }
 
+// ... and straight into the rows of fgvc_split_f16f6p (csrc/pair_topk_v7.hpp: what fgvc_pair_topk_f16f6 reads), C = 256: one wave per
+// pixel, lane = 4 consecutive channels.  A scale block of that format is the 32 channels 64 v + 16 m + 8 hi + i (m < 4, i < 8) = the 8
+// lanes {16 v + 4 m + 2 hi + b}: block maxima by three xor-shuffles (1, 4, 8), a lane's four FP6 codes are 24 bits of its block's
+// 192-bit string at bit 48 m + 24 b, and the lanes with piece index 2 m + b < 6 assemble one 32-bit word each from two pieces.
+__device__ __forceinline__ int n6_scale_exp(float m) {          // (= p6_scale_exp of pair_topk_v7.hpp)
+  if (!(m > 0.f)) return -40;
+  int e;
+  const float f = frexpf(m * (1.0f / 7.5f), &e);
+  int s = (f > 0.5f) ? e : e - 1;
+  if (m * exp2f((float)-s) > 7.5f) ++s;
+  return imax(s, -40);
+}
+__device__ __forceinline__ unsigned n6_code(float y) {
+  const float a = fabsf(y);
+  const float inv_step = a < 2.f ? 8.f : (a < 4.f ? 4.f : 2.f);
+  const float r = fminf(__builtin_rintf(a * inv_step) / inv_step, 7.5f);
+  const float c = r < 2.f ? 8.f * r : (r < 4.f ? 8.f + 4.f * r : 16.f + 2.f * r);
+  return (unsigned)c | (y < 0.f ? 32u : 0u);
+}
+__global__ __launch_bounds__(256) void normalize_f16f6p_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, int normalize,
+                                                                long long npix) {
+  const long long pixel = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (pixel >= npix) return;
+  // (the norm exactly as normalize_nhwc_kernel computes it, expression for expression: the rows then equal fgvc_split_f16f6p of that
+  // kernel's f32 rows bit for bit -- a sum contracted differently moves 1/|x| by an ulp and a few FP6 codes of the residual with it)
+  const float* src = in + (size_t)pixel * 256;
+  float ss;
+  {
+#pragma clang fp contract(off)      // (that kernel's sum compiles to four rounded squares and three adds: no fused multiply-add here either)
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * lane);
+    const float xx = v.x * v.x, yy = v.y * v.y, zz = v.z * v.z, ww = v.w * v.w;
+    ss = ((xx + yy) + zz) + ww;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+  const float inv = normalize ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+  f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * lane);
+  x *= inv;
+  unsigned char* row = out + (size_t)pixel * 1024;
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 hv;
+  float hf[4], lf[4], mh = 0.f, ml = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xs = x[i] * 256.f;
+    const _Float16 h = (_Float16)xs;
+    hv[i] = h;
+    hf[i] = (float)h;
+    lf[i] = (xs - hf[i]) * 256.f;
+    mh = fmaxf(mh, fabsf(hf[i]));
+    ml = fmaxf(ml, fabsf(lf[i]));
+  }
+  *reinterpret_cast<f16x4*>(row + 8 * lane) = hv;
+#pragma unroll
+  for (int m = 1; m <= 8; m <<= 1) {
+    if (m == 2) continue;                                       // bit 1 of the lane is hi: another block
+    mh = fmaxf(mh, __shfl_xor(mh, m));
+    ml = fmaxf(ml, __shfl_xor(ml, m));
+  }
+  const int sh = n6_scale_exp(mh), sl = n6_scale_exp(ml);
+  const float ih = exp2f((float)-sh), il = exp2f((float)-sl);
+  unsigned ph = 0, pl = 0;                                      // this lane's four codes: 24 bits
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ph |= n6_code(hf[i] * ih) << (6 * i);
+    pl |= n6_code(lf[i] * il) << (6 * i);
+  }
+  const int v = lane >> 4, hi = (lane >> 1) & 1, pi = ((lane >> 2) & 3) * 2 + (lane & 1);      // piece index inside the block
+  // word w = pi (w < 6) of the block's string: pieces pa = 4 w / 3 (from bit oa = 32 w - 24 pa of it) and pa + 1
+  const int w = pi < 6 ? pi : 0;
+  const int pa = (4 * w) / 3, oa = 32 * w - 24 * pa;
+  const int base = (lane & ~13) ;                                // lane of piece 0 of this block: 16 v + 2 hi
+  const int la = base + 4 * (pa >> 1) + (pa & 1), lb = base + 4 * ((pa + 1) >> 1) + ((pa + 1) & 1);
+  const unsigned ha = __shfl(ph, la), hb = __shfl(ph, lb), qa = __shfl(pl, la), qb = __shfl(pl, lb);
+  const unsigned wh = (ha >> oa) | (hb << (24 - oa)), wl = (qa >> oa) | (qb << (24 - oa));
+  if (pi < 4) {
+    *reinterpret_cast<unsigned*>(row + 512 + 32 * v + 16 * hi + 4 * pi) = wh;
+    *reinterpret_cast<unsigned*>(row + 704 + 32 * v + 16 * hi + 4 * pi) = wl;
+  } else if (pi < 6) {
+    *reinterpret_cast<unsigned*>(row + 640 + 32 * (v >> 1) + 16 * hi + 8 * (v & 1) + 4 * (pi - 4)) = wh;
+    *reinterpret_cast<unsigned*>(row + 832 + 32 * (v >> 1) + 16 * hi + 8 * (v & 1) + 4 * (pi - 4)) = wl;
+  } else if (pi == 6) {
+    row[896 + 16 * hi + v] = (unsigned char)(sh + 127 - 4);
+  } else {
+    row[896 + 16 * hi + 4 + v] = (unsigned char)(sl + 127 - 4);
+  }
+  // the rest of the row: [904, 912), [920, 928) pads of the scale area, [928, 1024) zero
+  if (lane < 2) *reinterpret_cast<unsigned long long*>(row + 904 + 16 * lane) = 0ull;
+  else if (lane < 26) *reinterpret_cast<unsigned*>(row + 928 + 4 * (lane - 2)) = 0u;
+}
+
 static int g_conv_debug = 0;
 void set_conv_debug(int v) { g_conv_debug = v; }
 static int g_conv_narrow = 1;       // bit 0: 64-channel layers, bit 1: 128-channel 3x3 layers (no gain measured) -- 4-row tiles, two workgroups per CU (0: 8-row tiles)
@@ -750,7 +842,8 @@ int nhwc_to_split_launch(float* x, uint16_t* out, int N, int C, int H, int W, in
 int normalize_nhwc_launch(const float* in, float* out, uint16_t* out_split, int N, int C, int H, int W, int normalize,
                           int split_fmt, hipStream_t s) {
   const long long npix = (long long)N * H * W;
-  if (split_fmt == 0) normalize_nhwc_kernel<0><<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
+  if (split_fmt == 2) normalize_f16f6p_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, reinterpret_cast<unsigned char*>(out_split), normalize, npix);
+  else if (split_fmt == 0) normalize_nhwc_kernel<0><<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
   else normalize_nhwc_kernel<1><<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
   FGVC_CHECK_LAUNCH("fgvc_normalize_nhwc_f32");
   return FGVC_OK;

@@ -215,11 +215,13 @@ __global__ __launch_bounds__(512, 1) void pair_topk_kernel_v5(PairParamsB p) {
         kbase = reinterpret_cast<const unsigned char*>(p.k_hl) + (size_t)kf * p.Hk * p.Wk * (4 * C);
       }
       const uint32_t ent = __builtin_amdgcn_readfirstlane(blist[e]);
-      const int sby = ent & 0xfff, sbx = (ent >> 12) & 0xfff;
+      int sby = ent & 0xfff, sbx = (ent >> 12) & 0xfff;
+      if (p.debug & 32768) { sby = blockIdx.x & 3; sbx = 0; }         // experiment: every workgroup reads the same few key blocks (L2-hot)
       const int ky = imin(sby * QBH + qb, p.Hk - 1), kx0 = sbx * QBW;
       const unsigned char* src = kbase + ((size_t)ky * p.Wk + kx0) * (4 * C) + lane16;
       const int xmax = p.Wk - 1 - kx0;                                 // >= 0: the block starts inside the frame
       unsigned char* dst = &smem[(G & (NSLOT - 1)) * BUFB + (qb * 8) * LDB];
+      if ((p.debug & 16384) && lane >= 32) return;                     // experiment: half of every row (bytes halved, instructions unchanged)
 #pragma unroll
       for (int i = 0; i < 8; ++i) lds_dma_16(src + (size_t)imin(i, xmax) * (4 * C), dst + i * LDB);
     };
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v6(PairParamsB p) {
       const unsigned long long bal = __ballot(ent != 0u);
       if (ent) {
         const int r = count + __popcll(bal & ((1ull << lane) - 1));
-        blist[r < head ? 2 * r : 2 * (total - 1 - r) + 1] = ent;
+        blist[(p.debug & 8192) ? r : (r < head ? 2 * r : 2 * (total - 1 - r) + 1)] = ent;      // debug & 8192: plain row-major order (A/B)
       }
       count += __popcll(bal);
     }
@@ -933,3 +935,5 @@ int pair_topk_v5_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_
 }
 
 }  // namespace fgvc
+
+#include "pair_topk_v7.hpp"      // fgvc_pair_topk_f16f6: the same protocol at 1.5 pipe units (shares the helpers above)

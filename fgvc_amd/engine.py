@@ -49,7 +49,9 @@ class TrackerConfig:
     test_mode: str = "v1"              # anything else = masked_attention_efficient_v2 (:379-392)
     sigma: float = 6.0
     pair_precision: str = "auto"   # ops.pair_topk_auto: "auto" | "f32" | "split" (not a reference key)
-    pair_split_fmt: str = "f16"    # operand format of the split pair kernel (fgvc_pair_topk_f16x3): "f16" is the only one
+    pair_split_fmt: str = "f16"    # operand format of the split pair kernel: "f16" = split_f16x2 rows -> fgvc_pair_topk_f16x3 (three f16 products, 1e-7-grade),
+                                   # "f16f6" = split_f16f6p rows -> fgvc_pair_topk_f16f6 (f16 + FP6 cross terms: half the matrix work, ~6e-5 logit);
+                                   # VanillaTracker picks "f16f6" when its encoder computes in f16f8 and the mask allows it (engine_config)
 
     @staticmethod
     def from_test_cfg(cfg) -> "TrackerConfig":
@@ -235,9 +237,14 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
         raise ValueError("run_pairs: sim_mode='l2-distance' needs channels= (the encoder's un-padded channel count)")
     if use_split:      # 16-bit matrix pipe on the two-part split of the (normalised) features, f32-grade scores
         fmt = cfg.pair_split_fmt
-        if fmt != "f16":
-            raise ValueError(f"pair_split_fmt={fmt!r}: the split pair kernel reads split_f16x2 operands ('f16') only")
-        split = feats_hwc if pre_split else ops.split_f16x2(feats_hwc)
+        if fmt not in ("f16", "f16f6"):
+            raise ValueError(f"pair_split_fmt={fmt!r}: 'f16' (split_f16x2 rows) or 'f16f6' (split_f16f6p rows)")
+        if fmt == "f16f6" and not ops.pair_f16f6_ok(feats_hwc.shape[-1], Hf, Wf, k, cfg.with_norm, None, cfg.mask, all_masked):
+            if pre_split:
+                raise ValueError("run_pairs: the bank is in the f16f6 format, but fgvc_pair_topk_f16f6 does not apply to this mask / pair list "
+                                 "(every pair masked, at most 64 key blocks in reach): encode with pair_split_fmt='f16'")
+            fmt = "f16"
+        split = feats_hwc if pre_split else (ops.split_f16x2(feats_hwc) if fmt == "f16" else ops.split_f16f6p(feats_hwc))
         pair_fn = lambda prs: ops.pair_topk_split(split, split, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False, all_masked=all_masked,
                                                   fmt=fmt)
     else:

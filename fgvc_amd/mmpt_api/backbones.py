@@ -23,6 +23,8 @@ import torch.nn.functional as F
 
 from .registry import BACKBONES
 
+_CAPTURING = [False]      # set while ResNet.forward_hwc captures a HIP graph: allocations / evictions / device syncs then raise
+
 
 class ConvBN(nn.Module):
     """conv(no bias) + BatchNorm2d [+ ReLU]; attribute names follow mmcv.cnn.ConvModule."""
@@ -273,6 +275,7 @@ class ResNet(nn.Module):
             self.__dict__.pop("_calib", None)
         scales = {k: ops.act_scale_log2(float(v)) for k, v in rec.items()}
         cache[("scales", dev)] = scales
+        self._drop_graphs(dev)                             # captured graphs carry the OLD scales as kernel arguments
         if ("overflow", dev) not in cache:
             cache[("overflow", dev)] = torch.zeros(1, dtype=torch.int32, device=dev)
         self._cache_filled(dev)
@@ -288,7 +291,19 @@ class ResNet(nn.Module):
                 hit = True
                 cache[k].zero_()
                 cache.pop(("scales", k[1]), None)
+                self._drop_graphs(k[1])                    # ... and so do the graphs captured with them
         return hit
+
+    def _drop_graphs(self, dev=None, shape_sig=None):
+        """Forget captured HIP graphs (all, those of one device, or those of one input shape (N, h, w, device)): a graph bakes in the
+        scales it was captured with and the addresses of the workspaces of its shape."""
+        cache = self.__dict__.get("_split_cache", {})
+        for k in [k for k in cache if isinstance(k, tuple) and k and k[0] == "graph"]:
+            if dev is not None and k[2] != dev:
+                continue
+            if shape_sig is not None and not (k[1][0] == shape_sig[0] and tuple(k[1][2:]) == tuple(shape_sig[1:3]) and k[2] == shape_sig[3]):
+                continue
+            del cache[k]
 
     def _load_from_state_dict(self, *args, **kwargs):
         # called for this module by ANY load_state_dict (its own or a parent model's): folded / split weights are derived
@@ -351,8 +366,11 @@ class ResNet(nn.Module):
         order.append(sig)
         while len(order) > max(1, int(self.max_workspace_shapes)):
             old = order.pop(0)
+            if _CAPTURING[0]:
+                raise RuntimeError("ResNet: a workspace eviction inside a HIP-graph capture (the graph would keep freed addresses)")
             if isinstance(sig[-1], torch.device) and sig[-1].type == "cuda":
                 torch.cuda.synchronize(sig[-1])                      # nothing in flight may still read the evicted buffers
+            self._drop_graphs(shape_sig=old)                         # a graph of that shape replays into the evicted buffers
             for k in [k for k in cache if isinstance(k, tuple) and len(k) > 1 and k[0] == "b" and k[1] == old]:
                 del cache[k]
         self.__dict__["_ws_sig"] = sig
@@ -361,6 +379,8 @@ class ResNet(nn.Module):
     def _cache_filled(device):
         """Cache entries (workspaces with zeroed borders, folded / split weights) are produced on whichever lane's stream
         asks first and then used by every lane: make them visible to all streams once, when they are made."""
+        if _CAPTURING[0]:
+            raise RuntimeError("ResNet: a cache entry was made inside a HIP-graph capture (the capture call must find everything in place)")
         torch.cuda.synchronize(device)
 
     @staticmethod
@@ -625,8 +645,8 @@ class ResNet(nn.Module):
         """forward_hwc_eager, or -- with `use_graph` on the GPU in eval mode -- the same work replayed from a HIP graph (torch.cuda.CUDAGraph
         on ROCm).  The graph of a shape is captured on its second call (the first runs eagerly: calibration, workspaces, weight
         layouts), reads a static copy of the input and writes a static output: the returned tensor is overwritten by the next call
-        with the same shape (the tracker consumes it before; `out` receives a copy).  Graphs live in the split cache: new weights,
-        another arithmetic or a re-calibration drop them."""
+        with the same shape, so the caller gets a COPY (`out` when given, else a fresh tensor).  Graphs live in the split cache: new
+        weights, a re-calibration, an overflow (`check_overflow`) and the eviction of the shape's workspaces drop them."""
         if not (self.use_graph and x.is_cuda and not self.training and x.dtype == torch.float32):
             return self.forward_hwc_eager(x, normalize, split_if, split_fmt, out)
         cache = self.__dict__.setdefault("_split_cache", {})
@@ -640,10 +660,17 @@ class ResNet(nn.Module):
                 return self.forward_hwc_eager(x, normalize, split_if, split_fmt, out)      # (scales were dropped: calibrate eagerly first)
             static_in = torch.empty_like(x)
             static_in.copy_(x)
+            # one more eager pass right in front of the capture: this shape's workspaces exist and are the most recently used ones, so
+            # the captured pass neither allocates nor evicts (both synchronise, and an evicted buffer's address would stay in the graph)
+            self.forward_hwc_eager(static_in, normalize, split_if, split_fmt, None)
             torch.cuda.synchronize(x.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                o, H, W = self.forward_hwc_eager(static_in, normalize, split_if, split_fmt, None)
+            _CAPTURING[0] = True
+            try:
+                with torch.cuda.graph(g):
+                    o, H, W = self.forward_hwc_eager(static_in, normalize, split_if, split_fmt, None)
+            finally:
+                _CAPTURING[0] = False
             ent = cache[key] = (g, static_in, o, H, W)
         g, static_in, o, H, W = ent
         static_in.copy_(x)
@@ -651,7 +678,7 @@ class ResNet(nn.Module):
         if out is not None and tuple(out.shape) == tuple(o.shape) and out.dtype == o.dtype:
             out.copy_(o)
             return out, H, W
-        return o, H, W
+        return o.clone(), H, W                                 # `o` is the graph's static output: the next replay overwrites it
 
     def forward_hwc_eager(self, x, normalize: bool = True, split_if=None, split_fmt: str = "bf16", out=None):
         """The tracker's fast path: features of the single requested stage as (N, H*W, C) f32 rows, L2-normalised if
@@ -686,7 +713,8 @@ class ResNet(nn.Module):
         C = y.shape[1]
         as_split = bool(split_if is not None and split_if(C, H, W))
         f = ops.normalize_to_hwc(y.float(), normalize, pad=True)
-        return ((ops.split_f16x2 if split_fmt == "f16" else ops.split_bf16)(f) if as_split and f.shape[-1] == C else f), H, W
+        splitter = {"f16": ops.split_f16x2, "f16f6": ops.split_f16f6p}.get(split_fmt, ops.split_bf16)
+        return (splitter(f) if as_split and f.shape[-1] == C else f), H, W
 
 
 def torchvision_key(name: str) -> str:

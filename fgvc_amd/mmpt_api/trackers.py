@@ -138,7 +138,16 @@ class VanillaTracker(BaseTracker):
         return (chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)), Hf, Wf       # (cat of one tensor is a copy)
 
     def engine_config(self) -> engine.TrackerConfig:
-        return engine.TrackerConfig.from_test_cfg(self.test_cfg)
+        """The test_cfg as the engine reads it.  Unless test_cfg names `pair_split_fmt` itself, the pair kernel follows the encoder's
+        arithmetic: an f16f8 trunk (features +-3e-5 logit from the reference's) goes with fgvc_pair_topk_f16f6 (+-6e-5, half the matrix
+        work) where that kernel applies -- every key slot masked, the mask within 64 key blocks of a query tile --, any other trunk
+        (set_arith('f16x3') / 'bf16x3') with the 1e-7-grade fgvc_pair_topk_f16x3."""
+        cfg = engine.TrackerConfig.from_test_cfg(self.test_cfg)
+        if "pair_split_fmt" not in self.test_cfg and getattr(self.backbone, "arith", None) == "f16f8":
+            all_masked = cfg.with_first_neighbor or not cfg.with_first
+            if all_masked and ops.pair_blocks_reached(cfg.mask) <= ops.PAIR_F16F6_MAX_BLOCKS and cfg.topk <= 10 and cfg.with_norm:
+                cfg.pair_split_fmt = "f16f6"
+        return cfg
 
     def _check_kernels(self):
         """Fail closed, per video: the pair kernel's LDS protocol waits with bounded spins, and a workgroup whose wait gave up writes

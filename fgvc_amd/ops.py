@@ -172,8 +172,12 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
     split_f16x2() of L2-NORMALISED features.  Same outputs as pair_topk().  all_masked=True: the caller built `pairs` with
     PAIR_MASKED on every row (then only the mask's reach, not the whole key grid, must fit the kernel's block list).
     `fmt` names the operand format; "f16" is the only one (the bf16 four-product kernel of rounds 1-2 is retired)."""
-    if fmt != "f16":
-        raise ValueError(f"pair_topk_split: fmt={fmt!r} (only 'f16': split_f16x2 operands)")
+    if fmt not in ("f16", "f16f6"):
+        raise ValueError(f"pair_topk_split: fmt={fmt!r} ('f16': split_f16x2 operands, 'f16f6': split_f16f6p operands)")
+    if fmt == "f16f6" and not (all_masked and pair_blocks_reached(mask) <= PAIR_F16F6_MAX_BLOCKS):
+        raise ValueError("pair_topk_split(fmt='f16f6'): every pair must be masked (all_masked=True) by an analytic mask that reaches at most "
+                         f"{PAIR_F16F6_MAX_BLOCKS} key blocks per query tile; use fmt='f16'")
+    sym = "fgvc_pair_topk_f16x3" if fmt == "f16" else "fgvc_pair_topk_f16f6"
     qsplit, ksplit = _chk(qsplit, torch.int16, "qsplit"), _chk(ksplit, torch.int16, "ksplit")
     pairs = _chk(pairs, torch.int32, "pairs")
     assert qsplit.dim() == 4 and ksplit.dim() == 4 and qsplit.shape[2] == 2 and ksplit.shape[2] == 2
@@ -187,11 +191,11 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
     score = torch.empty((n, Hq * Wq, topk), device=qsplit.device, dtype=torch.float32)
     runs = pair_runs(pairs) if (use_runs and n) else None
     if runs is not None:            # a query frame's pairs in one workgroup (query prologue once, the key-block ring never drains)
-        _lib.call("fgvc_pair_topk_f16x3_runs", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n, qsplit.shape[3], Hq, Wq, Hk, Wk,
+        _lib.call(sym + "_runs", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n, qsplit.shape[3], Hq, Wq, Hk, Wk,
                   mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(runs), runs.shape[0], _ptr(idx), _ptr(score),
                   _stream(qsplit))
         return idx, score
-    _lib.call("fgvc_pair_topk_f16x3", _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n,
+    _lib.call(sym, _ptr(qsplit), _ptr(ksplit), _ptr(pairs), n,
               qsplit.shape[3], Hq, Wq, Hk, Wk, mask.r2max, mask.ry, mask.rx, topk, int(all_masked), _ptr(idx), _ptr(score),
               _stream(qsplit))
     return idx, score
@@ -216,6 +220,41 @@ def pair_blocks_needed(Hk: int, Wk: int, mask: Optional[MaskSpec] = None, all_ma
     rr = math.isqrt(mask.r2max) if mask.r2max < NO_LIMIT else NO_LIMIT
     reach_y, reach_x = min(mask.ry, rr, Hk), min(mask.rx, rr, Wk)
     return min(-(-Hk // 4), (7 + 2 * reach_y) // 4 + 2) * min(-(-Wk // 8), (15 + 2 * reach_x) // 8 + 2)
+
+
+PAIR_F16F6_MAX_BLOCKS = 64   # key blocks one query tile may visit in fgvc_pair_topk_f16f6 (6 bits of a selection key name the block)
+
+
+def pair_blocks_reached(mask: Optional[MaskSpec]) -> int:
+    """Key blocks (4 x 8 pixels) an interior 8 x 16 query tile reaches under `mask` (csrc/pair_topk_v7.hpp: pair_v7_blocks_reached, the
+    same arithmetic); a huge number when there is no analytic mask."""
+    if mask is None or mask.is_none:
+        return 1 << 30
+    rr = math.isqrt(mask.r2max) if mask.r2max < NO_LIMIT else NO_LIMIT
+    reach_y, reach_x = min(mask.ry, rr), min(mask.rx, rr)
+    if reach_y > 4096 or reach_x > 4096:
+        return 1 << 30
+    QBH, QBW = 4, 8
+    ny, nx = (2 * QBH - 1 + 2 * reach_y) // QBH + 2, (2 * QBW - 1 + 2 * reach_x) // QBW + 2
+    TY0, TX0 = (reach_y // QBH + 1) * QBH, (reach_x // QBW + 1) * QBW
+    count = 0
+    for by in range(ny + reach_y // QBH + 2):
+        for bx in range(nx + reach_x // QBW + 2):
+            hit = False
+            for b in range(4):
+                wy0, wx0, ky0, kx0 = TY0 + (b & 1) * QBH, TX0 + (b >> 1) * QBW, by * QBH, bx * QBW
+                dy = max(0, ky0 - (wy0 + QBH - 1), wy0 - (ky0 + QBH - 1))
+                dx = max(0, kx0 - (wx0 + QBW - 1), wx0 - (kx0 + QBW - 1))
+                hit = hit or (dy * dy + dx * dx <= mask.r2max and dy <= mask.ry and dx <= mask.rx)
+            count += hit
+    return count
+
+
+def pair_f16f6_ok(C: int, Hk: int, Wk: int, topk: int, normalized: bool, dense_mask=None, mask: Optional[MaskSpec] = None,
+                  all_masked: bool = False) -> bool:
+    """Whether fgvc_pair_topk_f16f6 applies: what split_path_ok() asks, every pair masked, and a mask reach of at most 64 key blocks."""
+    return (split_path_ok(C, Hk, Wk, topk, normalized, dense_mask, mask, all_masked) and all_masked
+            and pair_blocks_reached(mask) <= PAIR_F16F6_MAX_BLOCKS)
 
 
 def split_path_ok(C: int, Hk: int, Wk: int, topk: int, normalized: bool, dense_mask=None, mask: Optional[MaskSpec] = None,
@@ -306,6 +345,24 @@ def split_f16x2(feat: torch.Tensor) -> torch.Tensor:
     out = torch.empty((*feat.shape[:-1], 2, Cc), device=feat.device, dtype=torch.int16)
     _lib.call("fgvc_split_f16x2", _ptr(feat), _ptr(out), n, Cc, _stream(feat))
     return out
+
+
+def split_f16f6p(feat: torch.Tensor) -> torch.Tensor:
+    """(…, 256) f32 L2-normalised rows -> (…, 2, 256) int16 = the 1 KiB rows of fgvc_split_f16f6p (h = f16(256 x) + FP6 forms of h
+    and of the residual with their block scales, laid out for the lanes of fgvc_pair_topk_f16f6; opaque bytes in the shape and dtype
+    of split_f16x2()'s output, so that a feature bank travels and is sliced the same way in either format)."""
+    feat = _chk(feat, torch.float32, "feat")
+    assert feat.shape[-1] == 256, "fgvc_split_f16f6p: 256 channels"
+    n = feat.numel() // 256
+    out = torch.empty((*feat.shape[:-1], 2, 256), device=feat.device, dtype=torch.int16)
+    _lib.call("fgvc_split_f16f6p", _ptr(feat), _ptr(out), n, 256, _stream(feat))
+    return out
+
+
+def unsplit_f16f6p(split: torch.Tensor) -> torch.Tensor:
+    """The h part of split_f16f6p() rows as f32: (…, 2, 256) int16 -> (…, 256) = h / 256 (an 11-bit approximation of the rows: tests)."""
+    b = split.contiguous().view(torch.uint8).reshape(*split.shape[:-2], 1024)
+    return b[..., :512].contiguous().view(torch.float16).float() * (1.0 / 256.0)
 
 
 def split_f16f8(feat: torch.Tensor) -> torch.Tensor:
@@ -764,7 +821,7 @@ def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split=False, out: Op
     returns split_bf16() of those rows instead, split="f16" their split_f16x2(), (N, H*W, 2, C) int16, produced in the same
     single pass over x.  `out`: write there."""
     fmt = "bf16" if split is True else split
-    assert fmt in (False, "bf16", "f16")
+    assert fmt in (False, "bf16", "f16", "f16f6")
     x = _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
     shape, dt = ((N, H * W, 2, C), torch.int16) if split else ((N, H * W, C), torch.float32)
@@ -772,6 +829,10 @@ def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split=False, out: Op
         out = torch.empty(shape, device=x.device, dtype=dt)
     else:
         assert tuple(out.shape) == shape and out.dtype == dt and out.is_contiguous() and out.device == x.device
+    if fmt == "f16f6":                                # the rows of split_f16f6p() (fgvc_pair_topk_f16f6's operands), same pass
+        assert C == 256
+        _lib.call("fgvc_normalize_split_f16f6p_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, int(normalize), _stream(x))
+        return out
     _lib.call("fgvc_normalize_split_f16x2_nhwc_f32" if fmt == "f16" else "fgvc_normalize_split_nhwc_f32", _ptr(x),
               _ptr(None if split else out), _ptr(out if split else None), N, C, H, W, int(normalize), _stream(x))
     return out

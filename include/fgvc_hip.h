@@ -121,6 +121,27 @@ int fgvc_pair_topk_f16x3_runs(const uint16_t* qsplit, const uint16_t* ksplit, co
                               int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs, int n_runs,
                               int32_t* idx_out, float* score_out, void* stream);
 int fgvc_pair_topk_f16x3_timed_out(void);
+
+/* The same operator (replaces local_attention.py:331-371) in the PRECISION-CONSISTENT arithmetic of the rest of the path -- the
+ * encoder computes in f16 + fp8, the dense volume in f16 + FP6: h = f16(256 x), the cross sums h_k l_q + l_k h_q in block-scaled FP6
+ * (e2m3, one E8M0 scale per 32 channels) on v_mfma_scale_f32_32x32x64_f8f6f4: 1.5 matrix-pipe units per product where
+ * fgvc_pair_topk_f16x3 spends 3, scores within ~6e-5 logit (tau 0.07) of float64 on Gaussian rows (bar: 1e-3), quantised to 2^-20
+ * (1.4e-5 logit); indices equal the reference's wherever its scores are further apart than that error.  The engine uses it when the
+ * encoder runs f16f8 (whose features are already +-3e-5 logit from the reference's); fgvc_pair_topk_f16x3 remains the 1e-7-grade form.
+ *   fgvc_split_f16f6p: feat [n][256] f32 (L2-normalised) -> rows [n][1024] bytes, laid out for the pair kernel's lanes:
+ *     [0, 512) h 256 f16 | [512, 640) h6 mains, group v at 32 v + 16 hi | [640, 704) h6 tails (8 B per group and lane half) |
+ *     [704, 832) l6 mains | [832, 896) l6 tails | [896, 928) scale bytes, 16 hi + {H v, 4 + L v} | zero.  Group v, lane half hi, element
+ *     e = 8 m + i is channel 64 v + 16 m + 8 hi + i (what a lane of the 32 x 32 x 16 f16 shape holds in fragments 4 v .. 4 v + 3);
+ *     those 32 channels are one scale block (fgvc_amd/csrc/pair_topk_v7.hpp).  A DIFFERENT layout from fgvc_split_f16f6's.
+ *   fgvc_pair_topk_f16f6[_runs]: arguments and outputs of fgvc_pair_topk_f16x3[_runs]; C == 256, topk <= 10, an analytic mask that
+ *   every pair carries (all_masked != 0) and that reaches at most 64 key blocks (4 x 8 pixels) per 8 x 16 query tile -- a radius-15
+ *   disc reaches 56 -- else FGVC_ERR_UNSUPPORTED.  Same fail-closed protocol; fgvc_pair_topk_f16x3_timed_out() reports for both. */
+int fgvc_split_f16f6p(const float* feat, uint8_t* rows, int64_t n_pixels, int C, void* stream);
+int fgvc_pair_topk_f16f6(const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq, int Hk,
+                         int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out, float* score_out, void* stream);
+int fgvc_pair_topk_f16f6_runs(const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
+                              int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs, int n_runs,
+                              int32_t* idx_out, float* score_out, void* stream);
 int fgvc_pair_topk_f16x3_probe(int64_t* out32);   /* debug: s_memtime words of one workgroup (pair_f16_debug = 256) */
 
 /* ---- A5 step 2: merge the per-pair lists of the T key slots of each query frame, divide by the
@@ -351,6 +372,8 @@ int fgvc_normalize_split_nhwc_f32(const float* in, float* out_f32, uint16_t* out
 /* the same with the split in the (h, l) f16 form of fgvc_split_f16x2 (what fgvc_pair_topk_f16x3 reads) */
 int fgvc_normalize_split_f16x2_nhwc_f32(const float* in, float* out_f32, uint16_t* out_split, int N, int C, int H, int W,
                                         int normalize, void* stream);
+/* ... and straight into the rows of fgvc_split_f16f6p (what fgvc_pair_topk_f16f6 reads): rows [N][H*W][1024] bytes, C == 256 */
+int fgvc_normalize_split_f16f6p_nhwc_f32(const float* in, uint8_t* rows, int N, int C, int H, int W, int normalize, void* stream);
 
 /* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
  * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).

@@ -690,6 +690,107 @@ def hr_forward_test_forward(feats: torch.Tensor, ref_yx: torch.Tensor, h: int, w
 
 
 # ----------------------------------------------------------------------------
+# Checker-side restatement of the PRODUCT's operand format fgvc_split_f16f6p (not a reference format: the reference computes
+# <k, q> in f32, local_attention.py:331-371).  Byte-exact twin of fgvc_amd/csrc/pair_topk_v7.hpp `split_f16f6p_kernel`, and the
+# arithmetic model of fgvc_pair_topk_f16f6's scores: 2^16 <k, q> = sum h_k h_q + 2^-8 (sum h6_k l6_q + sum l6_k h6_q).
+# ----------------------------------------------------------------------------
+def _e2m3_codes(y: np.ndarray) -> np.ndarray:
+    """|y| <= 7.5 (float32) -> e2m3 codes (sign << 5 | 5 magnitude bits), round to nearest even, as the kernel's p6_code."""
+    a = np.abs(y).astype(np.float32)
+    inv = np.where(a < 2, np.float32(8), np.where(a < 4, np.float32(4), np.float32(2))).astype(np.float32)
+    r = np.minimum(np.rint(a * inv) / inv, np.float32(7.5)).astype(np.float32)
+    c = np.where(r < 2, 8 * r, np.where(r < 4, 8 + 4 * r, 16 + 2 * r)).astype(np.uint32)
+    return c | np.where(y < 0, np.uint32(32), np.uint32(0))
+
+
+def _e2m3_value(c: np.ndarray) -> np.ndarray:
+    c = c.astype(np.int64)
+    ex, m = (c >> 3) & 3, c & 7
+    v = np.where(ex > 0, (1.0 + m / 8.0) * 2.0 ** (ex - 1), m / 8.0)
+    return np.where((c >> 5) & 1, -v, v)
+
+
+def _f6_scale_exp(m: np.ndarray) -> np.ndarray:
+    """E8M0 exponent s with max / 2^s <= 7.5, the kernel's p6_scale_exp in float32 (an all-zero block: -40)."""
+    m = m.astype(np.float32)
+    f, e = np.frexp((m * (np.float32(1.0) / np.float32(7.5))).astype(np.float32))
+    s = np.where(f > 0.5, e, e - 1).astype(np.int32)
+    s = np.where((m * np.exp2(-s.astype(np.float32))).astype(np.float32) > np.float32(7.5), s + 1, s)
+    return np.where(m > 0, np.maximum(s, -40), -40).astype(np.int32)
+
+
+def f16f6p_channels(v: int, hi: int) -> np.ndarray:
+    """the 32 channels of scale block (group v, lane half hi), element e = 8 m + i <-> channel 64 v + 16 m + 8 hi + i"""
+    return np.array([64 * v + 16 * m + 8 * hi + i for m in range(4) for i in range(8)])
+
+
+def f16f6p_encode(x: np.ndarray) -> np.ndarray:
+    """(n, 256) float32 L2-normalised rows -> (n, 1024) uint8 rows of fgvc_split_f16f6p."""
+    x = np.ascontiguousarray(x, np.float32)
+    n = x.shape[0]
+    xs = (x * np.float32(256.0)).astype(np.float32)
+    h = xs.astype(np.float16)
+    hf = h.astype(np.float32)
+    lf = ((xs - hf) * np.float32(256.0)).astype(np.float32)
+    rows = np.zeros((n, 1024), np.uint8)
+    rows[:, :512] = h.view(np.uint8).reshape(n, 512)
+    sh6 = (np.arange(32, dtype=np.uint64) * np.uint64(6))
+    for v in range(4):
+        for hi in range(2):
+            ch = f16f6p_channels(v, hi)
+            for vals, main, tail, sc in ((hf, 512, 640, 0), (lf, 704, 832, 4)):
+                b = vals[:, ch]
+                s = _f6_scale_exp(np.abs(b).max(1))
+                codes = _e2m3_codes((b * np.exp2(-s.astype(np.float32))[:, None]).astype(np.float32)).astype(np.uint64)
+                by = np.zeros((n, 24), np.uint8)                       # the 192-bit little-endian string, 64 bits (10 2/3 codes) at a time
+                for k in range(3):
+                    lo = np.zeros(n, np.uint64)
+                    for e in range(32):
+                        bit = 6 * e - 64 * k
+                        if -6 < bit < 64:
+                            lo |= (codes[:, e] << np.uint64(bit)) if bit >= 0 else (codes[:, e] >> np.uint64(-bit))
+                    by[:, 8 * k: 8 * k + 8] = lo.view(np.uint8).reshape(n, 8)
+                rows[:, main + 32 * v + 16 * hi: main + 32 * v + 16 * hi + 16] = by[:, :16]
+                t0 = tail + 32 * (v >> 1) + 16 * hi + 8 * (v & 1)
+                rows[:, t0: t0 + 8] = by[:, 16:]
+                rows[:, 896 + 16 * hi + sc + v] = (s + 123).astype(np.uint8)
+    return rows
+
+
+def f16f6p_decode(rows: np.ndarray):
+    """(n, 1024) uint8 rows -> (h, h6, l6) float64 (n, 256) in channel order: h = f16(256 x), h6 ~ h, l6 ~ 256 (256 x - h) as the
+    matrix instruction sees them (FP6 code x 2^s)."""
+    rows = np.ascontiguousarray(rows, np.uint8)
+    n = rows.shape[0]
+    h = rows[:, :512].copy().view(np.float16).astype(np.float64).reshape(n, 256)
+    h6, l6 = np.zeros((n, 256)), np.zeros((n, 256))
+    for v in range(4):
+        for hi in range(2):
+            ch = f16f6p_channels(v, hi)
+            for out, main, tail, sc in ((h6, 512, 640, 0), (l6, 704, 832, 4)):
+                t0 = tail + 32 * (v >> 1) + 16 * hi + 8 * (v & 1)
+                by = np.concatenate([rows[:, main + 32 * v + 16 * hi: main + 32 * v + 16 * hi + 16], rows[:, t0: t0 + 8]], 1)
+                w = np.ascontiguousarray(by).view(np.uint64).reshape(n, 3)
+                codes = np.zeros((n, 32), np.int64)
+                for e in range(32):
+                    k, bit = (6 * e) // 64, (6 * e) % 64
+                    c = w[:, k] >> np.uint64(bit)
+                    if bit > 58:
+                        c = c | (w[:, k + 1] << np.uint64(64 - bit))
+                    codes[:, e] = (c & np.uint64(63)).astype(np.int64)
+                s = rows[:, 896 + 16 * hi + sc + v].astype(np.int64) - 123
+                out[:, ch] = _e2m3_value(codes) * np.exp2(s.astype(np.float64))[:, None]
+    return h, h6, l6
+
+
+def f16f6_cosines(qrows: np.ndarray, krows: np.ndarray) -> np.ndarray:
+    """the cosines fgvc_pair_topk_f16f6 computes from two sets of rows, in float64: (nk, nq)"""
+    hq, h6q, l6q = f16f6p_decode(qrows)
+    hk, h6k, l6k = f16f6p_decode(krows)
+    return (hk @ hq.T + (h6k @ l6q.T + l6k @ h6q.T) / 256.0) / 65536.0
+
+
+# ----------------------------------------------------------------------------
 # tolerance-aware comparison of a top-k result against a dense score slab
 # ----------------------------------------------------------------------------
 def check_topk(dense: torch.Tensor, idx: torch.Tensor, score: torch.Tensor, k: int,

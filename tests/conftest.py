@@ -49,6 +49,14 @@ def pytest_sessionstart(session):
         TWO_RANKS["cfg4"] = dict(rc=r.returncode, out=r.stdout[-6000:], err=r.stderr[-3000:])
     except Exception as e:
         TWO_RANKS["cfg4"] = dict(rc=-1, out="", err=repr(e))
+    try:   # `python bench.py --gpus 2` on its own, with a clean environment: the bench starts its two ranks itself
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                                                                 "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "5", "--warmup", "2",
+                            "--repeats", "0", "--no-corr-volume", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+        TWO_RANKS["bench2"] = dict(rc=r.returncode, out=r.stdout[-12000:], err=r.stderr[-3000:])
+    except Exception as e:
+        TWO_RANKS["bench2"] = dict(rc=-1, out="", err=repr(e))
     try:   # four ranks (the two middle ones both send and receive a halo in one message batch), 26 frames, the full five-frame halo
         r = subprocess.run([sys.executable, tool, "--world", "4", "--frames", "26", "--precede", "5", "--halos", "exchange", "--tail-stream"],
                            capture_output=True, text=True, timeout=900)

@@ -412,6 +412,25 @@ def test_badja_adapter_end_to_end(dev, tmp_path):
     assert pck["PCK@0.2"] > 80.0 and pck["PCK@0.1"] <= pck["PCK@0.2"] <= pck["PCK@0.4"], pck
 
 
+def test_bench_launches_its_own_ranks(dev, two_ranks):
+    """`python bench.py --gpus 2 --rehearse-on-one-gpu --steps 5` with NO launcher and a clean environment (started by conftest before this
+    process touched the GPU): the parent starts two fresh rank processes (torch.distributed.run on 127.0.0.1), relays rank 0's one
+    JSON line and exits 0; the line says what the communication library saw."""
+    import json
+    b = two_ranks.get("bench2")
+    assert b, "the session-start hook did not run (is this a `-m gpu` session?)"
+    assert b["rc"] == 0, (b["out"][-2000:], b["err"][-3000:])
+    lines = [l for l in b["out"].splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                     # ONE line, from rank 0
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["value"] > 0 and res["scaling"] == "weak"
+    d = res["distributed"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert "rehearsal" in res and sum(res["config"]["query_frames_per_rank"]) == 15      # a 16-frame video: frame 0 + 15 query frames over two ranks
+    c = res["comm_bytes_per_step_rank0"]
+    assert c["broadcast"] == c["expected"]["broadcast"] > 0
+
+
 def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
     """World size 2 with the PRODUCT backend: tools/two_ranks_one_gpu.py (started by conftest before this process touched the
     GPU) runs fgvc_amd.dist.track_points_sharded(HipBackend) in two processes on this GPU -- over gloo with host staging, RCCL

@@ -370,12 +370,25 @@ def test_split_feature_bank_equals_f32_bank(dev):
     bank_f, Hf2, Wf2 = model.get_feats_hwc(frames)
     assert bank_s.dtype == torch.int16 and bank_s.shape == (5, Hf * Wf, 2, 256) and (Hf, Wf) == (Hf2, Wf2) == (16, 24)
     cfg = model.engine_config()
-    assert cfg.pair_split_fmt == "f16"
-    assert torch.equal(ops.split_f16x2(bank_f), bank_s)                 # the hand-written trunk is deterministic call to call
+    assert cfg.pair_split_fmt == "f16f6"                               # an f16f8 trunk goes with the f16 + FP6 pair kernel (round 4)
+    assert torch.equal(ops.normalize_nhwc(y, True, split="f16f6"), ops.split_f16f6p(f))    # ... whose rows the same single pass writes
+    assert float((ops.unsplit_f16f6p(ops.split_f16f6p(f)) - f).abs().max()) < 2.0 ** -12  # (their h part: 11 bits of 256 x, |x| <= 1)
+    assert torch.equal(ops.split_f16f6p(bank_f), bank_s)                # the hand-written trunk is deterministic call to call
     plan = engine.plan_clip(5, [0], cfg)
     a = engine.run_affinity(bank_s, Hf, Wf, plan, cfg)
     b = engine.run_affinity(bank_f, Hf, Wf, plan, cfg)                  # f32 form: split inside
     assert torch.equal(a.idx, b.idx) and torch.equal(a.weight, b.weight)
+    # the 1e-7-grade form on request (and by itself under any other arithmetic of the trunk): same lists wherever the float64 ranks are clear
+    model.test_cfg["pair_split_fmt"] = "f16"
+    cfg3 = model.engine_config()
+    bank_3 = model.get_feats_hwc(frames, split=True)[0]
+    assert cfg3.pair_split_fmt == "f16" and torch.equal(ops.split_f16x2(bank_f), bank_3)
+    a3 = engine.run_affinity(bank_3, Hf, Wf, plan, cfg3)
+    assert float((a3.logit - a.logit).abs().max()) < 2e-4 and float((a3.idx == a.idx).all(-1).float().mean()) > 0.97
+    del model.test_cfg["pair_split_fmt"]
+    model.backbone.set_arith("f16x3")
+    assert model.engine_config().pair_split_fmt == "f16"
+    model.backbone.set_arith("f16f8")
     cfg32 = engine.TrackerConfig(**{**cfg.__dict__, "pair_precision": "f32"})
     with pytest.raises(ValueError):
         engine.run_affinity(bank_s, Hf, Wf, plan, cfg32)
@@ -383,7 +396,7 @@ def test_split_feature_bank_equals_f32_bank(dev):
     model.test_cfg["pair_split_fmt"] = "bf16"
     with pytest.raises(ValueError):
         engine.run_affinity(bank_f, Hf, Wf, plan, model.engine_config())
-    model.test_cfg["pair_split_fmt"] = "f16"
+    del model.test_cfg["pair_split_fmt"]
     assert not ops.pair_f16x3_timed_out()
 
 
@@ -1273,6 +1286,61 @@ def test_encoder_hip_graph_replay(dev):
             assert torch.equal(f, want[0])
         finally:
             ResNet.use_graph = False
+    assert not net.check_overflow()
+
+
+@pytest.mark.gpu
+def test_encoder_hip_graph_in_the_tracker_and_invalidation(dev):
+    """(i) a replayed graph writes ONE static output; VanillaTracker.get_feats_hwc keeps the chunks of a clip in a list and
+    concatenates at the end, so with T > 2 batch_step every full chunk must come back as its own tensor (from the second video on, when
+    the chunk shape replays); (ii) a graph bakes in the calibrated scales and the addresses of its shape's workspaces: calibrate(),
+    an overflow and the eviction of the shape's workspaces must drop it."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    torch.manual_seed(31)
+    test_cfg = api.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512, with_first=True,
+                              with_first_neighbor=True, batch_step=3)
+    model = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                                                      pool_type="none", zero_init_residual=False)),
+                            train_cfg=None, test_cfg=test_cfg).to(dev).eval()
+    net = model.backbone
+    vids = [torch.randn(8, 3, 64, 96, device=dev) for _ in range(3)]          # 8 frames at batch_step 3: chunks of 3, 3, 2
+    with torch.no_grad():
+        want = [model.get_feats_hwc(v, split=True)[0].clone() for v in vids]
+        try:
+            ResNet.use_graph = True
+            for rnd in range(2):                                               # round 0 warms / captures, round 1 replays every full chunk
+                for v, w in zip(vids, want):
+                    got = model.get_feats_hwc(v, split=True)[0]
+                    assert torch.equal(got, w), f"round {rnd}: a chunk was overwritten by a later replay"
+            graphs = lambda: [k for k, e in net.__dict__["_split_cache"].items() if isinstance(k, tuple) and k and k[0] == "graph" and isinstance(e, tuple)]
+            assert len(graphs()) >= 1
+            # (ii-a) calibrate() changes the scales the kernels take as arguments: the graphs go
+            net.calibrate(vids[0][:3])
+            assert not graphs()
+            for v, w in zip(vids[:2], want[:2]):
+                assert torch.equal(model.get_feats_hwc(v, split=True)[0], w)
+            assert graphs()
+            # (ii-b) an overflow drops the scales AND the graphs (the retry must not replay the old ones)
+            ovf = [e for k, e in net.__dict__["_split_cache"].items() if isinstance(k, tuple) and k and k[0] == "overflow"]
+            assert ovf
+            ovf[0].fill_(1)
+            assert net.check_overflow() and not graphs()
+            for v, w in zip(vids[:2], want[:2]):
+                assert torch.equal(model.get_feats_hwc(v, split=True)[0], w)
+            assert graphs()
+            # (ii-c) more input shapes than max_workspace_shapes: the evicted shape's graph goes with its workspaces, and the shape still
+            # computes the same features when it comes back
+            g0 = set(graphs())
+            for hw in ((48, 64), (40, 72), (56, 56)):
+                for _ in range(2):
+                    net.forward_hwc(torch.randn(3, 3, *hw, device=dev), True, split_if=lambda C, H, W: True, split_fmt="f16")
+            assert not (g0 & set(graphs()))
+            for v, w in zip(vids, want):
+                assert torch.equal(model.get_feats_hwc(v, split=True)[0], w)
+        finally:
+            ResNet.use_graph = False
+    torch.cuda.synchronize()
     assert not net.check_overflow()
 
 

@@ -277,3 +277,36 @@ def test_l2_distance_and_dense_softmax_branches(golden):
                      ("out_cos", dict(neighbor_range=nr, mode="cosine")), ("out_l2", dict(neighbor_range=nr, sim_mode="l2-distance"))):
         out = O.masked_attention_efficient(q, k, v, temperature=0.07, topk=None, **kw)
         assert torch.allclose(out, T(g[name]), atol=1e-5, rtol=1e-5), name
+
+
+def test_f16f6p_format_model_known_answers():
+    """The checker's restatement of the product's fgvc_split_f16f6p rows (oracle.f16f6p_encode / _decode / f16f6_cosines), on values
+    worked out by hand: a one-hot row, an all-zero row, a block scale at its boundary -- and its error against float64 on Gaussian,
+    sparse and heavy-tailed rows (the bound the GPU kernel is held to: 1e-3 logit at tau 0.07)."""
+    import numpy as np
+    x = np.zeros((3, 256), np.float32)
+    x[0, 70] = 1.0                       # channel 70 = group 1, m = 0, hi = 0, i = 6 -> element 6 of block (1, 0)
+    x[2, :] = 1.0 / 16.0                 # |x| = 1: h = 16 everywhere; 16 / 2^2 = 4 -> code 24, scale byte 2 + 123
+    rows = O.f16f6p_encode(x)
+    assert rows.shape == (3, 1024) and not rows[1, :896].any()
+    assert rows[1, 896:904].tolist() == [83] * 8 and rows[1, 912:920].tolist() == [83] * 8          # zero blocks: 2^(-40 - 4)
+    h = rows[0, :512].view(np.float16)
+    assert h[70] == 256.0 and np.count_nonzero(h) == 1
+    # 256 / 2^6 = 4.0 -> e2m3 code 8 + 4 * 4 = 24 in element 6 (bits 36..41) of the piece of (v = 1, hi = 0); scale byte 6 + 123
+    piece = rows[0, 512 + 32: 512 + 32 + 16]
+    assert int.from_bytes(bytes(piece.tolist()), "little") == 24 << 36 and rows[0, 896 + 1] == 129
+    assert rows[0, 640:704].sum() == 0 and rows[0, 704:896].sum() == 0                                  # residual 0
+    assert (rows[2, 896:900] == 125).all() and (rows[2, 912:916] == 125).all()
+    hh, h6, l6 = O.f16f6p_decode(rows)
+    assert hh[0, 70] == 256.0 and h6[0, 70] == 256.0 and np.abs(h6[2] - 16.0).max() == 0 and np.abs(l6).max() == 0
+    # every channel belongs to exactly one scale block
+    chans = np.concatenate([O.f16f6p_channels(v, hi) for v in range(4) for hi in range(2)])
+    assert sorted(chans.tolist()) == list(range(256))
+    rng = np.random.default_rng(4)
+    fam = {"gauss": rng.standard_normal((600, 256)), "sparse": rng.standard_normal((600, 256)) * (rng.random((600, 256)) < 0.05) + 1e-4,
+           "heavy": rng.standard_t(1.5, (600, 256)), "relu": np.maximum(rng.standard_normal((600, 256)), 0)}
+    for name, a in fam.items():
+        a = (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+        r = O.f16f6p_encode(a)
+        err = np.abs(O.f16f6_cosines(r[:300], r[300:]) - a[300:].astype(np.float64) @ a[:300].astype(np.float64).T).max() / 0.07
+        assert err < (1.5e-4 if name in ("gauss", "relu") else 1e-3), (name, err)
