@@ -127,10 +127,12 @@ __device__ __forceinline__ i32x6 v7_cat6(const i32x4v& a, const i32x2v& b) { ret
 // waves 0-3 consumers, 4-7 selectors, 8-11 producers (one of each per SIMD), as in pair_topk_kernel_v6
 template <int K, bool PROBE>
 __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
-  constexpr int LDB = P6_ROWB + 16;              // padded LDS row of one pixel -> conflict-free b128 reads by lanes (n, hi)
+  constexpr int LDB = P6_END + 16;               // LDS row of one pixel: the 928 bytes that carry something + 16 -> 236 dwords = 44 mod 64:
+                                                 // conflict-free b128 reads by lanes (n, hi); the zero tail of a row is neither copied nor stored
   constexpr int BUFB = 32 * LDB;
   constexpr int NSLOT = 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * BUFB];
+  __shared__ __attribute__((aligned(16))) unsigned char q6h_lds[4][6144];   // per consumer: its queries' h6 pieces, [v][lane] 16 B mains, then [v][lane] 8 B tails
   __shared__ uint32_t blist[V7_MAX_BLOCKS];      // by | bx << 12 | (query blocks that reach it) << 24
   __shared__ __attribute__((aligned(16))) unsigned int hand[4][16 * 64];   // consumer -> selector: a tile's keys, register-major per 16-byte piece
   __shared__ int hand_full[4], hand_free[4];
@@ -167,14 +169,17 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
   const int qy = QY0 + (n >> 3), qx = QX0 + (n & 7);
 
   // ---- prologue 1: the query rows of the four blocks through the ring (coalesced 1 KiB rows by LDS-DMA)
-  if (role < 2) {
+  if (role < 2 && lane < P6_END / 16) {
     const unsigned char* qbase = reinterpret_cast<const unsigned char*>(p.q_hl) + (size_t)qf * p.Hq * p.Wq * P6_ROWB + 16 * lane;
+    i32x4v qr[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = role * 16 + i;
       const int y = imin(QY0 + (r >> 3), p.Hq - 1), x = imin(QX0 + (r & 7), p.Wq - 1);
-      lds_dma_16(qbase + ((size_t)y * p.Wq + x) * P6_ROWB, &smem[qb * BUFB + r * LDB]);
+      qr[i] = *reinterpret_cast<const i32x4v*>(qbase + ((size_t)y * p.Wq + x) * P6_ROWB);
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<i32x4v*>(&smem[qb * BUFB + (role * 16 + i) * LDB + 16 * lane]) = qr[i];
   }
   // ---- prologue 2 (overlaps the DMA): the key blocks this super-tile visits, row-major (debug & 8192: alternating from both ends)
   if (wave == 0) {
@@ -233,42 +238,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     const int n_total = g_count * n_steps;
     int cur_pair = -1;
     const unsigned char* kbase = nullptr;
-    auto stage = [&](int G) {
-      const int pi = G / n_steps, e = G - pi * n_steps;
-      if (pi != cur_pair) {
-        cur_pair = pi;
-        const int kf = p.pairs[g_start + pi].y;
-        kbase = reinterpret_cast<const unsigned char*>(p.k_hl) + (size_t)kf * p.Hk * p.Wk * P6_ROWB;
-      }
-      const uint32_t ent = __builtin_amdgcn_readfirstlane(blist[e]);
-      const int sby = ent & 0xfff, sbx = (ent >> 12) & 0xfff;
-      const int ky = imin(sby * QBH + qb, p.Hk - 1), kx0 = sbx * QBW;
-      const unsigned char* src = kbase + ((size_t)ky * p.Wk + kx0) * P6_ROWB + lane16;
-      const int xmax = p.Wk - 1 - kx0;
-      unsigned char* dst = &smem[(G & (NSLOT - 1)) * BUFB + (qb * 8) * LDB];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) lds_dma_16(src + (size_t)imin(i, xmax) * P6_ROWB, dst + i * LDB);
-    };
-    if (p.debug & 32768) {                                             // A/B: the ring filled by LDS-DMA, two blocks in flight (the f16x3 kernel's producer)
-      if (n_total > 0) {
-        stage(0);
-        for (int G = 0; G < n_total; ++G) {
-          if (G + 1 < n_total) {
-            const int s1 = (G + 1) & (NSLOT - 1), gen1 = (G + 1) / NSLOT;
-            if (gen1 > 0) spin_ge<6, false>(&done[s1], 4 * gen1, dead, &wg_dead);
-            asm volatile("" ::: "memory");
-            stage(G + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // block G landed, block G + 1 in flight
-          } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          if (lane == 0) __hip_atomic_fetch_add(&filled[G & (NSLOT - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      if (dead) g_pair_v5_timeout = 1;
-      return;
-    }
-    // Default: key rows through the producer's REGISTERS (global_load_dwordx4 -> ds_write_b128), PD blocks in flight.  Measured on the
+    // Key rows through the producer's REGISTERS (global_load_dwordx4 -> ds_write_b128), PD blocks in flight (LDS-DMA, the f16x3 kernel's way, was measured beside it: the same launch time).  Measured on the
     // f16x3 kernel's ring (profiles/r04_pair_ring.log): a CU takes in one 1-KiB LDS-DMA instruction per ~33 cycles whatever the four
     // producer waves do -- 0.63 ms for this launch's 317 520 key blocks even with every row an L2 hit and half its bytes masked off, 0.88
     // as it is -- while the vector-memory path delivers 64 B per cycle and CU, twice that, and a producer wave owns 168 registers it has
@@ -289,6 +259,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
       const int ky = imin(sby * QBH + qb, p.Hk - 1), kx0 = sbx * QBW;
       const unsigned char* src = kbase + ((size_t)ky * p.Wk + kx0) * P6_ROWB;
       const int xmax = p.Wk - 1 - kx0;
+      if ((p.debug & 1) || lane >= P6_END / 16) return;                  // (1: ablation, results wrong: the ring's counters only, no bytes moved)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const unsigned char* rowp = src + (size_t)imin(i, xmax) * P6_ROWB;     // wave-uniform: scalar base + one lane-offset register
@@ -298,11 +269,13 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     const uint32_t dst_lane = lds_addr_of(smem) + (uint32_t)((qb * 8) * LDB) + lane16;
     auto commit = [&](int G, i32x4v (&r)[8]) {
       const int slot = G & (NSLOT - 1), gen = G / NSLOT;
-      if (gen > 0) spin_ge<4, false>(&done[slot], 4 * gen, dead, &wg_dead);     // block G - NSLOT released by all four consumers
+      if (gen > 0) spin_ge<1, false>(&done[slot], 4 * gen, dead, &wg_dead);     // block G - NSLOT released by all four consumers
       asm volatile("" ::: "memory");
       const uint32_t dst = dst_lane + (uint32_t)(slot * BUFB);
+      if ((p.debug & 1) == 0 && lane < P6_END / 16) {                    // 58 lanes x 16 B = the 928 bytes of a row that carry something
 #pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(dst), "v"(r[i]), "n"(i * LDB) : "memory");
+        for (int i = 0; i < 8; ++i) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(dst), "v"(r[i]), "n"(i * LDB) : "memory");
+      }
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(&filled[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -337,7 +310,6 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     f16x32 qh4[4];
     i32x6 q6l[4];
     int sqH, sqL;
-    float qsc[4];                                  // (bisection build only: tools/gen_pair_v7.py V7_GEN_DBG=qscres)
     {
       const unsigned char* qp = &smem[qb * BUFB + n * LDB + 16 * hi];
 #pragma unroll
@@ -354,8 +326,17 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
       const i32x2v sc = *reinterpret_cast<const i32x2v*>(qp + P6_SC);
       sqH = sc[0];
       sqL = sc[1];
+    }
+    // the queries' own h6 pieces: the same for every tile.  Made once (v_cvt_scalef32_pk32_fp6_f16: 2^sh = (scale byte + 4) << 23 as a
+    // float) and parked in this consumer's 6 KiB of LDS -- mains [v][lane] 16 B, tails [v][lane] 8 B: contiguous, conflict-free
+    const uint32_t a_q6h = lds_addr_of(&q6h_lds[qb][16 * lane]), a_q6t = lds_addr_of(&q6h_lds[qb][4096 + 8 * lane]);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) qsc[v] = __builtin_bit_cast(float, (((sqH >> (8 * v)) & 255) + 4) << 23);
+    for (int v = 0; v < 4; ++v) {
+      u32x6 h6;
+      const unsigned int sc_bits = (unsigned int)(((sqH >> (8 * v)) & 255) + 4) << 23;
+      asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(h6) : "v"(qh4[v]), "v"(sc_bits));      // (early-clobber: the result must not land on the scale)
+      *reinterpret_cast<i32x4v*>(&q6h_lds[qb][1024 * v + 16 * lane]) = i32x4v{(int)h6[0], (int)h6[1], (int)h6[2], (int)h6[3]};
+      *reinterpret_cast<i32x2v*>(&q6h_lds[qb][4096 + 512 * v + 8 * lane]) = i32x2v{(int)h6[4], (int)h6[5]};
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -372,75 +353,60 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     const uint32_t lane_off = (uint32_t)(n * LDB + 16 * hi);
     const uint32_t smem_l = lds_addr_of(smem);
     const uint32_t a_hand_free = lds_addr_of(&hand_free[qb]);
-    const unsigned int c_exp4 = 4u << 23;
-    // The loop is skewed by one tile: a tile's scores stay in `acc` until the NEXT tile's first operand reads have been issued, and
-    // are handed over (conversion to keys, four LDS stores, the count) while those reads are in flight -- the read latency at the
-    // head of a chain and the hand-over's own work cover each other.  The counters a tile needs afterwards (has the selector read
-    // the previous tile, has the next key block landed) are asked for inside its chain.
-    int pend_e = -1;                               // list position of the tile waiting in `acc` (-1: none)
-    // debug & 256: s_memtime stamps of workgroup (100, 5): per consumer its loop cycles, cycles waiting for key blocks, in hand-overs
-    // (of which waiting for the selector), in chains, tiles (tools/experiments/time_pair_v7.py)
-    const bool probe = PROBE && blockIdx.x == 100 && blockIdx.y == 5;       // (a template parameter: the stamps cost registers the chain has not got)
+    // The consumer's stream is CONTINUOUS over the tiles of a run (round 4; measured before: a chain of 16 MFMAs took 1 150 cycles
+    // whatever the depth of its fragment ring -- 576 for the MFMAs, the rest an LDS round trip at its head and a drain at its end).
+    // Which list entries this consumer computes is a 64-bit mask in scalar registers; inside a tile's chain (after the last read of
+    // its key block) the NEXT tile is found, its key block waited for -- blocks land in list order, so it covers the entries skipped in
+    // between, which are released on the spot -- and the chain's last quarter issues the next tile's first reads into the registers its
+    // own last MFMAs have just consumed.  Between two chains only the hand-over remains (scores -> keys in place, four LDS stores).
+    unsigned long long comp_mask = __ballot(lane < n_steps && ((blist[imin(lane, V7_MAX_BLOCKS - 1)] >> (24 + qb)) & 1u) != 0u);
+    const int n_total = g_count * n_steps;
+    auto next_comp = [&](int G) -> int {           // first list position >= G (over the run) that this consumer computes; n_total: none
+      if (comp_mask == 0ull) return n_total;
+      while (G < n_total) {
+        const int pi = G / n_steps, e = G - pi * n_steps;
+        const unsigned long long m = comp_mask >> e;
+        if (m) return G + __builtin_ctzll(m);
+        G = (pi + 1) * n_steps;
+      }
+      return n_total;
+    };
+    auto wait_block = [&](int G) { spin_ge<1, false>(&filled[G & (NSLOT - 1)], 4 * (G / NSLOT + 1), dead, &wg_dead); };
+    // Entries [G0, G1) are not this consumer's: release each once it has landed (a release must never be sent for a block that is not
+    // staged yet: the counters are per slot, pair_topk_kernel_v5).  Blocks land in list order -- every producer wave stores its rows of
+    // block G before those of G + 1 -- so waiting for the last of up to NSLOT entries covers the group; never further ahead than that:
+    // the producers cannot stage block G + NSLOT before THIS consumer has released block G.
+    auto skip = [&](int G0, int G1) {
+      for (int g = G0; g < G1;) {
+        const int h = imin(g + NSLOT - 1, G1 - 1);
+        wait_block(h);
+        for (int G = g; G <= h; ++G)
+          if (lane == 0) __hip_atomic_fetch_add(&done[G & (NSLOT - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        g = h + 1;
+      }
+    };
+    const bool probe = PROBE && blockIdx.x == 100 && blockIdx.y == 5;       // debug & 256: s_memtime stamps (tools/experiments/time_pair_v7.py)
     long long pr_wait = 0, pr_hand = 0, pr_hwait = 0, pr_chain = 0, pr_t0 = probe ? __builtin_amdgcn_s_memtime() : 0;
     int pr_tiles = 0, pr_slow = 0;
-    int pfree = 0, fnext = -1;
-    auto hand_over = [&]() {
-      const long long h0 = probe ? __builtin_amdgcn_s_memtime() : 0;
-      if (pfree < t_con) {
-        spin_ge<2, false>(&hand_free[qb], t_con, dead, &wg_dead);      // the selector has read the tile before
-        if (probe) { pr_hwait += __builtin_amdgcn_s_memtime() - h0; ++pr_slow; }
-      }
-      asm volatile("" ::: "memory");
-      const unsigned int tag0 = ((unsigned int)(63 - pend_e) << 4) | 15u;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        uint4 kv;
-        kv.x = (__builtin_bit_cast(unsigned int, acc[4 * g4 + 0] + V7_BIAS) << 10) | (tag0 - (4 * g4 + 0));
-        kv.y = (__builtin_bit_cast(unsigned int, acc[4 * g4 + 1] + V7_BIAS) << 10) | (tag0 - (4 * g4 + 1));
-        kv.z = (__builtin_bit_cast(unsigned int, acc[4 * g4 + 2] + V7_BIAS) << 10) | (tag0 - (4 * g4 + 2));
-        kv.w = (__builtin_bit_cast(unsigned int, acc[4 * g4 + 3] + V7_BIAS) << 10) | (tag0 - (4 * g4 + 3));
-        *reinterpret_cast<uint4*>(hw + g4 * 256) = kv;
-      }
-      asm volatile("" ::: "memory");                 // the LDS executes a wave's operations in order: the count follows the data
-      if (lane == 0) __hip_atomic_fetch_add(&hand_full[qb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      ++t_con;
-      pend_e = -1;
-      if (probe) pr_hand += __builtin_amdgcn_s_memtime() - h0;
-    };
-    for (int pi = 0; pi < g_count; ++pi) {
-      for (int e = 0; e < n_loop; ++e) {
-        const uint32_t ent = __builtin_amdgcn_readfirstlane(blist[e]);
-        const int G = pi * n_steps + e;
-        const int slot = G & (NSLOT - 1), gen = G / NSLOT;
-        const bool comp = ((ent >> (24 + qb)) & 1) != 0;
-        // block G has landed; a consumer that does not reach it waits for this too before it releases the slot (pair_topk_kernel_v5)
-        // (after a chain the counter has been asked for inside it: normally the block is there and nothing is waited for)
-        if (fnext < 4 * (gen + 1)) {
-          const long long w0 = probe ? __builtin_amdgcn_s_memtime() : 0;
-          spin_ge<2, false>(&filled[slot], 4 * (gen + 1), dead, &wg_dead);
-          if (probe) pr_wait += __builtin_amdgcn_s_memtime() - w0;
-        }
-        fnext = -1;
-        asm volatile("" ::: "memory");
-        if (!comp) {
-          if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          continue;
-        }
-        const uint32_t ka_l = smem_l + (uint32_t)(slot * BUFB) + lane_off;
-        const uint32_t a_next_filled = lds_addr_of(&filled[(G + 1) & (NSLOT - 1)]);
-        f16x8 ah[12];                                   // (the generated chain uses the first RING of them)
-        i32x4v xm, ym;
-        i32x2v xt, yt, ksc;
-        u32x6 q6h;
-        int peek_free, peek_fill;
-        unsigned int qsc_t;                            // 2^sh of the query's h6 block of a group, as float bits: (scale byte + 4) << 23
-        // what the compiler's own LDS traffic of this iteration (blist, the counters) has outstanding is waited for here: the
-        // hand-counted waits of the chain only count the chain's own reads
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int G_cur = next_comp(0);
+    skip(0, G_cur);
+    if (G_cur < n_total) {
+      wait_block(G_cur);
+      uint32_t ka_l = smem_l + (uint32_t)((G_cur & (NSLOT - 1)) * BUFB) + lane_off, ka_n = ka_l;
+      f16x8 ah[4];
+      i32x4v xm, ym, qm;
+      i32x2v xt, yt, qt, ksc;
+      int peek_free, peek_fill;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the hand-counted waits below count the stream's own reads only)
 #define FGVC_V7_PART 1
 #include "pair_v7.inc"
 #undef FGVC_V7_PART
-        if (pend_e >= 0) hand_over();                  // the tile before this one, under the reads just issued
+      for (;;) {
+        const int slot = G_cur & (NSLOT - 1);
+        // the next tile: pure scalar arithmetic on the mask; the counter of its key block is asked for inside the chain
+        const int G_next = next_comp(G_cur + 1);
+        const int G_peek = imin(G_next, n_total - 1);
+        const uint32_t a_next_filled = lds_addr_of(&filled[G_peek & (NSLOT - 1)]);
         const long long c0 = probe ? __builtin_amdgcn_s_memtime() : 0;
 #define V7_RELEASE()                                                                                                         \
   do {                                                                                                                       \
@@ -448,19 +414,61 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                  \
     asm volatile("" ::: "memory");                                                                                           \
   } while (0)
+#define V7_LOOKAHEAD()                                                                                                       \
+  do {                                                                                                                       \
+    /* fast path: the block asked about has landed (so have the entries skipped before it: blocks land in list order) and   \
+       is within NSLOT of this one (the producers did not need any of the skipped entries released to stage it) */           \
+    if (G_peek - G_cur <= NSLOT && __builtin_amdgcn_readfirstlane(peek_fill) >= 4 * (G_peek / NSLOT + 1)) {                  \
+      for (int G = G_cur + 1; G < G_next; ++G)                                                                               \
+        if (lane == 0) __hip_atomic_fetch_add(&done[G & (NSLOT - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
+    } else {                                                                                                                 \
+      const long long w0 = probe ? __builtin_amdgcn_s_memtime() : 0;                                                         \
+      skip(G_cur + 1, G_next);                                                                                               \
+      if (G_next < n_total) wait_block(G_next);                                                                              \
+      if (probe) { pr_wait += __builtin_amdgcn_s_memtime() - w0; ++pr_slow; }                                                \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* (the compiler's own LDS reads above, not counted below) */     \
+    }                                                                                                                        \
+    ka_n = G_next < n_total ? smem_l + (uint32_t)((G_next & (NSLOT - 1)) * BUFB) + lane_off : ka_l;                          \
+  } while (0)
 #define FGVC_V7_PART 3
 #include "pair_v7.inc"
 #undef FGVC_V7_PART
 #undef V7_RELEASE
+#undef V7_LOOKAHEAD
+#define FGVC_V7_PART 5
+#include "pair_v7.inc"
+#undef FGVC_V7_PART
         // MFMA result -> vector read: the last MFMA's passes must have written back
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc), "+v"(peek_free), "+v"(peek_fill));
-        pfree = __builtin_amdgcn_readfirstlane(peek_free);
-        fnext = __builtin_amdgcn_readfirstlane(peek_fill);
-        pend_e = e;
         if (probe) { pr_chain += __builtin_amdgcn_s_memtime() - c0; ++pr_tiles; }
+        // ---- hand the tile over (the next tile's first reads are in flight): scores -> keys, four stores, the count
+        {
+          const long long h0 = probe ? __builtin_amdgcn_s_memtime() : 0;
+          if ((p.debug & 2) == 0) {                // (2: ablation, results wrong: nothing handed over, the selectors have gone home)
+            if (__builtin_amdgcn_readfirstlane(peek_free) < t_con) {
+              spin_ge<1, false>(&hand_free[qb], t_con, dead, &wg_dead);      // the selector has read the tile before
+              if (probe) { pr_hwait += __builtin_amdgcn_s_memtime() - h0; ++pr_slow; }
+            }
+            asm volatile("" ::: "memory");
+            // the raw accumulators: the selector (whose vector unit has the slack) turns them into keys
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+              *reinterpret_cast<f32x4*>(hw + g4 * 256) = f32x4{acc[4 * g4 + 0], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]};
+            asm volatile("" ::: "memory");           // the LDS executes a wave's operations in order: the count follows the data
+            if (lane == 0) __hip_atomic_fetch_add(&hand_full[qb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++t_con;
+          }
+          if (probe) pr_hand += __builtin_amdgcn_s_memtime() - h0;
+        }
+#define FGVC_V7_PART 4
+#include "pair_v7.inc"
+#undef FGVC_V7_PART
+        if (G_next >= n_total) break;
+        G_cur = G_next;
+        ka_l = ka_n;
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the last tile's look-ahead reads: nobody's operands)
     }
-    if (pend_e >= 0) hand_over();
     if (probe && lane == 0) {
       long long* o = &g_pair_v5_probe[8 * qb];
       o[0] = __builtin_amdgcn_s_memtime() - pr_t0; o[1] = pr_wait; o[2] = pr_hand; o[3] = pr_hwait; o[4] = pr_chain; o[5] = pr_tiles; o[6] = pr_slow; o[7] = n_steps;
@@ -471,6 +479,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
 
   // =============================================== selector of query block qb ===============================================
   __syncthreads();                                 // (the consumers read their query operands)
+  if (p.debug & 2) return;
   unsigned int lk[K];                              // running list, ASCENDING: lk[0] = K-th best ... lk[K-1] = best; 0 = empty
   unsigned int ck[16];
   int v_dy0 = 0, v_dx0 = 0;
@@ -496,14 +505,20 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     for (int e = 0; e < n_loop; ++e) {
       const uint32_t ent = __builtin_amdgcn_readfirstlane(blist[e]);
       if (((ent >> (24 + qb)) & 1) == 0) continue;   // not a tile of this query block
-      spin_ge<2, false>(&hand_full[qb], t_sel + 1, dead, &wg_dead);
+      spin_ge<1, false>(&hand_full[qb], t_sel + 1, dead, &wg_dead);
       asm volatile("" ::: "memory");
+      float sc_[16];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const uint4 kv = *reinterpret_cast<const uint4*>(hr + g4 * 256);
-        ck[4 * g4 + 0] = kv.x; ck[4 * g4 + 1] = kv.y; ck[4 * g4 + 2] = kv.z; ck[4 * g4 + 3] = kv.w;
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(hr + g4 * 256);
+        sc_[4 * g4 + 0] = kv.x; sc_[4 * g4 + 1] = kv.y; sc_[4 * g4 + 2] = kv.z; sc_[4 * g4 + 3] = kv.w;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {   // scores -> keys: (bits(acc + 2^19 + 2^17) << 10) | (63 - list position) << 4 | (15 - register)
+        const unsigned int tag0 = ((unsigned int)(63 - e) << 4) | 15u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ck[r] = (__builtin_bit_cast(unsigned int, sc_[r] + V7_BIAS) << 10) | (tag0 - r);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(ck[r]));
       if (lane == 0) __hip_atomic_fetch_add(&hand_free[qb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -12,7 +12,7 @@ plan = engine.plan_clip(T, [0], cfg)
 pairs = ops.make_pairs(plan.pairs, dev)
 f6 = lambda: ops.pair_topk_split(sp6, sp6, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16f6")
 buf = (ctypes.c_int64 * 32)()
-for extra, name in ((0, "default"), (2048, "selector only receives"), (32768, "LDS-DMA producers"), (2048 + 32768, "both")):
+for extra, name in ((0, "default"), (1, "producers move nothing"), (2, "no hand-over, no selectors"), (3, "consumers alone"), (2048, "selector only receives"), (8192, "alternating list")):
     ops.set_option("pair_f16_debug", 256 + extra)
     for _ in range(3):
         f6()

@@ -30,20 +30,27 @@ OFF_H6T = 640        # h6 tails: groups 2 w, 2 w + 1 at + 32 w (+ 8 for the odd 
 OFF_L6M = 704
 OFF_L6T = 832
 OFF_SC = 896         # 8 B per lane half: scale bytes H(v = 0..3), L(v = 0..3)
-RING = int(os.environ.get("V7_GEN_RING", "4"))             # key fragments in flight
-DBG = set(os.environ.get("V7_GEN_DBG", "").split(","))     # bisection toggles: f0early, qscres, nopeek, headall
+RING = int(os.environ.get("V7_GEN_RING", "4"))             # key fragments in flight (divides 16: the ring continues from one tile into the next; 8: micro-benchmarks only)
+
+
+MICRO = set(os.environ.get("V7_GEN_MICRO", "").split(","))   # timing-only toggles for tools/micro/pair_v7_stream.hip: nowait, nocvt, nop6
+HEAD = (["A0", "A1", "HM0", "HT0", "A2", "A3", "LM0", "LT0", "QM0", "QT0", "SC"] if RING == 4 else
+        ["A0", "A1", "A2", "A3", "A4", "A5", "HM0", "HT0", "A6", "A7", "LM0", "LT0", "QM0", "QT0", "SC"])     # the first reads of a tile, in the order they are ALWAYS issued
 
 
 def chain(ind="        "):
-    """One tile.  Expects in scope: f32x16 acc; f16x8 ah[4]; i32x4 xm, ym; i32x2 xt, yt, ksc; u32x6 q6h; f16x32 qh4[4]; i32x6 q6l[4];
-    int sqH, sqL; float qsc[4]; uint32_t ka_l (LDS address of the lane's key row); V7_RELEASE() = the statement that releases the
-    ring slot (placed after the last read of the block has been issued)."""
+    """The consumer's stream, continuous over tiles.  PART 1 = the first reads of a tile (HEAD) from `ka_l`, for the first tile of a run
+    only; PART 3 = a tile's body: it finds HEAD issued (by PART 1 or by the body before it), and issues the NEXT tile's HEAD from `ka_n`
+    in its last quarter -- the fragment ring simply runs on (A16 + j lands where A_j did), so that no chain starts with an LDS round trip
+    and none ends with a drain.  Expects in scope: f32x16 acc; f16x8 ah[4]; i32x4v xm, ym, qm; i32x2v xt, yt, qt, ksc; f16x32 qh4[4];
+    i32x6 q6l[4]; int sqH, sqL; uint32_t ka_l, ka_n, a_q6h, a_q6t, a_hand_free, a_next_filled; int peek_free, peek_fill; V7_RELEASE() = release this
+    tile's ring slot (every read of it has been issued); V7_LOOKAHEAD() = find the next tile, wait for its key block, set ka_n."""
     out = []
-    issued = []            # names of reads in issue order
-    done_upto = [0]        # reads [0, done_upto) are known complete after the last wait
+    issued = []
+    done_upto = [0]
 
-    def rd(kind, dst, off, name):
-        out.append(f'{ind}asm volatile("ds_read_{kind} %0, %1 offset:{off}" : "=v"({dst}) : "v"(ka_l) : "memory");')
+    def rd(kind, dst, off, name, addr="ka_l"):
+        out.append(f'{ind}asm volatile("ds_read_{kind} %0, %1 offset:{off}" : "=v"({dst}) : "v"({addr}) : "memory");')
         issued.append(name)
 
     def need(*names):
@@ -51,23 +58,34 @@ def chain(ind="        "):
         if last < done_upto[0]:
             return
         n_after = len(issued) - 1 - last
-        out.append(f'{ind}asm volatile("s_waitcnt lgkmcnt({n_after})" ::: "memory");')
+        assert n_after <= 15, n_after
+        if "nowait" not in MICRO:
+            out.append(f'{ind}asm volatile("s_waitcnt lgkmcnt({n_after})" ::: "memory");')
         done_upto[0] = last + 1
 
-    def A(j):
-        rd("b128", f"ah[{j % RING}]", OFF_H + 32 * j, f"A{j}")
+    def A(j, nxt=False):
+        rd("b128", f"ah[{j % RING}]", OFF_H + 32 * (j % 16), ("n" if nxt else "") + f"A{j % 16}", "ka_n" if nxt else "ka_l")
 
-    def HM(v):
-        if "nofp6" in DBG:
-            return
-        rd("b128", "xm", OFF_H6M + 32 * v, f"HM{v}")
-        rd("b64", "xt", OFF_H6T + 32 * (v >> 1) + 8 * (v & 1), f"HT{v}")
+    def HM(v, nxt=False):
+        a, p = ("ka_n", "n") if nxt else ("ka_l", "")
+        rd("b128", "xm", OFF_H6M + 32 * v, f"{p}HM{v}", a)
+        rd("b64", "xt", OFF_H6T + 32 * (v >> 1) + 8 * (v & 1), f"{p}HT{v}", a)
 
-    def LM(v):
-        if "nofp6" in DBG:
-            return
-        rd("b128", "ym", OFF_L6M + 32 * v, f"LM{v}")
-        rd("b64", "yt", OFF_L6T + 32 * (v >> 1) + 8 * (v & 1), f"LT{v}")
+    def LM(v, nxt=False):
+        a, p = ("ka_n", "n") if nxt else ("ka_l", "")
+        rd("b128", "ym", OFF_L6M + 32 * v, f"{p}LM{v}", a)
+        rd("b64", "yt", OFF_L6T + 32 * (v >> 1) + 8 * (v & 1), f"{p}LT{v}", a)
+
+    def QM(v, nxt=False):
+        # the query's own h6 piece of group v: the same bytes for every tile, parked in the LDS by the prologue (6 KiB per consumer).  Made
+        # on the fly from the resident f16 fragments it cost 53 cycles per v_cvt_scalef32_pk32_fp6_f16 with the matrix pipe idle behind
+        # it -- 212 of a tile's 1 140 (tools/micro/pair_v7_stream_variants.sh); resident it would need 24 registers the wave has not got
+        p = "n" if nxt else ""
+        rd("b128", "qm", 1024 * v, f"{p}QM{v}", "a_q6h")
+        rd("b64", "qt", 512 * v, f"{p}QT{v}", "a_q6t")
+
+    def SC(nxt=False):
+        rd("b64", "ksc", OFF_SC, "nSC" if nxt else "SC", "ka_n" if nxt else "ka_l")
 
     def mfma_f(j):
         v, m = j // 4, j % 4
@@ -75,85 +93,74 @@ def chain(ind="        "):
         if j == 0:
             # SrcC is the constant 0; `acc` is declared read-write all the same so that the compiler keeps the accumulator in the registers
             # of the tile before it (an early-clobber output got 16 registers of its own: two accumulators alive, operands spilled)
-            if "f0early" in DBG:
-                out.append(f'{ind}asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(ah[{j % RING}]), "v"({b}));')
-            else:
-                out.append(f'{ind}asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "+v"(acc) : "v"(ah[{j % RING}]), "v"({b}));')
+            out.append(f'{ind}asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "+v"(acc) : "v"(ah[{j % RING}]), "v"({b}));')
         else:
             out.append(f'{ind}asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[{j % RING}]), "v"({b}));')
 
-    def mfma_s(a6, b6, sa, sb, v, bcls="v"):
-        if "nofp6" in DBG:
+    def mfma_s(a6, b6, sa, sb, v):
+        if "nop6" in MICRO:
             return
         sel = f"op_sel:[{v & 1},{v & 1},0] op_sel_hi:[{v >> 1},{v >> 1},0]"
         out.append(f'{ind}asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 {sel} cbsz:2 blgp:2" '
-                   f': "+v"(acc) : "v"({a6}), "{bcls}"({b6}), "v"({sa}), "v"({sb}));')
+                   f': "+v"(acc) : "v"({a6}), "v"({b6}), "v"({sa}), "v"({sb}));')
 
-    # head of the tile: the first reads (the kernel hands the PREVIOUS tile over between these and the first MFMA: the latency of the
-    # reads and the conversion / LDS stores of the hand-over cover each other; LDS operations nobody counts here only make the waits
-    # stricter than they need be)
-    if "nofp6" not in DBG:
-        rd("b64", "ksc", OFF_SC, "SC")
-    if "headall" in DBG:
-        A(0); A(1); HM(0); A(2); A(3); LM(0)
-        out.append("#elif FGVC_V7_PART == 3")
+    # ---- PART 1: HEAD from ka_l (first tile of a run)
+    if RING == 4:
+        A(0); A(1); HM(0); A(2); A(3); LM(0); QM(0); SC()
     else:
-        A(0); A(1)
-        out.append("#elif FGVC_V7_PART == 3")
-        HM(0)                        # (after the hand-over: with more reads in front of it the kernel spilled query operands)
-        for j in range(2, RING):
-            A(j)
-        LM(0)
+        A(0); A(1); A(2); A(3); A(4); A(5); HM(0); A(6); A(7); LM(0); QM(0); SC()
+    assert issued == HEAD
+    out.append("#elif FGVC_V7_PART == 3")
+    # ---- PART 3: the body (HEAD in flight)
     for v in range(4):
-        # the scale of this group's conversion, 2^sh from the query's scale byte: (byte + 4) << 23 as a float (two operations instead of
-        # four resident registers), made two MFMAs ahead of the conversion that reads it
-        if "qscres" in DBG:
-            out.append(f'{ind}qsc_t = __builtin_bit_cast(unsigned int, qsc[{v}]);')
-        else:
-            out.append(f'{ind}asm volatile("v_bfe_u32 %0, %1, {8 * v}, 8\\n\\tv_lshl_add_u32 %0, %0, 23, %2" : "=&v"(qsc_t) : "v"(sqH), "v"(c_exp4));')
-            if "chkqsc" in DBG:
-                out.append(f'{ind}if (qsc_t != __builtin_bit_cast(unsigned int, qsc[{v}])) {{ g_pair_v5_timeout = 1; g_pair_v5_probe[{v}] = ((long long)qsc_t << 32) | __builtin_bit_cast(unsigned int, qsc[{v}]); g_pair_v5_probe[4 + {v}] = sqH; }}')
         for half in range(2):
             for m in (2 * half, 2 * half + 1):
                 j = 4 * v + m
                 need(f"A{j}")
                 mfma_f(j)
-                if j + RING < 16:
-                    A(j + RING)
+                A(j + RING, nxt=j + RING >= 16)          # the ring runs on into the next tile's first fragments
             if half == 0:
-                # the query's h part of this group in FP6, made two f16 MFMAs before its reader (a VALU result needs a few issue
-                # slots before a matrix instruction may read it; nothing in an asm statement is padded by the compiler)
-                # (early-clobber: given the chance the allocator puts the six result registers on top of the scale operand, and the
-                # instruction -- several passes over its 32 elements -- then reads a scale it has already overwritten: measured, 1e-4 cosine)
-                out.append(f'{ind}asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(q6h) : "v"(qh4[{v}]), "v"(qsc_t));')
-                if "nofp6" not in DBG:
-                    need("SC", f"HM{v}", f"HT{v}")
+                need("SC", f"HM{v}", f"HT{v}")
                 mfma_s("V7_CAT6(xm, xt)", f"q6l[{v}]", "ksc[0]", "sqL", v)       # h6_k x l6_q
-                if v + 1 < 4:
-                    HM(v + 1)
+                HM((v + 1) % 4, nxt=v == 3)
             else:
-                if "nofp6" not in DBG:
-                    need(f"LM{v}", f"LT{v}")
-                mfma_s("V7_CAT6(ym, yt)", "q6h", "ksc[1]", "sqH", v)              # l6_k x h6_q
-                if v + 1 < 4:
-                    LM(v + 1)
-                if v + 1 == 3:                 # A15, HM3 and now LM3: every read of the block has been issued
+                need(f"LM{v}", f"LT{v}", f"QM{v}", f"QT{v}")
+                mfma_s("V7_CAT6(ym, yt)", "V7_CAT6(qm, qt)", "ksc[1]", "sqH", v)  # l6_k x h6_q
+                LM((v + 1) % 4, nxt=v == 3) if v < 3 else None
+                if v == 1:
+                    # two counters asked for now: has the selector read the tile before this one (needed at the hand-over behind this
+                    # chain), has the NEXT tile's key block landed (needed six MFMAs on: normally it has, and nothing is waited for)
+                    out.append(f'{ind}asm volatile("ds_read_b32 %0, %1" : "=v"(peek_free) : "v"(a_hand_free) : "memory");')
+                    issued.append("PK")
+                    out.append(f'{ind}asm volatile("ds_read_b32 %0, %1" : "=v"(peek_fill) : "v"(a_next_filled) : "memory");')
+                    issued.append("PF")
+                if v == 2:
+                    # A15, HM3 and now LM3: every read of this key block has been issued -> release its slot; then the next tile
+                    # (the reads that follow go to ITS key block)
                     out.append(f"{ind}V7_RELEASE();")
-                    # two counters asked for now, needed after the chain: has the selector read the tile before this one, has the next
-                    # key block landed
-                    if "nopeek" in DBG:
-                        out.append(f"{ind}peek_free = 0; peek_fill = -1;")
-                    else:
-                        out.append(f'{ind}asm volatile("ds_read_b32 %0, %1" : "=v"(peek_free) : "v"(a_hand_free) : "memory");')
-                        issued.append("PK1")
-                        out.append(f'{ind}asm volatile("ds_read_b32 %0, %1" : "=v"(peek_fill) : "v"(a_next_filled) : "memory");')
-                        issued.append("PK2")
-    if "nopeek" not in DBG:
-        need("PK1", "PK2")
-    assert done_upto[0] == len(issued), "a read nobody waited for"
-    n_reads = len(issued)
-    out.insert(0, f"{ind}// one tile: {n_reads} LDS reads, 16 f16 + 8 scaled FP6 MFMAs (generated by tools/gen_pair_v7.py -- do not edit)")
-    # sanity: a ring register is re-read only after its reader has been issued (program order of the statements above)
+                    need("PF")
+                    out.append(f"{ind}V7_LOOKAHEAD();")
+                if v < 3:
+                    QM(v + 1)
+                if v == 3:
+                    # (the rest of the next tile's first reads follows the hand-over: a wave may have 15 LDS operations in flight, and the
+                    # hand-over's four stores and its count stalled behind eleven reads until some of them had returned)
+                    out.append("#elif FGVC_V7_PART == 4")
+                    LM(0, nxt=True)
+                    QM(0, nxt=True)
+                    SC(nxt=True)
+                    out.append("#elif FGVC_V7_PART == 5")
+    # (PART 5 = the wait for the counter the hand-over reads: placed by the kernel in front of PART 4)
+    last = issued.index("PK")
+    n_after = len([x for x in issued[last + 1:] if x not in ("nLM0", "nLT0", "nQM0", "nQT0", "nSC")])
+    if last >= done_upto[0]:
+        out.append(f'{ind}asm volatile("s_waitcnt lgkmcnt({n_after})" ::: "memory");')
+        done_upto[0] = last + 1
+    rest = issued[done_upto[0]:]
+    nxt = [x for x in issued if x.startswith("n")]
+    assert nxt == ["n" + h for h in HEAD] and rest == nxt[len(nxt) - len(rest):], (nxt, rest)   # the next tile's HEAD, in HEAD's order; what is in flight is its tail
+    n_reads = len([x for x in issued if not x.startswith("n")])
+    out.insert(0, f"{ind}// one tile: {n_reads} LDS reads (+ the next tile's first 9), 16 f16 + 8 scaled FP6 MFMAs (generated by tools/gen_pair_v7.py -- do not edit)")
     return "\n".join(out) + "\n"
 
 
