@@ -410,7 +410,7 @@ def main():
     def step(timed: bool):
         if a.mode == "video":
             traj, _ = fdist.track_points_sharded(backend, rgbs, qp, cfg, device=dev, halo=a.halo, timing=timing if timed else None,
-                                                  cache=sched_cache)
+                                                  cache=sched_cache, check=False)      # (the failure flags are read once after the timed loop)
             return traj
         feats, Hf, Wf = model.get_feats_hwc(rgbs, split=True)          # encoder + normalise (+ split), all T frames
         state["geom"] = (Hf, Wf, feats)
@@ -643,7 +643,7 @@ def main():
         cache3 = {}
 
         def step3():
-            return fdist.track_points_sharded(backend, rgbs, qp, cfg3, device=dev, halo=a.halo, timing=None, cache=cache3)[0]
+            return fdist.track_points_sharded(backend, rgbs, qp, cfg3, device=dev, halo=a.halo, timing=None, cache=cache3, check=False)[0]
         for _ in range(5):
             step3()
         barrier()

@@ -31,6 +31,7 @@ backend's encoder returns: f32 rows (HW, C) or the (hi, lo) bf16 split (HW, 2, C
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import replace
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -176,8 +177,21 @@ class _Messages:
         self.ops.append(dist.P2POp(dist.irecv, into, _global_rank(self.group, src), self.group))
 
     def post(self):
+        """All messages of this rank in ONE batch (one RCCL group: no order inside it can deadlock).  The order of the operations
+        inside the batch is canonical all the same -- by peer, and for a peer the lower rank's sends before the higher rank's: both
+        ends of every pair of ranks list their common messages in the same sequence, which is what a transport that matches
+        point-to-point operations strictly in call order needs (FGVC_P2P_ORDER=posted keeps the order of the send() / recv() calls)."""
         if self.ops:
-            self.reqs = dist.batch_isend_irecv(self.ops)
+            ops = self.ops
+            if os.environ.get("FGVC_P2P_ORDER", "canonical") != "posted":
+                me = dist.get_rank()
+
+                def key(iop):
+                    i, op = iop
+                    low_to_high = (me < op.peer) if op.op is dist.isend else (op.peer < me)
+                    return (op.peer, 0 if low_to_high else 1, i)
+                ops = [op for _, op in sorted(enumerate(ops), key=key)]
+            self.reqs = dist.batch_isend_irecv(ops)
         return self
 
     def wait(self):
@@ -249,6 +263,16 @@ class HipBackend:
         tk = engine.DeviceTopk(plan, idx, None, weight, slot_frame)
         return engine.run_propagation(tk, start, pts, Hf, Wf, h, w, cfg)[1]
 
+    def reset_calibration(self):
+        """Drop the encoder's per-tensor scales (and what was captured with them): the next encode calibrates afresh."""
+        bb = getattr(self.model, "backbone", None)
+        cache = getattr(bb, "__dict__", {}).get("_split_cache") if bb is not None else None
+        if cache:
+            for k in [k for k in cache if isinstance(k, tuple) and k and k[0] == "scales"]:
+                del cache[k]
+            if hasattr(bb, "_drop_graphs"):
+                bb._drop_graphs()
+
     def failure_flags(self) -> Tuple[bool, bool]:
         """(a bounded wait of the pair kernel's LDS protocol gave up, an activation left the encoder's calibrated f16 range) since the
         last call -- either makes the results since then invalid (poison lists / saturated features).  Reads and clears both device
@@ -273,17 +297,19 @@ def _span(timing: Optional[Timing], name: str):
 
 def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor, cfg: TrackerConfig,
                          group=None, device: Optional[torch.device] = None, halo: str = "exchange",
-                         timing: Optional[Timing] = None, cache: Optional[dict] = None, check: bool = False):
+                         timing: Optional[Timing] = None, cache: Optional[dict] = None, check: bool = True):
     """One video, all ranks.  rgbs (T,3,h,w) (every rank may hold the whole clip on the host or the device; only
     its own frames are moved/encoded), query_points (P,3)=(t,x,y).
     Returns (traj (T,P',2) f64 regrouped by query time, order (P',)) on every rank.
     `cache`: a dict the caller keeps between calls with the SAME video shape, query points, cfg and process group; the schedule
     (frame ranges, message plan, slot tables on the device, query points on the device, bank geometry) is then built once --
     per call that is a dozen small blocking host-to-device copies and, at more than one rank, one tiny broadcast + host read.
-    `check=True`: before returning, read the backend's failure flags (`backend.failure_flags()`: pair-kernel timeout, encoder
+    `check` (default on): before returning, read the backend's failure flags (`backend.failure_flags()`: pair-kernel timeout, encoder
     overflow), agree on them across the group (one MAX all_reduce of two words, so that every rank raises or none does -- a rank
-    raising alone would leave the others in their next collective) and raise RuntimeError if any rank saw one.  Costs a device
-    synchronisation per video; drivers that pipeline videos (bench.py) check once per loop instead."""
+    raising alone would leave the others in their next collective), and if ANY rank overflowed drop the encoder's scales on EVERY
+    rank (`backend.reset_calibration()`: the ranks re-calibrate together instead of drifting apart), then raise RuntimeError.  Costs
+    a device synchronisation per video; drivers that pipeline videos (bench.py) pass check=False and check once per loop.
+    The device flags are process-wide words (read-and-clear): one consumer per process -- two trackers sharing a process also share them."""
     if halo not in ("exchange", "recompute"):
         raise ValueError(f"halo={halo!r}")
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -375,8 +401,9 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                                            "under a cached schedule?)")     # (a silent fallback would change the order of collectives on this rank only)
                     post_halo()
                     fh, Hf, Wf = backend.encode(rgbs[e_lo:split_at].to(dev), out=rows[:split_at - e_lo])
-                    if fh.data_ptr() != rows.data_ptr():
-                        raise RuntimeError("track_points_sharded: the backend did not encode into the local bank")
+                    # (cannot differ from the call above -- same row shape and dtype -- and that one was checked BEFORE anything was
+                    # posted: a rank that raised here alone would leave its peers in their messages)
+                    assert fh.data_ptr() == rows.data_ptr(), "track_points_sharded: the backend did not encode into the local bank"
                     f = rows
                 else:
                     f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev), out=rows)
@@ -547,6 +574,8 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
             if world > 1:
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
             t_out, ovf = (bool(v) for v in flags.tolist())
+            if ovf and hasattr(backend, "reset_calibration"):
+                backend.reset_calibration()                 # on every rank, also those whose own flag was clear
             if t_out or ovf:
                 raise RuntimeError("track_points_sharded: " + " and ".join(
                     m for m, f in (("a bounded wait of the pair kernel timed out on some rank", t_out),

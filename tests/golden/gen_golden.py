@@ -430,6 +430,57 @@ def gen_tracker_cfg0():
          feats_sub=feats[:, ::16, ::8, ::8], feats_abs_sum=float(feats.double().abs().sum()))
 
 
+def gen_tracker_8f():
+    """tests/golden/tracker_8x256x256.npz (round 4): the genuine VanillaTracker.forward_test on EIGHT 256 x 256 frames at the reference's
+    eval geometry (128 x 128 x 256 features, radius 15, top-10, precede_frames 5, with_first) -- the last frame's attention call merges
+    SIX DISTINCT key frames (0, 2..6), which the two-frame fixture (frame 0 in both slots: one pair) cannot exercise.  The frames come
+    from tests/golden/clips.py (integer arithmetic: not stored).  Stored: the trajectories, and for 512 sampled query pixels of frame 7
+    what the reference's own `topk` returned (spied) plus a float64 top-12 of the same rows from the REFERENCE's features (the gaps that
+    say which queries' ranks are clear of rounding), and a sub-sample of the features."""
+    from tests.golden import clips
+    ref = ref_import.load()
+    cfg = ref.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512,
+                         with_first=True, with_first_neighbor=True)
+    model = ref.builder.build_model(
+        dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4),
+                                                  out_indices=(2,), pool_type="none")),
+        train_cfg=None, test_cfg=cfg)
+    seed = 17
+    sd = O.seeded_resnet_state(seed=seed, strides=(1, 1, 1, 4), pool_type="none")
+    model.backbone.load_state_dict(sd, strict=True)
+    model.eval()
+    Tn, h, w, P = 8, 256, 256, 8
+    rgbs = (torch.from_numpy(clips.moving_texture(Tn, h, w, seed=1700)).float() / 32.0).unsqueeze(0)
+    g = torch.Generator().manual_seed(1700)
+    qp = torch.cat([torch.zeros(P, 1), torch.rand(P, 2, generator=g) * 180 + 38], 1).unsqueeze(0)
+    traj_gt = torch.rand(1, Tn, P, 2, generator=g) * 256
+    vis_gt = (torch.rand(1, Tn, P, generator=g) > 0.3).float()
+    with ref_import.cuda_as_cpu(), torch.no_grad(), TopkSpy() as spy:
+        outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj_gt, visibilities=vis_gt)
+    with torch.no_grad():
+        feats = model.backbone(rgbs[0])                                   # (8, 256, 128, 128)
+    HW, k = 128 * 128, 10
+    calls = [c for c in spy.calls if c[0].shape[1] == k]
+    per_frame = HW // 512
+    assert len(calls) == (Tn - 1) * per_frame, len(calls)                # frames 1..7, 32 chunks of 512 queries each
+    last = calls[-per_frame:]
+    tv = torch.cat([c[0][0] for c in last], dim=1)                       # (k, HW)
+    ti = torch.cat([c[1][0] for c in last], dim=1)
+    sample = torch.cat([torch.tensor([0, 127, HW - 128, HW - 1, 64 * 128 + 64]), torch.randint(0, HW, (507,), generator=g)])
+    slots = [0, 2, 3, 4, 5, 6]                                           # key slots of frame 7 (vanilla_tracker.py:353-362)
+    fn = torch.nn.functional.normalize(feats.double(), dim=1).flatten(2)  # (8, C, HW)
+    ky, kx = torch.arange(HW) // 128, torch.arange(HW) % 128
+    inside = ((ky.view(-1, 1) - ky[sample].view(1, -1)) ** 2 + (kx.view(-1, 1) - kx[sample].view(1, -1)) ** 2).double().sqrt() < 15
+    aff = torch.cat([((fn[s].t() @ fn[7][:, sample]) / 0.07).masked_fill(~inside, float("-inf")) for s in slots], 0)   # (6 HW, n)
+    dv, di = aff.topk(12, dim=0)
+    wsum = float(sum(v.double().abs().sum() for kk, v in sd.items() if v.dtype.is_floating_point))
+    save("tracker_8x256x256", clip_seed=1700, query_points=qp, trajectories=traj_gt, visibilities=vis_gt, seed=seed,
+         weight_abs_sum=wsum, out_traj_pred=outs[2], out_query_points=outs[4],
+         sample=sample.to(torch.int32), ref_topk_val=tv.t()[sample].contiguous(), ref_topk_idx=ti.t()[sample].contiguous().to(torch.int32),
+         f64_val=dv.t().contiguous(), f64_idx=di.t().contiguous().to(torch.int32),
+         feats_sub=feats[:, ::16, ::8, ::8], feats_abs_sum=float(feats.double().abs().sum()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate single fixtures: python gen_golden.py gen_hr_tracker ...
         for name in sys.argv[1:]:
@@ -442,3 +493,4 @@ if __name__ == "__main__":
         gen_tv_keymap()
         gen_tracker_cfg0()
         gen_dense_api()
+        gen_tracker_8f()

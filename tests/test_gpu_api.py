@@ -162,6 +162,23 @@ def test_dense_softmax_branch_topk_none(dev, common, golden):
     assert float((out.cpu() - want).abs().max()) < TOL
 
 
+# Trajectory bounds per encoder arithmetic on the 4 x 64 x 64 fixture (pixels), tied to what was MEASURED (round 4, MI355X; the numbers are
+# written to gpurun_out/r04_precision_ledger.json by the test and committed as profiles/r04_precision_ledger.json): <= 2x the measurement.
+# Measured: bf16x3 2.1e-5, f16x3 2.1e-5, f16f8 (+ the f16f6 pair kernel) 1.6e-2 -- ONE read-out of the 32 x 32 feature grid whose top-5 boundary is a
+# near-tie (the un-regrouped path and the path without with_first: 1.8e-3); on the 256 x 256 fixtures every arithmetic is within 3.1e-5 px.
+TRAJ_TOL_PX = {"bf16x3": 5e-5, "f16x3": 5e-5, "f16f8": 3e-2}
+_LEDGER = {}
+
+
+def _ledger(key, value):
+    """precision ledger of this session -> gpurun_out/r04_precision_ledger.json (rewritten on every call)"""
+    import json, os
+    _LEDGER[key] = value
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/r04_precision_ledger.json", "w") as f:
+        json.dump(_LEDGER, f, indent=1)
+
+
 def _tracker(dev, typ, strides, test_cfg, seed):
     import fgvc_amd.mmpt_api as api
     model = api.build_model(dict(type=typ, backbone=dict(type="ResNet", depth=18, strides=strides, out_indices=(2,),
@@ -179,7 +196,8 @@ def test_vanilla_tracker_five_tuple_vs_reference_golden(dev, golden):
     rgbs, qp, traj, vis = (T(g[n]).to(dev) for n in ("rgbs", "query_points", "trajectories", "visibilities"))
     # every arithmetic of the encoder's wide layers: bf16x3 / f16x3 within 5e-3 px of the reference's trajectories (round 2's bound),
     # f16f8 (two pipe units per product instead of three, ~2x the feature noise) within 3e-2 px; last = the default, kept for what follows
-    for arith, tol_px in (("bf16x3", 5e-3), ("f16x3", 5e-3), ("f16f8", 3e-2)):
+    measured = {}
+    for arith, tol_px in (("bf16x3", TRAJ_TOL_PX["bf16x3"]), ("f16x3", TRAJ_TOL_PX["f16x3"]), ("f16f8", TRAJ_TOL_PX["f16f8"])):
         model.backbone.set_arith(arith)
         outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
         assert torch.equal(outs[0].cpu(), T(g["out_trajectories"]))
@@ -189,11 +207,13 @@ def test_vanilla_tracker_five_tuple_vs_reference_golden(dev, golden):
         assert outs[2].shape == g["out_traj_pred"].shape and outs[2].dtype == traj.dtype
         d = (outs[2].cpu().double() - T(g["out_traj_pred"]).double()).abs()
         d[0, 1, 2, 0] = 0          # the one read-out whose top-5 boundary is an exact tie in the reference (see test_oracle.py)
+        measured[arith] = float(d.max())
         assert float(d.max()) < tol_px, (arith, float(d.max()))
     # the un-regrouped main path (all points from frame 0), float64 like torch.from_numpy(...) in the reference
     main = model.forward_test_main(rgbs, qp[:, [0, 2]], torch.zeros(1, 4, 2, 2, device=dev), torch.zeros(1, 4, 2, device=dev))
     assert main[2].dtype == torch.float64
-    assert float((main[2].cpu() - T(g["main_traj_pred"]).double()).abs().max()) < 3e-2          # (the default arithmetic, f16f8, from here on)
+    measured["f16f8_main"] = float((main[2].cpu() - T(g["main_traj_pred"]).double()).abs().max())
+    assert measured["f16f8_main"] < TRAJ_TOL_PX["f16f8"]                               # (the default arithmetic, f16f8 + the f16f6 pair kernel, from here on)
     # test_mode='v2' (masked_attention_efficient_v2): same disc, same result; a config WITHOUT with_first: one group from frame 0
     m2 = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), dict(cfg, test_mode="v2"), int(g["seed"]))
     o2 = m2(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
@@ -206,7 +226,11 @@ def test_vanilla_tracker_five_tuple_vs_reference_golden(dev, golden):
     net.load_state_dict(O.seeded_resnet_state(int(g["seed"]), (1, 1, 1, 4), "none"))
     with torch.no_grad():
         want = O.forward_test_main(net.eval()(T(g["rgbs"])[0]), T(g["query_points"])[0, :, 1:], 64, 64)
-    assert float((o3[2].cpu() - want).abs().max()) < 3e-2
+    measured["f16f8_no_with_first_vs_oracle"] = float((o3[2].cpu() - want).abs().max())
+    assert measured["f16f8_no_with_first_vs_oracle"] < TRAJ_TOL_PX["f16f8"]
+    _ledger("traj_err_px_tracker_4x64x64", dict(measured=measured, bounds=TRAJ_TOL_PX,
+                                                   note="64 x 64 frames -> 32 x 32 features: a read-out moves by ~0.5 px per 1e-3 of label mass that changes sides; "
+                                                        "the bounds are <= 2x the largest error measured in round 4 (MI355X)"))
 
 
 def test_dense_api_operators_vs_reference_golden(dev, common, golden):
@@ -263,7 +287,7 @@ def test_tracker_cfg0_geometry_indices_through_the_encoder(dev, golden):
         outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
         assert torch.equal(outs[4].cpu(), T(g["out_query_points"]))
         d = float((outs[2].cpu().double() - T(g["out_traj_pred"]).double()).abs().max())
-        assert d < 5e-3, (arith, d)
+        assert d < 5e-5, (arith, d)                                                        # (measured: 1.5e-5 px)
         bank, Hf, Wf = model.get_feats_hwc(rgbs[0], split=True)
         assert (Hf, Wf) == (128, 128) and bank.dtype == torch.int16                        # the pair kernel's operand format, C = 256
         ecfg = model.engine_config()
@@ -277,12 +301,67 @@ def test_tracker_cfg0_geometry_indices_through_the_encoder(dev, golden):
         # also agree on every query whose ranks are 1e-4 apart (510 of the 512), and the scores within 1e-4
         n_tight, _ = _cfg0_compare_topk(g, tk.idx[0][sample].cpu().numpy(), tk.logit[0][sample].cpu().numpy(), gap=1e-4, score_tol=1e-4)
         assert n_tight >= 505
-        report[arith] = dict(traj_err_px=d, clear_queries_gap_1e_3=n_clear, clear_queries_gap_1e_4=n_tight, max_score_err=err)
+        report[arith] = dict(traj_err_px=d, clear_queries_gap_1e_3=n_clear, clear_queries_gap_1e_4=n_tight, max_score_err=err,
+                             pair_kernel=ecfg.pair_split_fmt, all_512=_cfg0_ledger(g, tk.idx[0][sample].cpu().numpy()))
+        # what the other queries did: every query that does not reproduce the reference's list has a float64 gap below
+        # the arithmetic's error bound, and the 1e-7-grade form matches on every query whose gap exceeds 1e-4
+        assert report[arith]["all_512"]["exact"] == 512, report[arith]["all_512"]      # (measured round 4: every sampled query, in every arithmetic)
     print("cfg0 through the encoder:", report)
-    import json, os
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/r03_cfg0_report.json", "w") as f:
-        json.dump(report, f, indent=1)
+    _ledger("tracker_cfg0_2x256x256", report)
+
+
+def _cfg0_ledger(g, idx, HW=128 * 128):
+    """Exact matches of the pixel sequences over ALL 512 sampled queries of the two-frame fixture (frame 0 in both key slots: the
+    reference returns the two copies of a pixel in either order), and the float64 gap of every query that does not match."""
+    import numpy as np
+    ri = np.asarray(g["ref_topk_idx"]).astype(np.int64)
+    dv = np.asarray(g["f64_distinct_val"])
+    gap = (dv[:, :-1] - dv[:, 1:])[:, :5].min(1)
+    exact = (np.asarray(idx).astype(np.int64) % HW == ri % HW).all(1)
+    return dict(queries=int(len(gap)), exact=int(exact.sum()),
+                mismatches=[dict(query=int(q), gap=float(gap[q])) for q in np.nonzero(~exact)[0]],
+                largest_gap_of_a_mismatch=float(max([gap[q] for q in np.nonzero(~exact)[0]], default=0.0)),
+                **{f"exact_of_clear_{t:g}": [int((exact & (gap > t)).sum()), int((gap > t).sum())] for t in (1e-5, 1e-4, 3e-4, 1e-3)})
+
+
+def test_tracker_8_frames_six_key_slots_through_the_encoder(dev, golden):
+    """The reference's own forward_test on eight 256 x 256 frames (tests/golden/tracker_8x256x256.npz, round 4): the last frame merges
+    SIX DISTINCT key frames at the real geometry (128 x 128 x 256, radius 15, top-10).  Through the hand-written encoder, in every
+    arithmetic: trajectories against the reference's, and the merged top-10 lists of 512 sampled queries of frame 7 against what the
+    reference's own `topk` returned -- the ledger (exact matches over all 512, the float64 gap of every mismatch) is written out; asserted:
+    scores within 1e-4 (f16f8 + f16f6: 2e-4) of the reference's, every mismatch has a gap below the arithmetic's error bound, and the
+    three-f16-product form reproduces every list whose ranks are 1e-4 apart."""
+    from fgvc_amd import engine, ops
+    from tests.test_oracle import _clip8, ledger_topk
+    g = golden("tracker_8x256x256")
+    cfg = dict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512, with_first=True, with_first_neighbor=True, batch_step=4)
+    model = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), cfg, int(g["seed"]))
+    rgbs = _clip8(g).to(dev)
+    qp, traj, vis = (T(g[n]).to(dev) for n in ("query_points", "trajectories", "visibilities"))
+    sample = T(g["sample"]).long().to(dev)
+    report = {}
+    for arith in model.backbone.supported_arith():
+        model.backbone.set_arith(arith)
+        outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
+        d = float((outs[2].cpu().double() - T(g["out_traj_pred"]).double()).abs().max())
+        bank, Hf, Wf = model.get_feats_hwc(rgbs[0], split=True)
+        ecfg = model.engine_config()
+        plan = engine.plan_clip(8, [0], ecfg)
+        tk = engine.run_affinity(bank, Hf, Wf, plan, ecfg)
+        row = plan.out_rows[(0, 7)]
+        assert plan.slot_frame[row] == [0, 2, 3, 4, 5, 6] and not ops.pair_f16x3_timed_out()
+        led = ledger_topk(g, tk.idx[row][sample].cpu().numpy(), tk.logit[row][sample].cpu().numpy())
+        led.update(traj_err_px=d, pair_kernel=ecfg.pair_split_fmt)
+        report[arith] = led
+        bound = 1.2e-4 if arith == "f16f8" else 1e-5            # measured: the largest gap of a mismatch is 5.9e-5 (f16f8 + f16f6), 5.6e-6 (bf16x3), none (f16x3)
+        assert d < 1e-4 and led["max_score_err"] < (2.3e-4 if arith == "f16f8" else 5e-5), (arith, d, led["max_score_err"])   # measured: 3.1e-5 px; 1.14e-4 / 2.8e-5 / 2.0e-5 logit
+        assert led["largest_gap_of_a_mismatch"] < bound, (arith, led["largest_gap_of_a_mismatch"])
+        assert all(m["same_set"] or m["gap"] < bound for m in led["mismatches"])
+    # the tie policy's own bar (a gap of 1e-5 in float64): the three-f16-product form reproduces EVERY such list of the reference (measured: all 512)
+    assert report["f16x3"]["exact_of_clear_1e-05"] == report["f16x3"]["clear_1e-05"] == 506
+    assert report["f16f8"]["exact_of_clear_0.0001"] == report["f16f8"]["clear_0.0001"] == 472
+    print("8 frames through the encoder:", {a: {k: v for k, v in r.items() if k != "mismatches"} for a, r in report.items()})
+    _ledger("tracker_8x256x256", report)
 
 
 def test_tracker_refuses_what_it_does_not_honour(dev):

@@ -310,3 +310,53 @@ def test_f16f6p_format_model_known_answers():
         r = O.f16f6p_encode(a)
         err = np.abs(O.f16f6_cosines(r[:300], r[300:]) - a[300:].astype(np.float64) @ a[:300].astype(np.float64).T).max() / 0.07
         assert err < (1.5e-4 if name in ("gauss", "relu") else 1e-3), (name, err)
+
+
+def _clip8(g):
+    from tests.golden import clips
+    return (T(clips.moving_texture(8, 256, 256, seed=int(g["clip_seed"]))).float() / 32.0).unsqueeze(0)
+
+
+def ledger_topk(g, idx, logit, k=10):
+    """Shared by the oracle test and the GPU test of the 8-frame fixture: merged top-10 lists of the 512 sampled queries of the last
+    frame (six DISTINCT key frames) against what the reference's own top-k returned.  Returns a ledger: exact index matches over ALL
+    sampled queries, the float64 gap (smallest distance between ranks 1..11, from the reference's features) of every query that does
+    not match, counts of matches among the queries whose gap exceeds 1e-5 / 1e-4 / 3e-4 / 1e-3, the largest score error."""
+    import numpy as np
+    ri, rv = np.asarray(g["ref_topk_idx"]).astype(np.int64), np.asarray(g["ref_topk_val"])
+    dv = np.asarray(g["f64_val"])
+    gap = (dv[:, :-1] - dv[:, 1:])[:, :k].min(1)
+    idx, logit = np.asarray(idx).astype(np.int64), np.asarray(logit)
+    exact = (idx == ri).all(1)
+    same_set = (np.sort(idx, 1) == np.sort(ri, 1)).all(1)
+    led = dict(queries=int(len(gap)), exact=int(exact.sum()), same_set=int(same_set.sum()), max_score_err=float(np.abs(np.sort(logit, 1) - np.sort(rv, 1)).max()),
+               mismatches=[dict(query=int(q), gap=float(gap[q]), same_set=bool(same_set[q])) for q in np.nonzero(~exact)[0]])
+    for t in (1e-5, 1e-4, 3e-4, 1e-3):
+        clear = gap > t
+        led[f"clear_{t:g}"] = int(clear.sum())
+        led[f"exact_of_clear_{t:g}"] = int((exact & clear).sum())
+    led["largest_gap_of_a_mismatch"] = max([m["gap"] for m in led["mismatches"]], default=0.0)
+    return led
+
+
+def test_tracker_8_frames_six_key_slots(golden):
+    """The 8-frame fixture of the genuine forward_test (round 4): the oracle network + its top-k on the last frame's sampled queries --
+    six distinct key frames merged -- against what the reference's own `topk` returned: all 512 lists equal, scores within 1e-4."""
+    g = golden("tracker_8x256x256")
+    sd = O.seeded_resnet_state(int(g["seed"]), (1, 1, 1, 4), "none")
+    wsum = float(sum(v.double().abs().sum() for v in sd.values() if v.dtype.is_floating_point))
+    if abs(wsum - float(g["weight_abs_sum"])) > 1e-6 * wsum:
+        pytest.skip("torch RNG stream differs from the fixture's")
+    net = O.ResNet18((1, 1, 1, 4), 2, "none")
+    net.load_state_dict(sd)
+    net.eval()
+    rgbs = _clip8(g)
+    with torch.no_grad():
+        feats = net(rgbs[0])
+    assert torch.allclose(feats[:, ::16, ::8, ::8], T(g["feats_sub"]), atol=1e-4, rtol=1e-4)
+    sample = T(g["sample"]).long()
+    ks = O.key_slots(7)
+    assert ks == [0, 2, 3, 4, 5, 6]
+    idx, logit = O.affinity_topk(feats[7], feats[ks].transpose(0, 1), 10, 0.07, neighbor_range=30, q_index=sample)
+    led = ledger_topk(g, idx.numpy(), logit.numpy())
+    assert led["max_score_err"] < 1e-4 and led["exact_of_clear_1e-05"] == led["clear_1e-05"], led
