@@ -301,6 +301,7 @@ def main():
     ap.add_argument("--no-conv64-f16f8", action="store_true", help="layer 1 and the stem's output in the bf16 form also when the trunk computes in f16f8 (A/B)")
     ap.add_argument("--encoder-graph", action="store_true", help="replay the encoder from a HIP graph (ResNet.use_graph: host time per call 0.7 -> 0.1 ms; "
                                                                  "no throughput change where the step is GPU-bound)")
+    ap.add_argument("--no-encoder-graph", action="store_true", help="never replay the encoder from a HIP graph (default: ResNet.use_graph = 'auto': small inputs only)")
     ap.add_argument("--res-split", action="store_true", help="layer-1 identities from the split form instead of dense f32 copies (A/B)")
     ap.add_argument("--enc-arith", default=None, choices=["f16f8", "bf16x3", "f16x3"],
                     help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f8; bf16x3 = round 2's)")
@@ -361,6 +362,8 @@ def main():
         ResNet.use_conv64 = False
     if a.encoder_graph:
         ResNet.use_graph = True
+    if a.no_encoder_graph:
+        ResNet.use_graph = False
     if a.res_split:
         ResNet.res_from_split = True
     if a.no_conv64_f16f8:

@@ -549,7 +549,9 @@ class ResNet(nn.Module):
             if self.arith != "bf16x3" and self._scales(dev) is None and "_calib" not in self.__dict__:
                 self.calibrate(x, last)               # first batch of these weights: one pass in the bf16 form fixes the f16 scales
             self._touch_workspace_shape((N, x.shape[2], x.shape[3], dev))
-            n_lanes = max(1, min(int(self.split_lanes), N))
+            # (one or two frames: one lane -- two streams of half-empty launches gain nothing there and cost the fork / join:
+            # 1 047 -> 1 375 frames/s on the 2 x 256 x 256 workload, profiles/r04_other_workloads.log)
+            n_lanes = 1 if N <= 2 else max(1, min(int(self.split_lanes), N))
             main = torch.cuda.current_stream(dev)
             c1 = self.conv1.conv
             stem7 = None
@@ -637,9 +639,12 @@ class ResNet(nn.Module):
         outs = [stage_out[i] for i in want]
         return outs[0] if len(outs) == 1 else tuple(outs)
 
-    use_graph = False              # True: forward_hwc replays a HIP graph of the whole NHWC trunk per input shape (captured on the second
-                                   # call of a shape).  For HOST-bound inputs: a 2-frame 256 x 256 call is 32 launches at ~25 us of Python
-                                   # each against 0.3 ms of GPU work; an 8-frame 480p clip is GPU-bound and gains nothing.
+    use_graph = "auto"             # True: forward_hwc replays a HIP graph of the whole NHWC trunk per input shape (captured on the second
+                                   # call of a shape); "auto" (default, round 4): for inputs of at most `graph_auto_max_px` pixels
+                                   # (N x h x w) only -- HOST-bound calls: a 2-frame 256 x 256 call is ~32 launches at ~25 us of Python
+                                   # each against 0.3 ms of GPU work (1 047 -> 2 001 frames/s on that workload); an 8-frame 480p clip is
+                                   # GPU-bound and gains nothing; False: never.
+    graph_auto_max_px = 300_000
 
     def forward_hwc(self, x, normalize: bool = True, split_if=None, split_fmt: str = "bf16", out=None):
         """forward_hwc_eager, or -- with `use_graph` on the GPU in eval mode -- the same work replayed from a HIP graph (torch.cuda.CUDAGraph
@@ -647,10 +652,14 @@ class ResNet(nn.Module):
         layouts), reads a static copy of the input and writes a static output: the returned tensor is overwritten by the next call
         with the same shape, so the caller gets a COPY (`out` when given, else a fresh tensor).  Graphs live in the split cache: new
         weights, a re-calibration, an overflow (`check_overflow`) and the eviction of the shape's workspaces drop them."""
-        if not (self.use_graph and x.is_cuda and not self.training and x.dtype == torch.float32):
+        want = self.use_graph is True or (self.use_graph == "auto" and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] <= self.graph_auto_max_px)
+        if not (want and x.is_cuda and not self.training and x.dtype == torch.float32) or torch.cuda.is_current_stream_capturing():
             return self.forward_hwc_eager(x, normalize, split_if, split_fmt, out)
         cache = self.__dict__.setdefault("_split_cache", {})
-        key = ("graph", tuple(x.shape), x.device, bool(normalize), split_fmt, split_if is not None)
+        # (everything a captured pass bakes in besides the input: the class-level switches tests and A/B runs flip between calls)
+        sig = (self.arith, self.split_lanes, self.use_conv64, self.use_stem7, self.use_s2_conv, self.conv64_f16f8, self.res_from_split,
+               self.use_split_conv, tuple(self.out_indices))
+        key = ("graph", tuple(x.shape), x.device, bool(normalize), split_fmt, split_if is not None, sig)
         ent = cache.get(key)
         if ent is None:                                        # first call of this shape: eager (it may calibrate and allocate)
             cache[key] = "warm"

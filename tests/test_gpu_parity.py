@@ -1264,7 +1264,9 @@ def test_encoder_hip_graph_replay(dev):
     net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")).to(dev).eval()
     split_if = lambda C, H, W: True
     xs = [torch.randn(3, 3, 72, 100, device=dev) for _ in range(4)] + [torch.randn(2, 3, 64, 64, device=dev)]
+    default_mode = ResNet.use_graph
     with torch.no_grad():
+        ResNet.use_graph = False                               # the eager baseline
         want = [net.forward_hwc(x, True, split_if=split_if, split_fmt="f16")[0].clone() for x in xs]
         try:
             ResNet.use_graph = True
@@ -1285,7 +1287,7 @@ def test_encoder_hip_graph_replay(dev):
             f, _, _ = net.forward_hwc(xs[0], True, split_if=split_if, split_fmt="f16")
             assert torch.equal(f, want[0])
         finally:
-            ResNet.use_graph = False
+            ResNet.use_graph = default_mode
     assert not net.check_overflow()
 
 
@@ -1305,7 +1307,9 @@ def test_encoder_hip_graph_in_the_tracker_and_invalidation(dev):
                             train_cfg=None, test_cfg=test_cfg).to(dev).eval()
     net = model.backbone
     vids = [torch.randn(8, 3, 64, 96, device=dev) for _ in range(3)]          # 8 frames at batch_step 3: chunks of 3, 3, 2
+    default_mode = ResNet.use_graph
     with torch.no_grad():
+        ResNet.use_graph = False                               # the eager baseline
         want = [model.get_feats_hwc(v, split=True)[0].clone() for v in vids]
         try:
             ResNet.use_graph = True
@@ -1339,7 +1343,7 @@ def test_encoder_hip_graph_in_the_tracker_and_invalidation(dev):
             for v, w in zip(vids, want):
                 assert torch.equal(model.get_feats_hwc(v, split=True)[0], w)
         finally:
-            ResNet.use_graph = False
+            ResNet.use_graph = default_mode
     torch.cuda.synchronize()
     assert not net.check_overflow()
 
