@@ -152,13 +152,28 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     g_start = gr.x;
     g_count = gr.y;
   }
+  int tile = xcd_remap(blockIdx.x, p.n_ty * p.n_tx);
+  if ((p.debug & 512) && !p.groups) {
+    // experiment: every XCD owns a contiguous range of the (pair, tile) sequence; tiles of a pair in column strips two tiles wide
+    const int ntile = p.n_ty * p.n_tx;
+    const int L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int item = xcd_remap(L, gridDim.x * gridDim.y);
+    g_start = item / ntile;
+    const int t2 = item - g_start * ntile;
+    const int full = (p.n_tx >> 1) * 2 * p.n_ty;
+    if (t2 < full) {
+      const int strip = t2 / (2 * p.n_ty), r = t2 - strip * 2 * p.n_ty;
+      tile = (r >> 1) * p.n_tx + 2 * strip + (r & 1);
+    } else {
+      tile = (t2 - full) * p.n_tx + p.n_tx - 1;
+    }
+  }
   const int4 pr = p.pairs[g_start];
   const int qf = pr.x;
   const bool masked = (pr.z & FGVC_PAIR_MASKED) != 0;
   const int reach_y = masked ? p.reach_y : FGVC_NO_LIMIT;
   const int reach_x = masked ? p.reach_x : FGVC_NO_LIMIT;
 
-  const int tile = xcd_remap(blockIdx.x, p.n_ty * p.n_tx);
   const int ty = tile / p.n_tx, tx = tile - ty * p.n_tx;
   ReachTest reach;
   reach.r2max = masked ? p.r2max : FGVC_NO_LIMIT;

@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the default bench command -> <out>/<name> (the kernel_stats CSV) + the bench's JSON line.
-#     bash tools/kernel_stats.sh gpurun_out/stats r03_bench_kernel_stats.csv
+#     bash tools/kernel_stats.sh gpurun_out/stats r04_bench_kernel_stats.csv
 set -e
 OUT=${1:-gpurun_out/stats}
-NAME=${2:-r03_bench_kernel_stats.csv}
+NAME=${2:-r04_bench_kernel_stats.csv}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 mkdir -p "$OUT"

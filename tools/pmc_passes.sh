@@ -1,10 +1,10 @@
 #!/bin/bash
 # Four separate rocprofv3 --pmc passes of tools/run_kernels_once.py (counters are never combined with traces; the interpreter
 # sits directly after `--`), then tools/pmc_report.py -> profiles/<name>.  Run from the repository root on the GPU box:
-#     bash tools/pmc_passes.sh gpurun_out/pmc r03_pmc.json
+#     bash tools/pmc_passes.sh gpurun_out/pmc r04_pmc.json
 set -e
 OUT=${1:-gpurun_out/pmc}
-NAME=${2:-r03_pmc.json}
+NAME=${2:-r04_pmc.json}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 mkdir -p "$OUT"

@@ -1,5 +1,5 @@
 """A few launches each of the roofline kernels at the bench shapes (cfg2: 8 x 480x854 -> 120x214x256), for rocprofv3 --pmc passes
-(tools/pmc_report.py turns the result directories into profiles/r03_pmc.json).  Run the interpreter directly after `--`."""
+(tools/pmc_report.py turns the result directories into profiles/rNN_pmc.json).  Run the interpreter directly after `--`."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,11 +11,13 @@ cfg = engine.TrackerConfig()
 plan = engine.plan_clip(T, [0], cfg)
 pairs = ops.make_pairs(plan.pairs, dev)
 h16_all = ops.split_f16x2(feats)
+h6_all = ops.split_f16f6p(feats)      # round 4: the rows of fgvc_pair_topk_f16f6 (the engine's default pair kernel)
 hl = ops.split_bf16(feats[:2])
 sp = ops.split_f16f8(feats[:2])
 sp6 = ops.split_f16f6(feats[:2])
 vol = torch.empty((HW, HW), device=dev)
 for _ in range(3):
+    ops.pair_topk_split(h6_all, h6_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16f6")
     ops.pair_topk_split(h16_all, h16_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16")
     ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False)
     ops.corr_volume(sp6[1], sp6[0], 0.07, "f16f6", out=vol)
