@@ -24,6 +24,8 @@
 //     running list is 10 keys; compare-exchange = v_max_u32 + v_min_u32.  212 vector operations per tile (293).
 //   * The block list in plain row-major order: the ring alone runs 21 % faster that way (neighbouring workgroups walk the same key
 //     rows at the same time; profiles/r04_pair_ring.log), which the f16x3 kernel could not use (its consumers were the pole).
+//     Later in round 4: rows rotated so that every tile visits key row r at step r mod 10 ("aligned walks"), and the workgroups of an
+//     XCD own a contiguous range of (run, tile) work in column strips -- see the work-order comment in the kernel.
 // Limits: C = 256, k <= 10, normalised rows, at most 64 key blocks per 8 x 16 query tile (a radius-15 disc has 56) -- everything else
 // stays on fgvc_pair_topk_f16x3 / fgvc_pair_topk_f32.  Same fail-closed protocol as the f16x3 kernel (bounded spins, poison lists).
 #pragma once
@@ -153,13 +155,48 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     g_count = gr.y;
   }
   int tile = xcd_remap(blockIdx.x, p.n_ty * p.n_tx);
-  if ((p.debug & 512) && !p.groups) {
-    // experiment: every XCD owns a contiguous range of the (pair, tile) sequence; tiles of a pair in column strips two tiles wide
+  if (!(p.debug & 512)) {                       // (512: the order of the first build -- an eighth of the tiles of every run per XCD, raster)
+    // ---- work order.  The hardware deals workgroups to the eight XCDs by their linear index; every XCD has its own L2.
+    // The runs of one length (a "class": equal work per workgroup; the runs come longest first) own a stretch of linear indices;
+    // the workgroups an XCD gets from that stretch take a CONTIGUOUS range of the class's (run, tile) sequence, tiles in column
+    // strips two tiles wide -- instead of an eighth of the tiles of every run (whose key windows overlap those of seven other L2s).
+    // With the aligned walks below: L2 fills 4.62 -> 3.54 GB per 27-pair launch at 480p (one pair per workgroup: 2.50 GB, but 3 %
+    // slower: the query prologue per pair); launch time 1.159 -> 1.150 ms there, 10.05 -> 9.77 ms for the 363 pairs of a 64-frame
+    // 256 x 256 video, 13.59 -> 12.65 ms for the 123 pairs of 24 frames of 720p (tools/experiments/order_pair_v7.py).
     const int ntile = p.n_ty * p.n_tx;
     const int L = blockIdx.x + gridDim.x * blockIdx.y;
-    const int item = xcd_remap(L, gridDim.x * gridDim.y);
-    g_start = item / ntile;
-    const int t2 = item - g_start * ntile;
+    int g_lo = 0, g_hi = (int)gridDim.y - 1;
+    if (p.groups) {
+      const int gi = blockIdx.y;
+      g_lo = gi; g_hi = gi;
+      for (int base = 0; base < (int)gridDim.y; base += 64) {          // maximal stretch of runs of this length around gi
+        const int i = base + lane;
+        const unsigned long long eq = __ballot(i < (int)gridDim.y && p.groups[imin(i, (int)gridDim.y - 1)].y == g_count);
+        const unsigned long long ne = ~eq;
+        if (gi >= base && gi < base + 64) {
+          const int o = gi - base;
+          const unsigned long long below = ne & ((1ull << o) - 1), above = o == 63 ? 0ull : (ne >> (o + 1));
+          g_lo = below ? base + 64 - __builtin_clzll(below) : (base == 0 ? 0 : -1);
+          g_hi = above ? gi + __builtin_ctzll(above) : -1;
+        }
+      }
+      // (stretches that cross a 64-run chunk are cut at the chunk: still a bijection, only a shorter class)
+      if (g_lo < 0) g_lo = (gi / 64) * 64;
+      if (g_hi < 0) g_hi = imin((gi / 64) * 64 + 63, (int)gridDim.y - 1);
+    }
+    const int a_ = g_lo * ntile, b_ = (g_hi + 1) * ntile, x_ = L & 7;
+    auto below_x = [&](int m) { return (m >> 3) * x_ + imin(m & 7, x_); };            // integers in [0, m) with residue < x_
+    const int L0 = a_ + ((x_ - (a_ & 7) + 8) & 7);                                   // first index of this XCD in the stretch
+    const int item = below_x(b_) - below_x(a_) + ((L - L0) >> 3);
+    const int gsel = g_lo + item / ntile;
+    const int t2 = item - (gsel - g_lo) * ntile;
+    if (p.groups) {
+      const int2 gr = p.groups[gsel];
+      g_start = gr.x;
+      g_count = gr.y;
+    } else {
+      g_start = gsel;
+    }
     const int full = (p.n_tx >> 1) * 2 * p.n_ty;
     if (t2 < full) {
       const int strip = t2 / (2 * p.n_ty), r = t2 - strip * 2 * p.n_ty;
@@ -196,7 +233,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) *reinterpret_cast<i32x4v*>(&smem[qb * BUFB + (role * 16 + i) * LDB + 16 * lane]) = qr[i];
   }
-  // ---- prologue 2 (overlaps the DMA): the key blocks this super-tile visits, row-major (debug & 8192: alternating from both ends)
+  // ---- prologue 2 (overlaps the DMA): the key blocks this super-tile visits, row by row (debug & 8192: alternating from both ends)
   if (wave == 0) {
     const int by_lo = imax(0, TY0 - imin(reach_y, TY0)) / QBH;
     const int by_hi = imin(p.Hk - 1, TY0 + 2 * QBH - 1 + imin(reach_y, p.Hk)) / QBH;
@@ -204,8 +241,14 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     const int bxh = imin(p.Wk - 1, TX0 + 2 * QBW - 1 + imin(reach_x, p.Wk)) / QBW;
     const int nbx = bxh - bxl + 1;
     const int nall = (by_hi - by_lo + 1) * nbx;
+    // Block rows in the order of (row mod M), M = the rows of a full window: workgroups that start together then read the same key
+    // rows at the same time whatever their own tile row ("aligned walks"; debug & 1024: every tile from its own top row)
+    const int M_ = (2 * QBH - 1 + imin(reach_y, p.Hk)) / QBH + (imin(reach_y, p.Hk) + QBH - 1) / QBH + 1;
+    int rot_s = ((by_lo + M_ - 1) / M_) * M_;
+    if (rot_s > by_hi || (p.debug & 1024)) rot_s = by_lo;
     auto reach_bits = [&](int c) -> uint32_t {
-      const int by = by_lo + c / nbx, bx = bxl + c % nbx;
+      const int j_ = c / nbx, bx = bxl + c % nbx;
+      const int by = rot_s + j_ <= by_hi ? rot_s + j_ : by_lo + (j_ - (by_hi - rot_s + 1));
       uint32_t m = 0;
 #pragma unroll
       for (int b = 0; b < 4; ++b)

@@ -14,5 +14,5 @@ for f in sorted(glob.glob("gpurun_out/pmc_order/*/**/*counter_collection.csv", r
     for r in rows:
         byd.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
     for i, (d, c) in enumerate(sorted(byd.items())):
-        print(f, "dispatch", d, "mode", i % 3, {k: (2 * v * 1024 / 1e9 if k == "FETCH_SIZE" else v) for k, v in c.items()})
+        print(f, "dispatch", d, "mode", i % 6, {k: (2 * v * 1024 / 1e9 if k == "FETCH_SIZE" else v) for k, v in c.items()})
 PY
