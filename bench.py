@@ -45,8 +45,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA p
 # fgvc_pair_topk_f16f6 = one f16 product + both cross sums in FP6 (a quarter unit each)
 PAIR_UNITS = {"f16": 3.0, "f16f6": 1.5}
 # pipe units (16-bit MFMA times) per f32-grade product of fgvc_conv_split_f32, by arithmetic: bf16x3 / f16x3 = three 16-bit products,
-# f16f8 = one f16 product + both cross sums in one K-64 fp8 MFMA (half a unit each)
-CONV_UNITS = {"bf16x3": 3.0, "f16x3": 3.0, "f16f8": 2.0}
+# f16f8 = one f16 product + both cross sums in one K-64 fp8 MFMA (half a unit each), f16f6 = the same MFMA on FP6 operands (a quarter each)
+CONV_UNITS = {"bf16x3": 3.0, "f16x3": 3.0, "f16f8": 2.0, "f16f6": 1.5}
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 # what the board SUSTAINS on matrix work alone at its 1.4 kW cap (tools/micro/mfma_sustained.hip, profiles/r03_mfma_sustained.log): the
 # 16-bit shapes do not reach the 2.4 GHz figure the roofline is priced against
@@ -303,7 +303,7 @@ def main():
                                                                  "no throughput change where the step is GPU-bound)")
     ap.add_argument("--no-encoder-graph", action="store_true", help="never replay the encoder from a HIP graph (default: ResNet.use_graph = 'auto': small inputs only)")
     ap.add_argument("--res-split", action="store_true", help="layer-1 identities from the split form instead of dense f32 copies (A/B)")
-    ap.add_argument("--enc-arith", default=None, choices=["f16f8", "bf16x3", "f16x3"],
+    ap.add_argument("--enc-arith", default=None, choices=["f16f8", "f16f6", "bf16x3", "f16x3"],
                     help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f8; bf16x3 = round 2's)")
     ap.add_argument("--no-clips-line", action="store_true", help="skip the extra `--mode clips` measurement that a `video` run appends")
     ap.add_argument("--repeats", type=int, default=5, help="extra blocks of 20 steps after the timed region, for the spread")
@@ -478,7 +478,7 @@ def main():
         tot_fl = sum(len(probe.ev[t]) * 2.0 * t[1] * HW * 256 * 256 * 9 for t in conv_tags)
         n_l = sum(len(probe.ev[t]) for t in conv_tags)
         f32_tf = tot_fl / (tot_ms * 1e-3) / 1e12
-        pm = pmc("fgvc_conv_split_fmt_f32[f16f8]" if arith == "f16f8" else "fgvc_conv_split_f32")   # (no PMC pass of the f16x3 form)
+        pm = pmc("fgvc_conv_split_fmt_f32[%s]" % arith if arith in ("f16f8", "f16f6") else "fgvc_conv_split_f32")   # (no PMC pass of the f16x3 form)
         kernels["encoder_conv"] = {
             "kernel": "fgvc_conv_split_f32 (256 -> 256, 3x3: the time-dominant kernel, 4 launches per clip and encoder lane)",
             "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f32_tf / BF16_MFMA_PEAK_TFLOPS,
@@ -489,12 +489,15 @@ def main():
             "executed_note": {"bf16x3": "3 bf16 partial products per f32-grade product (hi*hi + hi*lo + lo*hi)",
                               "f16x3": "3 f16 partial products per f32-grade product (h*h + h*l + l*h)",
                               "f16f8": "2 pipe units per f32-grade product: the f16 main product + both cross sums in one K-64 fp8 MFMA "
-                                       "(twice the f16 rate)"}[arith],
+                                       "(twice the f16 rate)",
+                              "f16f6": "1.5 pipe units per f32-grade product: the f16 main product + both cross sums in one K-64 FP6 MFMA "
+                                       "(block-scaled e2m3 operands: four times the f16 rate)"}[arith],
             "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
             "sustained_peak": {"bf16x3": SUSTAINED_TFLOPS["bf16"], "f16x3": SUSTAINED_TFLOPS["f16"],
-                               "f16f8": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"]}[arith],
+                               "f16f8": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"], "f16f6": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"]}[arith],
             "frac_executed_of_sustained": CONV_UNITS[arith] * f32_tf / {"bf16x3": SUSTAINED_TFLOPS["bf16"], "f16x3": SUSTAINED_TFLOPS["f16"],
-                                                                        "f16f8": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"]}[arith],
+                                                                        "f16f8": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"],
+                                                                        "f16f6": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"]}[arith],
             "sustained_note": "the matrix pipe alone, whole chip, at the board's power cap (tools/micro/mfma_sustained.hip: f16 1750, bf16 1950, "
                               "fp8 4900 TFLOP/s; the 2 f16 + 1 fp8 mix 0.95 of its nominal rate = 2375 in f16 units); the step itself "
                               "runs at the cap (1.27-1.37 kW)",

@@ -545,7 +545,7 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
                             float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu, int in_fmt,
                             int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, void* stream) {
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_f32: null pointer");
-  FGVC_REQUIRE(in_fmt >= 0 && in_fmt <= 2 && out_fmt >= 0 && out_fmt <= 2, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_fmt_f32: unknown format %d / %d", in_fmt, out_fmt);
+  FGVC_REQUIRE(in_fmt >= 0 && in_fmt <= 3 && out_fmt >= 0 && out_fmt <= 3, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_fmt_f32: unknown format %d / %d", in_fmt, out_fmt);
   FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || !y_split || overflow, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_fmt_f32: an f16-format output needs the overflow word");
   FGVC_REQUIRE(in_scale_log2 > -100 && in_scale_log2 < 100 && out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG,
                "fgvc_conv_split_fmt_f32: scale exponent out of range");
@@ -614,7 +614,7 @@ int fgvc_conv_s2_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float
                                int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int Hop, int Wop, int relu, int out_fmt,
                                int out_scale_log2, int* overflow, void* stream) {
   FGVC_REQUIRE(x && w && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: null pointer");
-  FGVC_REQUIRE(out_fmt >= 0 && out_fmt <= 2 && out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_fmt_f32: bad output format / scale");
+  FGVC_REQUIRE(out_fmt >= 0 && out_fmt <= 3 && out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_fmt_f32: bad output format / scale");
   FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || !y_split || overflow, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_fmt_f32: an f16-format output needs the overflow word");
   FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_s2_split_f32: bad shape");
   FGVC_REQUIRE(KS == 1 || KS == 3, FGVC_ERR_UNSUPPORTED, "fgvc_conv_s2_split_f32: kernel size %d (1 or 3, stride 2)", KS);

@@ -282,6 +282,77 @@ __device__ __forceinline__ void split_f16_4(const f32x4& x, float s, uint2& hw, 
   l8 = (uint32_t)b;
 }
 
+// FMT 3 (f16 + FP6, round 4): the words of one (pixel, 32-channel chunk) of a split tensor [h 64 B | slot 4 | slot 5 | slot 6 | slot 7]:
+// h = f16(s x) as in FMT 1; the two 32-element FP6 (e2m3) operands of the chunk with one E8M0 scale each,
+//     h6 = e2m3(h / 2^sh),   l6 = e2m3(f16(2^11 (s x - h)) / 2^sl),   2^s the smallest power of two that keeps the block's largest
+//     magnitude at or below 7.5 (v_cvt_scalef32_pk32_fp6_f16: round to nearest even), element e = channel e in bits [6 e, 6 e + 6)
+//     of a 24-byte string = 16 bytes "main" + 8 bytes "tail";
+// slot 4 = l6 main, slot 5 = h6 main, slot 6 = [l6 tail | byte 127 + sl - 11 | 0], slot 7 = [h6 tail | byte 127 + sh | 0]: lane half hh of
+// v_mfma_scale_f32_32x32x64_f8f6f4 reads slots 4 + hh and 6 + hh as eight registers -- six of FP6 data (the instruction ignores the
+// rest), the seventh carries its block's scale byte.  (Weights: the same with h6 in slots 4 / 6 and l6 in 5 / 7, so that lane half 0
+// multiplies h6_w . l6_x and lane half 1 l6_w . h6_x: ops.prepare_conv_split_f16.)
+// Called by a whole wave with the accumulator layout of the convolution epilogues: lane (pixel n, half h) holds channels
+// 8 g + 4 h + k of the chunk in v[g][k].  The halves trade registers (v_permlane32_swap) so that lane (n, 0) owns all 32 h values
+// and lane (n, 1) all 32 residuals: one conversion instruction each, no cross-lane maximum.  Returns the lane's own h words
+// (hw[g]: channels 8 g + 4 h ..+4) and the 2 x 16 bytes it stores at byte 80 - 16 h (main6) and 112 - 16 h (tail6) of the row.
+typedef int fgvc_i32x6 __attribute__((ext_vector_type(6)));
+typedef int fgvc_i32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void split_f16f6_chunk(const f32x4 (&v)[4], float s, int h, uint2 (&hw)[4], fgvc_i32x4& main6, fgvc_i32x4& tail6,
+                                                  bool& ovf) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  unsigned A[8], B[8];                 // A: packed h pairs, B: packed f16(2^11 l) pairs; register 2 g + j = channels 8 g + 4 h + 2 j, + 1
+  float mh = 0.f, ml = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f16x2 hp, lp;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float xs = v[g][2 * j + i] * s;
+        ovf |= fabsf(xs) > 57344.f;                      // (the bound of FMT 1, kept: one calibration rule for both formats)
+        const float c = __builtin_amdgcn_fmed3f(xs, -65504.f, 65504.f);
+        hp[i] = (_Float16)c;
+        const float hf = (float)hp[i];
+        const float lf = (c - hf) * 2048.f;
+        lp[i] = (_Float16)lf;
+        mh = fmaxf(mh, fabsf(hf));
+        ml = fmaxf(ml, fabsf(lf));
+      }
+      A[2 * g + j] = __builtin_bit_cast(unsigned, hp);
+      B[2 * g + j] = __builtin_bit_cast(unsigned, lp);
+    }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) hw[g] = {A[2 * g], A[2 * g + 1]};
+  // upper lanes of A <-> lower lanes of B: lane (n, 0) then holds h of channels 8 g + k (A) and 8 g + 4 + k (B), lane (n, 1) the residuals
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const auto t = __builtin_amdgcn_permlane32_swap(A[r], B[r], false, false);
+    A[r] = t[0]; B[r] = t[1];
+  }
+  // (the maximum of the two halves as UNSIGNED integers -- the order of non-negative floats: hipcc 7.2 folds fmaxf() of the two
+  // results of the swap builtin into its first result alone, tools/experiments/dbg_act_f16f6.py found the blocks one scale short)
+  const auto tm = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mh), __builtin_bit_cast(unsigned, ml), false, false);
+  const unsigned mu = tm[0] > tm[1] ? tm[0] : tm[1];
+  const float m16 = (float)(_Float16)__builtin_bit_cast(float, mu);     // the block's largest f16 magnitude (rounding is monotonic: = the largest rounded value)
+  const unsigned mb = __builtin_bit_cast(unsigned, m16);
+  int field = (int)(mb >> 23) - 2 + ((mb & 0x7fffffu) > 0x700000u ? 1 : 0);    // 127 + s: m / 2^s in (3.75, 7.5]
+  field = field < 32 ? 32 : field;                      // (an all-zero block: any scale)
+  fgvc_i32x16 T;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      T[4 * g + j] = (int)A[2 * g + j];                 // channels 8 g + 2 j, + 1
+      T[4 * g + 2 + j] = (int)B[2 * g + j];             // channels 8 g + 4 + 2 j, + 1
+    }
+  fgvc_i32x6 c6;
+  const unsigned sc_bits = (unsigned)field << 23;
+  asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(c6) : "v"(T), "v"(sc_bits));   // (early-clobber: not on top of the scale)
+  main6 = {c6[0], c6[1], c6[2], c6[3]};
+  tail6 = {c6[4], c6[5], field - (h ? 11 : 0), 0};
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }

@@ -31,7 +31,7 @@ struct ConvS2Params {
   int n_ty, n_tx;
   int debug;               // profiling ablations (results WRONG): 1 = no staging, 2 = no MFMA, 4 = no epilogue, 8 = no A loads
   float out_scale;         // out_fmt != 0: the split output stores s_out * y (conv_split.hip: the f16 forms)
-  int out_fmt;             // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16
+  int out_fmt;             // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16, 3 = f16f6
   int* overflow;           // out_fmt != 0: raised when |s_out * y| leaves the f16 range
 };
 
@@ -201,6 +201,17 @@ __global__ __launch_bounds__(64 * S2_NW, 2) void conv_s2_kernel(ConvS2Params p) 
           *reinterpret_cast<ushort4*>(o) = hv;
           *reinterpret_cast<ushort4*>(o + 64) = lv;
         }
+      } else if (p.out_fmt == 3) {                            // f16 + FP6 (common.hpp: split_f16f6_chunk)
+        bool ovf = false;
+        uint2 hw[4];
+        fgvc_i32x4 main6, tail6;
+        split_f16f6_chunk(v, p.out_scale, h, hw, main6, tail6, ovf);
+        unsigned char* o = tile + n * S2_RS;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw[g];
+        *reinterpret_cast<fgvc_i32x4*>(o + 80 - 16 * h) = main6;
+        *reinterpret_cast<fgvc_i32x4*>(o + 112 - 16 * h) = tail6;
+        if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.Wo) != 0ull && lane == 0) atomicOr(p.overflow, 1);
       } else {                                                // the f16 forms (conv_split.hip): [h 64 B | l8 32 B | h8 32 B] or [h 64 B | l 64 B]
         bool ovf = false;
 #pragma unroll

@@ -24,6 +24,12 @@
 //              rows keep their 128 bytes per (pixel | output channel, 32-channel chunk), activations [h 64 B | l8 32 B | h8 32 B],
 //              weights [h 64 B | h8 32 B | l8 32 B], and lane half hh of either operand reads the 16-byte slots 4 + hh and 6 + hh.
 //   2  f16x3 : h = f16(s x), l = f16(s x - h): h*h + h*l + l*h on the f16 pipe, three units, ~2^-22 per term.
+//   3  f16f6 : (round 4) as f16f8 with the cross sums on FP6 (e2m3) operands with one E8M0 scale per (pixel | output channel, 32-channel
+//              chunk): the same K = 64 instruction retires FP6 operands in HALF the cycles of fp8 (32 instead of 64: the rate of
+//              v_mfma_f32_32x32x16_f16 per instruction) -- 1.5 pipe units per product.  Here a lane's scale applies to ITS OWN 32
+//              elements (tools/micro/probe_fp6_32x32.hip), so lane half 0 carries h6_w . l6_x and lane half 1 l6_w . h6_x over all 32
+//              channels; rows [h 64 B | 4 x 16 B: main pieces, tails + scale bytes] (common.hpp: split_f16f6_chunk), read as the same
+//              two ds_read_b128 per operand as f16f8.  tools/sim_conv_formats.py: 1.40e-5 of the features against 1.26e-5 for f16f8.
 // The epilogue writes the split output in the format the NEXT layer reads (out_fmt, out_scale), whatever this layer's own arithmetic.
 // Work split (widest form): a 512-thread workgroup owns 8 rows x 32 columns of output pixels x 256 output channels; wave (pr, ch) owns
 // pixel rows 2pr, 2pr+1 (two 32-pixel MFMA B operands) x channels ch*128..+128 (four 32-channel A operands): 8 accumulator
@@ -46,7 +52,7 @@ struct ConvSplitParams {
   int debug;   // profiling ablations (results WRONG): 1 = patch staged once, 2 = no epilogue, 4 = no MFMA, 8 = s_memtime probe
   float acc_scale;   // accumulator -> convolution value: 1 / (s_x s_w) for the f16 forms, 1 for bf16x3
   float out_scale;   // out_fmt != 0: the split output stores s_out * y
-  int out_fmt;       // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16
+  int out_fmt;       // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16, 3 = f16f6
   int* overflow;     // out_fmt != 0: *overflow |= 1 when |s_out * y| leaves the f16 range (the scale must be re-calibrated)
 };
 
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   static_assert(RPW == 2 || RPW == 4, "pixel rows per wave");
   static_assert(!PINNED || RPW == 2, "the all-assembly stage has two pixel rows per wave");
   static_assert(!PINNED || ARITH == 0, "the all-assembly stage is the bf16x3 form");
-  static_assert(ARITH >= 0 && ARITH <= 2, "ARITH");
+  static_assert(ARITH >= 0 && ARITH <= 3, "ARITH");
   constexpr int T = KS * KS;
   constexpr int PADK = KS / 2;                  // 1 for 3x3, 0 for 1x1
   constexpr int NW = NWR * 2;                   // waves per workgroup
@@ -301,8 +307,8 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       }
 #undef CVR
 #undef CVM
-    } else if constexpr (ARITH == 1) {
-      // ---- f16f8.  Per tap and wave: NA "F" blocks (output-channel tile a: the two K-16 steps of the f16 main product against both
+    } else if constexpr (ARITH == 1 || ARITH == 3) {
+      // ---- f16f8 / f16f6 (the X block: fp8 with two fixed scales, or FP6 with the scale bytes that travel in the rows).  Per tap and wave: NA "F" blocks (output-channel tile a: the two K-16 steps of the f16 main product against both
       // pixel rows, 4 MFMAs = 128 pipe cycles) and NA "X" blocks (the K-64 fp8 MFMA of both cross sums against both pixel rows, 2 MFMAs
       // = 128 cycles).  Left to itself hipcc keeps ONE set of weight-fragment registers and waits for every read right in front of the
       // MFMAs that use it (ds_read, s_waitcnt lgkmcnt(0), two MFMAs, ds_read, ...): the whole LDS round trip of every block lies open
@@ -374,8 +380,12 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
             for (int b = 0; b < 2; ++b) acc[a][r0 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g % LOOK][s_], bf[b][s_], acc[a][r0 + b], 0, 0, 0);
         } else {
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-            acc[a][r0 + b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[g % LOOK], bx[b], acc[a][r0 + b], 0, 0, 0, scale_a, 0, scale_b);
+          for (int b = 0; b < 2; ++b) {
+            if constexpr (ARITH == 3)
+              acc[a][r0 + b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[g % LOOK], bx[b], acc[a][r0 + b], 2, 2, 0, ax[g % LOOK][6], 0, bx[b][6]);
+            else
+              acc[a][r0 + b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[g % LOOK], bx[b], acc[a][r0 + b], 0, 0, 0, scale_a, 0, scale_b);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         load_block(g + LOOK);                         // into the buffer block g just left
@@ -549,6 +559,20 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
             *reinterpret_cast<ushort4*>(o) = hv;
             *reinterpret_cast<ushort4*>(o + 64) = lv;
           }
+      } else if (p.out_fmt == 3) {                  // f16 + FP6: [h 64 B | l6, h6 main | l6, h6 tail + scale byte] (common.hpp)
+        bool ovf = false;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          uint2 hw[4];
+          i32x4 main6, tail6;
+          split_f16f6_chunk(v[a], p.out_scale, h, hw, main6, tail6, ovf);
+          unsigned char* o = tile + n * RS + a * 128;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw[g];
+          *reinterpret_cast<i32x4*>(o + 80 - 16 * h) = main6;
+          *reinterpret_cast<i32x4*>(o + 112 - 16 * h) = tail6;
+        }
+        if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.W) != 0ull && lane == 0) atomicOr(p.overflow, 1);
       } else {                                      // the f16 forms the next layer reads: [h 64 B | l8 32 B | h8 32 B] or [h 64 B | l 64 B]
         bool ovf = false;
 #pragma unroll
@@ -778,7 +802,7 @@ static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int
   }
 }
 
-// in_fmt / out_fmt: FGVC_ACT_* (0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16); in_scale_log2 = log2(s_x s_w) of the operands (0 for bf16),
+// in_fmt / out_fmt: FGVC_ACT_* (0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16, 3 = f16f6); in_scale_log2 = log2(s_x s_w) of the operands (0 for bf16),
 // out_scale_log2 = log2(s_out) of the split output (ignored for bf16); overflow: device word, required when out_fmt != 0
 int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                       float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu, int in_fmt,
@@ -794,6 +818,7 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
+  else if (in_fmt == 3) conv_split_dispatch<3>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 2) conv_split_dispatch<2>(p, grid, KS, cot_eff, narrow, s);
   else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16)) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads
   else conv_split_dispatch<0>(p, grid, KS, cot_eff, narrow, s);                                                                  // (16: the compiler's operand schedule)

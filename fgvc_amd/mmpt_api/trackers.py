@@ -143,7 +143,7 @@ class VanillaTracker(BaseTracker):
         work) where that kernel applies -- every key slot masked, the mask within 64 key blocks of a query tile --, any other trunk
         (set_arith('f16x3') / 'bf16x3') with the 1e-7-grade fgvc_pair_topk_f16x3."""
         cfg = engine.TrackerConfig.from_test_cfg(self.test_cfg)
-        if "pair_split_fmt" not in self.test_cfg and getattr(self.backbone, "arith", None) == "f16f8":
+        if "pair_split_fmt" not in self.test_cfg and getattr(self.backbone, "arith", None) in ("f16f8", "f16f6"):
             all_masked = cfg.with_first_neighbor or not cfg.with_first
             if all_masked and ops.pair_blocks_reached(cfg.mask) <= ops.PAIR_F16F6_MAX_BLOCKS and cfg.topk <= 10 and cfg.with_norm:
                 cfg.pair_split_fmt = "f16f6"

@@ -586,8 +586,8 @@ def prepare_conv_split(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d") -> Tupl
 
 # formats of the encoder's split activation / weight tensors (include/fgvc_hip.h: FGVC_ACT_*) and the fixed power-of-two scales of the
 # e4m3 parts of the F16F8 form (csrc/common.hpp: F8_AX ...): h8 = e4m3(h 2^-A), l8 = e4m3(l 2^B)
-ACT_BF16X2, ACT_F16F8, ACT_F16X2 = 0, 1, 2
-ACT_FMT = {"bf16x3": ACT_BF16X2, "f16f8": ACT_F16F8, "f16x3": ACT_F16X2}
+ACT_BF16X2, ACT_F16F8, ACT_F16X2, ACT_F16F6 = 0, 1, 2, 3
+ACT_FMT = {"bf16x3": ACT_BF16X2, "f16f8": ACT_F16F8, "f16x3": ACT_F16X2, "f16f6": ACT_F16F6}
 F8_AX, F8_BX, F8_AW, F8_BW = 7, 3, 2, 9
 F16_TARGET_LOG2 = 8            # a calibrated tensor's largest value sits at ~2^8 of the f16 range (top 2^16): 2^7-2^8 of headroom
 
@@ -609,11 +609,58 @@ def _pow2_exponent(amax: float, target_log2: int) -> int:
     return max(-45, min(45, target_log2 - int(math.ceil(math.log2(amax)))))
 
 
+def _e2m3_blocks(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(..., 32) f32 holding f16 values -> (24 bytes per block (..., 24) uint8, field (...,) int32): the block's FP6 (e2m3) string as
+    v_cvt_scalef32_pk32_fp6_f16 writes it (element e in bits [6 e, 6 e + 6), round to nearest even) under the scale 2^(field - 127) =
+    the smallest power of two that keeps the block's largest magnitude at or below 7.5 (csrc/common.hpp: split_f16f6_chunk)."""
+    m = x.abs().amax(-1).float().contiguous()
+    mb = m.view(torch.int32)
+    field = ((mb >> 23) - 2 + ((mb & 0x7FFFFF) > 0x700000).to(torch.int32)).clamp(min=32)
+    y = x.float() * torch.exp2((127 - field).float()).unsqueeze(-1)              # exact: a power of two
+    a = y.abs().clamp(max=7.5)
+    step = torch.where(a < 2, 0.125, torch.where(a < 4, 0.25, 0.5))
+    r = (torch.round(a / step) * step).clamp(max=7.5)                            # torch.round: half to even
+    code = torch.where(r < 2, 8 * r, torch.where(r < 4, 8 + 4 * r, 16 + 2 * r)).to(torch.int32) | ((y < 0).to(torch.int32) << 5)
+    c = code.reshape(*code.shape[:-1], 8, 4)
+    w24 = c[..., 0] | (c[..., 1] << 6) | (c[..., 2] << 12) | (c[..., 3] << 18)
+    by = torch.stack([w24 & 255, (w24 >> 8) & 255, (w24 >> 16) & 255], dim=-1).reshape(*code.shape[:-1], 24).to(torch.uint8)
+    return by, field
+
+
+def _e2m3_decode(by: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
+    """The inverse of _e2m3_blocks on its grid: (..., 24) uint8, (...,) scale fields -> (..., 32) f32."""
+    b = by.to(torch.int32).reshape(*by.shape[:-1], 8, 3)
+    w24 = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+    code = torch.stack([(w24 >> (6 * i)) & 63 for i in range(4)], dim=-1).reshape(*by.shape[:-1], 32)
+    e, mnt = (code >> 3) & 3, (code & 7).float()
+    mag = torch.where(e == 0, mnt * 0.125, (1.0 + mnt * 0.125) * torch.exp2((e - 1).float()))
+    val = torch.where((code & 32) != 0, -mag, mag)
+    return val * torch.exp2((field.to(torch.int32) - 127).float()).unsqueeze(-1)
+
+
+def _f16f6_slots(h: torch.Tensor, l: torch.Tensor, first: str) -> torch.Tensor:
+    """h (..., 32) f16, l (..., 32) f32 = the exact residuals -> the 128-byte rows (..., 128) uint8 of format ACT_F16F6:
+    [h 64 B | slot 4, 5: the main 16 bytes of the two FP6 blocks | slot 6, 7: their 8-byte tails + scale byte + zeros]; `first` names the
+    block in slots 4 / 6 ("l": activations, "h": weights)."""
+    h6, fh = _e2m3_blocks(h.float())
+    l6, fl = _e2m3_blocks((l * 2048.0).to(torch.float16).float())
+    fl = fl - 11
+
+    def tail(b6, f):
+        t = torch.zeros((*b6.shape[:-1], 16), dtype=torch.uint8, device=b6.device)
+        t[..., :8] = b6[..., 16:]
+        t[..., 8] = f.to(torch.uint8)
+        return t
+    A, B = ((l6, fl), (h6, fh)) if first == "l" else ((h6, fh), (l6, fl))
+    return torch.cat([h.contiguous().view(torch.uint8).reshape(*h.shape[:-1], 64), A[0][..., :16], B[0][..., :16], tail(*A), tail(*B)], dim=-1)
+
+
 def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """prepare_conv_split for the f16 operand forms: returns (w int16 [KS*KS][Cin/32][Cout][64] -- 128-byte rows in format `fmt` --,
     bias f32 [Cout], log2 of the weights' scale s_w).  ACT_F16F8 rows: [h = f16(s_w w) 32 | h8 = e4m3(h / 4) 32 B | l8 = e4m3(512 (s_w w - h))
-    32 B]; ACT_F16X2 rows: [h 32 | l = f16(s_w w - h) 32]; s_w = the power of two that puts max|w| at (2^9, 2^10]."""
-    assert fmt in (ACT_F16F8, ACT_F16X2)
+    32 B]; ACT_F16X2 rows: [h 32 | l = f16(s_w w - h) 32]; ACT_F16F6 rows: [h 32 | the block-scaled FP6 forms of h (slots 4, 6) and of
+    the residual (slots 5, 7): csrc/common.hpp]; s_w = the power of two that puts max|w| at (2^9, 2^10]."""
+    assert fmt in (ACT_F16F8, ACT_F16X2, ACT_F16F6)
     Cout, Cin, KS, _ = weight.shape
     scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
     w = weight.detach().float() * scale.view(-1, 1, 1, 1)
@@ -626,6 +673,8 @@ def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt
     if fmt == ACT_F16X2:
         packed = torch.cat([h, l.to(torch.float16)], dim=-1).contiguous().view(torch.int16)
         return packed, bias, e
+    if fmt == ACT_F16F6:
+        return _f16f6_slots(h, l, "h").contiguous().view(torch.int16), bias, e
     h8 = (h.float() * 2.0 ** -F8_AW).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
     l8 = (l * 2.0 ** F8_BW).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
     packed = torch.cat([h.contiguous().view(torch.uint8), h8.view(torch.uint8), l8.view(torch.uint8)], dim=-1).contiguous()   # 64 + 32 + 32 B
@@ -854,6 +903,8 @@ def unsplit_act(split: torch.Tensor, fmt: int, scale_log2: int = 0) -> torch.Ten
     h = b[..., :64].contiguous().view(torch.float16).float()
     if fmt == ACT_F16X2:
         l = b[..., 64:].contiguous().view(torch.float16).float()
+    elif fmt == ACT_F16F6:       # slots 4 / 6: the residual's FP6 block (main, tail + scale byte)
+        l = _e2m3_decode(torch.cat([b[..., 64:80], b[..., 96:104]], dim=-1), b[..., 104])
     else:
         l = b[..., 64:96].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -F8_BX
     return ((h + l) * 2.0 ** -scale_log2).reshape(*n5[:3], -1)

@@ -306,12 +306,18 @@ int fgvc_conv_split_f32(const uint16_t* x, const uint16_t* w, const float* bias,
  *   F16F8   [h 32 x f16 | l8 32 x e4m3 | h8 32 x e4m3]: h = f16(s x), l8 = e4m3(8 (s x - h)), h8 = e4m3(h / 128), s a per-tensor
  *           power of two (`*_scale_log2`) that puts the tensor's largest values around 2^8           2 products (f16 + one K-64 fp8 MFMA)
  *   F16X2   [h 32 x f16 | l 32 x f16], l = f16(s x - h)                                     3 f16 products, ~2^-22 per term
+ *   F16F6   (round 4) [h 32 x f16 | 4 x 16 B]: the FP6 (e2m3) forms of the residual and of h, 32 elements each under one E8M0 scale:
+ *           slot 4 = l6 bytes 0-15, slot 5 = h6 bytes 0-15, slot 6 = [l6 bytes 16-23 | scale byte | 0], slot 7 = the same for h6;
+ *           l6 = e2m3(f16(2^11 (s x - h)) / 2^sl) with byte 127 + sl - 11, h6 = e2m3(h / 2^sh) with byte 127 + sh, 2^s the smallest
+ *           power of two that keeps the block at or below 7.5; element e = channel e in bits [6 e, 6 e + 6)     1.5 products (f16 + one K-64
+ *           FP6 MFMA at twice the fp8 rate).  Weights (ops.prepare_conv_split_f16): h6 in slots 4 / 6, l6 in 5 / 7.
  * `in_fmt` is the format of x AND of w (weights: ops.prepare_conv_split(fmt=...): F16F8 rows are [h | h8 = e4m3(h / 4) | l8 =
  * e4m3(512 l)] with h = f16(s_w w)); in_scale_log2 = log2(s_x s_w); out_fmt / out_scale_log2 describe y_split (what the NEXT
  * layer reads); *overflow (device word, required for an f16-format output) is OR-ed with 1 when |s_out y| exceeds 65504. */
 #define FGVC_ACT_BF16X2 0
 #define FGVC_ACT_F16F8 1
 #define FGVC_ACT_F16X2 2
+#define FGVC_ACT_F16F6 3
 int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual,
                             uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
                             int KS, int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow,

@@ -783,6 +783,53 @@ def f16f6p_decode(rows: np.ndarray):
     return h, h6, l6
 
 
+def _pack_e2m3_24(codes: np.ndarray) -> np.ndarray:
+    """(n, 32) e2m3 codes -> (n, 24) uint8: element e in bits [6 e, 6 e + 6) of the 192-bit little-endian string."""
+    c = codes.astype(np.uint32).reshape(codes.shape[0], 8, 4)
+    w = c[:, :, 0] | (c[:, :, 1] << 6) | (c[:, :, 2] << 12) | (c[:, :, 3] << 18)
+    return np.stack([w & 255, (w >> 8) & 255, (w >> 16) & 255], -1).reshape(codes.shape[0], 24).astype(np.uint8)
+
+
+def act_f16f6_rows(x: np.ndarray, scale_log2: int) -> np.ndarray:
+    """Model of the encoder's f16 + FP6 activation rows (FGVC_ACT_F16F6; fgvc_amd/csrc/common.hpp: split_f16f6_chunk) -- (n, 32) float32
+    values of one 32-channel chunk -> (n, 128) uint8: [h = f16(s x) 64 B | l6 main 16 B | h6 main 16 B | l6 tail 8 B, scale byte, 0 x 7 |
+    h6 tail 8 B, scale byte, 0 x 7] with l6 = e2m3(f16(2^11 (s x - h)) / 2^sl) (byte 127 + sl - 11), h6 = e2m3(h / 2^sh) (byte 127 + sh),
+    2^s the smallest power of two that keeps the block's largest magnitude at or below 7.5 (>= 2^-95 for an all-zero block).  The
+    sign bit of a code whose magnitude rounds to zero follows the value's sign, as the hardware conversion leaves it."""
+    x = np.ascontiguousarray(x, np.float32)
+    n = x.shape[0]
+    xs = np.clip((x * np.float32(2.0 ** scale_log2)).astype(np.float32), -65504, 65504).astype(np.float32)
+    h = xs.astype(np.float16)
+    hf = h.astype(np.float32)
+    l16 = ((xs - hf) * np.float32(2048.0)).astype(np.float32).astype(np.float16).astype(np.float32)
+    rows = np.zeros((n, 128), np.uint8)
+    rows[:, :64] = h.view(np.uint8).reshape(n, 64)
+    for vals, main, tail, sub in ((l16, 64, 96, 11), (hf, 80, 112, 0)):
+        m = np.abs(vals).max(1)
+        s = np.maximum(_f6_scale_exp(m), 32 - 127)
+        s = np.where(m > 0, s, 32 - 127)
+        by = _pack_e2m3_24(_e2m3_codes((vals * np.exp2(-s.astype(np.float32))[:, None]).astype(np.float32)))
+        rows[:, main: main + 16] = by[:, :16]
+        rows[:, tail: tail + 8] = by[:, 16:]
+        rows[:, tail + 8] = (s + 127 - sub).astype(np.uint8)
+    return rows
+
+
+def act_f16f6_decode(rows: np.ndarray):
+    """(n, 128) uint8 rows of act_f16f6_rows -> (h, h6, l6) float64 (n, 32): h = f16(s x), h6 ~ h, l6 ~ s x - h as the matrix
+    instruction sees them."""
+    rows = np.ascontiguousarray(rows, np.uint8)
+    n = rows.shape[0]
+    h = rows[:, :64].copy().view(np.float16).astype(np.float64).reshape(n, 32)
+    out = []
+    for main, tail in ((80, 112), (64, 96)):
+        by = np.concatenate([rows[:, main: main + 16], rows[:, tail: tail + 8]], 1).astype(np.uint32).reshape(n, 8, 3)
+        w = by[:, :, 0] | (by[:, :, 1] << 8) | (by[:, :, 2] << 16)
+        codes = np.stack([(w >> (6 * i)) & 63 for i in range(4)], -1).reshape(n, 32)
+        out.append(_e2m3_value(codes) * np.exp2(rows[:, tail + 8].astype(np.float64) - 127.0)[:, None])
+    return h, out[0], out[1]
+
+
 def f16f6_cosines(qrows: np.ndarray, krows: np.ndarray) -> np.ndarray:
     """the cosines fgvc_pair_topk_f16f6 computes from two sets of rows, in float64: (nk, nq)"""
     hq, h6q, l6q = f16f6p_decode(qrows)

@@ -593,7 +593,7 @@ def test_encoder_fused_bn_act_matches_torch(dev):
     net = net.to(dev).eval()
     with torch.no_grad():
         b = ora.eval()(x)
-        for arith, atol in (("bf16x3", 2e-4), ("f16x3", 2e-4), ("f16f8", 6e-4)):       # whole trunk; features up to ~20: 1e-5 / 3e-5 of the largest
+        for arith, atol in (("bf16x3", 2e-4), ("f16x3", 2e-4), ("f16f8", 6e-4), ("f16f6", 6e-4)):       # whole trunk; features up to ~20: 1e-5 / 3e-5 of the largest
             net.set_arith(arith)
             a = net(x.to(dev)).cpu()
             assert a.shape == b.shape == (2, 256, 16, 24)
@@ -910,6 +910,10 @@ def _pack_act(x_nchw, fmt, scale_log2, dev):
     l = xs - h.float()
     if fmt == ops.ACT_F16X2:
         row = torch.cat([h.view(torch.uint8), l.to(torch.float16).view(torch.uint8)], -1)
+    elif fmt == ops.ACT_F16F6:            # the oracle's model of split_f16f6_chunk: FP6 blocks with their own scales
+        from oracle import fgvc_oracle as O
+        v = x_nchw.permute(0, 2, 3, 1).float().reshape(-1, 32).numpy()
+        row = torch.from_numpy(O.act_f16f6_rows(v, scale_log2)).reshape(N, H, W, C // 32, 128)
     else:
         l8 = (l * 2.0 ** ops.F8_BX).to(torch.float8_e4m3fn).view(torch.uint8)
         h8 = (h.float() * 2.0 ** -ops.F8_AX).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
@@ -919,12 +923,12 @@ def _pack_act(x_nchw, fmt, scale_log2, dev):
     return out
 
 
-@pytest.mark.parametrize("arith", ["f16f8", "f16x3"])
+@pytest.mark.parametrize("arith", ["f16f8", "f16f6", "f16x3"])
 @pytest.mark.parametrize("case", [(2, 128, 256, 3, 19, 45, True, True), (1, 256, 256, 3, 8, 32, False, True),
                                   (2, 128, 256, 1, 13, 70, False, False), (1, 64, 128, 3, 9, 40, False, True),
                                   (1, 128, 128, 3, 17, 31, True, True), (1, 32, 192, 3, 10, 34, True, False)])
 def test_conv_split_f16_forms_vs_torch(dev, case, arith):
-    """fgvc_conv_split_fmt_f32 in the two f16 arithmetics (input, weights AND split output in the f16 formats) against torch in
+    """fgvc_conv_split_fmt_f32 in the three f16 arithmetics (input, weights AND split output in the f16 formats) against torch in
     float64 of the EXACT f32 operands: the bound therefore covers the formats' own quantisation of input and weights.
     ReLU-like heavy-tailed activations (the case the static per-tensor scale has to survive).  Bounds: f16x3 5e-6 of max|y|,
     f16f8 3e-5 (simulated: 1.0-1.7e-5 on real activations, tools/sim_conv_formats.py; bf16x3's bound is 2e-5)."""
@@ -965,6 +969,14 @@ def test_conv_split_f16_forms_vs_torch(dev, case, arith):
     tol = 5e-6 if arith == "f16x3" else 3e-5
     err = float((got_f - ref).abs().max()) / scale
     assert err < tol, err
+    if arith == "f16f6":      # the split output, byte for byte what the oracle's model makes of the kernel's own f32 output: h, both FP6
+        from oracle import fgvc_oracle as O          # blocks as the matrix instruction decodes them, and the scale bytes
+        want = O.act_f16f6_rows(out_f.cpu().reshape(-1, 32).numpy(), so)
+        got = out_s[:, 1:H + 1, 1:W + 1].contiguous().cpu().view(torch.uint8).reshape(-1, 128).numpy()
+        for a_, b_ in zip(O.act_f16f6_decode(got), O.act_f16f6_decode(want)):
+            assert np.array_equal(a_, b_)
+        assert np.array_equal(got[:, 104], want[:, 104]) and np.array_equal(got[:, 120], want[:, 120])
+        assert int(got[:, 105:112].max()) == 0 and int(got[:, 121:128].max()) == 0
     assert float((got_s - got_f).abs().max()) < (1e-6 if arith == "f16x3" else 4e-5) * scale          # the output format's own rounding
     assert int(ovf.item()) == 0
     assert int(out_s[:, :, W + 1:].abs().max()) == 0 and int(out_s[:, H + 1:].abs().max()) == 0
@@ -1027,6 +1039,22 @@ def test_conv_s2_split_vs_torch(dev, case):
     only_s = ops.alloc_split_nhwc(N, Cout, Ho, Wo, dev)
     ops.conv_s2_split(xs, wp, bias, H, W, relu, out_split=only_s)
     assert torch.equal(only_f, out_f) and torch.equal(only_s, out_s)
+    # the split output in the f16 forms the stride-1 kernel behind it reads (what the encoder asks of the first block of a stage)
+    so = ops.act_scale_log2(scale)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    for fmt, tol in ((ops.ACT_F16F8, 4e-5), (ops.ACT_F16F6, 4e-5), (ops.ACT_F16X2, 1e-6)):
+        o = ops.alloc_split_nhwc(N, Cout, Ho, Wo, dev)
+        ops.conv_s2_split(xs, wp, bias, H, W, relu, out_split=o, out_fmt=fmt, out_scale_log2=so, overflow=ovf)
+        assert float((_padded_to_nchw(ops.unsplit_act(o.cpu(), fmt, so), Ho, Wo).double() - got_f).abs().max()) < tol * scale
+        assert int(ovf.item()) == 0
+        assert int(o[:, :, Wo + 1:].abs().max()) == 0 and int(o[:, Ho + 1:].abs().max()) == 0
+        if fmt == ops.ACT_F16F6:       # ... as the oracle's model of the format makes them from the kernel's f32 output
+            from oracle import fgvc_oracle as O
+            want = O.act_f16f6_rows(out_f.cpu().reshape(-1, 32).numpy(), so)
+            got = o[:, 1:Ho + 1, 1:Wo + 1].contiguous().cpu().view(torch.uint8).reshape(-1, 128).numpy()
+            for a_, b_ in zip(O.act_f16f6_decode(got), O.act_f16f6_decode(want)):
+                assert np.array_equal(a_, b_)
+            assert np.array_equal(got[:, 104], want[:, 104]) and np.array_equal(got[:, 120], want[:, 120])
 
 
 @pytest.mark.parametrize("case", [(2, 21, 50, True, True), (1, 4, 32, False, True), (1, 3, 5, True, False), (3, 61, 100, True, True),
@@ -1375,7 +1403,7 @@ def test_encoder_zero_initialised_residual_branch(dev):
             assert float((a - ref).abs().max()) <= 5e-5 * float(ref.abs().max()) + 1e-6, (arith, float((a - ref).abs().max()), float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("arith", ["f16f8", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("arith", ["f16f8", "f16f6", "bf16x3", "f16x3"])
 def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev, arith):
     """A1: the ResNet-18 trunk on the hand-written kernels (the default on the GPU), in each arithmetic of the wide layers, against
     the same network with every convolution in MIOpen (f32), against the CPU oracle network, and through the tracker's forward_hwc
@@ -1399,7 +1427,7 @@ def test_encoder_split_conv_stage_vs_miopen_and_oracle(dev, arith):
     ora.load_state_dict(sd)
     net = net.to(dev).eval()
     net.set_arith(arith)
-    tol, tol_n = (5e-5, 1.5e-5) if arith == "f16f8" else (2e-5, 8e-6)
+    tol, tol_n = (5e-5, 1.5e-5) if arith in ("f16f8", "f16f6") else (2e-5, 8e-6)
     x = torch.randn(3, 3, 76, 132, generator=g)              # features 19 x 33: ragged against the 8 x 32 tiles
     with torch.no_grad():
         assert net._split_stage_ok(net.layer3, torch.empty(1, 128, 4, 4, device=dev))
