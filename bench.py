@@ -8,9 +8,9 @@
 A "step" = one synthetic 480x854 video of N x 8 frames (BASELINE.json configs[1]: an 8-frame 480p clip per GPU) through the
 whole path, inputs resident in HBM, SHARDED BY CLIP over the N ranks exactly as BASELINE.json's north_star describes
 (fgvc_amd.dist.track_points_sharded with the product backend): every rank encodes its own 8-frame clip (hand-written HIP ResNet-18
-trunk on the 16-bit matrix pipe; `--enc-arith`: f16 main product + fp8 cross terms by default), rank 0 broadcasts the first-frame ("query") features over RCCL/xGMI, the 5-frame halo in front
+trunk on the matrix pipe; `--enc-arith`: f16 main product + block-scaled FP6 cross terms by default), rank 0 broadcasts the first-frame ("query") features over RCCL/xGMI, the 5-frame halo in front
 of a clip comes from the previous rank by a point-to-point message, windowed correlation + top-10 for the clip's (query, key) frame
-pairs (fgvc_pair_topk_*: features split into 16-bit + low-precision parts on the matrix pipe, f32 accumulate; `--pair-arith`), slot merge + softmax,
+pairs (fgvc_pair_topk_f16f6: f16 main product + FP6 cross terms on the matrix pipe, f32 accumulate; `--pair-fmt f16`: three f16 products), slot merge + softmax,
 all_gather of the merged lists, then the sequential label sweep + fused upsample / top-5 soft-argmax read-out over the whole video
 (replicated; on a side stream so that the next step's encoder starts under it).  Nothing is skipped or cached across steps.
 At N = 1 the same function runs without any collective (27 pairs, 7 propagations: the single-GPU figure of configs[1]).
@@ -18,7 +18,7 @@ Per-GPU work is fixed as N grows (one 8-frame clip each): scaling = "weak"; valu
 `--mode clips` times the reference's own data parallelism instead (independent 8-frame clips per rank, no data-path collective).
 
 Rank 0 prints ONE JSON line.  `roofline` = the time-dominant kernel of the step (fgvc_conv_split_f32 256 -> 256 3x3, four
-launches per clip and lane), priced both as algorithmic f32 FLOPs and as executed bf16 partial products; `kernels` = the other
+launches per clip and lane), priced both as algorithmic f32 FLOPs and as executed 16-bit pipe units (1.5 per product by default); `kernels` = the other
 hand-written kernels of the step, each with its own roofline object (launch durations from HIP events inside the timed region, on
 the launch stream); `corr_volume` = the dense materialised volume kernel that BASELINE.json's "ms/corr-volume" and the
 >= 50 % HBM-roofline target refer to, timed right after the steps; `mfma_util` / `traffic` come from the committed rocprofv3 PMC
@@ -85,7 +85,7 @@ def encoder_flops(wl, n_frames: int) -> float:
 
 
 def pmc(kernel: str):
-    """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r03_pmc.json, written by tools/pmc_report.py from
+    """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r04_pmc.json, written by tools/pmc_report.py from
     separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes); {} if absent."""
     for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
@@ -505,7 +505,7 @@ def main():
             "launch_note": "HIP events on the lane's stream inside the timed region; the encoder's lanes run concurrently, so a launch "
                            "shares the GPU with the other lane's kernels",
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch"),
-            "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone on the GPU (profiles/r03_pmc.json)"}
+            "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone on the GPU (profiles/r04_pmc.json)"}
     pair_tag = next((t for t in probe.ev if t[0] in ("pair_split", "pair_f32")), None)
     if pair_tag:
         pair_ms, n_l = probe.mean_ms(pair_tag)

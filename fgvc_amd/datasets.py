@@ -317,7 +317,10 @@ class BadjaPoses:
         h, w = self.size
         sy, sx = h / h0, w / w0
         frames = torch.from_numpy(np.stack([np.asarray(im) for im in imgs]))                       # (T,h0,w0,3)
-        segs = [np.asarray(Image.open(p).resize((w0, h0), Image.NEAREST).resize((w, h), Image.NEAREST)) for p in v["segs"][:n]]
+        # silhouette -> the frame's size, then the network size.  The reference's first resize is cv2.resize(sil, (w, h), cv2.INTER_NEAREST)
+        # (badja_dataset.py:255, :276): the flag sits in the `dst` position, so OpenCV runs its default, INTER_LINEAR -- when a mask and
+        # its frame differ in size the `seg > 0` area (the PCK threshold) is the bilinear one.  Same size: both are the identity.
+        segs = [np.asarray(Image.open(p).resize((w0, h0), Image.BILINEAR).resize((w, h), Image.NEAREST)) for p in v["segs"][:n]]
         joints = [None if j is None else j * np.array([sy, sx]) for j in v["joints"][:n]]          # (J,2) = (y,x) at the network size
         visibles = list(v["visibles"][:n])
         assert joints[0] is not None, "BADJA: the first frame of a video carries the query joints (badja_dataset.py:364)"

@@ -187,7 +187,7 @@ def badja_pck(pred_poses: Sequence[np.ndarray], joints: Sequence[Sequence[Option
     visibles[t] (J,); segs[t] the silhouette at that size.  A VISIBLE joint is correct at ratio r when its distance to the ground
     truth is < r * sqrt(number of silhouette pixels of that frame) (:541-546, strict).  Returns PCK@r over all counted joints of all
     videos (%), and "PCK@0.2 per-video mean": the mean of the per-video PCK@0.2 values (the number :552-557 / :578 write out --
-    under the label 'PCK@0.1 AVG')."""
+    under the label 'PCK@0.1 AVG'; NaN as soon as one video has no visible labelled joint, as there)."""
     counts = {r: [] for r in ratios}
     per_video = []
     for pred, js, vs, ss in zip(pred_poses, joints, visibles, segs):
@@ -205,8 +205,8 @@ def badja_pck(pred_poses: Sequence[np.ndarray], joints: Sequence[Sequence[Option
                     ok = d < r * thr0
                     counts[r].append(ok)
                     mine[r].append(ok)
-        if 0.2 in mine and mine[0.2]:
-            per_video.append(100.0 * float(np.mean(mine[0.2])))
+        if 0.2 in mine:      # (a video without one visible labelled joint: the reference's np.mean([]) is NaN and stays in the average, :552-557)
+            per_video.append(100.0 * float(np.mean(mine[0.2])) if mine[0.2] else float("nan"))
     out = {f"PCK@{r}": (100.0 * float(np.mean(counts[r])) if counts[r] else float("nan")) for r in ratios}
     out["PCK@0.2 per-video mean"] = float(np.mean(per_video)) if per_video else float("nan")
     return out

@@ -388,7 +388,7 @@ def test_split_feature_bank_equals_f32_bank(dev):
     del model.test_cfg["pair_split_fmt"]
     model.backbone.set_arith("f16x3")
     assert model.engine_config().pair_split_fmt == "f16"
-    model.backbone.set_arith("f16f8")
+    model.backbone.set_arith("f16f6")
     cfg32 = engine.TrackerConfig(**{**cfg.__dict__, "pair_precision": "f32"})
     with pytest.raises(ValueError):
         engine.run_affinity(bank_s, Hf, Wf, plan, cfg32)

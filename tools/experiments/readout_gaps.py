@@ -1,0 +1,45 @@
+"""tracker_4x64x64 fixture: which read-outs move by more than 1e-3 px in each encoder arithmetic, and how far apart the 5th and 6th
+largest label values of those read-outs are in the oracle's own maps (a near-tie of the top-5 boundary = a legitimate flip)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import fgvc_amd.mmpt_api as api
+from oracle import fgvc_oracle as O
+dev = torch.device("cuda:0")
+g = dict(np.load(os.path.join(ROOT, "tests", "golden", "tracker_4x64x64.npz"), allow_pickle=False))
+T = torch.from_numpy
+cfg = dict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512, with_first=True, with_first_neighbor=True)
+model = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4), out_indices=(2,), pool_type="none")),
+                        train_cfg=None, test_cfg=api.ConfigDict(**cfg))
+model.backbone.load_state_dict(O.seeded_resnet_state(int(g["seed"]), (1, 1, 1, 4), "none"), strict=False)
+model = model.to(dev).eval()
+rgbs, qp, traj, vis = (T(g[n]).to(dev) for n in ("rgbs", "query_points", "trajectories", "visibilities"))
+# the oracle's label maps per query-time group
+net = O.ResNet18((1, 1, 1, 4), 2, "none"); net.load_state_dict(O.seeded_resnet_state(int(g["seed"]), (1, 1, 1, 4), "none")); net.eval()
+gaps = {}
+qpc = T(g["query_points"])
+ts = sorted(set(int(v) for v in qpc[0, :, 0]))
+K = 0
+with torch.no_grad():
+    for t in ts:
+        sel = qpc[0, :, 0] == t
+        n = int(sel.sum())
+        tr, allv = O.forward_test_main(net(T(g["rgbs"])[0, t:]), qpc[0, sel][:, 1:], 64, 64, return_all=True, **{k: v for k, v in cfg.items() if k not in ("with_first",)}, with_first=True)
+        labs = allv["labels"]                      # (T', P, Hf, Wf)
+        maps = np.stack([O.upsample_bilinear(labs[f], 64, 64).numpy() for f in range(labs.shape[0])], 0)
+        maps[0] = 0
+        srt = np.sort(maps.reshape(maps.shape[0], n, -1), -1)
+        rel = (srt[..., -5] - srt[..., -6]) / np.maximum(srt[..., -1], 1e-30)
+        for f in range(maps.shape[0]):
+            for p in range(n):
+                gaps[(t + f, K + p)] = float(rel[f, p])
+        K += n
+for arith in ("bf16x3", "f16x3", "f16f8", "f16f6"):
+    model.backbone.set_arith(arith)
+    outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
+    d = (outs[2].cpu().double() - T(g["out_traj_pred"]).double()).abs()[0]      # (T, P, 2)
+    big = [(int(t), int(p), float(d[t, p].max()), gaps.get((int(t), int(p)))) for t in range(d.shape[0]) for p in range(d.shape[1]) if float(d[t, p].max()) > 1e-3]
+    clear = [float(d[t, p].max()) for t in range(d.shape[0]) for p in range(d.shape[1]) if gaps.get((t, p), 1.0) > 1e-3]
+    print(arith, "max", float(d.max()), "read-outs above 1e-3 px (t, p, err, rel gap of the 5th / 6th label value):", big, "| max over read-outs with a gap > 1e-3:", max(clear), flush=True)
+print("all gaps below 1e-2:", {k: v for k, v in gaps.items() if v < 1e-2})

@@ -33,10 +33,14 @@ wp, bs = ops.prepare_conv_split(wt, bn)
 xs = ops.nchw_to_split_nhwc(torch.relu(torch.randn(T, 256, H, W, device=dev)))
 ys = ops.alloc_split_nhwc(T, 256, H, W, dev)
 wp8, bs8, sw8 = ops.prepare_conv_split_f16(wt, bn, ops.ACT_F16F8)
+wp6, bs6, sw6 = ops.prepare_conv_split_f16(wt, bn, ops.ACT_F16F6)        # round 4's default arithmetic: f16 + block-scaled FP6
+xs6 = ops.alloc_split_nhwc(T, 256, H, W, dev)
 ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+ops.conv_split(xs, wp, bs, H, W, True, out_split=xs6, out_fmt=ops.ACT_F16F6, out_scale_log2=4, overflow=ovf)     # a genuine f16f6 input tensor
 for _ in range(3):
     ops.conv_split(xs, wp, bs, H, W, True, out_split=ys)
     ops.conv_split(xs, wp8, bs8, H, W, True, out_split=ys, in_fmt=ops.ACT_F16F8, in_scale_log2=sw8, out_fmt=ops.ACT_F16F8, out_scale_log2=0, overflow=ovf)
+    ops.conv_split(xs6, wp6, bs6, H, W, True, out_split=ys, in_fmt=ops.ACT_F16F6, in_scale_log2=4 + sw6, out_fmt=ops.ACT_F16F6, out_scale_log2=4, overflow=ovf)
 torch.cuda.synchronize()
 # layer 1 (64 -> 64, register-resident weights), the stem and the stride-2 block of layer 2 at the 480p clip's sizes
 frames = torch.randn(T, 3, 480, 854, device=dev)
