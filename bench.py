@@ -577,6 +577,13 @@ def main():
                               "ranks": [dict(rank=r_, local_rank=l_, device=n_, uuid=u_) for r_, l_, n_, u_ in devs],
                               "distinct_devices": len({u_ for _, _, _, u_ in devs if u_}) or None,
                               "early_halo": bool(getattr(backend, "early_halo", False)), "comm_timeout_s": a.comm_timeout}
+    else:
+        try:
+            rccl1 = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl1 = None
+        out["distributed"] = {"world_size": 1, "backend": None, "rccl_version": rccl1,
+                              "note": "one process, no process group: the sharded driver runs without any collective"}
     if a.rehearse_on_one_gpu:
         out["rehearsal"] = (f"{world} ranks on ONE GPU over gloo, device tensors staged through the host: a functional rehearsal of the "
                             "multi-rank path, not a measurement")
