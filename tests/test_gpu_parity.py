@@ -938,10 +938,14 @@ def test_conv_split_f16_forms_vs_torch(dev, case, arith):
     fmt = ops.ACT_FMT[arith]
     g = torch.Generator().manual_seed(sum(int(v) for v in case) + fmt)
     x = torch.randn(N, Cin, H, W, generator=g).abs() ** 1.5 * (torch.rand(N, Cin, H, W, generator=g) > 0.4)     # 40 % zeros, a long tail
+    if Cin >= 64:
+        x[:, 32:64] = 0                                                      # a whole 32-channel chunk of zeros: all-zero FP6 blocks on the way in
     wt = torch.randn(Cout, Cin, KS, KS, generator=g) * (2.0 / (Cin * KS * KS)) ** 0.5
     bn = torch.nn.BatchNorm2d(Cout).eval()
     bn.weight.data = torch.rand(Cout, generator=g) * 1.5 + 0.2
     bn.bias.data = torch.randn(Cout, generator=g) * 0.1
+    if relu and not with_res:
+        bn.bias.data[32:64] = -1e3                                           # ... and one the ReLU zeroes on the way out (the scale byte of an empty block)
     bn.running_mean = torch.randn(Cout, generator=g) * 0.1
     bn.running_var = torch.rand(Cout, generator=g) + 0.5
     res = torch.randn(N, Cout, H, W, generator=g) if with_res else None

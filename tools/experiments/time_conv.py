@@ -7,7 +7,7 @@ from fgvc_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 N, H, W = 8, 120, 214
 ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-for Cin, Cout, arith in [(256, 256, "bf16x3"), (256, 256, "f16f8"), (128, 128, "bf16x3"), (128, 128, "f16f8")]:
+for Cin, Cout, arith in [(256, 256, "bf16x3"), (256, 256, "f16f8"), (256, 256, "f16f6"), (128, 128, "f16f8"), (128, 128, "f16f6")]:
     wt = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02
     bn = torch.nn.BatchNorm2d(Cout).eval().to(dev)
     fmt = ops.ACT_FMT[arith]
