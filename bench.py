@@ -302,9 +302,11 @@ def main():
     ap.add_argument("--encoder-graph", action="store_true", help="replay the encoder from a HIP graph (ResNet.use_graph: host time per call 0.7 -> 0.1 ms; "
                                                                  "no throughput change where the step is GPU-bound)")
     ap.add_argument("--no-encoder-graph", action="store_true", help="never replay the encoder from a HIP graph (default: ResNet.use_graph = 'auto': small inputs only)")
+    ap.add_argument("--no-fuse-bank", action="store_true", help="the two-kernel route to the feature bank (dense f32 output + normalise pass) instead of "
+                                                                "the last convolution's own epilogue (ResNet.fuse_bank; A/B)")
     ap.add_argument("--res-split", action="store_true", help="layer-1 identities from the split form instead of dense f32 copies (A/B)")
     ap.add_argument("--enc-arith", default=None, choices=["f16f8", "f16f6", "bf16x3", "f16x3"],
-                    help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f8; bf16x3 = round 2's)")
+                    help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f6; f16f8 = round 3's, bf16x3 = round 2's)")
     ap.add_argument("--no-clips-line", action="store_true", help="skip the extra `--mode clips` measurement that a `video` run appends")
     ap.add_argument("--repeats", type=int, default=5, help="extra blocks of 20 steps after the timed region, for the spread")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
@@ -362,6 +364,8 @@ def main():
         ResNet.use_conv64 = False
     if a.encoder_graph:
         ResNet.use_graph = True
+    if a.no_fuse_bank:
+        ResNet.fuse_bank = False
     if a.no_encoder_graph:
         ResNet.use_graph = False
     if a.res_split:

@@ -39,7 +39,7 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
                       int, float, int, float*, int32_t*, float*, hipStream_t);
 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
-                      int, int, int, int, int, int, int, int, int*, hipStream_t);
+                      int, int, int, int, int, int, int, int, int*, hipStream_t, unsigned char* y_bank = nullptr, int bank_normalize = 1);
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
                    int, int, int, int, int*, hipStream_t);
 int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, const uint16_t*, uint16_t*, float*, int, int, int, int, int, int,
@@ -560,6 +560,23 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
   if (N == 0) return FGVC_OK;
   return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, in_fmt, in_scale_log2, out_fmt,
                            out_scale_log2, overflow, (hipStream_t)stream);
+}
+
+int fgvc_conv_split_bank_f16f6p_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank, int N,
+                                    int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
+                                    int normalize, void* stream) {
+  FGVC_REQUIRE(x && w && bias && bank, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: null pointer");
+  FGVC_REQUIRE(in_fmt >= 0 && in_fmt <= 3, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: unknown format %d", in_fmt);
+  FGVC_REQUIRE(in_scale_log2 > -100 && in_scale_log2 < 100, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: scale exponent out of range");
+  FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: bad shape");
+  FGVC_REQUIRE(KS == 3, FGVC_ERR_UNSUPPORTED, "fgvc_conv_split_bank_f16f6p_f32: kernel size %d (3 x 3, stride 1: the last convolution of a BasicBlock)", KS);
+  FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0, FGVC_ERR_UNSUPPORTED, "fgvc_conv_split_bank_f16f6p_f32: Cin=%d must be a multiple of 32 (Cout is 256)", Cin);
+  FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
+  FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(residual) && aligned16(bank), FGVC_ERR_INVALID_ARG,
+               "fgvc_conv_split_bank_f16f6p_f32: 16-byte alignment required");
+  if (N == 0) return FGVC_OK;
+  return conv_split_launch(x, w, bias, residual, nullptr, nullptr, N, H, W, Hp, Wp, Cin, 256, KS, relu, in_fmt, in_scale_log2, 0, 0, nullptr,
+                           (hipStream_t)stream, reinterpret_cast<unsigned char*>(bank), normalize);
 }
 
 /* debug: the 32 s_memtime sums workgroup 77 leaves with fgvc_set_option("conv64_variant", 8) (tools/experiments/time_conv64_variants.py) */

@@ -54,6 +54,8 @@ struct ConvSplitParams {
   float out_scale;   // out_fmt != 0: the split output stores s_out * y
   int out_fmt;       // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16, 3 = f16f6
   int* overflow;     // out_fmt != 0: *overflow |= 1 when |s_out * y| leaves the f16 range (the scale must be re-calibrated)
+  unsigned char* y_bank;   // optional (Cout = 256 only): the L2-normalised pixels as rows of fgvc_split_f16f6p, [N][H*W][1024 B], INSTEAD of
+  int bank_normalize;      // y_split / y_f32 (the trunk's last convolution writes the pair kernel's feature bank itself); 0: rows of the raw values
 };
 
 typedef fgvc_f16x8 f16x8;
@@ -86,8 +88,9 @@ __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^
 // RPW = pixel rows per wave: 2 in every launched form.  (4 = a "tall" 16 x 32 x 128-channel tile of the f16f8 form, which moves 31 %
 // fewer weight + patch bytes per MAC than 8 x 32 x 256; measured 0.67 against 0.49 ms on the 256 -> 256 layer -- register spills in
 // the stage loop -- and not instantiated: docs/LAB_NOTES.md, round 3.)
-template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0, int RPW = 2>
+template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0, int RPW = 2, bool BANK = false>
 __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel(ConvSplitParams p) {
+  static_assert(!BANK || (COT == 256 && NWR == 4 && RPW == 2 && !PINNED), "the bank epilogue: a pixel's 256 channels in one 8-wave workgroup");
   static_assert(RPW == 2 || RPW == 4, "pixel rows per wave");
   static_assert(!PINNED || RPW == 2, "the all-assembly stage has two pixel rows per wave");
   static_assert(!PINNED || ARITH == 0, "the all-assembly stage is the bf16x3 form");
@@ -493,6 +496,160 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   const int co_w = co_base + ch * CW;             // first output channel of this wave
   const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  if constexpr (BANK) {
+    {
+      // ---- the feature bank straight from the accumulators (round 4): what normalize_f16f6p_kernel makes of this convolution's dense
+      // f32 output, bit for bit, without that output ever reaching memory.  A workgroup holds all 256 channels of its pixels: wave
+      // (pr, ch) channels 128 ch ..+128 of pixel rows 2 pr, 2 pr + 1.  Per pixel row: (1) the sum of squares in that kernel's own
+      // association -- lane L of its wave-per-pixel layout holds channels 4 L ..+4 = here group (ch, a, g, h) with L = 32 ch + 8 a +
+      // 2 g + h, and its xor-shuffle tree adds partners 32, 16, 8, 4, 2, 1 apart: the other wave's partial through LDS, then a ^ 2,
+      // a ^ 1, g ^ 2, g ^ 1 in registers, then the other lane half; (2) x = v / |v|, h = f16(256 x), residual 256 (256 x - h);
+      // (3) a scale block of the row format = channels 64 v + 16 m + 8 hi + i = groups a = 2 (v & 1) + (m >> 1), g = hi + 2 (m & 1) of
+      // BOTH lane halves: the halves trade registers (v_permlane32_swap) so that lane (n, 0) holds the block's 32 h values and
+      // lane (n, 1) its 32 residuals, one v_cvt_scalef32_2xpk16_fp6_f32 each (position 2 e <- S0[e], 2 e + 1 <- S1[e], round to nearest
+      // even from f32: tools/micro/probe_cvt_fp6_f32.hip); (4) the pair of waves assembles the 1-KiB rows in LDS and stores them whole.
+      constexpr int BK_RS = 1024 + 16;
+      static_assert(NWR * 32 * BK_RS <= CV_PATCHB + NSLOT * CV_WSLOTB, "bank staging");
+      unsigned char* rows = smem + pr * (32 * BK_RS);
+      float* part = reinterpret_cast<float*>(rows);                 // [ch][a * 4 + g][lane]: aliases the rows, used before them
+#pragma unroll
+      for (int b = 0; b < RPW; ++b) {
+        const int y = y0 + RPW * pr + b;
+        const bool row_ok = y < p.H;                                // wave-uniform, the same for both waves of a pair; barriers are taken by all
+        const size_t fpix0 = ((size_t)nimg * p.H + imin(y, p.H - 1)) * p.W + x0;
+        if (p.residual) {
+          const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
+#pragma unroll
+          for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = i * RPI + mv_row;
+            if (x0 + row < p.W)
+              *reinterpret_cast<uint4*>(tile + row * RS + mv_col) = *reinterpret_cast<const uint4*>(src + (size_t)row * p.Cout * 4 + mv_col);
+          }
+          wave_sync();
+        }
+        f32x4 v[NA][4];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cw = a * 32 + 8 * g + 4 * h;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
+            if constexpr (ARITH == 0)
+              v[a][g] = {acc[a][b][4 * g + 0] + bv.x, acc[a][b][4 * g + 1] + bv.y, acc[a][b][4 * g + 2] + bv.z, acc[a][b][4 * g + 3] + bv.w};
+            else
+              v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
+                         fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
+            if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
+            if (p.relu) {
+              v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
+              v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
+            }
+          }
+        __syncthreads();                                            // (1) the private residual tiles are read: the region becomes the pairs' buffers
+        float pp[NA][4];
+        {
+#pragma clang fp contract(off)                                       // four rounded squares and three adds, as normalize_nhwc_kernel compiles
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float xx = v[a][g].x * v[a][g].x, yy = v[a][g].y * v[a][g].y, zz = v[a][g].z * v[a][g].z, ww = v[a][g].w * v[a][g].w;
+              pp[a][g] = ((xx + yy) + zz) + ww;
+              part[(ch * 16 + a * 4 + g) * 64 + lane] = pp[a][g];
+            }
+        }
+        __syncthreads();                                            // (2)
+        float ss;
+        {
+          float t[NA][4];
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t[a][g] = pp[a][g] + part[((ch ^ 1) * 16 + a * 4 + g) * 64 + lane];       // partner 32 lanes away
+          float u[2][4], w4[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { u[0][g] = t[0][g] + t[2][g]; u[1][g] = t[1][g] + t[3][g]; }                // 16
+#pragma unroll
+          for (int g = 0; g < 4; ++g) w4[g] = u[0][g] + u[1][g];                                                 // 8
+          const float z0 = w4[0] + w4[2], z1 = w4[1] + w4[3];                                                     // 4
+          const float s1 = z0 + z1;                                                                               // 2
+          ss = s1 + __shfl_xor(s1, 32);                                                                           // 1: the other lane half
+        }
+        __syncthreads();                                            // (3) the partials are read: rows may be written
+        const float inv = p.bank_normalize ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+        unsigned char* row = rows + n * BK_RS;
+#pragma unroll
+        for (int vl = 0; vl < 2; ++vl)
+#pragma unroll
+          for (int hi = 0; hi < 2; ++hi) {
+            unsigned A_[16], B_[16];
+            float mh = 0.f, ml = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const int a = 2 * vl + (m >> 1), g = hi + 2 * (m & 1);          // (every (a, g) group belongs to exactly one block)
+              f32x4 x = v[a][g];
+              x *= inv;
+              typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+              f16x4 hv;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float xs = x[k] * 256.f;
+                const _Float16 hh_ = (_Float16)xs;
+                hv[k] = hh_;
+                const float fh = (float)hh_, fl = (xs - fh) * 256.f;
+                mh = fmaxf(mh, fabsf(fh)); ml = fmaxf(ml, fabsf(fl));
+                A_[4 * m + k] = __builtin_bit_cast(unsigned, fh);
+                B_[4 * m + k] = __builtin_bit_cast(unsigned, fl);
+              }
+              *reinterpret_cast<f16x4*>(row + 2 * (128 * ch + 32 * a + 8 * g + 4 * h)) = hv;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {        // upper lanes of A_ <-> lower lanes of B_: A_ = the values of lane half 0, B_ of half 1
+              const auto t2 = __builtin_amdgcn_permlane32_swap(A_[j], B_[j], false, false);
+              A_[j] = t2[0]; B_[j] = t2[1];
+            }
+            const auto tm = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mh), __builtin_bit_cast(unsigned, ml), false, false);
+            const unsigned mb = tm[0] > tm[1] ? tm[0] : tm[1];     // (as unsigned integers: see split_f16f6_chunk)
+            int sexp = (int)(mb >> 23) - 129 + ((mb & 0x7fffffu) > 0x700000u ? 1 : 0);     // m / 2^s in (3.75, 7.5]: n6_scale_exp
+            sexp = (mb == 0u || sexp < -40) ? -40 : sexp;
+            fgvc_i32x16 S0, S1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              S0[4 * m + 0] = (int)A_[4 * m + 0]; S0[4 * m + 1] = (int)A_[4 * m + 2]; S0[4 * m + 2] = (int)B_[4 * m + 0]; S0[4 * m + 3] = (int)B_[4 * m + 2];
+              S1[4 * m + 0] = (int)A_[4 * m + 1]; S1[4 * m + 1] = (int)A_[4 * m + 3]; S1[4 * m + 2] = (int)B_[4 * m + 1]; S1[4 * m + 3] = (int)B_[4 * m + 3];
+            }
+            fgvc_i32x6 c6;
+            const unsigned sc_bits = (unsigned)(sexp + 127) << 23;
+            asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(c6) : "v"(S0), "v"(S1), "v"(sc_bits));
+            const int vg = 2 * ch + vl;
+            *reinterpret_cast<i32x4*>(row + (h ? 704 : 512) + 32 * vg + 16 * hi) = i32x4{c6[0], c6[1], c6[2], c6[3]};
+            *reinterpret_cast<uint2*>(row + (h ? 832 : 640) + 32 * (vg >> 1) + 16 * hi + 8 * (vg & 1)) = uint2{(unsigned)c6[4], (unsigned)c6[5]};
+            row[896 + 16 * hi + 4 * h + vg] = (unsigned char)(sexp + 127 - 4);
+          }
+        if (ch == 0) {                                              // the pads of the scale area and the row's zero tail
+          if (h == 0) {
+            *reinterpret_cast<unsigned long long*>(row + 904) = 0ull;
+            *reinterpret_cast<unsigned long long*>(row + 920) = 0ull;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) *reinterpret_cast<i32x4*>(row + 928 + 16 * i) = i32x4{0, 0, 0, 0};
+          }
+        }
+        __syncthreads();                                            // (4) the rows are whole
+        if (row_ok) {
+          unsigned char* dst = p.y_bank + fpix0 * 1024;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int r = 16 * ch + i;
+            if (x0 + r < p.W)
+              *reinterpret_cast<uint4*>(dst + (size_t)r * 1024 + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+          }
+        }
+        __syncthreads();                                            // (5) before the next pixel row's residual tiles
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int b = 0; b < RPW; ++b) {
     const int y = y0 + RPW * pr + b;
@@ -789,7 +946,8 @@ void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 template <int ARITH>
 static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int cot_eff, bool narrow, hipStream_t s) {
   if (KS == 3) {
-    if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
+    if (cot_eff == 256 && p.y_bank) conv_split_kernel<3, 256, 1, 3, 4, false, ARITH, 2, true><<<grid, 512, 0, s>>>(p);      // the bank epilogue
+    else if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
     else if (cot_eff == 128 && narrow) conv_split_kernel<3, 128, 1, 3, 2, false, ARITH><<<grid, 256, 0, s>>>(p);
     else if (cot_eff == 128) conv_split_kernel<3, 128, 3, 2, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
     else if (narrow) conv_split_kernel<3, 64, 3, 2, 2, false, ARITH><<<grid, 256, 0, s>>>(p);
@@ -806,13 +964,15 @@ static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int
 // out_scale_log2 = log2(s_out) of the split output (ignored for bf16); overflow: device word, required when out_fmt != 0
 int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                       float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu, int in_fmt,
-                      int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, hipStream_t s) {
+                      int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, hipStream_t s, unsigned char* y_bank,
+                      int bank_normalize) {
   ConvSplitParams p;
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   p.acc_scale = ldexpf(1.0f, -in_scale_log2); p.out_scale = ldexpf(1.0f, out_scale_log2); p.out_fmt = out_fmt; p.overflow = overflow;
+  p.y_bank = y_bank; p.bank_normalize = bank_normalize;
   const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
-  const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap) ? g_conv_cot_cap : cot;
+  const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap && !y_bank) ? g_conv_cot_cap : cot;     // (the bank epilogue needs a pixel's 256 channels in one workgroup)
   const bool narrow = (cot_eff == 64 && (g_conv_narrow & 1)) || (cot_eff == 128 && KS == 3 && (g_conv_narrow & 2));   // 4-row tiles, two workgroups per CU
   p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
@@ -820,7 +980,7 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 3) conv_split_dispatch<3>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 2) conv_split_dispatch<2>(p, grid, KS, cot_eff, narrow, s);
-  else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16)) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads
+  else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16) && !y_bank) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads
   else conv_split_dispatch<0>(p, grid, KS, cot_eff, narrow, s);                                                                  // (16: the compiler's operand schedule)
   FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
   return FGVC_OK;

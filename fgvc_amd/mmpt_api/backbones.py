@@ -156,6 +156,9 @@ class ResNet(nn.Module):
                                    # profiles/r03_bv_xcd.log); same precision (tools/experiments/res_split_precision.py)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
     arith = "f16f6"                # arithmetic of the stride-1 convolutions behind layer 1: see set_arith() (round 3: "f16f8")
+    fuse_bank = True               # the trunk's last convolution writes the pair kernel's feature bank itself (fgvc_conv_split_bank_f16f6p_f32)
+                                   # when the caller asks for f16f6 rows of a 256-channel stage: no dense f32 output, no normalise pass;
+                                   # byte-identical rows (False: the two-kernel route, kept for A/B and as the reference of the tests)
 
     @staticmethod
     def supported_arith():
@@ -525,6 +528,15 @@ class ResNet(nn.Module):
             if skip_f32:
                 f_y_ = None
             kw_res = dict(residual_split=idt_split) if idt_split is not None else dict(residual=idt)
+            bank = None
+            if (last_conv and si == call["last"] and call.get("bank_of") is not None and wt["c2"][3] == "s1" and Cout == 256
+                    and blk.conv2.conv.kernel_size == (3, 3) and idt_split is None and calib is None):
+                bank = call["bank_of"](lo, hi, Cout, H, W)              # the caller's rows for these frames, or None
+            if bank is not None:
+                ops.conv_split_to_bank(buf["s_a"], wt["c2"][0], wt["c2"][1], H, W, True, bank, residual=idt, in_fmt=f_a,
+                                       in_scale_log2=s_a + wt["c2"][2], normalize=call["bank_normalize"])
+                cur = dict(cur, split=None, f32=None, H=H, W=W, fmt=f_y, scale=s_y, banked=True)
+                continue
             conv_s1(buf["s_a"], wt["c2"], f_a, s_a, f_y, s_y, relu=True, out_split=None if last_conv else buf["s_y"], out_f32=f_y_, **kw_res)
             if calib is not None and not last_conv:
                 calib[(si, bi, "y")] = torch.maximum(calib.get((si, bi, "y"), torch.zeros((), device=dev)),
@@ -533,7 +545,7 @@ class ResNet(nn.Module):
         cur["full"] = full
         return cur
 
-    def _trunk(self, x, last: int, fresh=(), post=None):
+    def _trunk(self, x, last: int, fresh=(), post=None, bank_of=None, bank_normalize=True):
         """Stem and stages 0..last.  When every requested stage qualifies (and there is no pooling layer) the whole trunk
         stays in NHWC on the bf16 pipe: the 7x7 stride-2 stem in fgvc_stem7_split_f32 (any other stem: MIOpen on
         channels_last tensors with BatchNorm folded, ReLU fused into the split), the stages as _stage_split runs them.
@@ -541,7 +553,9 @@ class ResNet(nn.Module):
         3.3 times at 8 frames, and the other lane's workgroups fill the tail of each launch.
         Stage outputs listed in `fresh` are new tensors, the others views of cached workspaces (valid until the next call).
         `post(y_slice, lo, hi, C, H, W)`, if given, runs at the end of every lane on that lane's stream with the lane's slice of the
-        last stage's dense NHWC output (NHWC trunk only: check the returned flag).
+        last stage's dense NHWC output (NHWC trunk only: check the returned flag).  `bank_of(lo, hi, C, H, W)`, if given, may return
+        the caller's f16f6 feature rows for the lane's frames: the stage's last convolution then writes them itself
+        (fgvc_conv_split_bank_f16f6p_f32: normalised iff `bank_normalize`), the stage's dense output is NOT produced and `post` is skipped.
         Returns (list of NCHW outputs of stages < last, last stage output, NHWC flag, H, W)."""
         from .. import ops
         stages = [getattr(self, nm) for nm in self.res_layers[:last + 1]]
@@ -604,7 +618,7 @@ class ResNet(nn.Module):
                                                          sb["s_x"][lo:hi].view(torch.bfloat16)[..., :32].abs().amax().float())
                 lanes.append(dict(split=sb["s_x"][lo:hi], f32=t, H=H, W=W, lo=lo, hi=hi, N=N, need_split=True, fmt=f_stem, scale=s_stem))
             fulls = []
-            call = dict(main=main, streams=streams, fresh=tuple(fresh), out={}, last=last)
+            call = dict(main=main, streams=streams, fresh=tuple(fresh), out={}, last=last, bank_of=bank_of, bank_normalize=bool(bank_normalize))
             for i in range(last + 1):
                 need_f32 = True           # the stage output in f32: returned, or the next block's identity / MIOpen input
                 if i < last and i not in call["fresh"]:
@@ -617,6 +631,8 @@ class ResNet(nn.Module):
                 fulls.append(lanes[0]["full"])
             if post is not None:
                 for ln, s in zip(lanes, streams):
+                    if ln.get("banked"):                                         # the last convolution wrote this lane's rows itself
+                        continue
                     with torch.cuda.stream(s):
                         post(ln["f32"], ln["lo"], ln["hi"], ln["f32"].shape[-1], ln["H"], ln["W"])
             if n_lanes > 1:
@@ -662,7 +678,7 @@ class ResNet(nn.Module):
         cache = self.__dict__.setdefault("_split_cache", {})
         # (everything a captured pass bakes in besides the input: the class-level switches tests and A/B runs flip between calls)
         sig = (self.arith, self.split_lanes, self.use_conv64, self.use_stem7, self.use_s2_conv, self.conv64_f16f8, self.res_from_split,
-               self.use_split_conv, tuple(self.out_indices))
+               self.use_split_conv, self.fuse_bank, tuple(self.out_indices))
         key = ("graph", tuple(x.shape), x.device, bool(normalize), split_fmt, split_if is not None, sig)
         ent = cache.get(key)
         if ent is None:                                        # first call of this shape: eager (it may calibrate and allocate)
@@ -703,7 +719,7 @@ class ResNet(nn.Module):
         assert len(self.out_indices) == 1
         box = {}
 
-        def post(y_slice, lo, hi, C, H, W):      # each lane normalises (and splits) its own frames under the other lane's tail
+        def ensure_out(C, H, W):
             if "out" not in box:
                 as_split = bool(split_if is not None and split_if(C, H, W))
                 shape = (x.shape[0], H * W, 2, C) if as_split else (x.shape[0], H * W, C)
@@ -717,10 +733,19 @@ class ResNet(nn.Module):
                 box["split"] = as_split
             elif torch.cuda.current_stream(x.device) != main:
                 torch.cuda.current_stream(x.device).wait_stream(main)
+
+        def post(y_slice, lo, hi, C, H, W):      # each lane normalises (and splits) its own frames under the other lane's tail
+            ensure_out(C, H, W)
             ops.normalize_nhwc(y_slice, normalize, split=split_fmt if box["split"] else False, out=box["out"][lo:hi])
 
+        def bank_of(lo, hi, C, H, W):            # ... or hands its rows to the trunk's last convolution (f16f6 rows of 256 channels)
+            if not (self.fuse_bank and split_fmt == "f16f6" and C == 256 and split_if is not None and split_if(C, H, W)):
+                return None
+            ensure_out(C, H, W)
+            return box["out"][lo:hi] if box["split"] else None
+
         main = torch.cuda.current_stream(x.device) if x.is_cuda else None
-        _, y, nhwc, H, W = self._trunk(x, self.out_indices[0], post=post)
+        _, y, nhwc, H, W = self._trunk(x, self.out_indices[0], post=post, bank_of=bank_of, bank_normalize=normalize)
         if nhwc:
             return box["out"], H, W
         C = y.shape[1]

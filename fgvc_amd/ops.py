@@ -799,6 +799,25 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
               int(out_scale_log2), _ptr(overflow), _stream(x_split))
 
 
+def conv_split_to_bank(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool, bank: torch.Tensor,
+                       residual: Optional[torch.Tensor] = None, in_fmt: int = ACT_BF16X2, in_scale_log2: int = 0,
+                       normalize: bool = True) -> torch.Tensor:
+    """fgvc_conv_split_bank_f16f6p_f32: conv_split() for Cout = 256 whose epilogue L2-normalises every pixel and writes it as a row of
+    split_f16f6p() -- `bank` (N, H*W, 2, 256) int16 (a slice of the tracker's feature bank) -- instead of any dense or split tensor:
+    byte for byte normalize_nhwc(out_f32 of conv_split(...), split="f16f6")."""
+    x_split, w = _chk(x_split, torch.int16, "x_split"), _chk(w, torch.int16, "w")
+    bias = _chk(bias, torch.float32, "bias")
+    N, Hp, Wp, nch, _ = x_split.shape
+    taps, nch_w, Cout, _ = w.shape
+    assert nch_w == nch and taps == 9 and bias.shape == (Cout,) and Cout == 256, "conv_split_to_bank: a 3 x 3 convolution with 256 output channels"
+    assert bank.dtype == torch.int16 and tuple(bank.shape) == (N, H * W, 2, 256) and bank.is_contiguous() and bank.device == x_split.device
+    if residual is not None:
+        assert residual.dtype == torch.float32 and tuple(residual.shape) == (N, H, W, Cout) and residual.is_contiguous()
+    _lib.call("fgvc_conv_split_bank_f16f6p_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(bank), N, H, W, Hp, Wp,
+              nch * 32, 3, int(relu), int(in_fmt), int(in_scale_log2), int(normalize), _stream(x_split))
+    return bank
+
+
 def conv64_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
                  residual: Optional[torch.Tensor] = None, out_split: Optional[torch.Tensor] = None,
                  out_f32: Optional[torch.Tensor] = None, residual_split: Optional[torch.Tensor] = None,

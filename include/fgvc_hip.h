@@ -322,6 +322,14 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
                             uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
                             int KS, int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow,
                             void* stream);
+/* The trunk's LAST convolution writing the pair kernel's feature bank itself (round 4): fgvc_conv_split_fmt_f32 for Cout = 256, KS = 3 whose
+ * epilogue -- + bias [+ residual] [ReLU] -- goes on to L2-normalise every pixel's 256 channels (normalize = 1: F.normalize(dim = C),
+ * local_attention.py:312-318) and stores them as rows of fgvc_split_f16f6p: bank [N][H*W][1024 B], byte for byte what
+ * fgvc_normalize_split_f16f6p_nhwc_f32 makes of the dense f32 output the plain entry point would have written (same association of
+ * the sum of squares, same conversions) -- that output and the normalise pass's read of it never touch memory. */
+int fgvc_conv_split_bank_f16f6p_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank,
+                                    int N, int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
+                                    int normalize, void* stream);
 /* fgvc_conv_split_f32 for Cin = Cout = 64, 3x3 (ResNet layer 1: the largest activations of the trunk), as persistent
  * workgroups that keep the folded weights in registers instead of re-streaming them per tile.  Same tensors and epilogue;
  * weights in MFMA-operand order:

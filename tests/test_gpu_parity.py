@@ -1545,3 +1545,87 @@ def test_local_corr_split_path_vs_oracle(dev):
     o_out, o_idx, o_logit = O.local_corr_topk(q, key.transpose(0, 1), v.transpose(0, 1), R, topk, 0.07)
     assert torch.allclose(l1.cpu(), o_logit, atol=TOL) and torch.allclose(l1, l0, atol=1e-4)
     assert (i1.cpu().long() == o_idx).all(1).float().mean() > 0.98 and (i1 == i0).all(1).float().mean() > 0.98
+
+
+@pytest.mark.parametrize("arith", ["f16f6", "f16f8", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("case", [(2, 256, 19, 45, True, True), (1, 128, 8, 32, False, True), (1, 256, 17, 70, True, False), (3, 64, 5, 33, True, True)])
+def test_conv_split_writes_the_feature_bank_itself(dev, case, arith):
+    """fgvc_conv_split_bank_f16f6p_f32 (round 4): the trunk's last convolution (3 x 3, 256 output channels) normalises its pixels and
+    writes the pair kernel's f16f6 rows in its own epilogue.  Byte for byte what the two-kernel route makes -- the same convolution's
+    dense f32 output through fgvc_normalize_split_f16f6p_nhwc_f32 -- in every arithmetic, with and without the identity, ragged tiles,
+    rows beyond the image; and un-normalised rows (normalize = 0) likewise."""
+    from fgvc_amd import ops
+    N, Cin, H, W, with_res, normalize = case
+    fmt = ops.ACT_FMT[arith]
+    g = torch.Generator().manual_seed(7 + sum(int(v) for v in case) + fmt)
+    wt = (torch.randn(256, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(dev)
+    bn = torch.nn.BatchNorm2d(256).eval()
+    bn.weight.data = torch.rand(256, generator=g) + 0.5
+    bn.bias.data = torch.randn(256, generator=g) * 0.3
+    bn.running_mean = torch.randn(256, generator=g) * 0.1
+    bn.running_var = torch.rand(256, generator=g) + 0.5
+    bn = bn.to(dev)
+    x = torch.randn(N, Cin, H, W, generator=g).abs() * (torch.rand(N, Cin, H, W, generator=g) > 0.3)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    if fmt == ops.ACT_BF16X2:
+        wp, bias = ops.prepare_conv_split(wt, bn)
+        sw, sx = 0, 0
+        xs = ops.nchw_to_split_nhwc(x.to(dev))
+    else:
+        wp, bias, sw = ops.prepare_conv_split_f16(wt, bn, fmt)
+        sx = ops.act_scale_log2(float(x.abs().max()))
+        xs = _pack_act(x, fmt, sx, dev)
+    res = torch.randn(N, H, W, 256, generator=g).to(dev) if with_res else None
+    out_f = ops.alloc_nhwc(N, 256, H, W, dev)
+    ops.conv_split(xs, wp, bias, H, W, True, residual=res, out_f32=out_f, in_fmt=fmt, in_scale_log2=sx + sw)
+    want = ops.normalize_nhwc(out_f, normalize, split="f16f6")
+    bank = torch.full((N, H * W, 2, 256), 0x5a5a, dtype=torch.int16, device=dev)
+    ops.conv_split_to_bank(xs, wp, bias, H, W, True, bank, residual=res, in_fmt=fmt, in_scale_log2=sx + sw, normalize=normalize)
+    same = bank == want
+    assert bool(same.all()), (arith, case, int((~same).sum()), (~same).nonzero()[:4].tolist())
+    # ... and what the rows decode to is the normalised output (a check of the reference route itself)
+    f = torch.nn.functional.normalize(out_f.reshape(N, H * W, 256), dim=2) if normalize else out_f.reshape(N, H * W, 256)
+    if normalize:                                                            # (unsplit_f16f6p: the 11-bit h part alone)
+        assert float((ops.unsplit_f16f6p(bank) - f).abs().max()) < 2.5e-4
+    with pytest.raises(AssertionError):                                      # 1 x 1 kernels and other widths stay on the plain entry point
+        ops.conv_split_to_bank(xs, wp[:1], bias, H, W, True, bank)
+
+
+def test_encoder_bank_from_the_last_convolution(dev):
+    """ResNet.fuse_bank (default on): the f16f6 rows forward_hwc returns come out of the trunk's last convolution and equal the rows of
+    the two-kernel route bit for bit -- in every arithmetic, eagerly and from a HIP graph, into the caller's bank slice too."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import ops
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none"))
+    net.load_state_dict(O.seeded_resnet_state(5, (1, 2, 1, 1), "none"))
+    net = net.to(dev).eval()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 3, 76, 132, generator=g).to(dev)
+    yes = lambda C, H, W: True
+    with torch.no_grad():
+        for arith in net.supported_arith():
+            net.set_arith(arith)
+            try:
+                ResNet.fuse_bank = False
+                ref, Hf, Wf = net.forward_hwc(x, True, split_if=yes, split_fmt="f16f6")
+                ref = ref.clone()
+            finally:
+                ResNet.fuse_bank = True
+            net.reset_split_cache()
+            got, H2, W2 = net.forward_hwc(x, True, split_if=yes, split_fmt="f16f6")
+            assert (Hf, Wf) == (H2, W2) == (19, 33) and got.shape == (3, 19 * 33, 2, 256) and got.dtype == torch.int16
+            assert torch.equal(got, ref), (arith, int((got != ref).sum()))
+            bank = torch.zeros(5, 19 * 33, 2, 256, dtype=torch.int16, device=dev)
+            o2, _, _ = net.forward_hwc(x, True, split_if=yes, split_fmt="f16f6", out=bank[1:4])
+            assert o2.data_ptr() == bank[1:4].data_ptr() and torch.equal(bank[1:4], ref) and int(bank[0].abs().max()) == 0 and int(bank[4].abs().max()) == 0
+            net.check_overflow()
+        # small input: the graph route (use_graph = "auto") replays the same kernels
+        xs = x[:2, :, :48, :64].contiguous()
+        a, _, _ = net.forward_hwc(xs, True, split_if=yes, split_fmt="f16f6")
+        b, _, _ = net.forward_hwc(xs, True, split_if=yes, split_fmt="f16f6")
+        c, _, _ = net.forward_hwc(xs, True, split_if=yes, split_fmt="f16f6")
+        assert torch.equal(a, b) and torch.equal(b, c)
+        # other formats / widths keep the two-kernel route
+        f32, _, _ = net.forward_hwc(x, True)
+        assert f32.dtype == torch.float32 and float((ops.unsplit_f16f6p(ref) - f32).abs().max()) < 2.5e-4       # (the 11-bit h part alone)
