@@ -304,6 +304,8 @@ def main():
     ap.add_argument("--no-encoder-graph", action="store_true", help="never replay the encoder from a HIP graph (default: ResNet.use_graph = 'auto': small inputs only)")
     ap.add_argument("--no-fuse-bank", action="store_true", help="the two-kernel route to the feature bank (dense f32 output + normalise pass) instead of "
                                                                 "the last convolution's own epilogue (ResNet.fuse_bank; A/B)")
+    ap.add_argument("--no-fold-projection", action="store_true", help="layer 3's 1 x 1 projection shortcut as its own launch + dense f32 identity instead of "
+                                                                      "extra stages of the block's second convolution (ResNet.fold_projection; A/B)")
     ap.add_argument("--res-split", action="store_true", help="layer-1 identities from the split form instead of dense f32 copies (A/B)")
     ap.add_argument("--enc-arith", default=None, choices=["f16f8", "f16f6", "bf16x3", "f16x3"],
                     help="arithmetic of the encoder's wide convolutions (default: ResNet.arith = f16f6; f16f8 = round 3's, bf16x3 = round 2's)")
@@ -366,6 +368,8 @@ def main():
         ResNet.use_graph = True
     if a.no_fuse_bank:
         ResNet.fuse_bank = False
+    if a.no_fold_projection:
+        ResNet.fold_projection = False
     if a.no_encoder_graph:
         ResNet.use_graph = False
     if a.res_split:

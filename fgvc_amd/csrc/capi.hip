@@ -39,7 +39,8 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
                       int, float, int, float*, int32_t*, float*, hipStream_t);
 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
-                      int, int, int, int, int, int, int, int, int*, hipStream_t, unsigned char* y_bank = nullptr, int bank_normalize = 1);
+                      int, int, int, int, int, int, int, int, int*, hipStream_t, unsigned char* y_bank = nullptr, int bank_normalize = 1, const uint16_t* x2 = nullptr,
+                      const uint16_t* w2 = nullptr, int Cin2 = 0);
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
                    int, int, int, int, int*, hipStream_t);
 int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, const uint16_t*, uint16_t*, float*, int, int, int, int, int, int,
@@ -560,6 +561,27 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
   if (N == 0) return FGVC_OK;
   return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, Cout, KS, relu, in_fmt, in_scale_log2, out_fmt,
                            out_scale_log2, overflow, (hipStream_t)stream);
+}
+
+int fgvc_conv_split_proj_fmt_f32(const uint16_t* x, const uint16_t* w, const uint16_t* x2, const uint16_t* w2, const float* bias,
+                                 const float* residual, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cin2,
+                                 int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, void* stream) {
+  FGVC_REQUIRE(x && w && x2 && w2 && bias && (y_split || y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_proj_fmt_f32: null pointer");
+  FGVC_REQUIRE(in_fmt >= 0 && in_fmt <= 3 && out_fmt >= 0 && out_fmt <= 3, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_proj_fmt_f32: unknown format %d / %d", in_fmt, out_fmt);
+  FGVC_REQUIRE(out_fmt == FGVC_ACT_BF16X2 || !y_split || overflow, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_proj_fmt_f32: an f16-format output needs the overflow word");
+  FGVC_REQUIRE(in_scale_log2 > -100 && in_scale_log2 < 100 && out_scale_log2 > -100 && out_scale_log2 < 100, FGVC_ERR_INVALID_ARG,
+               "fgvc_conv_split_proj_fmt_f32: scale exponent out of range");
+  FGVC_REQUIRE(N >= 0 && H > 0 && W > 0, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_proj_fmt_f32: bad shape");
+  FGVC_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cin2 > 0 && Cin2 % 32 == 0, FGVC_ERR_UNSUPPORTED,
+               "fgvc_conv_split_proj_fmt_f32: Cin=%d and Cin2=%d must be multiples of 32 (Cout is 256)", Cin, Cin2);
+  FGVC_REQUIRE(conv_pad_ok(H, W, Hp, Wp), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_proj_fmt_f32: padded size %dx%d too small for %dx%d", Hp, Wp, H, W);
+  FGVC_REQUIRE(aligned16(x) && aligned16(w) && aligned16(x2) && aligned16(w2) && aligned16(bias) && aligned16(residual) && aligned16(y_split) &&
+               aligned16(y_f32), FGVC_ERR_INVALID_ARG, "fgvc_conv_split_proj_fmt_f32: 16-byte alignment required");
+  FGVC_REQUIRE((const void*)x != (const void*)y_split && (const void*)x2 != (const void*)y_split, FGVC_ERR_INVALID_ARG,
+               "fgvc_conv_split_proj_fmt_f32: in-place not supported");
+  if (N == 0) return FGVC_OK;
+  return conv_split_launch(x, w, bias, residual, y_split, y_f32, N, H, W, Hp, Wp, Cin, 256, 3, relu, in_fmt, in_scale_log2, out_fmt,
+                           out_scale_log2, overflow, (hipStream_t)stream, nullptr, 1, x2, w2, Cin2);
 }
 
 int fgvc_conv_split_bank_f16f6p_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank, int N,

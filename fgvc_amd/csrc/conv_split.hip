@@ -54,6 +54,9 @@ struct ConvSplitParams {
   float out_scale;   // out_fmt != 0: the split output stores s_out * y
   int out_fmt;       // format of y_split: 0 = (hi, lo) bf16, 1 = f16f8, 2 = (h, l) f16, 3 = f16f6
   int* overflow;     // out_fmt != 0: *overflow |= 1 when |s_out * y| leaves the f16 range (the scale must be re-calibrated)
+  const uint16_t* x2;      // optional (the 256-channel 3 x 3 form only): a SECOND input, padded split NHWC of the same H x W geometry with
+  const uint16_t* w2;      // Cin2 channels, and the [1][Cin2/32][Cout] rows of a 1 x 1 convolution over it that accumulates into the same
+  int Cin2;                // sums: y = conv3x3(x, w) + conv1x1(x2, w2) + bias -- a block's projection shortcut folded into its second convolution
   unsigned char* y_bank;   // optional (Cout = 256 only): the L2-normalised pixels as rows of fgvc_split_f16f6p, [N][H*W][1024 B], INSTEAD of
   int bank_normalize;      // y_split / y_f32 (the trunk's last convolution writes the pair kernel's feature bank itself); 0: rows of the raw values
 };
@@ -88,8 +91,9 @@ __device__ __forceinline__ int cv_swz(int row, int s) { return row * 128 + ((s ^
 // RPW = pixel rows per wave: 2 in every launched form.  (4 = a "tall" 16 x 32 x 128-channel tile of the f16f8 form, which moves 31 %
 // fewer weight + patch bytes per MAC than 8 x 32 x 256; measured 0.67 against 0.49 ms on the 256 -> 256 layer -- register spills in
 // the stage loop -- and not instantiated: docs/LAB_NOTES.md, round 3.)
-template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0, int RPW = 2, bool BANK = false>
+template <int KS, int COT, int TG, int NSLOT, int NWR, bool PINNED = false, int ARITH = 0, int RPW = 2, bool BANK = false, bool X2 = false>
 __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel(ConvSplitParams p) {
+  static_assert(!X2 || (KS == 3 && TG == 1 && !PINNED), "the second input: extra one-tap stages of the 3 x 3 form with one tap per stage");
   static_assert(!BANK || (COT == 256 && NWR == 4 && RPW == 2 && !PINNED), "the bank epilogue: a pixel's 256 channels in one 8-wave workgroup");
   static_assert(RPW == 2 || RPW == 4, "pixel rows per wave");
   static_assert(!PINNED || RPW == 2, "the all-assembly stage has two pixel rows per wave");
@@ -121,6 +125,8 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   const int co_base = blockIdx.y * COT;
   const int nchunk = p.Cin / 32;
   const size_t pix_bytes_in = (size_t)nchunk * 128;
+  const int nchunk2 = X2 ? p.Cin2 / 32 : 0;                    // chunks of the second input: one extra stage each (its only tap = the centre)
+  const size_t pix_bytes_in2 = (size_t)nchunk2 * 128;
 
   // ---- staging helpers: lane L of a DMA instruction fills LDS bytes [16L, 16L+16) of a 1-KiB piece = 8 rows x 8 slots
   const int d_row = lane >> 3, d_slot = lane & 7;
@@ -155,12 +161,17 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   // patch pixel, ((prow_ * 40 + pc0_ + d_row) >> 1) & 7, is (d_row >> 1) ^ 4 * ((prow_ + pc0_ / 8) & 1): one lane constant, XORed with 64
   // bytes for every other piece -- no per-piece 64-bit lane addresses (hipcc hoisted twelve of them out of the stage loop and spilled them)
   const uint32_t pf_lane_off = (uint32_t)(d_row * (int)pix_bytes_in + ((d_slot ^ (d_row >> 1)) << 4));
+  const uint32_t pf_lane_off2 = (uint32_t)(d_row * (int)pix_bytes_in2 + ((d_slot ^ (d_row >> 1)) << 4));
+  const unsigned char* xb2 = reinterpret_cast<const unsigned char*>(p.x2);
+  // (CHUNK counts through both inputs: chunks nchunk .. nchunk + nchunk2 - 1 are the second input's)
 #define CV_PREFETCH(J, CHUNK)                                                                         \
   if ((J) < MAXP) {                                                                                   \
     CV_PIECE_GEOM(J)                                                                                  \
     const size_t g_ = ((size_t)nimg * p.Hp + imin(y0 + 1 - PADK + prow_, p.Hp - 1)) * p.Wp + (x0 + 1 - PADK + pc0_); \
-    const unsigned char* b_ = xb0 + (size_t)(CHUNK) * 128 + g_ * pix_bytes_in;                       \
-    const uint32_t o_ = pf_lane_off ^ (uint32_t)(((prow_ + (pc0_ >> 3)) & 1) << 6);                   \
+    const bool second_ = X2 && (CHUNK) >= nchunk;                                                     \
+    const unsigned char* b_ = second_ ? xb2 + (size_t)((CHUNK) - nchunk) * 128 + g_ * pix_bytes_in2    \
+                                      : xb0 + (size_t)(CHUNK) * 128 + g_ * pix_bytes_in;              \
+    const uint32_t o_ = (second_ ? pf_lane_off2 : pf_lane_off) ^ (uint32_t)(((prow_ + (pc0_ >> 3)) & 1) << 6); \
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pre##J) : "v"(o_), "s"(b_) : "memory");   \
   }
 #define CV_COMMIT(J)                                                                                  \
@@ -186,6 +197,10 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     // for every other piece
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w) +
                               ((((size_t)tap * nchunk + chunk) * p.Cout + co_base) + c0) * 128;
+    if constexpr (X2) {                                              // a stage of the second input: chunk q - nchunk * SPC of its one tap
+      if (q >= nchunk * SPC)
+        wb = reinterpret_cast<const unsigned char*>(p.w2) + (((size_t)(q - nchunk * SPC) * p.Cout + co_base) + c0) * 128;
+    }
     uint32_t wo_;                                                    // (volatile: not another lane constant held across the stage loop)
     asm volatile("v_xor_b32 %0, %1, %2" : "=v"(wo_) : "s"((uint32_t)((c0 & 8) << 3)), "v"(w_lane_off));
     conv_lds_dma_16s(wo_, wb, lds_addr(dst + (tg * COT + c0) * 128));
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int n_stage = nchunk * SPC;
+  const int n_stage = nchunk * SPC + nchunk2;
   constexpr int LA = NSLOT - 1;                  // stages in flight ahead of the one being multiplied
   stage_patch(0);
 #pragma unroll
@@ -213,7 +228,9 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   long long t_wait = 0, t_issue = 0, t_mma = 0, t_bound = 0, t_start = 0;
   if (timing) t_start = __builtin_amdgcn_s_memtime();
   for (int q = 0; q < n_stage; ++q) {
-    const int chunk = q / SPC, sg = q - chunk * SPC;
+    int chunk = q / SPC, sg = q - chunk * SPC;
+    const bool second = X2 && q >= nchunk * SPC;   // a stage of the second input: its own chunk, the centre tap's pixels
+    if (second) { chunk = nchunk + (q - nchunk * SPC); sg = T / 2; }
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if (timing) c0 = __builtin_amdgcn_s_memtime();
     if (q + LA - 1 < n_stage) {
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     }
     lds_barrier();
     if (timing) c1 = __builtin_amdgcn_s_memtime();
-    const bool last_of_chunk = sg == SPC - 1 && chunk + 1 < nchunk && (p.debug & 1) == 0;
+    const bool last_of_chunk = (second || sg == SPC - 1) && q + 1 < n_stage && (p.debug & 1) == 0;
     if (last_of_chunk) {                            // next chunk's patch: lands while this stage multiplies.  Issued BEFORE
       // this stage's weight DMAs: hipcc guards the reuse of these registers with a vmcnt wait that knows nothing of the
       // inline-assembly DMAs and would otherwise wait for the ones issued a moment ago
@@ -947,6 +964,7 @@ template <int ARITH>
 static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int cot_eff, bool narrow, hipStream_t s) {
   if (KS == 3) {
     if (cot_eff == 256 && p.y_bank) conv_split_kernel<3, 256, 1, 3, 4, false, ARITH, 2, true><<<grid, 512, 0, s>>>(p);      // the bank epilogue
+    else if (cot_eff == 256 && p.x2) conv_split_kernel<3, 256, 1, 3, 4, false, ARITH, 2, false, true><<<grid, 512, 0, s>>>(p);   // + a 1 x 1 convolution of a second input
     else if (cot_eff == 256) conv_split_kernel<3, 256, 1, 3, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
     else if (cot_eff == 128 && narrow) conv_split_kernel<3, 128, 1, 3, 2, false, ARITH><<<grid, 256, 0, s>>>(p);
     else if (cot_eff == 128) conv_split_kernel<3, 128, 3, 2, 4, false, ARITH><<<grid, 512, 0, s>>>(p);
@@ -965,14 +983,15 @@ static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int
 int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                       float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu, int in_fmt,
                       int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, hipStream_t s, unsigned char* y_bank,
-                      int bank_normalize) {
+                      int bank_normalize, const uint16_t* x2, const uint16_t* w2, int Cin2) {
   ConvSplitParams p;
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   p.acc_scale = ldexpf(1.0f, -in_scale_log2); p.out_scale = ldexpf(1.0f, out_scale_log2); p.out_fmt = out_fmt; p.overflow = overflow;
   p.y_bank = y_bank; p.bank_normalize = bank_normalize;
+  p.x2 = x2; p.w2 = w2; p.Cin2 = Cin2;
   const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
-  const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap && !y_bank) ? g_conv_cot_cap : cot;     // (the bank epilogue needs a pixel's 256 channels in one workgroup)
+  const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap && !y_bank && !x2) ? g_conv_cot_cap : cot;     // (the bank epilogue needs a pixel's 256 channels in one workgroup)
   const bool narrow = (cot_eff == 64 && (g_conv_narrow & 1)) || (cot_eff == 128 && KS == 3 && (g_conv_narrow & 2));   // 4-row tiles, two workgroups per CU
   p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
@@ -980,7 +999,7 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 3) conv_split_dispatch<3>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 2) conv_split_dispatch<2>(p, grid, KS, cot_eff, narrow, s);
-  else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16) && !y_bank) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads
+  else if (KS == 3 && cot_eff == 256 && !(g_conv_debug & 16) && !y_bank && !x2) conv_split_kernel<3, 256, 1, 3, 4, true><<<grid, 512, 0, s>>>(p);   // hand-placed operand reads
   else conv_split_dispatch<0>(p, grid, KS, cot_eff, narrow, s);                                                                  // (16: the compiler's operand schedule)
   FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
   return FGVC_OK;

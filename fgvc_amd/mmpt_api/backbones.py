@@ -156,6 +156,9 @@ class ResNet(nn.Module):
                                    # profiles/r03_bv_xcd.log); same precision (tools/experiments/res_split_precision.py)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
     arith = "f16f6"                # arithmetic of the stride-1 convolutions behind layer 1: see set_arith() (round 3: "f16f8")
+    fold_projection = True         # a block's stride-1 1 x 1 projection shortcut rides in the sums of the block's second convolution
+                                   # (fgvc_conv_split_proj_fmt_f32: 256 output channels, 3 x 3; not in the f16f8 arithmetic, whose e4m3
+                                   # forms cannot take a forced weight scale): no projection launch, no dense f32 identity (False: A/B)
     fuse_bank = True               # the trunk's last convolution writes the pair kernel's feature bank itself (fgvc_conv_split_bank_f16f6p_f32)
                                    # when the caller asks for f16f6 rows of a 256-channel stage: no dense f32 output, no normalise pass;
                                    # byte-identical rows (False: the two-kernel route, kept for A/B and as the reference of the tests)
@@ -248,6 +251,33 @@ class ResNet(nn.Module):
     def _block_formats(self, si: int, bi: int, last: int):
         return self._format_plan(last)[(si, bi)]
 
+
+    def _projection_fold(self, blk, wt, si, bi, dev, f_in, f_a, s_in, s_a, Cout, banked):
+        """(w2, bias) for fgvc_conv_split_proj_fmt_f32 -- the block's 1 x 1 stride-1 projection as extra stages of its second
+        convolution -- or None when the fold does not apply: other shapes / kernels, the f16f8 arithmetic (fixed e4m3 scales), the
+        bank-writing form of the last convolution, a forced weight scale s_w2 = s_a s_w / s_x2 that would leave the f16 range."""
+        from .. import ops
+        ds, c2 = blk.downsample, blk.conv2
+        if not (self.fold_projection and not banked and f_in == f_a and f_a != ops.ACT_F16F8 and wt["c2"][3] == "s1" and wt["ds"] is not None
+                and wt["ds"][3] == "s1" and Cout == 256 and c2.conv.kernel_size == (3, 3) and ds.conv.kernel_size == (1, 1)
+                and ds.conv.stride == (1, 1) and ds.conv.in_channels % 32 == 0):
+            return None
+        cache = self.__dict__.setdefault("_split_cache", {})
+        e = s_a + wt["c2"][2] - s_in                                       # log2 of the projection's weight scale
+        key = ("wproj", si, bi, dev, self.arith, f_a, e)
+        if key not in cache:
+            w = ds.conv.weight.detach()
+            if f_a == ops.ACT_BF16X2:
+                w2, b2 = ops.prepare_conv_split(w, ds.bn)
+            else:
+                sc = (ds.bn.weight / torch.sqrt(ds.bn.running_var + ds.bn.eps)).detach().float().abs().view(-1, 1, 1, 1)
+                top = float((w.detach().float().abs() * sc).max()) * 2.0 ** e
+                if not (2.0 ** -6 <= top < 2.0 ** 14) and top != 0.0:        # keep the folded weights well inside f16's normal range
+                    cache[key] = None
+                    return None
+                w2, b2, _ = ops.prepare_conv_split_f16(w, ds.bn, f_a, force_exp=e)
+            cache[key] = (w2, (wt["c2"][1] + b2).contiguous())
+        return cache[key]
 
     def _identity_from_split(self, blk) -> bool:
         """Whether `blk` adds its identity from the SPLIT form of its input (hi + lo, the value its first convolution multiplies)
@@ -476,6 +506,8 @@ class ResNet(nn.Module):
                                    out_scale_log2=out_scale, overflow=ovf, **kw)
 
             last_conv = bi == len(stage) - 1 and not cur["need_split"]        # nobody reads the split form of the trunk output
+            proj = None
+            x_in_split = cur["split"]
             if blk.conv1.conv.stride == (2, 2) and self.use_s2_conv:
                 # stride-2 3x3 and stride-2 projection on the bf16 pipe as well (fgvc_conv_s2_split_f32)
                 Hi, Wi = H, W
@@ -501,6 +533,10 @@ class ResNet(nn.Module):
                 bufs = self._split_buffers((si, bi), N, Cout, H, W, dev, ("s_a", "s_y", "f_y", "f_idt"))
                 buf = {k: v[lo:hi] for k, v in bufs.items()}
                 if blk.downsample is not None:
+                    proj = self._projection_fold(blk, wt, si, bi, dev, f_in, f_a, s_in, s_a, Cout, last_conv and si == call["last"] and call.get("bank_of") is not None)
+                if proj is not None:
+                    idt = None                                             # (w2, summed bias): the projection rides in conv2's sums
+                elif blk.downsample is not None:
                     conv_s1(cur["split"], wt["ds"], f_in, s_in, relu=False, out_f32=buf["f_idt"])
                     idt = buf["f_idt"]
                 elif self._identity_from_split(blk):
@@ -537,7 +573,12 @@ class ResNet(nn.Module):
                                        in_scale_log2=s_a + wt["c2"][2], normalize=call["bank_normalize"])
                 cur = dict(cur, split=None, f32=None, H=H, W=W, fmt=f_y, scale=s_y, banked=True)
                 continue
-            conv_s1(buf["s_a"], wt["c2"], f_a, s_a, f_y, s_y, relu=True, out_split=None if last_conv else buf["s_y"], out_f32=f_y_, **kw_res)
+            if proj is not None:
+                ops.conv_split(buf["s_a"], wt["c2"][0], proj[1], H, W, True, out_split=None if last_conv else buf["s_y"], out_f32=f_y_,
+                               in_fmt=f_a, in_scale_log2=s_a + wt["c2"][2], out_fmt=f_y, out_scale_log2=s_y, overflow=ovf,
+                               x2_split=x_in_split, w2=proj[0])
+            else:
+                conv_s1(buf["s_a"], wt["c2"], f_a, s_a, f_y, s_y, relu=True, out_split=None if last_conv else buf["s_y"], out_f32=f_y_, **kw_res)
             if calib is not None and not last_conv:
                 calib[(si, bi, "y")] = torch.maximum(calib.get((si, bi, "y"), torch.zeros((), device=dev)),
                                                      buf["s_y"].view(torch.bfloat16)[..., :32].abs().amax().float())
@@ -678,7 +719,7 @@ class ResNet(nn.Module):
         cache = self.__dict__.setdefault("_split_cache", {})
         # (everything a captured pass bakes in besides the input: the class-level switches tests and A/B runs flip between calls)
         sig = (self.arith, self.split_lanes, self.use_conv64, self.use_stem7, self.use_s2_conv, self.conv64_f16f8, self.res_from_split,
-               self.use_split_conv, self.fuse_bank, tuple(self.out_indices))
+               self.use_split_conv, self.fuse_bank, self.fold_projection, tuple(self.out_indices))
         key = ("graph", tuple(x.shape), x.device, bool(normalize), split_fmt, split_if is not None, sig)
         ent = cache.get(key)
         if ent is None:                                        # first call of this shape: eager (it may calibrate and allocate)

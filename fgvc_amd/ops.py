@@ -655,11 +655,11 @@ def _f16f6_slots(h: torch.Tensor, l: torch.Tensor, first: str) -> torch.Tensor:
     return torch.cat([h.contiguous().view(torch.uint8).reshape(*h.shape[:-1], 64), A[0][..., :16], B[0][..., :16], tail(*A), tail(*B)], dim=-1)
 
 
-def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
+def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt: int, force_exp: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """prepare_conv_split for the f16 operand forms: returns (w int16 [KS*KS][Cin/32][Cout][64] -- 128-byte rows in format `fmt` --,
     bias f32 [Cout], log2 of the weights' scale s_w).  ACT_F16F8 rows: [h = f16(s_w w) 32 | h8 = e4m3(h / 4) 32 B | l8 = e4m3(512 (s_w w - h))
     32 B]; ACT_F16X2 rows: [h 32 | l = f16(s_w w - h) 32]; ACT_F16F6 rows: [h 32 | the block-scaled FP6 forms of h (slots 4, 6) and of
-    the residual (slots 5, 7): csrc/common.hpp]; s_w = the power of two that puts max|w| at (2^9, 2^10]."""
+    the residual (slots 5, 7): csrc/common.hpp]; s_w = the power of two that puts max|w| at (2^9, 2^10], or 2^force_exp."""
     assert fmt in (ACT_F16F8, ACT_F16X2, ACT_F16F6)
     Cout, Cin, KS, _ = weight.shape
     scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
@@ -667,6 +667,9 @@ def prepare_conv_split_f16(weight: torch.Tensor, bn: "torch.nn.BatchNorm2d", fmt
     bias = (bn.bias - bn.running_mean * scale).detach().float().contiguous()
     w = w.permute(2, 3, 1, 0).reshape(KS * KS, Cin // 32, 32, Cout).permute(0, 1, 3, 2).contiguous()   # [tap][chunk][co][32 ci]
     e = _pow2_exponent(float(w.abs().max()), 10)
+    if force_exp is not None:         # (a projection folded into another convolution's sums shares that convolution's combined scale)
+        e = int(force_exp)
+        assert float(w.abs().max()) * 2.0 ** e < 32768.0, "prepare_conv_split_f16: the forced scale leaves the f16 range"
     ws = w * (2.0 ** e)
     h = ws.to(torch.float16)
     l = ws - h.float()                                                  # exact in f32
@@ -778,8 +781,12 @@ def nchw_to_split_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_
 def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, relu: bool,
                residual: Optional[torch.Tensor] = None, out_split: Optional[torch.Tensor] = None,
                out_f32: Optional[torch.Tensor] = None, in_fmt: int = ACT_BF16X2, in_scale_log2: int = 0,
-               out_fmt: int = ACT_BF16X2, out_scale_log2: int = 0, overflow: Optional[torch.Tensor] = None) -> None:
+               out_fmt: int = ACT_BF16X2, out_scale_log2: int = 0, overflow: Optional[torch.Tensor] = None,
+               x2_split: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None) -> None:
     """fgvc_conv_split_fmt_f32: y = conv(x, w) + bias [+ residual] [ReLU] into out_split and/or out_f32 (interiors only).
+    With `x2_split` / `w2` (fgvc_conv_split_proj_fmt_f32; 3 x 3, 256 output channels): + conv1x1(x2, w2) in the same sums -- a block's
+    projection shortcut; x2 in x's format and geometry, w2 (1, Cin2/32, 256, 64) scaled so that s_x2 s_w2 = 2^in_scale_log2 too, `bias`
+    the sum of both folded biases.
     in_fmt: ACT_* format of x_split AND w (prepare_conv_split / prepare_conv_split_f16), in_scale_log2 = log2(s_x s_w);
     out_fmt / out_scale_log2: format and scale of out_split; overflow: int32 device word OR-ed with 1 when an f16-format output
     leaves the f16 range."""
@@ -794,6 +801,14 @@ def conv_split(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: in
             assert t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous() and t.device == x_split.device, "conv_split buffer"
     if out_fmt != ACT_BF16X2 and out_split is not None:
         assert overflow is not None and overflow.dtype == torch.int32 and overflow.device == x_split.device
+    if x2_split is not None:
+        x2_split, w2 = _chk(x2_split, torch.int16, "x2_split"), _chk(w2, torch.int16, "w2")
+        assert taps == 9 and Cout == 256, "conv_split: a second input goes with the 3 x 3 form of 256 output channels"
+        assert tuple(x2_split.shape[:3]) == (N, Hp, Wp) and x2_split.shape[4] == 64 and tuple(w2.shape) == (1, x2_split.shape[3], Cout, 64)
+        _lib.call("fgvc_conv_split_proj_fmt_f32", _ptr(x_split), _ptr(w), _ptr(x2_split), _ptr(w2), _ptr(bias), _ptr(residual), _ptr(out_split),
+                  _ptr(out_f32), N, H, W, Hp, Wp, nch * 32, x2_split.shape[3] * 32, int(relu), int(in_fmt), int(in_scale_log2), int(out_fmt),
+                  int(out_scale_log2), _ptr(overflow), _stream(x_split))
+        return
     _lib.call("fgvc_conv_split_fmt_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out_split), _ptr(out_f32),
               N, H, W, Hp, Wp, nch * 32, Cout, 3 if taps == 9 else 1, int(relu), int(in_fmt), int(in_scale_log2), int(out_fmt),
               int(out_scale_log2), _ptr(overflow), _stream(x_split))

@@ -322,6 +322,16 @@ int fgvc_conv_split_fmt_f32(const uint16_t* x, const uint16_t* w, const float* b
                             uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout,
                             int KS, int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow,
                             void* stream);
+/* A BasicBlock's second convolution with the block's PROJECTION SHORTCUT folded in (round 4; resnet.py:96-106 `identity =
+ * self.downsample(x) ... out += identity` for a stride-1 1 x 1 projection): y = conv3x3(x, w) + conv1x1(x2, w2) + bias [+ residual]
+ * [ReLU], Cout = 256.  x2 is a second padded split NHWC tensor of the same H x W with Cin2 channels, w2 the [1][Cin2/32][256] rows
+ * of the projection (BatchNorm folded; ops.prepare_conv_split*), in the SAME format as x / w and scaled so that s_x2 s_w2 = s_x s_w =
+ * 2^in_scale_log2 (both products accumulate in one set of sums: the projection costs Cin2 / 32 extra stages of the 9 Cin / 32, its
+ * own launch and the dense f32 copy of the identity disappear); bias = the sum of both folded biases. */
+int fgvc_conv_split_proj_fmt_f32(const uint16_t* x, const uint16_t* w, const uint16_t* x2, const uint16_t* w2, const float* bias,
+                                 const float* residual, uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin,
+                                 int Cin2, int relu, int in_fmt, int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow,
+                                 void* stream);
 /* The trunk's LAST convolution writing the pair kernel's feature bank itself (round 4): fgvc_conv_split_fmt_f32 for Cout = 256, KS = 3 whose
  * epilogue -- + bias [+ residual] [ReLU] -- goes on to L2-normalise every pixel's 256 channels (normalize = 1: F.normalize(dim = C),
  * local_attention.py:312-318) and stores them as rows of fgvc_split_f16f6p: bank [N][H*W][1024 B], byte for byte what

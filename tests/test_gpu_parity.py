@@ -1629,3 +1629,110 @@ def test_encoder_bank_from_the_last_convolution(dev):
         # other formats / widths keep the two-kernel route
         f32, _, _ = net.forward_hwc(x, True)
         assert f32.dtype == torch.float32 and float((ops.unsplit_f16f6p(ref) - f32).abs().max()) < 2.5e-4       # (the 11-bit h part alone)
+
+
+@pytest.mark.parametrize("arith", ["f16f6", "bf16x3", "f16x3"])        # (not f16f8: its e4m3 forms have FIXED scales that assume weights at 2^9-2^10,
+@pytest.mark.parametrize("case", [(2, 256, 128, 19, 45, True), (1, 256, 64, 8, 32, False), (1, 128, 32, 17, 70, True)])   # a forced scale breaks that)
+def test_conv_split_with_the_projection_folded_in(dev, case, arith):
+    """fgvc_conv_split_proj_fmt_f32 (round 4): y = conv3x3(x, w) + conv1x1(x2, w2) + bias [ReLU] in ONE accumulation -- a BasicBlock's
+    second convolution with the block's 1 x 1 projection shortcut folded in -- against torch in float64 of the exact f32 operands, and
+    against the three-launch route (projection -> dense f32 identity -> convolution with `residual`) within the arithmetic's bound."""
+    import torch.nn.functional as F
+    from fgvc_amd import ops
+    N, Cin, Cin2, H, W, relu = case
+    fmt = ops.ACT_FMT[arith]
+    g = torch.Generator().manual_seed(11 + sum(int(v) for v in case) + fmt)
+    mk = lambda c: torch.randn(N, c, H, W, generator=g).abs() ** 1.3 * (torch.rand(N, c, H, W, generator=g) > 0.4)
+    x, x2 = mk(Cin), mk(Cin2) * 3.0                                           # different magnitudes: different activation scales
+    wt = torch.randn(256, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    wt2 = torch.randn(256, Cin2, 1, 1, generator=g) * (1.0 / Cin2) ** 0.5
+
+    def mkbn():
+        bn = torch.nn.BatchNorm2d(256).eval()
+        bn.weight.data = torch.rand(256, generator=g) + 0.5
+        bn.bias.data = torch.randn(256, generator=g) * 0.1
+        bn.running_mean = torch.randn(256, generator=g) * 0.1
+        bn.running_var = torch.rand(256, generator=g) + 0.5
+        return bn
+    bn, bn2 = mkbn(), mkbn()
+
+    def ref_of(xx, ww, b, pad):
+        r = F.conv2d(xx.double(), ww.double(), padding=pad)
+        sc = (b.weight / torch.sqrt(b.running_var + b.eps)).double().view(1, -1, 1, 1)
+        return (r - b.running_mean.double().view(1, -1, 1, 1)) * sc + b.bias.double().view(1, -1, 1, 1)
+    ref = (ref_of(x, wt, bn, 1) + ref_of(x2, wt2, bn2, 0)).detach()
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = float(ref.abs().max())
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    bn, bn2 = bn.to(dev), bn2.to(dev)
+    if fmt == ops.ACT_BF16X2:
+        wp, bias = ops.prepare_conv_split(wt.to(dev), bn)
+        wp2, bias2 = ops.prepare_conv_split(wt2.to(dev), bn2)
+        sx = sx2 = sw = sw2 = 0
+        xs, xs2 = ops.nchw_to_split_nhwc(x.to(dev)), ops.nchw_to_split_nhwc(x2.to(dev))
+    else:
+        sx, sx2 = ops.act_scale_log2(float(x.abs().max())), ops.act_scale_log2(float(x2.abs().max()))
+        wp, bias, sw = ops.prepare_conv_split_f16(wt.to(dev), bn, fmt)
+        wp2, bias2, sw2 = ops.prepare_conv_split_f16(wt2.to(dev), bn2, fmt, force_exp=sx + sw - sx2)       # s_x2 s_w2 = s_x s_w
+        assert sw2 == sx + sw - sx2
+        xs, xs2 = _pack_act(x, fmt, sx, dev), _pack_act(x2, fmt, sx2, dev)
+    so = ops.act_scale_log2(scale) if fmt != ops.ACT_BF16X2 else 0
+    out_s, out_f = ops.alloc_split_nhwc(N, 256, H, W, dev), ops.alloc_nhwc(N, 256, H, W, dev)
+    ops.conv_split(xs, wp, bias + bias2, H, W, relu, out_split=out_s, out_f32=out_f, in_fmt=fmt, in_scale_log2=sx + sw, out_fmt=fmt,
+                   out_scale_log2=so, overflow=ovf, x2_split=xs2, w2=wp2)
+    got = _nhwc_to_nchw(out_f.cpu()).double()
+    tol = {"f16x3": 5e-6, "bf16x3": 2e-5}.get(arith, 3e-5)
+    err = float((got - ref).abs().max()) / scale
+    assert err < tol, (arith, err)
+    assert int(ovf.item()) == 0
+    assert float((_padded_to_nchw(ops.unsplit_act(out_s.cpu(), fmt, so), H, W).double() - got).abs().max()) < 4e-5 * scale
+    # the three-launch route: the projection's own launch writes the identity in f32, the convolution adds it
+    idt = ops.alloc_nhwc(N, 256, H, W, dev)
+    if fmt == ops.ACT_BF16X2:
+        ops.conv_split(xs2, wp2, bias2, H, W, False, out_f32=idt)
+    else:
+        wp2n, bias2n, sw2n = ops.prepare_conv_split_f16(wt2.to(dev), bn2, fmt)
+        ops.conv_split(xs2, wp2n, bias2n, H, W, False, out_f32=idt, in_fmt=fmt, in_scale_log2=sx2 + sw2n)
+    out3 = ops.alloc_nhwc(N, 256, H, W, dev)
+    ops.conv_split(xs, wp, bias, H, W, relu, residual=idt, out_f32=out3, in_fmt=fmt, in_scale_log2=sx + sw)
+    assert float((out3 - out_f).abs().max()) < 2 * tol * scale
+    with pytest.raises(AssertionError):
+        ops.conv_split(xs, wp[:1], bias, H, W, relu, out_f32=out3, x2_split=xs2, w2=wp2)       # 1 x 1 main convolution: not this entry point
+
+
+def test_encoder_projection_rides_in_the_second_convolution(dev):
+    """ResNet.fold_projection (default on): layer 3's 1 x 1 stride-1 projection shortcut is folded into the block's second convolution
+    (fgvc_conv_split_proj_fmt_f32) in the f16f6 / bf16x3 / f16x3 arithmetics -- not in f16f8 -- and the trunk stays within the
+    arithmetic's bound of the route with the projection's own launch and of the MIOpen f32 network."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none"))
+    net.load_state_dict(O.seeded_resnet_state(6, (1, 2, 1, 1), "none"))
+    net = net.to(dev).eval()
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(3, 3, 76, 132, generator=g).to(dev)
+    with torch.no_grad():
+        try:
+            ResNet.use_split_conv = False
+            ref = net(x).clone()
+        finally:
+            ResNet.use_split_conv = True
+        top = float(ref.abs().max())
+        for arith in net.supported_arith():
+            net.set_arith(arith)
+            try:
+                ResNet.fold_projection = False
+                net.reset_split_cache()
+                sep = net(x).clone()
+            finally:
+                ResNet.fold_projection = True
+            net.reset_split_cache()
+            got = net(x).clone()
+            net.check_overflow()
+            folded = [k for k, v in net._split_cache.items() if isinstance(k, tuple) and k and k[0] == "wproj" and k[4] == arith and v is not None]
+            assert (len(folded) == 1) == (arith != "f16f8"), (arith, folded)
+            tol = 5e-5 if arith in ("f16f8", "f16f6") else 2e-5
+            assert float((got - ref).abs().max()) <= tol * top + 1e-6, (arith, float((got - ref).abs().max()), top)
+            assert float((got - sep).abs().max()) <= tol * top + 1e-6
+            assert (arith == "f16f8") == bool(torch.equal(got, sep))          # (the fold did change the arithmetic where it applies)
