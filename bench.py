@@ -405,7 +405,11 @@ def main():
 
     probe = KernelProbe()
     # launch probes: the 256 -> 256 3x3 convolutions of encoder layer 3 and the pair top-k, timed where they run
-    ops.conv_split = probe.wrap(ops.conv_split, lambda x, wt, *r, **k: ("conv256", x.shape[0]) if (wt.shape[0] == 9 and wt.shape[2] == 256 and x.shape[3] * 32 == 256) else None)
+    # (tag = (name, frames, channels of a folded projection's input): all three forms of the layer's kernel -- plain, with layer 3's projection
+    # shortcut in its sums, and the bank-writing last one)
+    ops.conv_split = probe.wrap(ops.conv_split, lambda x, wt, *r, **k: ("conv256", x.shape[0], 0 if k.get("x2_split") is None else k["x2_split"].shape[3] * 32)
+                                if (wt.shape[0] == 9 and wt.shape[2] == 256 and x.shape[3] * 32 == 256) else None)
+    ops.conv_split_to_bank = probe.wrap(ops.conv_split_to_bank, lambda x, wt, *r, **k: ("conv256", x.shape[0], 0) if x.shape[3] * 32 == 256 else None)
     ops.pair_topk_split = probe.wrap(ops.pair_topk_split, lambda q, k_, prs, *r, **kw: ("pair_split", prs.shape[0]))
     ops.pair_topk = probe.wrap(ops.pair_topk, lambda q, k_, prs, *r, **kw: ("pair_f32", prs.shape[0]))
 
@@ -483,15 +487,16 @@ def main():
     if conv_tags:
         # per launch: the lane's batch slice (N frames) of one 256 -> 256 3x3 convolution
         tot_ms = sum(sum(e0.elapsed_time(e1) for e0, e1 in probe.ev[t]) for t in conv_tags)
-        tot_fl = sum(len(probe.ev[t]) * 2.0 * t[1] * HW * 256 * 256 * 9 for t in conv_tags)
+        tot_fl = sum(len(probe.ev[t]) * 2.0 * t[1] * HW * 256 * (256 * 9 + t[2]) for t in conv_tags)      # (+ the folded 1 x 1 projection's products)
         n_l = sum(len(probe.ev[t]) for t in conv_tags)
         f32_tf = tot_fl / (tot_ms * 1e-3) / 1e12
         pm = pmc("fgvc_conv_split_fmt_f32[%s]" % arith if arith in ("f16f8", "f16f6") else "fgvc_conv_split_f32")   # (no PMC pass of the f16x3 form)
         kernels["encoder_conv"] = {
-            "kernel": "fgvc_conv_split_f32 (256 -> 256, 3x3: the time-dominant kernel, 4 launches per clip and encoder lane)",
+            "kernel": "fgvc_conv_split_fmt_f32 (256 -> 256, 3x3: the time-dominant kernel; per clip and encoder lane one plain launch, one with layer 3's "
+                      "1x1 projection shortcut in its sums (fgvc_conv_split_proj_fmt_f32) and the bank-writing last one (fgvc_conv_split_bank_f16f6p_f32))",
             "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f32_tf / BF16_MFMA_PEAK_TFLOPS,
-            "what": "ALGORITHMIC f32 FLOPs of the convolution (2 N H W Cin Cout 9) / mean launch duration, against the dense peak of "
-                    "the bf16 pipe it runs on",
+            "what": "ALGORITHMIC f32 FLOPs of the convolution (2 N H W Cin Cout 9, + 2 N H W 128 Cout for the folded projection) / mean launch "
+                    "duration, against the dense peak of the 16-bit pipe it runs on",
             "arith": arith,
             "executed_tflops": CONV_UNITS[arith] * f32_tf, "frac_executed": CONV_UNITS[arith] * f32_tf / BF16_MFMA_PEAK_TFLOPS,
             "executed_note": {"bf16x3": "3 bf16 partial products per f32-grade product (hi*hi + hi*lo + lo*hi)",
@@ -511,7 +516,8 @@ def main():
                               "runs at the cap (1.27-1.37 kW)",
             "ms_per_launch": tot_ms / n_l, "launches_timed": n_l,
             "launch_note": "HIP events on the lane's stream inside the timed region; the encoder's lanes run concurrently, so a launch "
-                           "shares the GPU with the other lane's kernels",
+                           "shares the GPU with the other lane's kernels and its events also span its wait for the first free CUs: rocprofv3's "
+                           "kernel-only averages of the same command are 5-8 % shorter (profiles/r04_bench_kernel_stats.csv), `frac` uses the longer figure",
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch"),
             "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone on the GPU (profiles/r04_pmc.json)"}
     pair_tag = next((t for t in probe.ev if t[0] in ("pair_split", "pair_f32")), None)
