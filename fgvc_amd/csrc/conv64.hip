@@ -211,12 +211,11 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
                                     ((((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x + 1)) * 2 + ct) * 128 + 8 * h;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
+            // the RAW words ride in the registers until the epilogue (round 4): converted here, the first shift waited for the loads --
+            // vmcnt(0) in the middle of the multiplies of the SIMD's only wave, once per tile (round 3: 0.07 ms per launch slower)
             const uint2 hv = *reinterpret_cast<const uint2*>(rp + 16 * q);
             const uint2 lv = *reinterpret_cast<const uint2*>(rp + 64 + 16 * q);
-            res[b][q] = {__builtin_bit_cast(float, hv.x << 16) + __builtin_bit_cast(float, lv.x << 16),
-                         __builtin_bit_cast(float, hv.x & 0xffff0000u) + __builtin_bit_cast(float, lv.x & 0xffff0000u),
-                         __builtin_bit_cast(float, hv.y << 16) + __builtin_bit_cast(float, lv.y << 16),
-                         __builtin_bit_cast(float, hv.y & 0xffff0000u) + __builtin_bit_cast(float, lv.y & 0xffff0000u)};
+            res[b][q] = {__builtin_bit_cast(float, hv.x), __builtin_bit_cast(float, hv.y), __builtin_bit_cast(float, lv.x), __builtin_bit_cast(float, lv.y)};
           }
         }
       }
@@ -363,7 +362,15 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
         else          // the accumulator holds s_x s_w times the convolution (powers of two: the product below is exact)
           v[g] = {fmaf(acc[b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[b][4 * g + 1], p.acc_scale, bv.y),
                   fmaf(acc[b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[b][4 * g + 3], p.acc_scale, bv.w)};
-        if (p.residual || p.res_split) v[g] += res[b][g];
+        if (p.residual) v[g] += res[b][g];
+        if (p.res_split) {                                  // (hi, lo) bf16 pairs -> f32: hi + lo
+          const uint32_t h0 = __builtin_bit_cast(uint32_t, res[b][g].x), h1 = __builtin_bit_cast(uint32_t, res[b][g].y);
+          const uint32_t l0 = __builtin_bit_cast(uint32_t, res[b][g].z), l1 = __builtin_bit_cast(uint32_t, res[b][g].w);
+          v[g] += f32x4{__builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16),
+                        __builtin_bit_cast(float, h0 & 0xffff0000u) + __builtin_bit_cast(float, l0 & 0xffff0000u),
+                        __builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16),
+                        __builtin_bit_cast(float, h1 & 0xffff0000u) + __builtin_bit_cast(float, l1 & 0xffff0000u)};
+        }
         if (p.relu) {
           v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f);
         }

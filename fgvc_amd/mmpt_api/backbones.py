@@ -151,9 +151,10 @@ class ResNet(nn.Module):
                                    # writes it.  Stand-alone those launches are 4-11 % faster (profiles/r03_time_conv64_arith.log); in the step
                                    # nothing (4.99-5.01 against 4.95-5.00 ms on one box, profiles/r03_bv_conv64_f16f8.log) at 15 % more trunk
                                    # error (rms 3.6e-6 -> 4.2e-6 of the largest feature): off
-    res_from_split = False         # True: layer 1 adds its identities from the split form and nobody writes f32 copies of them --
+    res_from_split = False         # True: layer 1 adds its identities from the split form and nobody writes f32 copies of them (round 4: the
+                                   # conversion deferred to the epilogue: the same step time as f32 identities, 840 MB less traffic; round 3:
                                    # fewer bytes, but 0.08 ms per clip SLOWER (8-byte loads + conversions in the owner wave's MFMA stream;
-                                   # profiles/r03_bv_xcd.log); same precision (tools/experiments/res_split_precision.py)
+                                   # profiles/r03_bv_xcd.log)); same precision (tools/experiments/res_split_precision.py)
     use_split_conv = True          # class-level switch (tests / A-B timing): False = every convolution through MIOpen
     arith = "f16f6"                # arithmetic of the stride-1 convolutions behind layer 1: see set_arith() (round 3: "f16f8")
     fold_projection = True         # a block's stride-1 1 x 1 projection shortcut rides in the sums of the block's second convolution
