@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
     if (has_next) tile_origin(next, nimg_n, y0_n, x0_n);
 
     f32x4 res[2][4];
+    fgvc_i32x4 resw[2][4];                                  // ... or its raw (hi, lo) bf16 words, converted in the epilogue
 
     f32x16 acc[2];                                          // (written first by the zero-SrcC products of group 0)
     // B operands of group g = (tap, chunk, k-step): [row][hi | lo], read one group ahead of the multiplies (left to itself
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
             // vmcnt(0) in the middle of the multiplies of the SIMD's only wave, once per tile (round 3: 0.07 ms per launch slower)
             const uint2 hv = *reinterpret_cast<const uint2*>(rp + 16 * q);
             const uint2 lv = *reinterpret_cast<const uint2*>(rp + 64 + 16 * q);
-            res[b][q] = {__builtin_bit_cast(float, hv.x), __builtin_bit_cast(float, hv.y), __builtin_bit_cast(float, lv.x), __builtin_bit_cast(float, lv.y)};
+            resw[b][q] = fgvc_i32x4{(int)hv.x, (int)hv.y, (int)lv.x, (int)lv.y};
           }
         }
       }
@@ -364,8 +365,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
                   fmaf(acc[b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[b][4 * g + 3], p.acc_scale, bv.w)};
         if (p.residual) v[g] += res[b][g];
         if (p.res_split) {                                  // (hi, lo) bf16 pairs -> f32: hi + lo
-          const uint32_t h0 = __builtin_bit_cast(uint32_t, res[b][g].x), h1 = __builtin_bit_cast(uint32_t, res[b][g].y);
-          const uint32_t l0 = __builtin_bit_cast(uint32_t, res[b][g].z), l1 = __builtin_bit_cast(uint32_t, res[b][g].w);
+          const uint32_t h0 = (uint32_t)resw[b][g][0], h1 = (uint32_t)resw[b][g][1], l0 = (uint32_t)resw[b][g][2], l1 = (uint32_t)resw[b][g][3];
           v[g] += f32x4{__builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16),
                         __builtin_bit_cast(float, h0 & 0xffff0000u) + __builtin_bit_cast(float, l0 & 0xffff0000u),
                         __builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16),
