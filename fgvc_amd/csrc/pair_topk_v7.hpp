@@ -305,8 +305,10 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     // follows the eight stores is seen after their data.
     constexpr int PD = 4;
     i32x4v R[PD][8];
-    auto issue = [&](int G, i32x4v (&r)[8]) {
-      const int pi = G / n_steps, e = G - pi * n_steps;
+    int iss_pi = 0, iss_e = 0;                                       // (pair, list entry) of the next block to issue: blocks are issued in order
+    auto issue = [&](int G, i32x4v (&r)[8]) {                        // (no division per block: an integer division is a dozen vector operations)
+      const int pi = iss_pi, e = iss_e;
+      if (++iss_e == n_steps) { iss_e = 0; ++iss_pi; }
       if (pi != cur_pair) {
         cur_pair = pi;
         const int kf = p.pairs[g_start + pi].y;
@@ -419,15 +421,17 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     // own last MFMAs have just consumed.  Between two chains only the hand-over remains (scores -> keys in place, four LDS stores).
     unsigned long long comp_mask = __ballot(lane < n_steps && ((blist[imin(lane, V7_MAX_BLOCKS - 1)] >> (24 + qb)) & 1u) != 0u);
     const int n_total = g_count * n_steps;
-    auto next_comp = [&](int G) -> int {           // first list position >= G (over the run) that this consumer computes; n_total: none
+    // first list position >= the one after (cur_pi, cur_e) (over the run) that this consumer computes; n_total: none.  The position is
+    // kept as (pair, entry) so that no step divides by n_steps (an integer division is a dozen vector operations on the port this
+    // kernel is bound by)
+    const int first_e = comp_mask ? __builtin_ctzll(comp_mask) : 0;
+    int cur_pi = 0, cur_e = -1;
+    auto next_comp = [&]() -> int {
       if (comp_mask == 0ull) return n_total;
-      while (G < n_total) {
-        const int pi = G / n_steps, e = G - pi * n_steps;
-        const unsigned long long m = comp_mask >> e;
-        if (m) return G + __builtin_ctzll(m);
-        G = (pi + 1) * n_steps;
-      }
-      return n_total;
+      const unsigned long long m = cur_e >= 63 ? 0ull : (comp_mask >> (cur_e + 1));
+      if (m) cur_e += 1 + __builtin_ctzll(m);
+      else { ++cur_pi; cur_e = first_e; }
+      return cur_pi < g_count ? cur_pi * n_steps + cur_e : n_total;
     };
     auto wait_block = [&](int G) { spin_ge<1, false>(&filled[G & (NSLOT - 1)], 4 * (G / NSLOT + 1), dead, &wg_dead); };
     // Entries [G0, G1) are not this consumer's: release each once it has landed (a release must never be sent for a block that is not
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
     const bool probe = PROBE && blockIdx.x == 100 && blockIdx.y == 5;       // debug & 256: s_memtime stamps (tools/experiments/time_pair_v7.py)
     long long pr_wait = 0, pr_hand = 0, pr_hwait = 0, pr_chain = 0, pr_t0 = probe ? __builtin_amdgcn_s_memtime() : 0;
     int pr_tiles = 0, pr_slow = 0;
-    int G_cur = next_comp(0);
+    int G_cur = next_comp();
     skip(0, G_cur);
     if (G_cur < n_total) {
       wait_block(G_cur);
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
       for (;;) {
         const int slot = G_cur & (NSLOT - 1);
         // the next tile: pure scalar arithmetic on the mask; the counter of its key block is asked for inside the chain
-        const int G_next = next_comp(G_cur + 1);
+        const int G_next = next_comp();
         const int G_peek = imin(G_next, n_total - 1);
         const uint32_t a_next_filled = lds_addr_of(&filled[G_peek & (NSLOT - 1)]);
         const long long c0 = probe ? __builtin_amdgcn_s_memtime() : 0;
