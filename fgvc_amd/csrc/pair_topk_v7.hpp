@@ -288,7 +288,12 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
   __syncthreads();
   const int n_steps = blist_n;
   bool dead = false;
-
+  // Wave priority: the SIMD arbitrates vector issue by priority, then age, and the selector -- the wave with the most vector work -- is
+  // younger than its consumer.  One s_setprio 1 for the selectors: 1.155 -> 1.131 ms per 480p launch (priority 3 the same; a prioritised
+  // consumer nothing, a prioritised producer +9 %: tools/experiments/prio_pair_v7.py).  debug & 16384: everybody at priority 0.
+  if (role == 1 && !(p.debug & 16384)) __builtin_amdgcn_s_setprio(1);
+  if (role == 0 && (p.debug & 65536)) __builtin_amdgcn_s_setprio(1);       // (experiment switches; results unchanged)
+  if (role == 2 && (p.debug & 131072)) __builtin_amdgcn_s_setprio(1);
   if (role == 2) {
     // =========================================== producer: pixel row qb of every key block ===========================================
     __syncthreads();                                                 // the consumers have read their query operands: the ring is free
