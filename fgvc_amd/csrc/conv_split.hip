@@ -219,6 +219,12 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int n_stage = nchunk * SPC + nchunk2;
+  // static wave priorities (experiment switches, results unchanged): the two waves of a SIMD are arbitrated by priority, then age
+  if (NW == 8) {
+    if ((p.debug & 32) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if ((p.debug & 64) && wave < 4) __builtin_amdgcn_s_setprio(1);
+    if ((p.debug & 128) && wave >= 4) __builtin_amdgcn_s_setprio(3);
+  }
   constexpr int LA = NSLOT - 1;                  // stages in flight ahead of the one being multiplied
   stage_patch(0);
 #pragma unroll
