@@ -145,6 +145,11 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
+  // static wave priorities (round 4's attempt on this kernel; corr6_skew bits 8 / 9 / 10: younger half 1, older half 1, younger half 3)
+  if ((skew & 0x100) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  if ((skew & 0x200) && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
+  if ((skew & 0x400) && wave >= NW / 2) __builtin_amdgcn_s_setprio(3);
+  skew &= 0xff;
   // Work split.  A tile = (256-query column tile xq, row class cls) with s_tile 64-key stages; tiles are taken in PAIRS (2 P, 2 P + 1)
   // and a pair's 2 s_tile stages are cut into c_half equal pieces, one per workgroup: c_half / 2 key chunks per tile.  An odd c_half
   // lets a workgroup run from the tail of one tile into the head of the next (two segments = two prologues): 2.5 chunks per tile at
