@@ -185,11 +185,16 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
   }
   const uint32_t lane16 = (uint32_t)lane * 16u;
   const uint32_t w_lane_off = (uint32_t)(d_row * 128 + ((d_slot ^ (d_row >> 1)) << 4));
+  // conv_debug & 256 (experiment, the f16f8 / f16f6 stage of the 8-wave forms): ALL weight DMAs of a stage are issued by the older wave of
+  // every SIMD (waves 0 .. NW/2 - 1, 2 PPW pieces each) -- the wave that wins the arbitration for the matrix pipe and then idles at the
+  // barrier -- and none by the younger
+  const bool dma_older = (ARITH == 1 || ARITH == 3) && NW == 8 && (p.debug & 256) != 0;
+  const bool dma_issuer = !dma_older || wave < NW / 2;
   // one 1-KiB piece (8 output channels of one tap) of the weight slab of stage q = chunk * SPC + tap group
   auto stage_weight_piece = [&](int q, int j) {
     const int chunk = q / SPC, tap0 = (q - chunk * SPC) * TG;
     unsigned char* dst = wring + (q % NSLOT) * CV_WSLOTB;
-    const int piece = wave * PPW + j;                                  // always PPW pieces per wave (a short last group
+    const int piece = dma_older ? wave * (2 * PPW) + j : wave * PPW + j;   // always PPW pieces per wave (a short last group
     const int tg = piece / (COT / 8), c0 = (piece - tg * (COT / 8)) * 8;     // re-reads its last tap): the vmcnt
     const int tap = imin(tap0 + tg, T - 1);                            // arithmetic stays fixed
     // wave-uniform base (tap, chunk, first output channel of the piece) + lane offset: row d_row of the piece, slot d_slot swizzled by
@@ -206,8 +211,10 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     conv_lds_dma_16s(wo_, wb, lds_addr(dst + (tg * COT + c0) * 128));
   };
   auto stage_weights = [&](int q) {
+    if (!dma_issuer) return;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) stage_weight_piece(q, j);
+    for (int j = 0; j < 2 * PPW; ++j)
+      if (j < PPW || dma_older) stage_weight_piece(q, j);
   };
 
   f32x16 acc[NA][RPW];
@@ -240,6 +247,10 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if (timing) c0 = __builtin_amdgcn_s_memtime();
     if (q + LA - 1 < n_stage) {
+      if (dma_older) {
+        if (dma_issuer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * 2 * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * PPW) : "memory");   // all but the stages after q have landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -421,7 +432,12 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < PPW; ++j)
-            if (j * NBLK / PPW == g) stage_weight_piece(q + LA, j);
+            if (!dma_older && j * NBLK / PPW == g) stage_weight_piece(q + LA, j);
+          if (dma_older && dma_issuer) {
+#pragma unroll
+            for (int j = 0; j < 2 * PPW; ++j)
+              if (j * NBLK / (2 * PPW) == g) stage_weight_piece(q + LA, j);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -479,6 +495,10 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
       t_wait += c1 - c0; t_issue += c2 - c1; t_mma += c3 - c2;
     }
     if (last_of_chunk) {                            // chunk boundary (the registers live only inside this iteration)
+      if (dma_older && q + LA < n_stage) {
+        if (dma_issuer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else
       if (q + LA < n_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // prefetch landed; this stage's
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // weight DMAs stay in flight
       lds_barrier();                                // everyone is done reading this chunk's patch

@@ -1,4 +1,5 @@
-"""256 -> 256 and 128 -> 128 3 x 3 in f16f6 under static wave priorities (conv_debug 32: younger half 1, 64: older half 1, 128: younger half 3)."""
+"""256 -> 256 and 128 -> 128 3 x 3 in f16f6 under static wave priorities (conv_debug 32: younger half 1, 64: older half 1, 128: younger half 3) and
+with every weight DMA of a stage issued by the older wave of each SIMD (256)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fgvc_amd import ops
@@ -28,7 +29,7 @@ for C in (256, 128):
     ys = ops.alloc_split_nhwc(N, C, H, W, dev)
     kw = dict(in_fmt=ops.ACT_F16F6, in_scale_log2=4 + sw, out_fmt=ops.ACT_F16F6, out_scale_log2=4, overflow=ovf)
     ref = None
-    for name, dbg in (("priority 0", 0), ("younger half 1", 32), ("older half 1", 64), ("younger half 3", 128), ("priority 0", 0)):
+    for name, dbg in (("default", 0), ("DMAs by older waves", 256), ("younger half 1", 32), ("DMAs older + younger 1", 256 + 32), ("DMAs older + older 1", 256 + 64), ("default", 0)):
         ops.set_option("conv_debug", dbg)
         t = timeit(lambda: ops.conv_split(xs, wp, bias, H, W, True, out_split=ys, **kw))
         ops.conv_split(xs, wp, bias, H, W, True, out_split=ys, **kw)
@@ -36,4 +37,4 @@ for C in (256, 128):
         same = None if ref is None else bool(torch.equal(ys, ref))
         if ref is None:
             ref = ys.clone()
-        print(f"{C} -> {C}: {name:16s} {t:.4f} ms  same bytes: {same}", flush=True)
+        print(f"{C} -> {C}: {name:24s} {t:.4f} ms  same bytes: {same}", flush=True)
