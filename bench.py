@@ -298,6 +298,7 @@ def main():
                     help="what runs on the side stream: the label sweep + read-out only, or everything after the encoder (pair top-k, "
                          "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
+    ap.add_argument("--conv64-f16f8", action="store_true", help="with --enc-arith f16f8: layer 1 and the stem's output in the f16 + fp8 form too (ResNet.conv64_f16f8; A/B)")
     ap.add_argument("--no-conv64-f16f8", action="store_true", help="layer 1 and the stem's output in the bf16 form also when the trunk computes in f16f8 (A/B)")
     ap.add_argument("--encoder-graph", action="store_true", help="replay the encoder from a HIP graph (ResNet.use_graph: host time per call 0.7 -> 0.1 ms; "
                                                                  "no throughput change where the step is GPU-bound)")
@@ -374,6 +375,8 @@ def main():
         ResNet.use_graph = False
     if a.res_split:
         ResNet.res_from_split = True
+    if a.conv64_f16f8:
+        ResNet.conv64_f16f8 = True
     if a.no_conv64_f16f8:
         ResNet.conv64_f16f8 = False
     model = build_tracker(wl, dev)

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
           for (int q = 0; q < 4; ++q) res[b][q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
         }
       }
-      if (k == k_res && p.res_split) {  // the same from the bf16 split form: channel c of a pixel's 32-channel chunk is hi at byte 2 c, lo at 64 + 2 c
+      if (ARITH == 0 && k == k_res && p.res_split) {  // the same from the bf16 split form: channel c of a pixel's 32-channel chunk is hi at byte 2 c, lo at 64 + 2 c
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int y = imin(y0 + 2 * rg + b, p.H - 1), x = imin(x0 + n, p.W - 1);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
           v[g] = {fmaf(acc[b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[b][4 * g + 1], p.acc_scale, bv.y),
                   fmaf(acc[b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[b][4 * g + 3], p.acc_scale, bv.w)};
         if (p.residual) v[g] += res[b][g];
-        if (p.res_split) {                                  // (hi, lo) bf16 pairs -> f32: hi + lo
+        if (ARITH == 0 && p.res_split) {                    // (hi, lo) bf16 pairs -> f32: hi + lo (bf16 tensors only: capi)
           const uint32_t h0 = (uint32_t)resw[b][g][0], h1 = (uint32_t)resw[b][g][1], l0 = (uint32_t)resw[b][g][2], l1 = (uint32_t)resw[b][g][3];
           v[g] += f32x4{__builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16),
                         __builtin_bit_cast(float, h0 & 0xffff0000u) + __builtin_bit_cast(float, l0 & 0xffff0000u),

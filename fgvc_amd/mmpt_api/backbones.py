@@ -147,10 +147,11 @@ class ResNet(nn.Module):
     use_conv64 = True              # 64 -> 64 3x3 layers on fgvc_conv64_split_f32 (register-resident weights)
     use_stem7 = True               # 7x7 stride-2 stem on fgvc_stem7_split_f32 (False: MIOpen f32 + ReLU/split pass)
     use_s2_conv = True             # stride-2 blocks on fgvc_conv_s2_split_f32 (False: MIOpen f32 for the two strided convolutions)
-    conv64_f16f8 = False           # True: with arith "f16f8" layer 1 (fgvc_conv64_split_fmt_f32) computes in the f16 + fp8 form too and the stem
-                                   # writes it.  Stand-alone those launches are 4-11 % faster (profiles/r03_time_conv64_arith.log); in the step
-                                   # nothing (4.99-5.01 against 4.95-5.00 ms on one box, profiles/r03_bv_conv64_f16f8.log) at 15 % more trunk
-                                   # error (rms 3.6e-6 -> 4.2e-6 of the largest feature): off
+    conv64_f16f8 = True            # with arith "f16f6" / "f16f8" layer 1 (fgvc_conv64_split_fmt_f32) computes in the f16 + fp8 form (a third fewer
+                                   # matrix passes than bf16x3; layer 1 has no FP6 form) and the stem writes that form.  Round 3 measured nothing
+                                   # in the step (4.99-5.01 against 4.95-5.00 ms); round 4, with the rest of the step lighter: 4.60 -> 4.52 ms
+                                   # (1737 -> 1768 frames/s, same box, A/B/A/B), trunk error unchanged (1.8e-5 of the largest feature): ON.
+                                   # (False: layer 1 in bf16x3, as the "bf16x3" / "f16x3" trunks always run it)
     res_from_split = False         # True: layer 1 adds its identities from the split form and nobody writes f32 copies of them (round 4: the
                                    # conversion deferred to the epilogue: the same step time as f32 identities, 840 MB less traffic; round 3:
                                    # fewer bytes, but 0.08 ms per clip SLOWER (8-byte loads + conversions in the owner wave's MFMA stream;
@@ -181,8 +182,8 @@ class ResNet(nn.Module):
           "f16x3"   (h, l) f16 operands, three units, ~2^-22 per term.
         The f16 forms store s x with a per-tensor power-of-two scale s, calibrated on the first batch a set of weights sees
         (`calibrate`), with 2^7-2^8 of headroom; a value beyond the f16 range raises a device flag that `check_overflow` turns into an
-        error (and a re-calibration).  The stem, layer 1 and the stride-2 convolutions keep the bf16 form (`conv64_f16f8 = True` moves layer 1
-        and the stem's output to the f16 + fp8 form as well: measured, no gain end to end)."""
+        error (and a re-calibration).  The stride-2 convolutions keep the bf16 form; layer 1 and the stem's output run in f16 + fp8 under the two
+        mixed arithmetics (`conv64_f16f8`, default on since round 4; False keeps them in bf16x3)."""
         if arith not in self.supported_arith():
             raise ValueError(f"arith={arith!r}: one of {self.supported_arith()}")
         if arith != self.arith:
@@ -218,7 +219,7 @@ class ResNet(nn.Module):
         key = ("fmt_plan", self.arith, last, self.use_conv64, self.use_s2_conv, self.use_stem7, self.conv64_f16f8)
         if key not in cache:
             blocks = [(s_i, b_i, blk) for s_i in range(last + 1) for b_i, blk in enumerate(getattr(self, self.res_layers[s_i]))]
-            f64 = ops.ACT_F16F8 if (fmt == ops.ACT_F16F8 and self.conv64_f16f8) else bf
+            f64 = ops.ACT_F16F8 if (fmt in (ops.ACT_F16F8, ops.ACT_F16F6) and self.conv64_f16f8) else bf      # (layer 1 has no FP6 form: f16 + fp8 under either)
 
             def reads(cb):                 # the format this convolution takes its input in
                 if self._is_conv64(cb):
@@ -285,7 +286,7 @@ class ResNet(nn.Module):
         instead of a dense f32 copy: the 64-channel blocks of layer 1 on fgvc_conv64_split_res_f32 -- their kernels are bound by the
         bytes they move, and the producer of the input then writes 4 bytes per value instead of 8."""
         c2 = getattr(blk, "conv2", None)
-        return bool(self.use_conv64 and self.res_from_split and not (self.arith == "f16f8" and self.conv64_f16f8)      # (hi, lo) bf16 tensors only
+        return bool(self.use_conv64 and self.res_from_split and not (self.arith in ("f16f8", "f16f6") and self.conv64_f16f8)      # (hi, lo) bf16 tensors only
                     and isinstance(blk, BasicBlock) and blk.downsample is None
                     and c2 is not None and tuple(c2.conv.weight.shape) == (64, 64, 3, 3) and c2.conv.stride == (1, 1)
                     and tuple(blk.conv1.conv.weight.shape) == (64, 64, 3, 3) and blk.conv1.conv.stride == (1, 1))
