@@ -41,6 +41,18 @@ for _ in range(3):
     ops.conv_split(xs, wp, bs, H, W, True, out_split=ys)
     ops.conv_split(xs, wp8, bs8, H, W, True, out_split=ys, in_fmt=ops.ACT_F16F8, in_scale_log2=sw8, out_fmt=ops.ACT_F16F8, out_scale_log2=0, overflow=ovf)
     ops.conv_split(xs6, wp6, bs6, H, W, True, out_split=ys, in_fmt=ops.ACT_F16F6, in_scale_log2=4 + sw6, out_fmt=ops.ACT_F16F6, out_scale_log2=4, overflow=ovf)
+# ... the two special forms of the same layer (round 4): with layer 3's 1 x 1 projection shortcut in its sums, and the last one writing the feature bank
+wt2 = torch.randn(256, 128, 1, 1, device=dev) * 0.05
+x2 = ops.alloc_split_nhwc(T, 128, H, W, dev)
+wq0, bq0 = ops.prepare_conv_split(torch.randn(128, 128, 3, 3, device=dev) * 0.03, torch.nn.BatchNorm2d(128).eval().to(dev))
+ops.conv_split(ops.nchw_to_split_nhwc(torch.relu(torch.randn(T, 128, H, W, device=dev))), wq0, bq0, H, W, True, out_split=x2, out_fmt=ops.ACT_F16F6, out_scale_log2=4, overflow=ovf)
+wp2, bs2, _ = ops.prepare_conv_split_f16(wt2, torch.nn.BatchNorm2d(256).eval().to(dev), ops.ACT_F16F6, force_exp=sw6)     # s_x2 s_w2 = s_x s_w (both inputs at 2^4)
+bank = torch.empty((T, H * W, 2, 256), dtype=torch.int16, device=dev)
+idt = ops.alloc_nhwc(T, 256, H, W, dev); idt.normal_()
+for _ in range(3):
+    ops.conv_split(xs6, wp6, bs6 + bs2, H, W, True, out_split=ys, out_f32=idt, in_fmt=ops.ACT_F16F6, in_scale_log2=4 + sw6, out_fmt=ops.ACT_F16F6, out_scale_log2=4,
+                   overflow=ovf, x2_split=x2, w2=wp2)
+    ops.conv_split_to_bank(xs6, wp6, bs6, H, W, True, bank, residual=idt, in_fmt=ops.ACT_F16F6, in_scale_log2=4 + sw6)
 torch.cuda.synchronize()
 # layer 1 (64 -> 64, register-resident weights), the stem and the stride-2 block of layer 2 at the 480p clip's sizes
 frames = torch.randn(T, 3, 480, 854, device=dev)
