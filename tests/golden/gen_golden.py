@@ -494,4 +494,3 @@ if __name__ == "__main__":
         gen_tracker_cfg0()
         gen_dense_api()
         gen_tracker_8f()
-        gen_tracker_8f()
