@@ -275,7 +275,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
       }
       count += __popcll(bal);
     }
-    if (lane == 0) blist_n = count;
+    if (lane == 0) blist_n = (p.debug & 524288) ? 0 : count;      // 524288: ablation (results wrong): no key blocks -- what a workgroup costs by itself
   }
   if (tid < NSLOT) {
     filled[tid] = 0;
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
   if (tid == 0) wg_dead = (p.debug & 4096) ? 1 : 0;      // 4096: fault injection for the fail-closed test
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (p.debug & 1048576) return;                        // ablation (nothing written): launch + query rows + block list only
   const int n_steps = blist_n;
   bool dead = false;
   // Wave priority: the SIMD arbitrates vector issue by priority, then age, and the selector -- the wave with the most vector work -- is
