@@ -380,3 +380,41 @@ def test_f16_scale_exponents_of_degenerate_tensors():
     for bad in (math.inf, math.nan):
         with pytest.raises(ValueError):
             ops.act_scale_log2(bad)
+
+
+def test_f16f6_weight_rows_agree_with_the_oracle_model():
+    """The product's host-side packer of the encoder's f16 + FP6 rows (ops._e2m3_blocks / _f16f6_slots: torch, scale from the exponent
+    field) against the oracle's model of the same format (numpy, scale by frexp, codes by rint): byte for byte on heavy-tailed, sparse,
+    tiny, huge and all-zero blocks; weights (h6 first) are the activation layout with the two FP6 blocks swapped; a forced weight scale
+    (the projection folded into another convolution's sums) only moves the exponent."""
+    import numpy as np
+    from fgvc_amd import ops
+    from oracle import fgvc_oracle as O
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(400, 32, generator=g).abs() ** 1.5 * (torch.rand(400, 32, generator=g) > 0.4) * torch.exp2(torch.randint(-12, 9, (400, 1), generator=g).float())
+    x[5] = 0
+    x[6, 1:] = 0
+    x[7] = 7.5 * 16 * torch.sign(torch.randn(32, generator=g))
+    for s_log2 in (0, 5, -3):
+        want = O.act_f16f6_rows(x.numpy(), s_log2)
+        xs = x * 2.0 ** s_log2
+        h = xs.to(torch.float16)
+        got = ops._f16f6_slots(h, xs - h.float(), "l").numpy()
+        assert np.array_equal(got, want), int((got != want).sum())
+        w_rows = ops._f16f6_slots(h, xs - h.float(), "h").numpy()           # the weight layout: h6 in slots 4 / 6, l6 in 5 / 7
+        assert np.array_equal(w_rows[:, :64], want[:, :64])
+        assert np.array_equal(w_rows[:, 64:80], want[:, 80:96]) and np.array_equal(w_rows[:, 80:96], want[:, 64:80])
+        assert np.array_equal(w_rows[:, 96:112], want[:, 112:128]) and np.array_equal(w_rows[:, 112:128], want[:, 96:112])
+        hh, h6, l6 = O.act_f16f6_decode(want)
+        top = np.abs(hh).max(1, keepdims=True) + 1e-30
+        assert float((np.abs(h6 - hh) / top).max()) <= 1.0 / 15 + 1e-6             # half an e2m3 step of the block's scale: 0.25 x 2^s <= max / 15
+    wt = torch.randn(256, 64, 1, 1, generator=g) * 0.1
+    bn = torch.nn.BatchNorm2d(256).eval()
+    a, ba, ea = ops.prepare_conv_split_f16(wt, bn, ops.ACT_F16F6)
+    b, bb, eb = ops.prepare_conv_split_f16(wt, bn, ops.ACT_F16F6, force_exp=ea - 2)
+    assert eb == ea - 2 and torch.equal(ba, bb)
+    ha = a.view(torch.uint8).reshape(-1, 128)[:, :64].contiguous().view(torch.float16).float()
+    hb = b.view(torch.uint8).reshape(-1, 128)[:, :64].contiguous().view(torch.float16).float()
+    assert torch.equal(ha, hb * 4.0)                                               # the same weights, two binades lower
+    with pytest.raises(AssertionError):
+        ops.prepare_conv_split_f16(wt, bn, ops.ACT_F16F6, force_exp=ea + 8)        # would leave the f16 range
