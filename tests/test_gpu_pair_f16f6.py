@@ -243,3 +243,37 @@ def test_pair_f16f6_soak_and_fail_closed(dev, shape):
         ops.set_option("pair_f16_debug", 0)
     pl = engine.run_pairs(clip, H, W, plan, cfg)
     assert torch.equal(pl.idx, ref.idx) and not ops.pair_f16x3_timed_out()
+
+
+@pytest.mark.parametrize("shape", [(16, 40, 150), (9, 17, 70), (24, 24, 66)])
+def test_pair_f16f6_work_order_over_many_runs(dev, shape):
+    """The kernel's work order (XCD-contiguous ranges of the runs of one length, column strips, aligned walks) on launches with MORE THAN
+    64 runs -- the stretch of equal-length runs around a workgroup's own is found 64 runs at a time -- of mixed lengths, odd numbers of
+    tile columns (a last strip one tile wide) and fewer workgroups than XCDs' shares: every (pair, query) list
+    equals what one workgroup per pair, the first build's order (debug 512 + 1024) and fgvc_pair_topk_f16x3 give."""
+    from fgvc_amd import ops
+    H, W, Tn = shape
+    f = _pairs_case(dev, H, W, Tn, seed=H + W + Tn)
+    sp6, sp3 = ops.split_f16f6p(f), ops.split_f16x2(f)
+    rows = []
+    for q in range(1, Tn):                                  # runs of 1 .. 4 pairs per query frame, in no particular order of length
+        for kk in range(max(0, q - 1 - (q * 7) % 4), q):
+            rows.append((q, kk, True))
+    pairs = ops.make_pairs(rows, dev)
+    runs = ops.pair_runs(pairs)
+    assert runs.shape[0] == Tn - 1 > 64 and len(set(runs[:, 1].tolist())) >= 3
+    mask = ops.MaskSpec.from_neighbor_range(12)
+    ia, sa = ops.pair_topk_split(sp6, sp6, pairs, H, W, H, W, mask, 10, all_masked=True, fmt="f16f6")
+    ib, sb = ops.pair_topk_split(sp6, sp6, pairs, H, W, H, W, mask, 10, all_masked=True, fmt="f16f6", use_runs=False)
+    assert torch.equal(ia, ib) and torch.equal(sa, sb)
+    ops.set_option("pair_f16_debug", 512 + 1024)
+    try:
+        ic, sc = ops.pair_topk_split(sp6, sp6, pairs, H, W, H, W, mask, 10, all_masked=True, fmt="f16f6")
+    finally:
+        ops.set_option("pair_f16_debug", 0)
+    assert torch.equal(ia, ic) and torch.equal(sa, sc)
+    i3, s3 = ops.pair_topk_split(sp3, sp3, pairs, H, W, H, W, mask, 10, all_masked=True, fmt="f16")
+    assert not ops.pair_f16x3_timed_out()
+    fin = torch.isfinite(s3)
+    assert bool((torch.isfinite(sa) == fin).all()) and float((sa[fin] - s3[fin]).abs().max()) < 1.2e-5
+    assert float((~(ia == i3).all(-1)).float().mean()) < 2e-2
