@@ -87,7 +87,7 @@ def encoder_flops(wl, n_frames: int) -> float:
 def pmc(kernel: str):
     """Offline rocprofv3 PMC figures of `kernel` at the cfg2 shapes (profiles/r04_pmc.json, written by tools/pmc_report.py from
     separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes); {} if absent."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -415,6 +415,8 @@ def main():
     ops.conv_split_to_bank = probe.wrap(ops.conv_split_to_bank, lambda x, wt, *r, **k: ("conv256", x.shape[0], 0) if x.shape[3] * 32 == 256 else None)
     ops.pair_topk_split = probe.wrap(ops.pair_topk_split, lambda q, k_, prs, *r, **kw: ("pair_split", prs.shape[0]))
     ops.pair_topk = probe.wrap(ops.pair_topk, lambda q, k_, prs, *r, **kw: ("pair_f32", prs.shape[0]))
+    ops.merge_refine_topk = probe.wrap(ops.merge_refine_topk, lambda pi, *r, **kw: ("merge_refine", pi.shape[0]))
+    ops.merge_topk = probe.wrap(ops.merge_topk, lambda pi, *r, **kw: ("merge", pi.shape[0]))
 
     tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
     backend = fdist.HipBackend(model, tail_stream=tail_stream, tail_from=a.tail_from)
@@ -495,11 +497,9 @@ def main():
         f32_tf = tot_fl / (tot_ms * 1e-3) / 1e12
         pm = pmc("fgvc_conv_split_fmt_f32[%s]" % arith if arith in ("f16f8", "f16f6") else "fgvc_conv_split_f32")   # (no PMC pass of the f16x3 form)
         kernels["encoder_conv"] = {
-            "kernel": "fgvc_conv_split_fmt_f32 (256 -> 256, 3x3: the time-dominant kernel; per clip and encoder lane one plain launch, one with layer 3's "
-                      "1x1 projection shortcut in its sums (fgvc_conv_split_proj_fmt_f32) and the bank-writing last one (fgvc_conv_split_bank_f16f6p_f32))",
+            "kernel": "fgvc_conv_split_fmt_f32",      # (256 -> 256 3x3; its _proj_ and _bank_ entry points are instances of the same kernel: DESIGN section 6)
             "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f32_tf / BF16_MFMA_PEAK_TFLOPS,
-            "what": "ALGORITHMIC f32 FLOPs of the convolution (2 N H W Cin Cout 9, + 2 N H W 128 Cout for the folded projection) / mean launch "
-                    "duration, against the dense peak of the 16-bit pipe it runs on",
+            "what": "algorithmic f32 FLOPs (2 N H W 256 256 9 + folded projection) / mean launch time vs the 16-bit MFMA peak",
             "arith": arith,
             "executed_tflops": CONV_UNITS[arith] * f32_tf, "frac_executed": CONV_UNITS[arith] * f32_tf / BF16_MFMA_PEAK_TFLOPS,
             "executed_note": {"bf16x3": "3 bf16 partial products per f32-grade product (hi*hi + hi*lo + lo*hi)",
@@ -514,15 +514,11 @@ def main():
             "frac_executed_of_sustained": CONV_UNITS[arith] * f32_tf / {"bf16x3": SUSTAINED_TFLOPS["bf16"], "f16x3": SUSTAINED_TFLOPS["f16"],
                                                                         "f16f8": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"],
                                                                         "f16f6": SUSTAINED_TFLOPS["f16f8_mix_per_f16_unit"]}[arith],
-            "sustained_note": "the matrix pipe alone, whole chip, at the board's power cap (tools/micro/mfma_sustained.hip: f16 1750, bf16 1950, "
-                              "fp8 4900 TFLOP/s; the 2 f16 + 1 fp8 mix 0.95 of its nominal rate = 2375 in f16 units); the step itself "
-                              "runs at the cap (1.27-1.37 kW)",
+            "sustained_note": "matrix pipe alone at the power cap: profiles/r03_mfma_sustained.log",
             "ms_per_launch": tot_ms / n_l, "launches_timed": n_l,
-            "launch_note": "HIP events on the lane's stream inside the timed region; the encoder's lanes run concurrently, so a launch "
-                           "shares the GPU with the other lane's kernels and its events also span its wait for the first free CUs: rocprofv3's "
-                           "kernel-only averages of the same command are 5-8 % shorter (profiles/r04_bench_kernel_stats.csv), `frac` uses the longer figure",
+            "launch_note": "HIP events on the lane's stream in the timed region (lanes overlap: rocprofv3 kernel-only times are 5-8 % shorter)",
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch"),
-            "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone on the GPU (profiles/r04_pmc.json)"}
+            "pmc_note": "rocprofv3 PMC passes of one whole-clip launch alone (profiles/r0N_pmc.json)"}
     pair_tag = next((t for t in probe.ev if t[0] in ("pair_split", "pair_f32")), None)
     if pair_tag:
         pair_ms, n_l = probe.mean_ms(pair_tag)
@@ -530,9 +526,9 @@ def main():
         fl = 2.0 * HW * n_disc * C * pair_tag[1]                       # windowed FLOPs of the launch's pairs
         f32_tf = fl / (pair_ms * 1e-3) / 1e12
         split = pair_tag[0] == "pair_split"
-        name = ("fgvc_pair_topk_f16f6" if pair_fmt == "f16f6" else "fgvc_pair_topk_f16x3") if split else "fgvc_pair_topk_f32"
+        name = ({"f16f6x": "fgvc_pair_topk_f16f6x", "f16f6": "fgvc_pair_topk_f16f6"}.get(cfg.bank_fmt, "fgvc_pair_topk_f16x3")) if split else "fgvc_pair_topk_f32"
         n_prod = PAIR_UNITS[pair_fmt] if split else 1
-        pm = pmc(name)
+        pm = pmc(name) or pmc(name.replace("f16f6x", "f16f6"))
         kernels["pair_topk"] = {
             "kernel": name, "bound": "mfma", "achieved": f32_tf, "peak": BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": f32_tf / (BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS),
@@ -547,6 +543,11 @@ def main():
             "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
             "ms_per_launch": pair_ms, "pairs_per_launch": pair_tag[1], "launches_timed": n_l,
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch")}
+    for tag_ in [t for t in probe.ev if t[0] in ("merge_refine", "merge")]:
+        ms_, n_ = probe.mean_ms(tag_)
+        kernels[tag_[0]] = {"kernel": "fgvc_merge_refine_topk_f32" if tag_[0] == "merge_refine" else "fgvc_merge_topk_f32", "ms_per_launch": ms_,
+                            "launches_timed": n_, "pairs": tag_[1],
+                            "note": "HIP events on the stream the merge runs on (the tail stream: overlaps the next step's encoder)"}
     head = kernels.get("encoder_conv") or kernels.get("pair_topk")
     roofline = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "what", "executed_tflops",
                                      "frac_executed", "frac_of_f32_mfma_peak", "sustained_peak", "frac_executed_of_sustained", "sustained_note", "ms_per_launch", "mfma_util", "launch_note", "pmc_note")
@@ -557,8 +558,11 @@ def main():
         "value": n_frames_total / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (f32-grade results from 16-bit / 8-bit / 6-bit parts on the MFMA pipe, f32 accumulate: encoder " + arith +
-                 ", correlation " + {"f16": "f16 h/l x3", "f16f6": "f16 + FP6 cross terms"}[pair_fmt] + ")",
+        "dtype": "f16 + fp6 (e2m3) MFMA operands, f32 accumulate; top-k near-ties re-scored in f64 from f32 features" if cfg.bank_fmt == "f16f6x" else
+                 ("MFMA operands: encoder " + arith + ", correlation " + {"f16": "f16 h/l x3", "f16f6": "f16 + FP6 cross terms (no re-scoring)"}[pair_fmt] + "; f32 accumulate"),
+        "parity": {"f16f6x": "top-10 lists = the reference's own on every list whose float64 ranks are 1e-5 apart (profiles/r05_precision_ledger.json)",
+                   "f16f6": "round 4's arithmetic: lists exact only where float64 ranks are 1e-4 apart",
+                   "f16": "three f16 products per f32-grade product: lists exact at 1e-5"}[cfg.bank_fmt],
         "data": "synthetic",
         "config": {"workload": (f"{a.workload}: one {T}x{h}x{w} video per step = {world} clip(s) of {Tc} frames, one per rank -> {Hf}x{Wf}x{C} "
                                 f"features, top-10, radius 15, tau 0.07, P={P}" if a.mode == "video" else
@@ -626,7 +630,7 @@ def main():
 
     if a.mode == "video":
         # what this rank handed to the exchange steps per step, against the schedule's arithmetic (N = 1: nothing moves)
-        frame_bytes = HW * C * 4                                           # one frame of the bank (f32 or 2 x 16-bit: the same bytes)
+        frame_bytes = HW * C * (8 if cfg.bank_fmt == "f16f6x" else 4)      # one frame of the bank: 1 KiB per pixel (f32 or 2 x 16-bit parts), 2 KiB for split_f16f6x() rows
         list_bytes = HW * cfg.topk * 8                                      # idx int32 + weight f32 of one frame's merged list
         rr = fdist.shard_frames(T, world, first=1)
         exp = {"broadcast": frame_bytes if world > 1 else 0,
@@ -697,13 +701,35 @@ def main():
                                                                              "weight encoder: label maps there are nearly flat, and a near-tie at the top-5 boundary "
                                                                              "of the soft-argmax (discontinuous: vanilla_tracker.py:181) moves a read-out by pixels; on "
                                                                              "the reference's fixtures every arithmetic stays within 3.1e-5 px "
-                                                                             "(profiles/r04_precision_ledger.json)"})(
+                                                                             "(profiles/r05_precision_ledger.json)"})(
                                   (out3.to(torch.float64) - out_coords.to(torch.float64)).abs().amax(-1).flatten())}
         model.backbone.set_arith(arith)
         if a.pair_fmt != "auto":
             model.test_cfg["pair_split_fmt"] = a.pair_fmt
         else:
             model.test_cfg.pop("pair_split_fmt", None)
+    if a.mode == "video" and not a.no_f16x3_line and cfg.bank_fmt == "f16f6x":
+        # ... and round 4's arithmetic (the f16 + FP6 pair kernel WITHOUT the refining merge, 1 KiB bank rows): what exactness costs
+        model.test_cfg["pair_refine"] = False
+        cfg4 = model.engine_config()
+        cfg4.pair_precision, cfg4.regroup = cfg.pair_precision, False
+        cache4 = {}
+        for _ in range(5):
+            fdist.track_points_sharded(backend, rgbs, qp, cfg4, device=dev, halo=a.halo, timing=None, cache=cache4, check=False)
+        barrier()
+        t1 = time.perf_counter()
+        n4 = max(20, a.steps // 2)
+        for _ in range(n4):
+            fdist.track_points_sharded(backend, rgbs, qp, cfg4, device=dev, halo=a.halo, timing=None, cache=cache4, check=False)
+        barrier()
+        el4 = time.perf_counter() - t1
+        if world > 1:
+            t4_ = torch.tensor([el4], device=dev, dtype=torch.float64)
+            dist.all_reduce(t4_, op=dist.ReduceOp.MAX)
+            el4 = float(t4_.item())
+        out["value_unrefined"] = {"what": "the same steps without the refining merge (pair_refine = False: round 4's default, lists exact at 1e-4 only)",
+                                  "value": T * n4 / el4, "unit": "frames/s", "ms_per_step": el4 / n4 * 1e3, "steps": n4}
+        model.test_cfg.pop("pair_refine")
     if rank == 0 and not a.no_corr_volume:
         gq = torch.Generator(device=dev).manual_seed(5)
         feats2 = torch.nn.functional.normalize(torch.randn(2, HW, C, generator=gq, device=dev), dim=2)
@@ -748,6 +774,10 @@ def main():
                          "note": "median of 6 rounds x 10 launches (HIP events), round-robin with the other variants, first round dropped"},
             "variants": var,
         }
+        if out.get("roofline") is not None:      # the second half of BASELINE's metric, where the driver's record keeps it
+            out["roofline"].update(corr_volume_kernel="fgvc_corr_volume_f16f6", ms_per_corr_volume=var["f16f6"]["ms"],
+                                   corr_volume_frac=var["f16f6"]["frac"], corr_volume_gbps=var["f16f6"]["achieved"],
+                                   corr_volume_traffic=pm.get("hbm_bytes_per_launch"), corr_volume_peak_gbps=HBM_PEAK_GBPS)
         del vol
     if rank == 0 and world == 1 and not a.no_cpu_baseline:          # reported at N = 1 only (the other ranks would sit at the barrier)
         out["cpu_baseline"] = cpu_baseline(wl)

@@ -35,6 +35,12 @@ SIGNATURES = {
     "fgvc_split_f16f6p": (_i, [_p, _p, C.c_int64, _i, _p]),
     "fgvc_pair_topk_f16f6": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "fgvc_pair_topk_f16f6_runs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
+    "fgvc_split_f16f6x": (_i, [_p, _p, C.c_int64, _i, _p]),
+    "fgvc_pair_topk_f16f6x": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "fgvc_pair_topk_f16f6x_runs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
+    "fgvc_merge_refine_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "fgvc_merge_refine_topk_f32": (_i, [_p, _p, _p, _p, _p, C.c_int64, _i, _p, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _i, _i,
+                                        _p, _p, _p, _p, _p]),
     "fgvc_pair_topk_f16x3_timed_out": (_i, []),
     "fgvc_pair_topk_f16x3_probe": (_i, [_p]),
     "fgvc_conv64_probe": (_i, [_p]),
@@ -43,6 +49,7 @@ SIGNATURES = {
     "fgvc_conv_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_conv_split_proj_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_conv_split_bank_f16f6p_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fgvc_conv_split_bank_f16f6x_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv64_split_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv64_split_res_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fgvc_conv64_split_fmt_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
@@ -55,6 +62,7 @@ SIGNATURES = {
     "fgvc_normalize_split_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_split_f16x2_nhwc_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_normalize_split_f16f6p_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "fgvc_normalize_split_f16f6x_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "fgvc_merge_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
     "fgvc_propagate_topk_f32": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "fgvc_corr_volume_f32": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),

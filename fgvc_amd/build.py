@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "lib", "libfgvc_hip.so")
-SOURCES = ["capi.hip", "pair_topk.hip", "pair_topk_v5.hip", "conv_split.hip", "conv_s2.hip", "conv64.hip", "stem7.hip", "post.hip", "corr_volume.hip", "corr_volume_f8.hip", "corr_volume_f6.hip", "local.hip", "dense_attend.hip"]
+SOURCES = ["capi.hip", "pair_topk.hip", "pair_topk_v5.hip", "conv_split.hip", "conv_s2.hip", "conv64.hip", "stem7.hip", "post.hip", "corr_volume.hip", "corr_volume_f8.hip", "corr_volume_f6.hip", "local.hip", "dense_attend.hip", "refine.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "pair_common.hpp"), os.path.join(CSRC, "sortnet.hpp"), os.path.join(ROOT, "include", "fgvc_hip.h"),
            os.path.join(CSRC, "pair_topk_v7.hpp"), os.path.join(CSRC, "pair_v7.inc"), os.path.join(CSRC, "pair_v5_chain.inc")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

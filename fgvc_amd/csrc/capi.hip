@@ -40,7 +40,7 @@ int c2f_refine_launch(const int32_t*, const float*, const float*, const float*, 
 
 int conv_split_launch(const uint16_t*, const uint16_t*, const float*, const float*, uint16_t*, float*, int, int, int, int, int,
                       int, int, int, int, int, int, int, int, int*, hipStream_t, unsigned char* y_bank = nullptr, int bank_normalize = 1, const uint16_t* x2 = nullptr,
-                      const uint16_t* w2 = nullptr, int Cin2 = 0);
+                      const uint16_t* w2 = nullptr, int Cin2 = 0, int bank_row_bytes = 1024);
 int conv_s2_launch(const uint16_t*, const uint16_t*, const float*, uint16_t*, float*, int, int, int, int, int, int, int, int, int,
                    int, int, int, int, int*, hipStream_t);
 int conv64_launch(const uint16_t*, const uint16_t*, const float*, const float*, const uint16_t*, uint16_t*, float*, int, int, int, int, int, int,
@@ -62,9 +62,9 @@ void set_pair_debug(int);
 void set_readout_prune(int);
 void set_conv_s2_debug(int);
 int split_f16x2_launch(const float*, uint16_t*, long long, int, hipStream_t);
-int split_f16f6p_launch(const float*, unsigned char*, long long, hipStream_t);
+int split_f16f6p_launch(const float*, unsigned char*, long long, int, hipStream_t);
 int pair_topk_v7_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, const int32_t*, int,
-                        int32_t*, float*, hipStream_t);
+                        int32_t*, float*, int, hipStream_t);
 int pair_topk_v5_launch(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int, int, int, int, int, int, int, const int32_t*,
                         int, int32_t*, float*, hipStream_t);
 void set_pair_v5_debug(int);
@@ -248,12 +248,21 @@ int fgvc_split_f16f6p(const float* feat, uint8_t* rows, int64_t n_pixels, int C,
   FGVC_REQUIRE(n_pixels >= 0 && n_pixels < (1ll << 40), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6p: bad n_pixels");
   FGVC_REQUIRE(aligned16(feat) && aligned16(rows), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6p: 16-byte alignment required");
   if (n_pixels == 0) return FGVC_OK;
-  return split_f16f6p_launch(feat, rows, n_pixels, (hipStream_t)stream);
+  return split_f16f6p_launch(feat, rows, n_pixels, 1024, (hipStream_t)stream);
+}
+
+int fgvc_split_f16f6x(const float* feat, uint8_t* rows, int64_t n_pixels, int C, void* stream) {
+  FGVC_REQUIRE(feat && rows, FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6x: null pointer");
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_split_f16f6x: C=%d unsupported (256 only)", C);
+  FGVC_REQUIRE(n_pixels >= 0 && n_pixels < (1ll << 40), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6x: bad n_pixels");
+  FGVC_REQUIRE(aligned16(feat) && aligned16(rows), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6x: 16-byte alignment required");
+  if (n_pixels == 0) return FGVC_OK;
+  return split_f16f6p_launch(feat, rows, n_pixels, 2048, (hipStream_t)stream);
 }
 
 static int pair_f16f6_common(const char* what, const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C,
                              int Hq, int Wq, int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs,
-                             int n_runs, int32_t* idx_out, float* score_out, void* stream) {
+                             int n_runs, int32_t* idx_out, float* score_out, void* stream, int row_bytes = 1024) {
   FGVC_REQUIRE(qsplit && ksplit && pairs && idx_out && score_out, FGVC_ERR_INVALID_ARG, "%s: null pointer", what);
   FGVC_REQUIRE(aligned16(qsplit) && aligned16(ksplit) && aligned16(pairs), FGVC_ERR_INVALID_ARG,
                "%s: qsplit/ksplit/pairs must be 16-byte aligned", what);
@@ -272,7 +281,7 @@ static int pair_f16f6_common(const char* what, const uint8_t* qsplit, const uint
   FGVC_REQUIRE(Hk < 16384 && Wk < 32768 && (long long)Hk * Wk < (1ll << 30), FGVC_ERR_UNSUPPORTED, "%s: grid too large", what);
   if (n_pairs == 0) return FGVC_OK;
   return pair_topk_v7_launch(reinterpret_cast<const uint16_t*>(qsplit), reinterpret_cast<const uint16_t*>(ksplit), pairs, n_pairs, Hq, Wq, Hk, Wk,
-                             r2max, ry, rx, topk, runs, n_runs, idx_out, score_out, (hipStream_t)stream);
+                             r2max, ry, rx, topk, runs, n_runs, idx_out, score_out, row_bytes, (hipStream_t)stream);
 }
 
 int fgvc_pair_topk_f16f6(const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq, int Hk,
@@ -287,6 +296,20 @@ int fgvc_pair_topk_f16f6_runs(const uint8_t* qsplit, const uint8_t* ksplit, cons
   FGVC_REQUIRE(runs, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16f6_runs: null runs");
   return pair_f16f6_common("fgvc_pair_topk_f16f6_runs", qsplit, ksplit, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
                            runs, n_runs, idx_out, score_out, stream);
+}
+
+int fgvc_pair_topk_f16f6x(const uint8_t* qrows, const uint8_t* krows, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq, int Hk,
+                          int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out, float* score_out, void* stream) {
+  return pair_f16f6_common("fgvc_pair_topk_f16f6x", qrows, krows, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
+                           nullptr, 0, idx_out, score_out, stream, 2048);
+}
+
+int fgvc_pair_topk_f16f6x_runs(const uint8_t* qrows, const uint8_t* krows, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
+                               int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs, int n_runs,
+                               int32_t* idx_out, float* score_out, void* stream) {
+  FGVC_REQUIRE(runs, FGVC_ERR_INVALID_ARG, "fgvc_pair_topk_f16f6x_runs: null runs");
+  return pair_f16f6_common("fgvc_pair_topk_f16f6x_runs", qrows, krows, pairs, n_pairs, C, Hq, Wq, Hk, Wk, r2max, ry, rx, topk, all_masked,
+                           runs, n_runs, idx_out, score_out, stream, 2048);
 }
 
 /* debug: the 32 s_memtime words one workgroup leaves with fgvc_set_option("pair_f16_debug", 256) (tools/experiments/time_pair_v5.py) */
@@ -584,9 +607,9 @@ int fgvc_conv_split_proj_fmt_f32(const uint16_t* x, const uint16_t* w, const uin
                            out_scale_log2, overflow, (hipStream_t)stream, nullptr, 1, x2, w2, Cin2);
 }
 
-int fgvc_conv_split_bank_f16f6p_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank, int N,
-                                    int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
-                                    int normalize, void* stream) {
+static int conv_split_bank_common(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank, int N,
+                                  int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
+                                  int normalize, void* stream, int row_bytes) {
   FGVC_REQUIRE(x && w && bias && bank, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: null pointer");
   FGVC_REQUIRE(in_fmt >= 0 && in_fmt <= 3, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: unknown format %d", in_fmt);
   FGVC_REQUIRE(in_scale_log2 > -100 && in_scale_log2 < 100, FGVC_ERR_INVALID_ARG, "fgvc_conv_split_bank_f16f6p_f32: scale exponent out of range");
@@ -598,7 +621,19 @@ int fgvc_conv_split_bank_f16f6p_f32(const uint16_t* x, const uint16_t* w, const 
                "fgvc_conv_split_bank_f16f6p_f32: 16-byte alignment required");
   if (N == 0) return FGVC_OK;
   return conv_split_launch(x, w, bias, residual, nullptr, nullptr, N, H, W, Hp, Wp, Cin, 256, KS, relu, in_fmt, in_scale_log2, 0, 0, nullptr,
-                           (hipStream_t)stream, reinterpret_cast<unsigned char*>(bank), normalize);
+                           (hipStream_t)stream, reinterpret_cast<unsigned char*>(bank), normalize, nullptr, nullptr, 0, row_bytes);
+}
+
+int fgvc_conv_split_bank_f16f6p_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank, int N,
+                                    int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
+                                    int normalize, void* stream) {
+  return conv_split_bank_common(x, w, bias, residual, bank, N, H, W, Hp, Wp, Cin, KS, relu, in_fmt, in_scale_log2, normalize, stream, 1024);
+}
+
+int fgvc_conv_split_bank_f16f6x_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank, int N,
+                                    int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
+                                    int normalize, void* stream) {
+  return conv_split_bank_common(x, w, bias, residual, bank, N, H, W, Hp, Wp, Cin, KS, relu, in_fmt, in_scale_log2, normalize, stream, 2048);
 }
 
 /* debug: the 32 s_memtime sums workgroup 77 leaves with fgvc_set_option("conv64_variant", 8) (tools/experiments/time_conv64_variants.py) */
@@ -726,6 +761,11 @@ int fgvc_normalize_split_f16x2_nhwc_f32(const float* in, float* out_f32, uint16_
 int fgvc_normalize_split_f16f6p_nhwc_f32(const float* in, uint8_t* rows, int N, int C, int H, int W, int normalize, void* stream) {
   FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_normalize_split_f16f6p_nhwc_f32: C=%d unsupported (256 only)", C);
   return normalize_split_common("fgvc_normalize_split_f16f6p_nhwc_f32", in, nullptr, reinterpret_cast<uint16_t*>(rows), N, C, H, W, normalize, 2, stream);
+}
+
+int fgvc_normalize_split_f16f6x_nhwc_f32(const float* in, uint8_t* rows, int N, int C, int H, int W, int normalize, void* stream) {
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "fgvc_normalize_split_f16f6x_nhwc_f32: C=%d unsupported (256 only)", C);
+  return normalize_split_common("fgvc_normalize_split_f16f6x_nhwc_f32", in, nullptr, reinterpret_cast<uint16_t*>(rows), N, C, H, W, normalize, 3, stream);
 }
 
 int fgvc_normalize_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int normalize, void* stream) {

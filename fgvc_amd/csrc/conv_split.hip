@@ -59,6 +59,7 @@ struct ConvSplitParams {
   int Cin2;                // sums: y = conv3x3(x, w) + conv1x1(x2, w2) + bias -- a block's projection shortcut folded into its second convolution
   unsigned char* y_bank;   // optional (Cout = 256 only): the L2-normalised pixels as rows of fgvc_split_f16f6p, [N][H*W][1024 B], INSTEAD of
   int bank_normalize;      // y_split / y_f32 (the trunk's last convolution writes the pair kernel's feature bank itself); 0: rows of the raw values
+  int bank_row_bytes;      // 1024: fgvc_split_f16f6p rows; 2048: fgvc_split_f16f6x rows (+ the normalised f32 channels in the second KiB)
 };
 
 typedef fgvc_f16x8 f16x8;
@@ -680,15 +681,36 @@ __global__ __launch_bounds__(NWR * 128, NWR == 2 ? 2 : 1) void conv_split_kernel
         }
         __syncthreads();                                            // (4) the rows are whole
         if (row_ok) {
-          unsigned char* dst = p.y_bank + fpix0 * 1024;
+          unsigned char* dst = p.y_bank + fpix0 * p.bank_row_bytes;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int r = 16 * ch + i;
             if (x0 + r < p.W)
-              *reinterpret_cast<uint4*>(dst + (size_t)r * 1024 + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+              *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
           }
         }
         __syncthreads();                                            // (5) before the next pixel row's residual tiles
+        if (p.bank_row_bytes > 1024) {                              // (uniform) round 5: the exact channels x themselves, second KiB of every row
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x4 x = v[a][g];
+              x *= inv;
+              *reinterpret_cast<f32x4*>(row + 4 * (128 * ch + 32 * a + 8 * g + 4 * h)) = x;
+            }
+          __syncthreads();
+          if (row_ok) {
+            unsigned char* dst = p.y_bank + fpix0 * p.bank_row_bytes + 1024;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int r = 16 * ch + i;
+              if (x0 + r < p.W)
+                *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+            }
+          }
+          __syncthreads();
+        }
       }
       return;
     }
@@ -907,7 +929,7 @@ __device__ __forceinline__ unsigned n6_code(float y) {
   return (unsigned)c | (y < 0.f ? 32u : 0u);
 }
 __global__ __launch_bounds__(256) void normalize_f16f6p_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, int normalize,
-                                                                long long npix) {
+                                                                long long npix, int rowb) {
   const long long pixel = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pixel >= npix) return;
@@ -926,7 +948,8 @@ __global__ __launch_bounds__(256) void normalize_f16f6p_kernel(const float* __re
   const float inv = normalize ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
   f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * lane);
   x *= inv;
-  unsigned char* row = out + (size_t)pixel * 1024;
+  unsigned char* row = out + (size_t)pixel * rowb;
+  if (rowb > 1024) *reinterpret_cast<f32x4*>(row + 1024 + 16 * lane) = x;      // fgvc_split_f16f6x rows: the exact channels in the second KiB
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   f16x4 hv;
   float hf[4], lf[4], mh = 0.f, ml = 0.f;
@@ -1009,12 +1032,12 @@ static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int
 int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, uint16_t* y_split,
                       float* y_f32, int N, int H, int W, int Hp, int Wp, int Cin, int Cout, int KS, int relu, int in_fmt,
                       int in_scale_log2, int out_fmt, int out_scale_log2, int* overflow, hipStream_t s, unsigned char* y_bank,
-                      int bank_normalize, const uint16_t* x2, const uint16_t* w2, int Cin2) {
+                      int bank_normalize, const uint16_t* x2, const uint16_t* w2, int Cin2, int bank_row_bytes) {
   ConvSplitParams p;
   p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.y_split = y_split; p.y_f32 = y_f32;
   p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   p.acc_scale = ldexpf(1.0f, -in_scale_log2); p.out_scale = ldexpf(1.0f, out_scale_log2); p.out_fmt = out_fmt; p.overflow = overflow;
-  p.y_bank = y_bank; p.bank_normalize = bank_normalize;
+  p.y_bank = y_bank; p.bank_normalize = bank_normalize; p.bank_row_bytes = bank_row_bytes;
   p.x2 = x2; p.w2 = w2; p.Cin2 = Cin2;
   const int cot = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0) ? 128 : 64;
   const int cot_eff = (g_conv_cot_cap && cot > g_conv_cot_cap && !y_bank && !x2) ? g_conv_cot_cap : cot;     // (the bank epilogue needs a pixel's 256 channels in one workgroup)
@@ -1072,7 +1095,8 @@ int nhwc_to_split_launch(float* x, uint16_t* out, int N, int C, int H, int W, in
 int normalize_nhwc_launch(const float* in, float* out, uint16_t* out_split, int N, int C, int H, int W, int normalize,
                           int split_fmt, hipStream_t s) {
   const long long npix = (long long)N * H * W;
-  if (split_fmt == 2) normalize_f16f6p_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, reinterpret_cast<unsigned char*>(out_split), normalize, npix);
+  if (split_fmt == 2 || split_fmt == 3)      // 3: the 2 KiB rows of fgvc_split_f16f6x
+    normalize_f16f6p_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, reinterpret_cast<unsigned char*>(out_split), normalize, npix, split_fmt == 3 ? 2048 : 1024);
   else if (split_fmt == 0) normalize_nhwc_kernel<0><<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
   else normalize_nhwc_kernel<1><<<(unsigned)((npix + 3) / 4), 256, 0, s>>>(in, out, out_split, C, normalize, npix);
   FGVC_CHECK_LAUNCH("fgvc_normalize_nhwc_f32");

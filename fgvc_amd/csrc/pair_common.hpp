@@ -96,6 +96,8 @@ struct PairParamsB {
   float* score_out;
   const int2* groups;     // optional [n_groups] (first pair, count) -- runs of pairs with one query frame and one
                           // mask flag that a workgroup takes in one go (query prologue once, the ring never drains); null: each pair alone
+  int rowb;               // fgvc_pair_topk_f16f6 only: bytes from one pixel's row to the next (1024: fgvc_split_f16f6p rows; 2048: the rows of
+                          // fgvc_split_f16f6x, whose second KiB carries the pixel's exact f32 channels for fgvc_merge_refine_topk_f32)
 };
 
 // block-to-block reach test of the mask predicate (all operands wave-uniform or per-lane, no state)

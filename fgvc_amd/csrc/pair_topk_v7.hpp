@@ -61,13 +61,14 @@ __device__ __forceinline__ unsigned p6_code(float y) {          // |y| <= 7.5 ->
 }
 
 // f32 rows [pixel][256] (L2-normalised) -> fgvc_split_f16f6p rows; one thread per (pixel, group v, lane half hi)
-__global__ __launch_bounds__(256) void split_f16f6p_kernel(const float* __restrict__ feat, unsigned char* __restrict__ out, long long n_blocks) {
+// (rowb = 2048, fgvc_split_f16f6x: the second KiB of a row is the pixel's 256 f32 channels themselves -- the exact rows the refining merge reads)
+__global__ __launch_bounds__(256) void split_f16f6p_kernel(const float* __restrict__ feat, unsigned char* __restrict__ out, long long n_blocks, int rowb) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_blocks) return;
   const long long pix = t >> 3;
   const int blk = (int)(t & 7), v = blk >> 1, hi = blk & 1;
   const float* src = feat + pix * 256 + 64 * v + 8 * hi;
-  unsigned char* row = out + pix * P6_ROWB;
+  unsigned char* row = out + pix * rowb;
   float hf[32], lf[32];
   float mh = 0.f, ml = 0.f;
 #pragma unroll
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void split_f16f6p_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(src + 16 * m + 4 * q);
+      if (rowb > P6_ROWB) *reinterpret_cast<f32x4*>(row + P6_ROWB + 4 * (64 * v + 8 * hi + 16 * m + 4 * q)) = x;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int e = 8 * m + 4 * q + j;
@@ -115,9 +117,9 @@ __global__ __launch_bounds__(256) void split_f16f6p_kernel(const float* __restri
   if (blk < 6) *reinterpret_cast<i32x4v*>(row + P6_END + 16 * blk) = i32x4v{0, 0, 0, 0};
 }
 
-int split_f16f6p_launch(const float* feat, unsigned char* out, long long n_pixels, hipStream_t s) {
+int split_f16f6p_launch(const float* feat, unsigned char* out, long long n_pixels, int rowb, hipStream_t s) {
   const long long nb = n_pixels * 8;
-  split_f16f6p_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(feat, out, nb);
+  split_f16f6p_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(feat, out, nb, rowb);
   FGVC_CHECK_LAUNCH("fgvc_split_f16f6p");
   return FGVC_OK;
 }
@@ -222,13 +224,13 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
 
   // ---- prologue 1: the query rows of the four blocks through the ring (coalesced 1 KiB rows by LDS-DMA)
   if (role < 2 && lane < P6_END / 16) {
-    const unsigned char* qbase = reinterpret_cast<const unsigned char*>(p.q_hl) + (size_t)qf * p.Hq * p.Wq * P6_ROWB + 16 * lane;
+    const unsigned char* qbase = reinterpret_cast<const unsigned char*>(p.q_hl) + (size_t)qf * p.Hq * p.Wq * p.rowb + 16 * lane;
     i32x4v qr[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = role * 16 + i;
       const int y = imin(QY0 + (r >> 3), p.Hq - 1), x = imin(QX0 + (r & 7), p.Wq - 1);
-      qr[i] = *reinterpret_cast<const i32x4v*>(qbase + ((size_t)y * p.Wq + x) * P6_ROWB);
+      qr[i] = *reinterpret_cast<const i32x4v*>(qbase + ((size_t)y * p.Wq + x) * p.rowb);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) *reinterpret_cast<i32x4v*>(&smem[qb * BUFB + (role * 16 + i) * LDB + 16 * lane]) = qr[i];
@@ -318,17 +320,17 @@ __global__ __launch_bounds__(768, 1) void pair_topk_kernel_v7(PairParamsB p) {
       if (pi != cur_pair) {
         cur_pair = pi;
         const int kf = p.pairs[g_start + pi].y;
-        kbase = reinterpret_cast<const unsigned char*>(p.k_hl) + (size_t)kf * p.Hk * p.Wk * P6_ROWB;
+        kbase = reinterpret_cast<const unsigned char*>(p.k_hl) + (size_t)kf * p.Hk * p.Wk * p.rowb;
       }
       const uint32_t ent = __builtin_amdgcn_readfirstlane(blist[e]);
       const int sby = ent & 0xfff, sbx = (ent >> 12) & 0xfff;
       const int ky = imin(sby * QBH + qb, p.Hk - 1), kx0 = sbx * QBW;
-      const unsigned char* src = kbase + ((size_t)ky * p.Wk + kx0) * P6_ROWB;
+      const unsigned char* src = kbase + ((size_t)ky * p.Wk + kx0) * p.rowb;
       const int xmax = p.Wk - 1 - kx0;
       if ((p.debug & 1) || lane >= P6_END / 16) return;                  // (1: ablation, results wrong: the ring's counters only, no bytes moved)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const unsigned char* rowp = src + (size_t)imin(i, xmax) * P6_ROWB;     // wave-uniform: scalar base + one lane-offset register
+        const unsigned char* rowp = src + (size_t)imin(i, xmax) * p.rowb;      // wave-uniform: scalar base + one lane-offset register
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[i]) : "v"(lane16), "s"(rowp) : "memory");
       }
     };
@@ -703,8 +705,9 @@ static int pair_v7_blocks_reached(int r2max, int ry, int rx, int reach_y, int re
 
 int pair_topk_v7_launch(const uint16_t* q_sp, const uint16_t* k_sp, const int32_t* pairs, int n_pairs, int Hq, int Wq, int Hk, int Wk,
                         int r2max, int ry, int rx, int topk, const int32_t* groups, int n_groups, int32_t* idx_out, float* score_out,
-                        hipStream_t s) {
+                        int row_bytes, hipStream_t s) {
   PairParamsB p;
+  p.rowb = row_bytes;
   p.q_hl = q_sp; p.k_hl = k_sp; p.pairs = reinterpret_cast<const int4*>(pairs);
   p.Hq = Hq; p.Wq = Wq; p.Hk = Hk; p.Wk = Wk;
   p.r2max = r2max; p.ry = ry; p.rx = rx;

@@ -1,0 +1,678 @@
+// fgvc_merge_refine_topk_f32: the merge of fgvc_merge_topk_f32 behind a pair kernel whose scores are APPROXIMATE (fgvc_pair_topk_f16f6:
+// f16 main product + FP6 cross sums, within `eps` of the exact product), made index-exact again.
+//
+// Why (round 5): on the reference's own 8-frame fixture the f16f6 pair kernel reproduced 503 of the 506 top-10 lists whose float64 ranks
+// are 1e-5 apart -- with ANY encoder arithmetic, MIOpen's f32 included -- and the f16x3 / f32 pair kernels all 506 behind any encoder
+// (profiles/r05_ledger_matrix.json): the lists are lost in the pair kernel's 1e-4 logit, not in the encoder.  Re-scoring the candidates of
+// the f16f6 lists exactly gives all 506 back.  Only near-ties need it:
+//
+//   * every candidate the pair kernel did NOT list has an approximate score <= the 10th of its list (the kernel's selection is exact on
+//     its own scores), and |approximate - exact| <= eps for every score;
+//   * so with t = the approximate score of merged rank k: a candidate below t - 2 eps cannot be among the exact top k, two neighbours of
+//     the merged order more than 2 eps apart are in their exact order, and a maximal chain of neighbours within 2 eps of each other (a
+//     "cluster") is the only place where the exact order can differ from the approximate one.
+//
+// Kernel 1 (one thread per (output frame, query), as the plain merge): merges the slots' lists into the 16 best by approximate score,
+// finds the clusters among the entries at or above t - 2 eps and either writes the final lists (no cluster: the order is proven) or
+// queues a work item.  Two copies of one key frame in two slots (frame 0 while idx <= precede_frames, vanilla_tracker.py:353-362) are
+// exact twins: never ambiguous with each other (the lower slot first), re-scored together.
+// Kernel 2 (one wave per work item): re-scores the clustered entries from the EXACT rows -- f32 features, products and sums in f64, one
+// rounding to f32 -- sorts, writes the final lists with the weights of the plain merge.  An item whose window was not closed by what the
+// pair kernel listed (a slot's own 10th inside the window, or more than 16 listed candidates inside it) is recomputed from scratch: every
+// candidate of every slot under the mask predicate, exactly ("scan": rare by construction -- it needs one key frame to own the whole
+// list; 78 of 179 760 queries of a 480p clip).  Kernel 3 (eight 8-wave workgroups per such item): every candidate of every slot, eight
+// coalesced 1 KiB rows per pass (rf_reduce8: f64 sums, a transposing butterfly over the wave), the passes dealt to the waves, the k best of all.
+// (The first build recomputed such an item inside kernel 2, candidate by candidate on one wave: 0.35 us per candidate, 1.5 ms per item --
+// one straggling wave made the launch 2.1 ms.)  Items beyond the scan queue's capacity still take that path: slow, never wrong.
+#include "common.hpp"
+
+namespace fgvc {
+
+constexpr int RF_KX = 16;             // merged candidates kept per query
+constexpr int RF_KMAX = 10;           // largest top-k of this route (the f16f6 pair kernel's)
+constexpr int RF_BRUTE = 1 << 30;
+
+struct RefineItem {
+  int row, q, flags, m;               // flags: bits 0..15 = entries to re-score, RF_BRUTE = recompute from scratch; m = entries inside the window
+  int gid[RF_KX];
+  float sc[RF_KX];
+};
+static_assert(sizeof(RefineItem) == 144, "RefineItem");
+constexpr int RF_INLINE = 1 << 29;    // a scan item that found the queue full: recomputed inside the refine kernel (slow path)
+
+struct RefineParams {
+  const int32_t* pair_idx;
+  const float* pair_score;
+  const int32_t* slot_pair;           // [n_out][T]
+  const int4* pairs;                  // [n_pairs] (query frame, key frame, flags, 0)
+  const unsigned char* q_exact;       // f32[256] rows: q_exact + frame * q_frame_bytes + pixel * q_row_bytes
+  const unsigned char* k_exact;
+  long long q_frame_bytes, k_frame_bytes;
+  int q_row_bytes, k_row_bytes;
+  int T, Hq, Wq, Hk, Wk, kin, kout;
+  float temperature, eps;
+  int weight_mode;
+  int r2max, ry, rx, reach_y, reach_x;
+  int32_t* idx_out;
+  float* logit_out;
+  float* weight_out;
+  int* counters;                      // [0] work items, [1] items recomputed from scratch, [2] candidates re-scored, [3] scan items beyond the queue
+  RefineItem* items;
+  int* scan_ids;                      // [scan_cap] work-item index of every queued scan item
+  int* scan_done;                     // [scan_cap] workgroups of the item that have written their part
+  unsigned long long* scan_parts;     // [scan_cap][RF_SCAN_PARTS][RF_KMAX] keys
+  int scan_cap;
+};
+
+// the k logits -> weights, as merge_topk_kernel computes them (post.hip): expression for expression
+__device__ __forceinline__ void rf_write(const RefineParams& p, int row, int q, const float (&sc)[RF_KMAX], const int (&id)[RF_KMAX]) {
+  float lg[RF_KMAX], w[RF_KMAX];
+#pragma unroll
+  for (int j = 0; j < RF_KMAX; ++j) lg[j] = sc[j] / p.temperature;
+  if (p.weight_mode == FGVC_WEIGHT_SOFTMAX) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < RF_KMAX; ++j) {
+      w[j] = (j < p.kout) ? expf(lg[j] - lg[0]) : 0.f;
+      sum += w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < RF_KMAX; ++j) w[j] = w[j] / sum;
+  } else {
+#pragma unroll
+    for (int j = 0; j < RF_KMAX; ++j) {
+      const float c = fmaxf(lg[j], 0.f);
+      w[j] = c * c;
+    }
+  }
+  const size_t o = ((size_t)row * p.Hq * p.Wq + q) * p.kout;
+#pragma unroll
+  for (int j = 0; j < RF_KMAX; ++j) {
+    if (j < p.kout) {
+      p.idx_out[o + j] = id[j] == IDX_EMPTY ? -1 : id[j];
+      p.logit_out[o + j] = lg[j];
+      p.weight_out[o + j] = w[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
+  const int HWq = p.Hq * p.Wq, HWk = p.Hk * p.Wk;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (q >= HWq) return;
+  TopK<RF_KX> top;
+  top.init();
+  float drop_max = -INFINITY;         // best approximate score of a LISTED candidate that is not among the 16
+  float tau_max = -INFINITY;          // best "last entry of a full list": nothing the pair kernel did not list scores above it
+  float tau[16];                      // ... per slot (-inf: the list is not full -- every candidate of the slot is listed)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) tau[t] = -INFINITY;
+  auto take = [&](int t, int id, float s) -> bool {          // one listed candidate of slot t; false: the rest of this (sorted) list is out
+    const int gid = t * HWk + id;
+    if (!top.accepts(s, gid)) {
+      drop_max = fmaxf(drop_max, s);
+      return false;
+    }
+    if (top.ix[RF_KX - 1] != IDX_EMPTY) drop_max = fmaxf(drop_max, top.v[RF_KX - 1]);
+    top.insert(s, gid);
+    return true;
+  };
+  if (p.kin == RF_KMAX) {
+    // full-length lists: a slot's 80 bytes by 8-byte loads, issued for slot t + 1 before slot t is merged (read entry by entry with an
+    // early exit, every load waited for the one before it: 60 dependent round trips per thread, 111 us per launch for 47 of the plain merge)
+    int2 ii[RF_KMAX / 2], ni[RF_KMAX / 2];
+    float2 ss[RF_KMAX / 2], ns[RF_KMAX / 2];
+    auto fetch = [&](int t, int2 (&I)[RF_KMAX / 2], float2 (&S)[RF_KMAX / 2]) -> int {
+      const int pid = t < p.T ? p.slot_pair[f * p.T + t] : -1;
+      if (pid >= 0) {
+        const size_t o = ((size_t)pid * HWq + q) * RF_KMAX;
+#pragma unroll
+        for (int j = 0; j < RF_KMAX / 2; ++j) {
+          I[j] = reinterpret_cast<const int2*>(p.pair_idx + o)[j];
+          S[j] = reinterpret_cast<const float2*>(p.pair_score + o)[j];
+        }
+      }
+      return pid;
+    };
+    int pid = fetch(0, ii, ss);
+    for (int t = 0; t < p.T; ++t) {
+      const int npid = fetch(t + 1, ni, ns);
+      if (pid >= 0) {
+        if (ii[RF_KMAX / 2 - 1].y >= 0) {
+          tau_max = fmaxf(tau_max, ss[RF_KMAX / 2 - 1].y);
+#pragma unroll
+          for (int u = 0; u < 16; ++u) tau[u] = u == t ? ss[RF_KMAX / 2 - 1].y : tau[u];
+        }
+        bool more = true;
+#pragma unroll
+        for (int j = 0; j < RF_KMAX; ++j) {
+          const int id = (j & 1) ? ii[j / 2].y : ii[j / 2].x;
+          const float sv = (j & 1) ? ss[j / 2].y : ss[j / 2].x;
+          more = more && id >= 0;
+          if (more) more = take(t, id, sv);
+        }
+      }
+      pid = npid;
+#pragma unroll
+      for (int j = 0; j < RF_KMAX / 2; ++j) { ii[j] = ni[j]; ss[j] = ns[j]; }
+    }
+  } else {
+    for (int t = 0; t < p.T; ++t) {
+      const int pid = p.slot_pair[f * p.T + t];
+      if (pid < 0) continue;
+      const size_t o = ((size_t)pid * HWq + q) * p.kin;
+      if (p.pair_idx[o + p.kin - 1] >= 0) {
+        const float tv = p.pair_score[o + p.kin - 1];
+        tau_max = fmaxf(tau_max, tv);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tau[u] = u == t ? tv : tau[u];
+      }
+      for (int j = 0; j < p.kin; ++j) {
+        const int id = p.pair_idx[o + j];
+        if (id < 0) break;
+        if (!take(t, id, p.pair_score[o + j])) break;
+      }
+    }
+  }
+  const float two_eps = 2.f * p.eps;
+  float t_k = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < RF_KX; ++j)
+    if (j == p.kout - 1 && top.ix[j] != IDX_EMPTY) t_k = top.v[j];
+  const float thr = t_k - two_eps;    // (-inf when fewer than k candidates exist: every one of them is inside the window)
+  int m = 0;
+#pragma unroll
+  for (int j = 0; j < RF_KX; ++j) m += (top.ix[j] != IDX_EMPTY && top.v[j] >= thr) ? 1 : 0;
+  // (fewer than k listed candidates, thr = -inf: still closed unless a list is full or a listed candidate was dropped)
+  const bool brute = (drop_max > -INFINITY && drop_max >= thr) || (tau_max > -INFINITY && tau_max >= thr);
+  // twins: the same pair feeding two slots, the same key pixel -- they carry ONE approximate score (one list read twice), so only
+  // neighbours with EQUAL scores are examined (an integer division per entry otherwise: twice the kernel's time)
+  unsigned twins = 0;                                 // bit j: entries j and j + 1 are twins
+#pragma unroll
+  for (int j = 0; j + 1 < RF_KX; ++j) {
+    if (j + 1 < m && top.v[j] == top.v[j + 1]) {
+      const int ta = top.ix[j] / HWk, tb = top.ix[j + 1] / HWk;
+      if (top.ix[j] - ta * HWk == top.ix[j + 1] - tb * HWk && p.slot_pair[f * p.T + ta] == p.slot_pair[f * p.T + tb]) twins |= 1u << j;
+    }
+  }
+  unsigned mask = 0;
+#pragma unroll
+  for (int j = 0; j + 1 < RF_KX; ++j) {
+    const bool inside = j + 1 < m;
+    if (inside && !((twins >> j) & 1u) && top.v[j] - top.v[j + 1] <= two_eps) mask |= 3u << j;
+  }
+#pragma unroll
+  for (int j = 0; j + 1 < RF_KX; ++j)                 // a re-scored entry takes its twin along (both then carry the same exact score)
+    if (((twins >> j) & 1u) && ((mask >> j) & 3u)) mask |= 3u << j;
+#pragma unroll
+  for (int j = RF_KX - 2; j >= 0; --j)
+    if (((twins >> j) & 1u) && ((mask >> j) & 3u)) mask |= 3u << j;
+  if (!brute && mask == 0u) {
+    float sc[RF_KMAX];
+    int id[RF_KMAX];
+#pragma unroll
+    for (int j = 0; j < RF_KMAX; ++j) { sc[j] = top.v[j]; id[j] = top.ix[j]; }
+    rf_write(p, f, q, sc, id);
+    return;
+  }
+  const int slot = atomicAdd(&p.counters[0], 1);
+  int flags = (int)mask;
+  if (brute) {
+    const int b = atomicAdd(&p.counters[1], 1);
+    // which slots must be scanned: those whose own last entry lies inside the window (an unlisted candidate of theirs may belong to the
+    // list); every slot when more listed candidates lie inside the window than the 16 kept.  The other slots' contenders are among the 16.
+    unsigned open = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) open |= (tau[t] > -INFINITY && tau[t] >= thr) ? (1u << t) : 0u;
+    if (drop_max > -INFINITY && drop_max >= thr) open = 0xffffu;
+    flags = RF_BRUTE | (int)open;
+    if (b < p.scan_cap) p.scan_ids[b] = slot;
+    else { flags |= RF_INLINE; atomicAdd(&p.counters[3], 1); }
+  } else {
+    atomicAdd(&p.counters[2], __popc(mask));
+  }
+  RefineItem* it = p.items + slot;
+  it->row = f; it->q = q; it->flags = flags; it->m = m;
+#pragma unroll
+  for (int j = 0; j < RF_KX; ++j) { it->gid[j] = top.ix[j]; it->sc[j] = top.v[j]; }
+}
+
+// <q, k_v> for EIGHT key rows at once, one wave: lane l holds channels 4 l ..+4 of the query and reads the same 16 bytes of every row
+// (eight coalesced 1 KiB loads in flight), products and sums in f64; the eight partial sums per lane are reduced across the wave by a
+// transposing butterfly -- each of the first three exchanges halves the values a lane carries -- in 10 exchanges instead of 48.
+// Returns the total of row ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1): rf_mine(lane).  Exact products, a fixed
+// order of sums: the same bits wherever a row is scored (re-scoring and the from-scratch scan share this routine).
+__device__ __forceinline__ int rf_mine(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
+__device__ __forceinline__ void rf_load8(const unsigned char* const (&krow)[8], int lane, f32x4 (&b)[8]) {
+#pragma unroll
+  for (int v = 0; v < 8; ++v) b[v] = *reinterpret_cast<const f32x4*>(krow[v] + 16 * lane);
+}
+__device__ __forceinline__ double rf_reduce8(const f32x4& a, const f32x4 (&b)[8], int lane) {
+  double p[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    double s = (double)a.x * (double)b[v].x;
+    s = fma((double)a.y, (double)b[v].y, s);
+    s = fma((double)a.z, (double)b[v].z, s);
+    s = fma((double)a.w, (double)b[v].w, s);
+    p[v] = s;
+  }
+  const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+  double q4[4], q2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q4[i] = (h5 ? p[i + 4] : p[i]) + __shfl_xor(h5 ? p[i] : p[i + 4], 32);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) q2[i] = (h4 ? q4[i + 2] : q4[i]) + __shfl_xor(h4 ? q4[i] : q4[i + 2], 16);
+  double c = (h3 ? q2[1] : q2[0]) + __shfl_xor(h3 ? q2[0] : q2[1], 8);
+  c += __shfl_xor(c, 4);
+  c += __shfl_xor(c, 2);
+  c += __shfl_xor(c, 1);
+  return c;
+}
+__device__ __forceinline__ double rf_dot8(const f32x4& a, const unsigned char* const (&krow)[8], int lane) {
+  f32x4 b[8];
+  rf_load8(krow, lane, b);
+  return rf_reduce8(a, b, lane);
+}
+
+__global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const int n_waves = (int)gridDim.x * 4;
+  const int n_items = __builtin_amdgcn_readfirstlane(p.counters[0]);
+  const int HWk = p.Hk * p.Wk;
+  for (int it = wave; it < n_items; it += n_waves) {
+    const RefineItem* I = p.items + it;
+    const int row = __builtin_amdgcn_readfirstlane(I->row), q = __builtin_amdgcn_readfirstlane(I->q);
+    const int flags = __builtin_amdgcn_readfirstlane(I->flags);
+    if ((flags & RF_BRUTE) && !(flags & RF_INLINE)) continue;            // queued for the scan kernels
+    int m = __builtin_amdgcn_readfirstlane(I->m);
+    int gid = I->gid[lane & 15];
+    float sc = I->sc[lane & 15];
+    int qf = 0;
+    for (int t = 0; t < p.T; ++t) {
+      const int pid = p.slot_pair[row * p.T + t];
+      if (pid >= 0) { qf = p.pairs[pid].x; break; }
+    }
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(p.q_exact + (size_t)qf * p.q_frame_bytes + (size_t)q * p.q_row_bytes + 16 * lane);
+    if (!(flags & RF_BRUTE)) {
+      const unsigned char* qrow = p.q_exact + (size_t)qf * p.q_frame_bytes + (size_t)q * p.q_row_bytes;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (!((flags >> (8 * half)) & 255)) continue;                    // wave-uniform
+        const unsigned char* kr[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const int e = 8 * half + v;
+          kr[v] = qrow;                                                  // (an entry that needs no re-scoring: any valid row, result unused)
+          if ((flags >> e) & 1) {
+            const int g = __builtin_amdgcn_readlane(gid, e);
+            const int t = g / HWk, pix = g - t * HWk;
+            const int kf = p.pairs[p.slot_pair[row * p.T + t]].y;
+            kr[v] = p.k_exact + (size_t)kf * p.k_frame_bytes + (size_t)pix * p.k_row_bytes;
+          }
+        }
+        const float sv = (float)rf_dot8(qv, kr, lane);
+        // the total of row v sits in the lanes with rf_mine() == v; entry 8 half + v is kept by lane (lane & 15) == 8 half + v:
+        // fetch it from the first lane that holds it
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const int e = 8 * half + v;
+          const int src = ((v >> 2) & 1) * 32 + ((v >> 1) & 1) * 16 + (v & 1) * 8;
+          const float got = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), src));
+          if (((flags >> e) & 1) && (lane & 15) == e) sc = got;
+        }
+      }
+    } else {
+      // every candidate of every slot, exactly
+      TopK<RF_KMAX> ex;
+      ex.init();
+      const int qy = q / p.Wq, qx = q - qy * p.Wq;
+      for (int t = 0; t < p.T; ++t) {
+        const int pid = p.slot_pair[row * p.T + t];
+        if (pid < 0) continue;
+        const int4 pr = p.pairs[pid];
+        const bool masked = (pr.z & FGVC_PAIR_MASKED) != 0;
+        const int y0 = masked ? imax(0, qy - imin(p.reach_y, qy)) : 0, y1 = masked ? imin(p.Hk - 1, qy + imin(p.reach_y, p.Hk)) : p.Hk - 1;
+        const int x0 = masked ? imax(0, qx - imin(p.reach_x, qx)) : 0, x1 = masked ? imin(p.Wk - 1, qx + imin(p.reach_x, p.Wk)) : p.Wk - 1;
+        const unsigned char* kb = p.k_exact + (size_t)pr.y * p.k_frame_bytes;
+        for (int y = y0; y <= y1; ++y)
+          for (int x = x0; x <= x1; ++x) {
+            if (masked) {
+              const int dy = y - qy, dx = x - qx, ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+              const long long d2 = (long long)dy * dy + (long long)dx * dx;
+              if (!(d2 <= p.r2max && ady <= p.ry && adx <= p.rx)) continue;
+            }
+            const int pix = y * p.Wk + x;
+            const unsigned char* r1 = kb + (size_t)pix * p.k_row_bytes;
+            const unsigned char* kr[8] = {r1, r1, r1, r1, r1, r1, r1, r1};
+            const float s = (float)rf_dot8(qv, kr, lane);               // (every lane: the same total)
+            const int g = t * HWk + pix;
+            if (ex.accepts(s, g)) ex.insert(s, g);
+          }
+      }
+      gid = IDX_EMPTY; sc = -INFINITY; m = 0;
+#pragma unroll
+      for (int j = 0; j < RF_KMAX; ++j) {
+        if ((lane & 15) == j) { gid = ex.ix[j]; sc = ex.v[j]; }
+        m += ex.ix[j] != IDX_EMPTY ? 1 : 0;
+      }
+    }
+    // rank of entry i among the m entries of the window: (score desc, index asc)
+    const int i = lane & 15;
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < RF_KX; ++j) {
+      const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), j));
+      const int gj = __builtin_amdgcn_readlane(gid, j);
+      rank += (j < m && (sj > sc || (sj == sc && gj < gid))) ? 1 : 0;
+    }
+    float osc[RF_KMAX];
+    int oid[RF_KMAX];
+#pragma unroll
+    for (int r = 0; r < RF_KMAX; ++r) {
+      const unsigned long long b = __ballot(lane < 16 && i < m && rank == r);
+      if (b) {
+        const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(b));
+        osc[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), src));
+        oid[r] = __builtin_amdgcn_readlane(gid, src);
+      } else {
+        osc[r] = -INFINITY;
+        oid[r] = IDX_EMPTY;
+      }
+    }
+    if (lane == 0) rf_write(p, row, q, osc, oid);
+  }
+}
+
+// ---- scan: RF_SCAN_PARTS workgroups of 8 waves per item.  The passes (8 box positions of one slot each: eight coalesced 1 KiB rows,
+// rf_reduce8) are dealt to the item's 64 waves, the next pass's rows are in flight while a pass is reduced; a workgroup's k best come
+// out of rounds of "largest head wins" on (score, ~index) keys, the LAST workgroup of an item to finish (a counter per item) merges the
+// parts and writes the item's final lists.  (One workgroup per item with one candidate per lane: 0.16 ms for 78 items -- 64 lanes x 64
+// cache lines per load instruction; one workgroup per item with coalesced rows: 0.20 ms -- a chain of HBM latencies, 90 passes long.)
+constexpr int RF_SCAN_WAVES = 8;
+constexpr int RF_SCAN_PARTS = 8;
+
+// the k largest of up to two keys per lane (hi >= lo; 0 = none; keys unique), in order, to every lane
+__device__ __forceinline__ void rf_wave_topk(unsigned long long hi, unsigned long long lo, unsigned long long (&out)[RF_KMAX]) {
+#pragma unroll 1
+  for (int r = 0; r < RF_KMAX; ++r) {
+    unsigned long long best = hi;
+#pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1) {
+      const unsigned long long o = __shfl_xor(best, mm);
+      best = o > best ? o : best;
+    }
+    if (hi == best) { hi = lo; lo = 0ull; }
+#pragma unroll
+    for (int j = 0; j < RF_KMAX; ++j) out[j] = j == r ? best : out[j];
+  }
+}
+
+__global__ __launch_bounds__(RF_SCAN_WAVES * 64) void refine_scan_kernel(RefineParams p) {
+  __shared__ unsigned long long wl[RF_SCAN_WAVES][RF_KMAX];
+  __shared__ unsigned long long w2[RF_SCAN_WAVES / 4][RF_KMAX];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n_scan = imin(p.counters[1], p.scan_cap);
+  const int HWk = p.Hk * p.Wk;
+  const int mine_v = rf_mine(lane);
+  constexpr int NWI = RF_SCAN_WAVES * RF_SCAN_PARTS;                    // waves per item
+  for (int u = blockIdx.x; u < n_scan * RF_SCAN_PARTS; u += gridDim.x) {
+    const int b = u / RF_SCAN_PARTS, part = u - b * RF_SCAN_PARTS;
+    const int wi = part * RF_SCAN_WAVES + wave;                         // this wave among the item's
+    const RefineItem* I = p.items + p.scan_ids[b];
+    const int row = __builtin_amdgcn_readfirstlane(I->row), q = __builtin_amdgcn_readfirstlane(I->q);
+    int qf = 0;
+    for (int t = 0; t < p.T; ++t) {
+      const int pid = p.slot_pair[row * p.T + t];
+      if (pid >= 0) { qf = p.pairs[pid].x; break; }
+    }
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(p.q_exact + (size_t)qf * p.q_frame_bytes + (size_t)q * p.q_row_bytes + 16 * lane);
+    const int qy = q / p.Wq, qx = q - qy * p.Wq;
+    TopK<RF_KMAX> loc;
+    loc.init();
+    const unsigned open = (unsigned)__builtin_amdgcn_readfirstlane(I->flags) & 0xffffu;
+    const int m_in = __builtin_amdgcn_readfirstlane(I->m);
+    int pass = 0;                                                       // passes so far over all slots: pass g belongs to wave g % NWI of the item
+    if (wi == NWI - 1) {
+      // the listed contenders of the slots that are NOT scanned: the entries of the item's 16 inside the window (the first m), re-scored
+      const int gid = I->gid[lane & 15];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned char* kr[8];
+        bool any = false;
+        int my_g = IDX_EMPTY;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const int e = 8 * half + v;
+          const int g = __builtin_amdgcn_readlane(gid, e);
+          kr[v] = p.q_exact + (size_t)qf * p.q_frame_bytes + (size_t)q * p.q_row_bytes;      // (unused entry: any valid row)
+          if (e < m_in && g != IDX_EMPTY) {
+            const int t = g / HWk, pix = g - t * HWk;
+            if (!((open >> t) & 1u)) {
+              kr[v] = p.k_exact + (size_t)p.pairs[p.slot_pair[row * p.T + t]].y * p.k_frame_bytes + (size_t)pix * p.k_row_bytes;
+              any = true;
+              if (v == mine_v) my_g = g;
+            }
+          }
+        }
+        if (any) {                                                      // wave-uniform
+          const float sc = (float)rf_dot8(qv, kr, lane);
+          if (my_g != IDX_EMPTY && (lane & 7) == 0 && loc.accepts(sc, my_g)) loc.insert(sc, my_g);
+        }
+      }
+    }
+    for (int t = 0; t < p.T; ++t) {
+      const int pid = p.slot_pair[row * p.T + t];
+      if (pid < 0 || !((open >> t) & 1u)) continue;
+      bool twin_done = false;                                           // an open slot fed by the same pair was scanned already (and inserted for this one too)
+      for (int t2 = 0; t2 < t; ++t2) twin_done = twin_done || (((open >> t2) & 1u) && p.slot_pair[row * p.T + t2] == pid);
+      if (twin_done) continue;
+      const int4 pr = p.pairs[pid];
+      const bool masked = (pr.z & FGVC_PAIR_MASKED) != 0;
+      const int y0 = masked ? imax(0, qy - imin(p.reach_y, qy)) : 0, y1 = masked ? imin(p.Hk - 1, qy + imin(p.reach_y, p.Hk)) : p.Hk - 1;
+      const int x0 = masked ? imax(0, qx - imin(p.reach_x, qx)) : 0, x1 = masked ? imin(p.Wk - 1, qx + imin(p.reach_x, p.Wk)) : p.Wk - 1;
+      const int nbx = x1 - x0 + 1, nbox = (y1 - y0 + 1) * nbx, npass = (nbox + 7) / 8;
+      const unsigned char* kb = p.k_exact + (size_t)pr.y * p.k_frame_bytes;
+      const int first = (wi - pass % NWI + NWI) % NWI;
+      auto rows_of = [&](int i, const unsigned char* (&kr)[8], int& my_pix, bool& my_ok) {
+        my_pix = 0; my_ok = false;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const int c = imin(8 * i + v, nbox - 1);                       // wave-uniform
+          const int yy = c / nbx;
+          const int y = y0 + yy, x = x0 + (c - yy * nbx);
+          bool ok = 8 * i + v < nbox;
+          if (masked) {
+            const int dy = y - qy, dx = x - qx, ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+            ok = ok && ((long long)dy * dy + (long long)dx * dx <= p.r2max && ady <= p.ry && adx <= p.rx);
+          }
+          const int pix = y * p.Wk + x;
+          kr[v] = kb + (size_t)pix * p.k_row_bytes;
+          if (v == mine_v) { my_pix = pix; my_ok = ok; }
+        }
+      };
+      f32x4 cur[8], nxt[8];
+      int pix_c = 0, pix_n = 0;
+      bool ok_c = false, ok_n = false;
+      if (first < npass) {
+        const unsigned char* kr[8];
+        rows_of(first, kr, pix_c, ok_c);
+        rf_load8(kr, lane, cur);
+      }
+      for (int i = first; i < npass; i += NWI) {
+        const bool more = i + NWI < npass;                               // wave-uniform
+        if (more) {
+          const unsigned char* kr[8];
+          rows_of(i + NWI, kr, pix_n, ok_n);
+          rf_load8(kr, lane, nxt);
+        }
+        const float sc = (float)rf_reduce8(qv, cur, lane);
+        for (int t2 = t; t2 < p.T; ++t2) {                               // this slot and the open slots fed by the same pair after it
+          if (t2 > t && !(((open >> t2) & 1u) && p.slot_pair[row * p.T + t2] == pid)) continue;
+          const int g = t2 * HWk + pix_c;
+          if (ok_c && (lane & 7) == 0 && loc.accepts(sc, g)) loc.insert(sc, g);    // one lane of the eight that hold this row's total
+        }
+        if (more) {
+#pragma unroll
+          for (int v = 0; v < 8; ++v) cur[v] = nxt[v];
+          pix_c = pix_n; ok_c = ok_n;
+        }
+      }
+      pass += npass;
+    }
+    __syncthreads();                                                    // (the previous unit's readers of wl / w2 / s_last)
+    // this wave's k best: k rounds over the lanes' own sorted lists
+    for (int r = 0; r < RF_KMAX; ++r) {
+      const unsigned long long key = loc.ix[0] == IDX_EMPTY ? 0ull : TopK64<1>::make_key(loc.v[0], loc.ix[0]);
+      unsigned long long best = key;
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) {
+        const unsigned long long o = __shfl_xor(best, mm);
+        best = o > best ? o : best;
+      }
+      const bool pop = best != 0ull && key == best;
+#pragma unroll
+      for (int j = 0; j + 1 < RF_KMAX; ++j) {
+        loc.v[j] = pop ? loc.v[j + 1] : loc.v[j];
+        loc.ix[j] = pop ? loc.ix[j + 1] : loc.ix[j];
+      }
+      if (pop) { loc.v[RF_KMAX - 1] = -INFINITY; loc.ix[RF_KMAX - 1] = IDX_EMPTY; }
+      if (lane == 0) wl[wave][r] = best;
+    }
+    __syncthreads();
+    if (wave < RF_SCAN_WAVES / 4) {                                     // a wave merges four lists ...
+      unsigned long long o4[RF_KMAX];
+      rf_wave_topk(lane < 4 * RF_KMAX ? wl[4 * wave + lane / RF_KMAX][lane % RF_KMAX] : 0ull, 0ull, o4);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < RF_KMAX; ++j) w2[wave][j] = o4[j];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {                                                    // ... wave 0 the merged ones: this workgroup's part
+      unsigned long long fin[RF_KMAX];
+      rf_wave_topk(lane < (RF_SCAN_WAVES / 4) * RF_KMAX ? w2[lane / RF_KMAX][lane % RF_KMAX] : 0ull, 0ull, fin);
+      unsigned long long* dst = p.scan_parts + ((size_t)b * RF_SCAN_PARTS + part) * RF_KMAX;
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < RF_KMAX; ++j) dst[j] = fin[j];
+        __threadfence();                                                // the part is visible before the count says so
+        s_last = atomicAdd(&p.scan_done[b], 1) == RF_SCAN_PARTS - 1;
+      }
+    }
+    __syncthreads();
+    if (s_last && wave == 0) {                                          // the item's last workgroup: all parts are written
+      __threadfence();
+      const unsigned long long* src = p.scan_parts + (size_t)b * RF_SCAN_PARTS * RF_KMAX;
+      constexpr int NE = RF_SCAN_PARTS * RF_KMAX;
+      static_assert(NE <= 128, "two keys per lane");
+      // (device-scope atomic loads: served by the L2, never by a line this CU's L1 may still hold)
+      unsigned long long hi = lane < NE ? __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      unsigned long long lo = lane + 64 < NE ? __hip_atomic_load(src + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      if (lo > hi) { const unsigned long long tmp = hi; hi = lo; lo = tmp; }
+      unsigned long long fin[RF_KMAX];
+      rf_wave_topk(hi, lo, fin);
+      if (lane == 0) {
+        float osc[RF_KMAX];
+        int oid[RF_KMAX];
+        TopK64<RF_KMAX> dec;
+#pragma unroll
+        for (int j = 0; j < RF_KMAX; ++j) dec.k[j] = fin[j];
+#pragma unroll
+        for (int j = 0; j < RF_KMAX; ++j) {
+          osc[j] = dec.score(j);
+          oid[j] = fin[j] == 0ull ? IDX_EMPTY : dec.index(j);
+        }
+        rf_write(p, row, q, osc, oid);
+      }
+    }
+  }
+}
+
+size_t merge_refine_scan_cap(int n_out, int HWq) { return (size_t)imax(4096, (int)(((long long)n_out * HWq + 31) / 32)); }
+
+int merge_refine_launch(const RefineParams& p_in, int n_out, void* workspace, hipStream_t s) {
+  RefineParams p = p_in;
+  // workspace: [64 B counters][scan_done: cap ints, zeroed with the counters][scan_ids: cap ints][scan_parts][items]
+  p.scan_cap = (int)merge_refine_scan_cap(n_out, p.Hq * p.Wq);
+  const size_t cap4 = (((size_t)p.scan_cap * 4 + 15) / 16) * 16;
+  p.counters = reinterpret_cast<int*>(workspace);
+  unsigned char* w = reinterpret_cast<unsigned char*>(workspace) + 64;
+  p.scan_done = reinterpret_cast<int*>(w);
+  w += cap4;
+  p.scan_ids = reinterpret_cast<int*>(w);
+  w += cap4;
+  p.scan_parts = reinterpret_cast<unsigned long long*>(w);
+  w += (size_t)p.scan_cap * RF_SCAN_PARTS * RF_KMAX * 8;
+  p.items = reinterpret_cast<RefineItem*>(w);
+  if (hipMemsetAsync(workspace, 0, 64 + cap4, s) != hipSuccess) {
+    set_error("fgvc_merge_refine_topk_f32: hipMemsetAsync failed");
+    return FGVC_ERR_LAUNCH;
+  }
+  dim3 grid(cdiv(p.Hq * p.Wq, 256), n_out);
+  merge_mark_kernel<<<grid, 256, 0, s>>>(p);
+  FGVC_CHECK_LAUNCH("fgvc_merge_refine_topk_f32 (merge)");
+  refine_kernel<<<1024, 256, 0, s>>>(p);
+  FGVC_CHECK_LAUNCH("fgvc_merge_refine_topk_f32 (refine)");
+  refine_scan_kernel<<<1024, RF_SCAN_WAVES * 64, 0, s>>>(p);
+  FGVC_CHECK_LAUNCH("fgvc_merge_refine_topk_f32 (scan)");
+  return FGVC_OK;
+}
+
+}  // namespace fgvc
+
+using namespace fgvc;
+
+extern "C" {
+
+size_t fgvc_merge_refine_workspace_bytes(int n_out, int HWq) {
+  if (n_out < 0 || HWq < 0) return 0;
+  const size_t cap = fgvc::merge_refine_scan_cap(n_out, HWq);
+  return 64 + 2 * (((cap * 4 + 15) / 16) * 16) + cap * fgvc::RF_SCAN_PARTS * fgvc::RF_KMAX * 8 + (size_t)n_out * HWq * sizeof(RefineItem);
+}
+
+int fgvc_merge_refine_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, const int32_t* pairs,
+                               const void* q_exact, int64_t q_frame_bytes, int q_row_bytes, const void* k_exact, int64_t k_frame_bytes,
+                               int k_row_bytes, int n_out, int T, int Hq, int Wq, int Hk, int Wk, int C, int topk, float temperature,
+                               int weight_mode, float eps, int r2max, int ry, int rx, int32_t* idx_out, float* logit_out,
+                               float* weight_out, void* workspace, void* stream) {
+  const char* what = "fgvc_merge_refine_topk_f32";
+  FGVC_REQUIRE(pair_idx && pair_score && slot_pair && pairs && q_exact && k_exact && idx_out && logit_out && weight_out && workspace,
+               FGVC_ERR_INVALID_ARG, "%s: null pointer", what);
+  FGVC_REQUIRE(C == 256, FGVC_ERR_UNSUPPORTED, "%s: C=%d unsupported (256 only)", what, C);
+  FGVC_REQUIRE(topk >= 1 && topk <= RF_KMAX, FGVC_ERR_UNSUPPORTED, "%s: topk=%d outside 1..%d", what, topk, RF_KMAX);
+  FGVC_REQUIRE(T <= 16, FGVC_ERR_UNSUPPORTED, "%s: T=%d key slots (at most 16)", what, T);
+  FGVC_REQUIRE(n_out >= 0 && n_out <= 65535 && T >= 1 && Hq > 0 && Wq > 0 && Hk > 0 && Wk > 0, FGVC_ERR_INVALID_ARG, "%s: bad shape", what);
+  FGVC_REQUIRE((long long)Hq * Wq < (1ll << 30) && (long long)Hk * Wk * T < (1ll << 31), FGVC_ERR_UNSUPPORTED, "%s: grid too large", what);
+  FGVC_REQUIRE(q_row_bytes >= 1024 && k_row_bytes >= 1024 && q_row_bytes % 16 == 0 && k_row_bytes % 16 == 0 &&
+                   (reinterpret_cast<uintptr_t>(q_exact) & 15u) == 0 && (reinterpret_cast<uintptr_t>(k_exact) & 15u) == 0 &&
+                   q_frame_bytes % 16 == 0 && k_frame_bytes % 16 == 0,
+               FGVC_ERR_INVALID_ARG, "%s: the exact rows are 256 f32 = 1024 bytes each, 16-byte aligned", what);
+  FGVC_REQUIRE((reinterpret_cast<uintptr_t>(pairs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0, FGVC_ERR_INVALID_ARG,
+               "%s: pairs / workspace must be 16-byte aligned", what);
+  FGVC_REQUIRE(temperature > 0.f && eps >= 0.f && eps < 1.f, FGVC_ERR_INVALID_ARG, "%s: bad temperature / eps", what);
+  FGVC_REQUIRE(weight_mode == FGVC_WEIGHT_SOFTMAX || weight_mode == FGVC_WEIGHT_COSINE, FGVC_ERR_INVALID_ARG, "%s: bad weight mode", what);
+  FGVC_REQUIRE(r2max >= 0 && ry >= 0 && rx >= 0, FGVC_ERR_INVALID_ARG, "%s: negative mask parameter", what);
+  const bool any_limit = r2max < FGVC_NO_LIMIT || ry < FGVC_NO_LIMIT || rx < FGVC_NO_LIMIT;
+  FGVC_REQUIRE(!any_limit || (Hq == Hk && Wq == Wk), FGVC_ERR_INVALID_ARG, "%s: a spatial mask needs equal query/key grids", what);
+  if (n_out == 0) return FGVC_OK;
+  RefineParams p;
+  p.pair_idx = pair_idx; p.pair_score = pair_score; p.slot_pair = slot_pair; p.pairs = reinterpret_cast<const int4*>(pairs);
+  p.q_exact = static_cast<const unsigned char*>(q_exact); p.k_exact = static_cast<const unsigned char*>(k_exact);
+  p.q_frame_bytes = q_frame_bytes; p.k_frame_bytes = k_frame_bytes; p.q_row_bytes = q_row_bytes; p.k_row_bytes = k_row_bytes;
+  p.T = T; p.Hq = Hq; p.Wq = Wq; p.Hk = Hk; p.Wk = Wk; p.kin = topk; p.kout = topk;
+  p.temperature = temperature; p.eps = eps; p.weight_mode = weight_mode;
+  p.r2max = r2max; p.ry = ry; p.rx = rx;
+  int rr = 0;
+  while (rr < 46340 && (long long)(rr + 1) * (rr + 1) <= (long long)r2max) ++rr;
+  p.reach_y = imin(ry, rr); p.reach_x = imin(rx, rr);
+  p.idx_out = idx_out; p.logit_out = logit_out; p.weight_out = weight_out;
+  p.counters = nullptr; p.items = nullptr; p.scan_ids = nullptr; p.scan_done = nullptr; p.scan_parts = nullptr; p.scan_cap = 0;
+  return merge_refine_launch(p, n_out, workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -248,6 +248,7 @@ class HipBackend:
         self.tail_stream = tail_stream
         self.tail_from = tail_from          # "pairs": everything after the encoder runs on the side stream
         self.tail_event = None
+        self.merge_on_tail = False          # True: the slot merge (pairs() / merge()) joins the sweep on the side stream
 
     def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None):
         # the bank in the form the pair kernel reads (the (h, l) f16 split where it applies): no second pass, same bytes to ship.
@@ -257,6 +258,18 @@ class HipBackend:
     def affinity(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig, phases=None):
         """`phases` = (plan indices of the pairs to launch first, callable to run before the others): see engine.run_pairs."""
         tk = engine.run_affinity(bank, Hf, Wf, plan, cfg, phases=phases, channels=getattr(self.model, "feat_channels", None))
+        return tk.idx, tk.weight
+
+    def pairs(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig, phases=None):
+        """affinity() in two steps: the pair top-k here (the caller's stream) ..."""
+        return engine.run_pairs(bank, Hf, Wf, plan, cfg, phases=phases, channels=getattr(self.model, "feat_channels", None))
+
+    def merge(self, pl, cfg: TrackerConfig):
+        """... and the slot merge (+ the exact re-scoring of near-ties where the pair kernel's scores are approximate) wherever the caller
+        puts it: track_points_sharded runs it on the side stream, under the next video's encoder (a chain of latency-bound launches:
+        0.2 ms at 480p on the critical path otherwise)."""
+        tk = engine.merge_pairs(pl, cfg)
+        self.refine_stats = tk.refine_stats
         return tk.idx, tk.weight
 
     def sweep(self, idx, weight, slot_frame, plan: Plan, start: int, pts, Hf, Wf, h, w, cfg):
@@ -403,7 +416,8 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                     fh, Hf, Wf = backend.encode(rgbs[e_lo:split_at].to(dev), out=rows[:split_at - e_lo])
                     # (cannot differ from the call above -- same row shape and dtype -- and that one was checked BEFORE anything was
                     # posted: a rank that raised here alone would leave its peers in their messages)
-                    assert fh.data_ptr() == rows.data_ptr(), "track_points_sharded: the backend did not encode into the local bank"
+                    if fh.data_ptr() != rows.data_ptr():      # (an explicit raise: `python -O` strips asserts, and the pair kernel would read rows nobody wrote)
+                        raise RuntimeError("track_points_sharded: the backend did not encode into the local bank")
                     f = rows
                 else:
                     f, Hf, Wf = backend.encode(rgbs[e_lo:e_hi].to(dev), out=rows)
@@ -505,6 +519,13 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                 with _span(timing, "halo_wait"):
                     pending.wait()
 
+        # the merge of the pair lists goes to the side stream with the sweep where the backend offers the two steps
+        pl = None
+        # (`backend.merge_on_tail`; off by default: measured at 480p, N = 1 -- 4.76 ms per step with the merge on the side stream against
+        # 4.68 behind the pair kernel: its launches are latency-bound, but their workgroups keep the next video's convolutions off the CUs
+        # they sit on, and the encode phase grows by more than the 0.2 ms the merge takes alone)
+        split_merge = (getattr(backend, "tail_stream", None) is not None and not early and getattr(backend, "merge_on_tail", False)
+                       and hasattr(backend, "pairs") and hasattr(backend, "merge"))
         with _span(timing, "affinity"):
             if plan.pairs:
                 if sc["lplan"] is None or sc["lplan"][0] != local_ids:
@@ -518,11 +539,16 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
                         bank = enc_bank                                    # nothing came from elsewhere: the encoder's own tensor, no copy
                     else:
                         bank = torch.stack([feats[f] for f in local_ids], 0)
+                run = backend.pairs if split_merge else backend.affinity
                 if pending is not None and _takes_phases(backend):
-                    idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg, phases=(sc["lplan"][2], halo_landed))
+                    res = run(bank, Hf, Wf, sc["lplan"][1], cfg, phases=(sc["lplan"][2], halo_landed))
                 else:
                     halo_landed()
-                    idx, weight = backend.affinity(bank, Hf, Wf, sc["lplan"][1], cfg)
+                    res = run(bank, Hf, Wf, sc["lplan"][1], cfg)
+                if split_merge:
+                    pl, idx, weight = res, None, None
+                else:
+                    idx, weight = res
             else:
                 halo_landed()
                 idx = torch.empty((0, HW, k), device=dev, dtype=torch.int32)
@@ -536,10 +562,15 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
             tail.wait_stream(torch.cuda.current_stream(dev))
             # everything the side stream reads that was allocated on another stream: keep it from the caching allocator until the side
             # stream is done (without a `cache` the schedule -- slot table, the groups' query points -- dies when this function returns)
-            for t in [idx, weight, slot_frame_dev] + [pts for (_, _, pts) in sc["groups"]]:
+            held = [slot_frame_dev] + [pts for (_, _, pts) in sc["groups"]]
+            held += [idx, weight] if pl is None else [t for t in (pl.idx, pl.score, pl.exact) if t is not None]
+            for t in held:
                 if t.is_cuda:
                     t.record_stream(tail)
         with (torch.cuda.stream(tail) if tail is not None else _Null()):
+            if pl is not None:
+                with _span(timing, "merge"):
+                    idx, weight = backend.merge(pl, cfg)
             with _span(timing, "all_gather_lists"):
                 if world > 1:
                     mx = max(rows)

@@ -51,7 +51,12 @@ class TrackerConfig:
     pair_precision: str = "auto"   # ops.pair_topk_auto: "auto" | "f32" | "split" (not a reference key)
     pair_split_fmt: str = "f16"    # operand format of the split pair kernel: "f16" = split_f16x2 rows -> fgvc_pair_topk_f16x3 (three f16 products, 1e-7-grade),
                                    # "f16f6" = split_f16f6p rows -> fgvc_pair_topk_f16f6 (f16 + FP6 cross terms: half the matrix work, ~6e-5 logit);
-                                   # VanillaTracker picks "f16f6" when its encoder computes in f16f8 and the mask allows it (engine_config)
+                                   # VanillaTracker picks "f16f6" when its encoder computes in f16f8 / f16f6 and the mask allows it (engine_config)
+    pair_refine: bool = True       # with "f16f6": the bank carries the exact f32 channels behind every row (split_f16f6x: 2 KiB rows) and the
+                                   # merge re-scores near-ties from them (fgvc_merge_refine_topk_f32): the lists are the exact top-k in the exact
+                                   # order wherever the approximate scores are within `pair_refine_eps` of the exact products (round 5: the
+                                   # reference's own lists, profiles/r05_precision_ledger.json).  False: round 4's plain merge of approximate scores
+    pair_refine_eps: float = ops.REFINE_EPS
 
     @staticmethod
     def from_test_cfg(cfg) -> "TrackerConfig":
@@ -78,7 +83,14 @@ class TrackerConfig:
             neighbor_range=neighbor_range, mask_mode=mask_mode,
             with_first=bool(g("with_first", True)), regroup=bool(g("with_first", False)),
             with_first_neighbor=with_first_neighbor, with_norm=with_norm, sim_mode=sim_mode, test_mode=test_mode,
-            pair_precision=g("pair_precision", "auto"), pair_split_fmt=g("pair_split_fmt", "f16"))   # the last two: extension keys
+            pair_precision=g("pair_precision", "auto"), pair_split_fmt=g("pair_split_fmt", "f16"),   # from here on: extension keys
+            pair_refine=bool(g("pair_refine", True)), pair_refine_eps=float(g("pair_refine_eps", ops.REFINE_EPS)))
+
+    @property
+    def bank_fmt(self) -> str:
+        """The format get_feats_hwc(split=True) / run_pairs() build the bank in: split_f16f6x() rows where the f16 + FP6 pair kernel runs
+        with the refining merge behind it, else what `pair_split_fmt` names."""
+        return "f16f6x" if (self.pair_split_fmt == "f16f6" and self.pair_refine) else self.pair_split_fmt
 
     @property
     def mask(self) -> MaskSpec:
@@ -167,6 +179,7 @@ class DeviceTopk:
     weight: torch.Tensor     # (rows, HW, k)
     slot_frame: torch.Tensor  # (rows, t_max) int32
     row_map: Optional[Dict[int, int]] = None    # plan row -> row of idx / weight / slot_frame when only some rows were merged
+    refine_stats: Optional[torch.Tensor] = None # the refining merge's int32 counters (3,) on the device: queries re-scored, of them from scratch, candidates
 
     def row(self, plan_row: int) -> int:
         return plan_row if self.row_map is None else self.row_map[plan_row]
@@ -180,6 +193,8 @@ class PairLists:
     score: torch.Tensor      # (pairs, HW, k)
     HW: int
     channels: int = 256      # un-padded feature channels (only 'l2-distance' reads it)
+    exact: Optional[torch.Tensor] = None    # the scores are fgvc_pair_topk_f16f6's approximations; the bank whose exact rows re-score them
+    geom: Optional[Tuple[int, int]] = None  # (Hf, Wf) (the refining merge needs the grid for the mask predicate)
 
 
 def run_affinity(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig,
@@ -204,6 +219,15 @@ def merge_pairs(pl: PairLists, cfg: TrackerConfig, rows: Optional[Sequence[int]]
     if slot_pair.shape[0] == 0:
         e = torch.empty((0, pl.HW, cfg.topk), device=pl.idx.device)
         return DeviceTopk(plan, e.int(), e, e, slot_frame, row_map)
+    if pl.exact is not None:
+        pairs_dev = plan.tables(pl.idx.device)[0]
+        Hf, Wf = pl.geom
+        idx, logit, weight, stats = ops.merge_refine_topk(pl.idx, pl.score, slot_pair, pairs_dev, pl.exact, pl.exact, Hf, Wf, Hf, Wf,
+                                                          cfg.mask, cfg.topk, cfg.softmax_temperature(pl.channels), cfg.mode,
+                                                          eps=cfg.pair_refine_eps)
+        tk = DeviceTopk(plan, idx, logit, weight, slot_frame, row_map)
+        tk.refine_stats = stats
+        return tk
     idx, logit, weight = ops.merge_topk(pl.idx, pl.score, slot_pair, pl.HW, cfg.topk, cfg.softmax_temperature(pl.channels),
                                         cfg.mode, validate=False)
     return DeviceTopk(plan, idx, logit, weight, slot_frame, row_map)
@@ -225,8 +249,12 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
     n = len(plan.pairs)
     pairs_dev, slot_pair, slot_frame = plan.tables(dev)
     rows = len(plan.slot_pair)
-    pre_split = feats_hwc.dtype == torch.int16            # (T, HW, 2, C): the bank already as split_bf16() of the normalised rows
-    all_masked = bool(plan.pairs) and all(m for (_, _, m) in plan.pairs)
+    exact = None
+    pre_split = feats_hwc.dtype == torch.int16            # (T, HW, 2 | 4, C): the bank already in a pair kernel's operand format
+    if n == 0:                                            # a one-frame clip, or every query point on the last frame: nothing to correlate
+        e = torch.empty((0, HW, k), device=dev)
+        return PairLists(plan, e.int(), e, HW, feats_hwc.shape[-1] if channels is None else channels)
+    all_masked = all(m for (_, _, m) in plan.pairs)
     use_split = cfg.pair_precision == "split" or (
         cfg.pair_precision == "auto" and ops.split_path_ok(feats_hwc.shape[-1], Hf, Wf, k, cfg.with_norm, None, cfg.mask, all_masked))
     if pre_split and not use_split:
@@ -236,15 +264,22 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
         # att_channels); the row length may be that count rounded up with zero channels (normalize_to_hwc(pad=True)), so it must be given
         raise ValueError("run_pairs: sim_mode='l2-distance' needs channels= (the encoder's un-padded channel count)")
     if use_split:      # 16-bit matrix pipe on the two-part split of the (normalised) features, f32-grade scores
-        fmt = cfg.pair_split_fmt
-        if fmt not in ("f16", "f16f6"):
-            raise ValueError(f"pair_split_fmt={fmt!r}: 'f16' (split_f16x2 rows) or 'f16f6' (split_f16f6p rows)")
-        if fmt == "f16f6" and not ops.pair_f16f6_ok(feats_hwc.shape[-1], Hf, Wf, k, cfg.with_norm, None, cfg.mask, all_masked):
+        if cfg.pair_split_fmt not in ("f16", "f16f6"):
+            raise ValueError(f"pair_split_fmt={cfg.pair_split_fmt!r}: 'f16' (split_f16x2 rows) or 'f16f6' (split_f16f6p / split_f16f6x rows)")
+        # a pre-split bank says itself whether its rows are split_f16f6x()'s; between split_f16x2() and split_f16f6p() rows (one shape) the
+        # configuration's word is all there is -- VanillaTracker.get_feats_hwc builds the bank from the same configuration
+        fmt = ops.bank_format(feats_hwc, cfg.pair_split_fmt) if pre_split else cfg.bank_fmt
+        if pre_split and fmt == "f16f6x" and cfg.pair_split_fmt != "f16f6":
+            raise ValueError("run_pairs: the bank holds split_f16f6x() rows, but the configuration asks for pair_split_fmt='f16' "
+                             "(build the bank and run the pairs from ONE configuration: VanillaTracker.engine_config())")
+        if fmt != "f16" and not ops.pair_f16f6_ok(feats_hwc.shape[-1], Hf, Wf, k, cfg.with_norm, None, cfg.mask, all_masked):
             if pre_split:
                 raise ValueError("run_pairs: the bank is in the f16f6 format, but fgvc_pair_topk_f16f6 does not apply to this mask / pair list "
                                  "(every pair masked, at most 64 key blocks in reach): encode with pair_split_fmt='f16'")
             fmt = "f16"
-        split = feats_hwc if pre_split else (ops.split_f16x2(feats_hwc) if fmt == "f16" else ops.split_f16f6p(feats_hwc))
+        split = feats_hwc if pre_split else {"f16": ops.split_f16x2, "f16f6": ops.split_f16f6p, "f16f6x": ops.split_f16f6x}[fmt](feats_hwc)
+        if fmt == "f16f6x":
+            exact = split                                 # the refining merge reads the rows' second KiB
         pair_fn = lambda prs: ops.pair_topk_split(split, split, prs, Hf, Wf, Hf, Wf, cfg.mask, k, validate=False, all_masked=all_masked,
                                                   fmt=fmt)
     else:
@@ -280,7 +315,7 @@ def run_pairs(feats_hwc: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: Tracke
             pidx[c0:c1], pscore[c0:c1] = i, s
     if events is not None:
         events[1].record()
-    return PairLists(plan, pidx, pscore, HW, feats_hwc.shape[-1] if channels is None else channels)
+    return PairLists(plan, pidx, pscore, HW, feats_hwc.shape[-1] if channels is None else channels, exact=exact, geom=(Hf, Wf))
 
 
 def run_propagation(topk: DeviceTopk, start: int, points_xy: torch.Tensor, Hf: int, Wf: int, h: int, w: int,
@@ -317,8 +352,9 @@ def run_propagation_async(topk, start: int, points_xy: torch.Tensor, Hf: int, Wf
     stream.wait_stream(cur)
     with torch.cuda.stream(stream):
         if isinstance(topk, PairLists):
-            for t in (topk.idx, topk.score):
-                t.record_stream(stream)
+            for t in (topk.idx, topk.score, topk.exact):
+                if t is not None:
+                    t.record_stream(stream)
             topk = merge_pairs(topk, cfg)
         for t in (topk.idx, topk.logit, topk.weight, topk.slot_frame, points_xy):
             t.record_stream(stream)

@@ -765,7 +765,7 @@ class ResNet(nn.Module):
         def ensure_out(C, H, W):
             if "out" not in box:
                 as_split = bool(split_if is not None and split_if(C, H, W))
-                shape = (x.shape[0], H * W, 2, C) if as_split else (x.shape[0], H * W, C)
+                shape = (x.shape[0], H * W, 4 if split_fmt == "f16f6x" else 2, C) if as_split else (x.shape[0], H * W, C)
                 dtype = torch.int16 if as_split else torch.float32
                 if out is not None and tuple(out.shape) == shape and out.dtype == dtype and out.is_contiguous() and out.device == x.device:
                     box["out"] = out                                           # the caller's rows (a slice of its feature bank): no copy later
@@ -782,7 +782,7 @@ class ResNet(nn.Module):
             ops.normalize_nhwc(y_slice, normalize, split=split_fmt if box["split"] else False, out=box["out"][lo:hi])
 
         def bank_of(lo, hi, C, H, W):            # ... or hands its rows to the trunk's last convolution (f16f6 rows of 256 channels)
-            if not (self.fuse_bank and split_fmt == "f16f6" and C == 256 and split_if is not None and split_if(C, H, W)):
+            if not (self.fuse_bank and split_fmt in ("f16f6", "f16f6x") and C == 256 and split_if is not None and split_if(C, H, W)):
                 return None
             ensure_out(C, H, W)
             return box["out"][lo:hi] if box["split"] else None
@@ -794,7 +794,7 @@ class ResNet(nn.Module):
         C = y.shape[1]
         as_split = bool(split_if is not None and split_if(C, H, W))
         f = ops.normalize_to_hwc(y.float(), normalize, pad=True)
-        splitter = {"f16": ops.split_f16x2, "f16f6": ops.split_f16f6p}.get(split_fmt, ops.split_bf16)
+        splitter = {"f16": ops.split_f16x2, "f16f6": ops.split_f16f6p, "f16f6x": ops.split_f16f6x}.get(split_fmt, ops.split_bf16)
         return (splitter(f) if as_split and f.shape[-1] == C else f), H, W
 
 

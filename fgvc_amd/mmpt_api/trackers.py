@@ -94,9 +94,10 @@ class VanillaTracker(BaseTracker):
     @torch.no_grad()
     def get_feats_hwc(self, frames: torch.Tensor, split: bool = False, out: Optional[torch.Tensor] = None):
         """frames (T,3,h,w) -> normalised channels-last (T, HfWf, C'), Hf, Wf.
-        batch_step frames per encoder call (vanilla_tracker.py:135-147).  split=True: the bank comes back as its two-part 16-bit
-        split (T, HfWf, 2, C') int16, in the format engine_config().pair_split_fmt names, wherever the engine's split pair kernel
-        applies (one pass less; engine.run_affinity takes either form), f32 otherwise.
+        batch_step frames per encoder call (vanilla_tracker.py:135-147).  split=True: the bank comes back in the pair kernel's operand
+        format -- (T, HfWf, 2, C') int16 in the format engine_config().pair_split_fmt names, or (T, HfWf, 4, 256) int16 = split_f16f6x()
+        rows (2 KiB per pixel: the f16 + FP6 row and the exact f32 channels behind it; engine_config().bank_fmt, the default) --
+        wherever the engine's split pair kernel applies (one pass less; engine.run_affinity takes either form), f32 otherwise.
         `out`: rows of the caller's own feature bank (T, ...) of the shape / dtype this call produces; the encoder then writes there
         and `out` itself is returned (clip sharding: the frames a rank encodes land in its local bank without a copy).  A mismatch
         falls back to a fresh tensor -- compare the result with `out` by identity."""
@@ -114,7 +115,7 @@ class VanillaTracker(BaseTracker):
         split_fmt = "bf16"
         if split and fast:
             cfg = self.engine_config()
-            split_fmt = cfg.pair_split_fmt
+            split_fmt = cfg.bank_fmt                 # "f16f6x" (2 KiB rows: + the exact f32 channels) where the refining merge runs
             if cfg.pair_precision in ("auto", "split"):
                 split_if = lambda C, H, W: ops.split_path_ok(C, H, W, cfg.topk, cfg.with_norm, None, cfg.mask,
                                                              cfg.with_first_neighbor or not cfg.with_first)

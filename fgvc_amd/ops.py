@@ -9,6 +9,7 @@ top-k lists (…, HW, k) in canonical order (score desc, index asc).
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -171,16 +172,20 @@ def pair_topk_split(qsplit: torch.Tensor, ksplit: torch.Tensor, pairs: torch.Ten
     """pair_topk() on the 16-bit matrix pipe (fgvc_pair_topk_f16x3): qsplit (nq, HqWq, 2, 256), ksplit (nk, HkWk, 2, 256) int16 =
     split_f16x2() of L2-NORMALISED features.  Same outputs as pair_topk().  all_masked=True: the caller built `pairs` with
     PAIR_MASKED on every row (then only the mask's reach, not the whole key grid, must fit the kernel's block list).
-    `fmt` names the operand format; "f16" is the only one (the bf16 four-product kernel of rounds 1-2 is retired)."""
-    if fmt not in ("f16", "f16f6"):
-        raise ValueError(f"pair_topk_split: fmt={fmt!r} ('f16': split_f16x2 operands, 'f16f6': split_f16f6p operands)")
-    if fmt == "f16f6" and not (all_masked and pair_blocks_reached(mask) <= PAIR_F16F6_MAX_BLOCKS):
-        raise ValueError("pair_topk_split(fmt='f16f6'): every pair must be masked (all_masked=True) by an analytic mask that reaches at most "
+    `fmt` names the operand format: "f16" = split_f16x2() rows -> fgvc_pair_topk_f16x3; "f16f6" = split_f16f6p() rows ->
+    fgvc_pair_topk_f16f6; "f16f6x" = split_f16f6x() rows (frames, HW, 4, 256) -> fgvc_pair_topk_f16f6x (the same kernel at a row stride
+    of 2 KiB).  split_f16x2() and split_f16f6p() rows have ONE shape and dtype: the caller's `fmt` is all that tells them apart."""
+    if fmt not in ("f16", "f16f6", "f16f6x"):
+        raise ValueError(f"pair_topk_split: fmt={fmt!r} ('f16': split_f16x2 operands, 'f16f6': split_f16f6p operands, 'f16f6x': split_f16f6x operands)")
+    if fmt != "f16" and not (all_masked and pair_blocks_reached(mask) <= PAIR_F16F6_MAX_BLOCKS):
+        raise ValueError(f"pair_topk_split(fmt={fmt!r}): every pair must be masked (all_masked=True) by an analytic mask that reaches at most "
                          f"{PAIR_F16F6_MAX_BLOCKS} key blocks per query tile; use fmt='f16'")
-    sym = "fgvc_pair_topk_f16x3" if fmt == "f16" else "fgvc_pair_topk_f16f6"
+    sym = {"f16": "fgvc_pair_topk_f16x3", "f16f6": "fgvc_pair_topk_f16f6", "f16f6x": "fgvc_pair_topk_f16f6x"}[fmt]
     qsplit, ksplit = _chk(qsplit, torch.int16, "qsplit"), _chk(ksplit, torch.int16, "ksplit")
     pairs = _chk(pairs, torch.int32, "pairs")
-    assert qsplit.dim() == 4 and ksplit.dim() == 4 and qsplit.shape[2] == 2 and ksplit.shape[2] == 2
+    parts = 4 if fmt == "f16f6x" else 2          # a bank says whether its rows are 2 KiB (f16f6x): a mismatch would be read as garbage, not refused
+    assert qsplit.dim() == 4 and ksplit.dim() == 4 and qsplit.shape[2] == parts and ksplit.shape[2] == parts, \
+        f"pair_topk_split(fmt={fmt!r}): operands must be (frames, HW, {parts}, 256) int16, got {tuple(qsplit.shape)} / {tuple(ksplit.shape)}"
     assert qsplit.shape[1] == Hq * Wq and ksplit.shape[1] == Hk * Wk and qsplit.shape[3] == ksplit.shape[3]
     n = pairs.shape[0]
     if n and validate:
@@ -227,13 +232,22 @@ PAIR_F16F6_MAX_BLOCKS = 64   # key blocks one query tile may visit in fgvc_pair_
 
 def pair_blocks_reached(mask: Optional[MaskSpec]) -> int:
     """Key blocks (4 x 8 pixels) an interior 8 x 16 query tile reaches under `mask` (csrc/pair_topk_v7.hpp: pair_v7_blocks_reached, the
-    same arithmetic); a huge number when there is no analytic mask."""
+    same arithmetic); a huge number when there is no analytic mask.  Cached per mask; a reach whose bounding box alone holds more than
+    4 x 64 blocks is answered without counting (the only question asked of the result is `<= 64`)."""
     if mask is None or mask.is_none:
         return 1 << 30
+    return _pair_blocks_reached(int(mask.r2max), int(mask.ry), int(mask.rx))
+
+
+@functools.lru_cache(maxsize=256)
+def _pair_blocks_reached(r2max: int, ry: int, rx: int) -> int:
+    mask = MaskSpec(r2max, ry, rx)
     rr = math.isqrt(mask.r2max) if mask.r2max < NO_LIMIT else NO_LIMIT
     reach_y, reach_x = min(mask.ry, rr), min(mask.rx, rr)
     if reach_y > 4096 or reach_x > 4096:
         return 1 << 30
+    if (2 * reach_y // 4) * (2 * reach_x // 8) > 4 * PAIR_F16F6_MAX_BLOCKS and mask.r2max >= reach_y * reach_y + reach_x * reach_x:
+        return 1 << 30                                  # a rectangle (no disc cutting its corners) far beyond the bound: no loop
     QBH, QBW = 4, 8
     ny, nx = (2 * QBH - 1 + 2 * reach_y) // QBH + 2, (2 * QBW - 1 + 2 * reach_x) // QBW + 2
     TY0, TX0 = (reach_y // QBH + 1) * QBH, (reach_x // QBW + 1) * QBW
@@ -283,8 +297,15 @@ def pair_topk_auto(qfeat: torch.Tensor, kfeat: torch.Tensor, pairs: torch.Tensor
     if not ok:
         raise ValueError("the split pair kernels need C == 256, topk <= 10, an analytic mask, normalised features and "
                          f"<= {PAIR_LIST_CAP} key blocks per query tile")
-    ks = split_f16x2(kfeat)
-    qs = ks if qfeat is kfeat else split_f16x2(qfeat)
+    if split_fmt not in ("f16", "f16f6", "f16f6x"):
+        raise ValueError(f"split_fmt={split_fmt!r}")
+    if split_fmt != "f16" and not pair_f16f6_ok(qfeat.shape[2], Hk, Wk, topk, normalized, dense_mask, mask, all_masked):
+        if precision == "split":
+            raise ValueError("fgvc_pair_topk_f16f6 needs every pair masked by an analytic mask within 64 key blocks of a query tile")
+        split_fmt = "f16"                         # "auto": the three-product kernel takes what the f16 + FP6 one cannot
+    splitter = {"f16": split_f16x2, "f16f6": split_f16f6p, "f16f6x": split_f16f6x}[split_fmt]      # the rows the kernel of `split_fmt` reads
+    ks = splitter(kfeat)
+    qs = ks if qfeat is kfeat else splitter(qfeat)
     return pair_topk_split(qs, ks, pairs, Hq, Wq, Hk, Wk, mask, topk, validate, all_masked, fmt=split_fmt)
 
 
@@ -357,6 +378,90 @@ def split_f16f6p(feat: torch.Tensor) -> torch.Tensor:
     out = torch.empty((*feat.shape[:-1], 2, 256), device=feat.device, dtype=torch.int16)
     _lib.call("fgvc_split_f16f6p", _ptr(feat), _ptr(out), n, 256, _stream(feat))
     return out
+
+
+def split_f16f6x(feat: torch.Tensor) -> torch.Tensor:
+    """(…, 256) f32 L2-normalised rows -> (…, 4, 256) int16 = 2 KiB per pixel: [the row of split_f16f6p() | the 256 f32 channels
+    themselves].  The bank of the default configuration (round 5): fgvc_pair_topk_f16f6x multiplies the first KiB, the refining merge
+    (merge_refine_topk) re-scores near-ties exactly from the second; one tensor, sliced and sent like any other bank."""
+    feat = _chk(feat, torch.float32, "feat")
+    assert feat.shape[-1] == 256, "fgvc_split_f16f6x: 256 channels"
+    n = feat.numel() // 256
+    out = torch.empty((*feat.shape[:-1], 4, 256), device=feat.device, dtype=torch.int16)
+    _lib.call("fgvc_split_f16f6x", _ptr(feat), _ptr(out), n, 256, _stream(feat))
+    return out
+
+
+def bank_format(bank: torch.Tensor, declared: str = "f16") -> str:
+    """What a feature bank holds, from the tensor itself where it says so: f32 rows (…, C) -> "f32"; int16 (…, 4, 256) -> "f16f6x" (no other
+    format has four 512-byte parts); int16 (…, 2, C): `declared` -- split_f16x2() and split_f16f6p() rows are both two 512-byte parts and
+    cannot be told apart ("f16" | "f16f6" | "bf16": the caller's word, checked for shape only)."""
+    if bank.dtype == torch.float32:
+        return "f32"
+    if bank.dtype == torch.int16 and bank.dim() >= 3 and bank.shape[-2] == 4 and bank.shape[-1] == 256:
+        return "f16f6x"
+    if bank.dtype == torch.int16 and bank.dim() >= 3 and bank.shape[-2] == 2:
+        if declared == "f16f6x":
+            raise ValueError("a (…, 2, C) int16 bank cannot be in the f16f6x format (2 KiB rows: (…, 4, 256))")
+        return declared
+    raise TypeError(f"not a feature bank: {bank.dtype} {tuple(bank.shape)}")
+
+
+def exact_rows(bank: torch.Tensor):
+    """(tensor, byte offset, frame bytes, row bytes) of the EXACT f32 rows inside a bank (frames, HW, …): an f32 bank (frames, HW, 256) or
+    the second KiB of split_f16f6x() rows."""
+    assert bank.is_contiguous() and bank.dim() in (3, 4)
+    if bank.dtype == torch.float32:
+        assert bank.shape[-1] == 256
+        return bank, 0, bank.shape[1] * 1024, 1024
+    assert bank_format(bank) == "f16f6x"
+    return bank, 1024, bank.shape[1] * 2048, 2048
+
+
+def f32_of_f16f6x(bank: torch.Tensor) -> torch.Tensor:
+    """The f32 channels of split_f16f6x() rows as a (…, 256) f32 VIEW of the bank's second KiB."""
+    assert bank_format(bank) == "f16f6x"
+    return bank[..., 2:, :].view(torch.float32).flatten(-2)      # (…, 2, 128) f32 -> (…, 256): the two parts are adjacent in memory
+
+
+REFINE_EPS = 2e-5   # |fgvc_pair_topk_f16f6 score - exact product| assumed by the refining merge, raw dot-product units (2.9e-4 logit at tau = 0.07);
+                    # measured on the fixtures and at 480p: 7e-6 (tests/test_gpu_refine.py holds every launch's scores to half of this)
+
+
+def merge_refine_workspace(n_out: int, HWq: int, device) -> torch.Tensor:
+    nbytes = _lib.load().fgvc_merge_refine_workspace_bytes(int(n_out), int(HWq))
+    return torch.empty(((nbytes + 15) // 16) * 4, dtype=torch.int32, device=device)
+
+
+def merge_refine_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pair: torch.Tensor, pairs: torch.Tensor,
+                      q_bank: torch.Tensor, k_bank: torch.Tensor, Hq: int, Wq: int, Hk: int, Wk: int, mask: MaskSpec, topk: int,
+                      temperature: float, mode: str = "softmax", eps: float = REFINE_EPS, workspace: Optional[torch.Tensor] = None):
+    """merge_topk() behind the approximate scores of fgvc_pair_topk_f16f6, index-exact: candidates whose approximate scores are within
+    2 eps of a neighbour are re-scored from the exact rows of `q_bank` / `k_bank` (f32 (frames, HW, 256), or split_f16f6x() banks),
+    queries whose window the pair lists do not close are recomputed from every candidate under `mask`.
+    Returns idx, logit, weight as merge_topk(), and the int32 statistics {queries re-scored, of them from scratch, candidates re-scored,
+    from-scratch queries beyond the scan queue (slow path)} as a device tensor (4,) (a view of the workspace: read it before the next
+    call that uses the same workspace)."""
+    pair_idx, pair_score = _chk(pair_idx, torch.int32, "pair_idx"), _chk(pair_score, torch.float32, "pair_score")
+    slot_pair, pairs = _chk(slot_pair, torch.int32, "slot_pair"), _chk(pairs, torch.int32, "pairs")
+    assert pair_idx.shape == pair_score.shape and pair_idx.shape[2] == topk and pair_idx.shape[1] == Hq * Wq and pairs.shape[0] == pair_idx.shape[0]
+    n_out, T = slot_pair.shape
+    qb, qo, qfb, qrb = exact_rows(q_bank)
+    kb, ko, kfb, krb = exact_rows(k_bank)
+    assert qb.is_cuda and kb.is_cuda and qb.shape[1] == Hq * Wq and kb.shape[1] == Hk * Wk
+    wm = {"softmax": WEIGHT_SOFTMAX, "cosine": WEIGHT_COSINE}[mode]
+    dev = pair_idx.device
+    idx = torch.empty((n_out, Hq * Wq, topk), device=dev, dtype=torch.int32)
+    logit = torch.empty((n_out, Hq * Wq, topk), device=dev, dtype=torch.float32)
+    weight = torch.empty_like(logit)
+    need = _lib.load().fgvc_merge_refine_workspace_bytes(int(n_out), int(Hq * Wq))
+    if workspace is None or workspace.numel() * workspace.element_size() < need or workspace.device != dev:
+        workspace = merge_refine_workspace(n_out, Hq * Wq, dev)
+    _lib.call("fgvc_merge_refine_topk_f32", _ptr(pair_idx), _ptr(pair_score), _ptr(slot_pair), _ptr(pairs),
+              C.c_void_p(qb.data_ptr() + qo), C.c_int64(qfb), qrb, C.c_void_p(kb.data_ptr() + ko), C.c_int64(kfb), krb,
+              n_out, T, Hq, Wq, Hk, Wk, 256, topk, float(temperature), wm, float(eps), mask.r2max, mask.ry, mask.rx,
+              _ptr(idx), _ptr(logit), _ptr(weight), _ptr(workspace), _stream(pair_idx))
+    return idx, logit, weight, workspace.view(torch.int32)[:4]
 
 
 def unsplit_f16f6p(split: torch.Tensor) -> torch.Tensor:
@@ -825,10 +930,11 @@ def conv_split_to_bank(x_split: torch.Tensor, w: torch.Tensor, bias: torch.Tenso
     N, Hp, Wp, nch, _ = x_split.shape
     taps, nch_w, Cout, _ = w.shape
     assert nch_w == nch and taps == 9 and bias.shape == (Cout,) and Cout == 256, "conv_split_to_bank: a 3 x 3 convolution with 256 output channels"
-    assert bank.dtype == torch.int16 and tuple(bank.shape) == (N, H * W, 2, 256) and bank.is_contiguous() and bank.device == x_split.device
+    assert bank.dtype == torch.int16 and tuple(bank.shape) in ((N, H * W, 2, 256), (N, H * W, 4, 256)) and bank.is_contiguous() and bank.device == x_split.device
     if residual is not None:
         assert residual.dtype == torch.float32 and tuple(residual.shape) == (N, H, W, Cout) and residual.is_contiguous()
-    _lib.call("fgvc_conv_split_bank_f16f6p_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(bank), N, H, W, Hp, Wp,
+    # (N, H*W, 4, 256): the 2 KiB rows of split_f16f6x() -- the normalised f32 channels behind every row
+    _lib.call("fgvc_conv_split_bank_f16f6x_f32" if bank.shape[2] == 4 else "fgvc_conv_split_bank_f16f6p_f32", _ptr(x_split), _ptr(w), _ptr(bias), _ptr(residual), _ptr(bank), N, H, W, Hp, Wp,
               nch * 32, 3, int(relu), int(in_fmt), int(in_scale_log2), int(normalize), _stream(x_split))
     return bank
 
@@ -904,17 +1010,18 @@ def normalize_nhwc(x: torch.Tensor, normalize: bool = True, split=False, out: Op
     returns split_bf16() of those rows instead, split="f16" their split_f16x2(), (N, H*W, 2, C) int16, produced in the same
     single pass over x.  `out`: write there."""
     fmt = "bf16" if split is True else split
-    assert fmt in (False, "bf16", "f16", "f16f6")
+    assert fmt in (False, "bf16", "f16", "f16f6", "f16f6x")
     x = _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
-    shape, dt = ((N, H * W, 2, C), torch.int16) if split else ((N, H * W, C), torch.float32)
+    shape, dt = ((N, H * W, 4 if fmt == "f16f6x" else 2, C), torch.int16) if split else ((N, H * W, C), torch.float32)
     if out is None:
         out = torch.empty(shape, device=x.device, dtype=dt)
     else:
         assert tuple(out.shape) == shape and out.dtype == dt and out.is_contiguous() and out.device == x.device
-    if fmt == "f16f6":                                # the rows of split_f16f6p() (fgvc_pair_topk_f16f6's operands), same pass
+    if fmt in ("f16f6", "f16f6x"):                    # the rows of split_f16f6p() / split_f16f6x() (fgvc_pair_topk_f16f6's operands), same pass
         assert C == 256
-        _lib.call("fgvc_normalize_split_f16f6p_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W, int(normalize), _stream(x))
+        _lib.call(f"fgvc_normalize_split_{fmt}p_nhwc_f32" if fmt == "f16f6" else "fgvc_normalize_split_f16f6x_nhwc_f32", _ptr(x), _ptr(out), N, C, H, W,
+                  int(normalize), _stream(x))
         return out
     _lib.call("fgvc_normalize_split_f16x2_nhwc_f32" if fmt == "f16" else "fgvc_normalize_split_nhwc_f32", _ptr(x),
               _ptr(None if split else out), _ptr(out if split else None), N, C, H, W, int(normalize), _stream(x))

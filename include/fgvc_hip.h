@@ -142,6 +142,16 @@ int fgvc_pair_topk_f16f6(const uint8_t* qsplit, const uint8_t* ksplit, const int
 int fgvc_pair_topk_f16f6_runs(const uint8_t* qsplit, const uint8_t* ksplit, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
                               int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs, int n_runs,
                               int32_t* idx_out, float* score_out, void* stream);
+/* The same rows with the pixel's EXACT channels behind them (round 5: the bank of the default configuration): 2 KiB per pixel =
+ * [the 1 KiB row of fgvc_split_f16f6p | 256 f32 = the normalised channels themselves].  fgvc_pair_topk_f16f6x[_runs] = fgvc_pair_topk_f16f6[_runs]
+ * on these rows (same arithmetic, same lists, a row stride of 2048 bytes); fgvc_merge_refine_topk_f32 reads the second KiB
+ * (row_bytes = 2048, base + 1024) to re-score near-ties exactly.  One tensor, one slice per frame, one message per halo frame. */
+int fgvc_split_f16f6x(const float* feat, uint8_t* rows, int64_t n_pixels, int C, void* stream);
+int fgvc_pair_topk_f16f6x(const uint8_t* qrows, const uint8_t* krows, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq, int Hk,
+                          int Wk, int r2max, int ry, int rx, int topk, int all_masked, int32_t* idx_out, float* score_out, void* stream);
+int fgvc_pair_topk_f16f6x_runs(const uint8_t* qrows, const uint8_t* krows, const int32_t* pairs, int n_pairs, int C, int Hq, int Wq,
+                               int Hk, int Wk, int r2max, int ry, int rx, int topk, int all_masked, const int32_t* runs, int n_runs,
+                               int32_t* idx_out, float* score_out, void* stream);
 int fgvc_pair_topk_f16x3_probe(int64_t* out32);   /* debug: s_memtime words of one workgroup (pair_f16_debug = 256) */
 
 /* ---- A5 step 2: merge the per-pair lists of the T key slots of each query frame, divide by the
@@ -154,6 +164,26 @@ int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const 
                         int n_out, int T, int HWq, int HWk, int topk, float temperature,
                         int weight_mode, int32_t* idx_out, float* logit_out, float* weight_out,
                         void* stream);
+
+/* ---- A5 step 2 behind a pair kernel with APPROXIMATE scores (fgvc_pair_topk_f16f6: |score - exact| <= eps): the same merge, made
+ * index-exact again.  Replaces the global topk over T*HW (local_attention.py:353-356) like fgvc_merge_topk_f32; the lists it writes are
+ * the exact top-k in the exact order wherever the pair kernel's scores are within `eps` (raw dot-product units) of the exact products.
+ *   Candidates whose approximate scores lie within 2 eps of a neighbour in the merged order (and can reach the top k) are re-scored
+ *   from the EXACT rows -- q_exact / k_exact: 256 f32 per pixel at `base + frame * frame_bytes + pixel * row_bytes` (row_bytes >= 1024:
+ *   a plain [frame][pixel][256] f32 bank, or the f32 half of the 2 KiB rows of fgvc_split_f16f6x) -- with products and sums in f64;
+ *   a query whose window the pair lists do not close (a slot's own last entry inside it) is recomputed from every candidate under the
+ *   mask predicate (r2max / ry / rx as the pair kernel got them; pairs without FGVC_PAIR_MASKED scan the whole frame).
+ *   pairs [n_pairs][4] int32 as the pair kernel took them; slot_pair, outputs, weight modes as fgvc_merge_topk_f32; 1 <= topk <= 10 = the
+ *   length of the pair lists; C == 256.  Two slots fed by ONE pair (frame 0 twice while idx <= precede_frames,
+ *   vanilla_tracker.py:353-362) are exact twins: the lower slot first, as equal scores are ordered everywhere.
+ *   workspace: fgvc_merge_refine_workspace_bytes(n_out, HWq) bytes, 16-byte aligned; after the call its first four int32 hold
+ *   {queries re-scored, of them recomputed from scratch, candidates re-scored, from-scratch queries beyond the scan queue}. */
+size_t fgvc_merge_refine_workspace_bytes(int n_out, int HWq);
+int fgvc_merge_refine_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, const int32_t* pairs,
+                               const void* q_exact, int64_t q_frame_bytes, int q_row_bytes, const void* k_exact, int64_t k_frame_bytes,
+                               int k_row_bytes, int n_out, int T, int Hq, int Wq, int Hk, int Wk, int C, int topk, float temperature,
+                               int weight_mode, float eps, int r2max, int ry, int rx, int32_t* idx_out, float* logit_out,
+                               float* weight_out, void* workspace, void* stream);
 
 /* ---- A5 step 3: label propagation  out[i][p] = sum_r weight[i][r] * labels[slot(idx)][pix(idx)][p]
  * replaces the index_select + einsum of local_attention.py:360-375.
@@ -340,6 +370,10 @@ int fgvc_conv_split_proj_fmt_f32(const uint16_t* x, const uint16_t* w, const uin
 int fgvc_conv_split_bank_f16f6p_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank,
                                     int N, int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
                                     int normalize, void* stream);
+/* ... as rows of fgvc_split_f16f6x: bank [N][H*W][2048 B], the normalised f32 channels in the second KiB (what the refining merge reads) */
+int fgvc_conv_split_bank_f16f6x_f32(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, void* bank,
+                                    int N, int H, int W, int Hp, int Wp, int Cin, int KS, int relu, int in_fmt, int in_scale_log2,
+                                    int normalize, void* stream);
 /* fgvc_conv_split_f32 for Cin = Cout = 64, 3x3 (ResNet layer 1: the largest activations of the trunk), as persistent
  * workgroups that keep the folded weights in registers instead of re-streaming them per tile.  Same tensors and epilogue;
  * weights in MFMA-operand order:
@@ -398,6 +432,8 @@ int fgvc_normalize_split_f16x2_nhwc_f32(const float* in, float* out_f32, uint16_
                                         int normalize, void* stream);
 /* ... and straight into the rows of fgvc_split_f16f6p (what fgvc_pair_topk_f16f6 reads): rows [N][H*W][1024] bytes, C == 256 */
 int fgvc_normalize_split_f16f6p_nhwc_f32(const float* in, uint8_t* rows, int N, int C, int H, int W, int normalize, void* stream);
+/* ... and into the 2 KiB rows of fgvc_split_f16f6x (the same 1 KiB + the normalised f32 channels) */
+int fgvc_normalize_split_f16f6x_nhwc_f32(const float* in, uint8_t* rows, int N, int C, int H, int W, int normalize, void* stream);
 
 /* ---- A3: initial labels  g = exp(-((x*s-cx)^2+(y*s-cy)^2)/(2 sigma^2)) on the feature grid
  * replaces vanilla_tracker.py:204-221 ([::stride] subsample of the full-resolution Gaussian).

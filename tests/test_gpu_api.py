@@ -162,20 +162,22 @@ def test_dense_softmax_branch_topk_none(dev, common, golden):
     assert float((out.cpu() - want).abs().max()) < TOL
 
 
-# Trajectory bounds per encoder arithmetic on the 4 x 64 x 64 fixture (pixels), tied to what was MEASURED (round 4, MI355X; the numbers are
-# written to gpurun_out/r04_precision_ledger.json by the test and committed as profiles/r04_precision_ledger.json): <= 2x the measurement.
-# Measured: bf16x3 2.1e-5, f16x3 2.1e-5, f16f8 (+ the f16f6 pair kernel) 1.6e-2 -- ONE read-out of the 32 x 32 feature grid whose top-5 boundary is a
-# near-tie (the un-regrouped path and the path without with_first: 1.8e-3); on the 256 x 256 fixtures every arithmetic is within 3.1e-5 px.
-TRAJ_TOL_PX = {"bf16x3": 5e-5, "f16x3": 5e-5, "f16f8": 3e-2, "f16f6": 3e-2}
+# Trajectory bounds per encoder arithmetic on the 4 x 64 x 64 fixture (pixels), tied to what was MEASURED (MI355X; the numbers are written to
+# gpurun_out/r05_precision_ledger.json by the test and committed as profiles/r05_precision_ledger.json): <= 2x the measurement.
+# Round 5: every arithmetic <= 1e-4 px.  Round 4's f16f8 / f16f6 bounds were 3e-2: the f16 + FP6 pair kernel's 1e-4 logit swapped k-th places
+# of near-tied lists (tools/experiments/ledger_matrix.py traj: up to 1.8e-3 px with ANY encoder in front of it, 5e-5 with an exact pair
+# kernel behind the same encoders); the refining merge re-scores those near-ties exactly.  Measured: bf16x3 2.4e-5, f16x3 1.1e-5,
+# f16f8 3.2e-5, f16f6 4.9e-5; on the 256 x 256 fixtures every arithmetic is within 3.1e-5 px (one f32 ulp of a coordinate).
+TRAJ_TOL_PX = {"bf16x3": 5e-5, "f16x3": 5e-5, "f16f8": 1e-4, "f16f6": 1e-4}
 _LEDGER = {}
 
 
 def _ledger(key, value):
-    """precision ledger of this session -> gpurun_out/r04_precision_ledger.json (rewritten on every call)"""
+    """precision ledger of this session -> gpurun_out/r05_precision_ledger.json (rewritten on every call)"""
     import json, os
     _LEDGER[key] = value
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/r04_precision_ledger.json", "w") as f:
+    with open("gpurun_out/r05_precision_ledger.json", "w") as f:
         json.dump(_LEDGER, f, indent=1)
 
 
@@ -401,17 +403,28 @@ def test_tracker_8_frames_six_key_slots_through_the_encoder(dev, golden):
         row = plan.out_rows[(0, 7)]
         assert plan.slot_frame[row] == [0, 2, 3, 4, 5, 6] and not ops.pair_f16x3_timed_out()
         led = ledger_topk(g, tk.idx[row][sample].cpu().numpy(), tk.logit[row][sample].cpu().numpy())
-        led.update(traj_err_px=d, pair_kernel=ecfg.pair_split_fmt)
+        fp = arith in ("f16f8", "f16f6")                        # the trunks that go with the f16 + FP6 pair kernel + the refining merge
+        led.update(traj_err_px=d, pair_kernel=ecfg.pair_split_fmt, bank=ecfg.bank_fmt if fp else ecfg.pair_split_fmt,
+                   refine_stats=(tk.refine_stats.cpu().tolist() if tk.refine_stats is not None else None))
+        assert (tk.refine_stats is not None) == fp
         report[arith] = led
-        fp = arith in ("f16f8", "f16f6")                        # the trunks that go with the f16 + FP6 pair kernel
-        bound = 1.2e-4 if fp else 1e-5            # measured: the largest gap of a mismatch is 5.9e-5 (f16f8 + f16f6), 5.6e-6 (bf16x3), none (f16x3)
+        # SURVEY section 7's tie policy, for EVERY arithmetic (round 5; round 4 allowed the f16 + FP6 pair kernel 1.2e-4): a list may differ
+        # from the reference's own only where its float64 ranks are closer than 1e-5 logit.  Measured: the largest gap of a mismatch is
+        # 9.7e-6 (f16f6), 7.9e-6 (f16f8), 5.6e-6 (bf16x3), none (f16x3).  Scores: the un-refined entries keep the pair kernel's 1e-4 logit.
         assert d < 1e-4 and led["max_score_err"] < (2.3e-4 if fp else 5e-5), (arith, d, led["max_score_err"])   # measured: 3.1e-5 px; 1.14e-4 / 2.8e-5 / 2.0e-5 logit
-        assert led["largest_gap_of_a_mismatch"] < bound, (arith, led["largest_gap_of_a_mismatch"])
-        assert all(m["same_set"] or m["gap"] < bound for m in led["mismatches"])
-    # the tie policy's own bar (a gap of 1e-5 in float64): the three-f16-product form reproduces EVERY such list of the reference (measured: all 512)
-    assert report["f16x3"]["exact_of_clear_1e-05"] == report["f16x3"]["clear_1e-05"] == 506
-    assert report["f16f8"]["exact_of_clear_0.0001"] == report["f16f8"]["clear_0.0001"] == 472
-    assert report["f16f6"]["exact_of_clear_0.0001"] == report["f16f6"]["clear_0.0001"] == 472
+        assert led["largest_gap_of_a_mismatch"] < 1e-5, (arith, led["largest_gap_of_a_mismatch"])
+        assert led["exact_of_clear_1e-05"] == led["clear_1e-05"] == 506, (arith, led)
+    # ... and round 4's arithmetic for comparison (pair_refine = False: the plain merge of the approximate scores), recorded, not asserted
+    model.backbone.set_arith("f16f6")
+    model.test_cfg["pair_refine"] = False
+    try:
+        bank, Hf, Wf = model.get_feats_hwc(rgbs[0], split=True)
+        ecfg = model.engine_config()
+        assert ecfg.bank_fmt == "f16f6" and bank.shape[2] == 2
+        tk = engine.run_affinity(bank, Hf, Wf, engine.plan_clip(8, [0], ecfg), ecfg)
+        report["f16f6 without the refining merge (round 4)"] = ledger_topk(g, tk.idx[row][sample].cpu().numpy(), tk.logit[row][sample].cpu().numpy())
+    finally:
+        model.test_cfg.pop("pair_refine")
     print("8 frames through the encoder:", {a: {k: v for k, v in r.items() if k != "mismatches"} for a, r in report.items()})
     _ledger("tracker_8x256x256", report)
 

@@ -368,12 +368,13 @@ def test_split_feature_bank_equals_f32_bank(dev):
     frames = torch.randn(5, 3, 64, 96, generator=g).to(dev)
     bank_s, Hf, Wf = model.get_feats_hwc(frames, split=True)            # 3 encoder calls (2 + 2 + 1 frames), concatenated
     bank_f, Hf2, Wf2 = model.get_feats_hwc(frames)
-    assert bank_s.dtype == torch.int16 and bank_s.shape == (5, Hf * Wf, 2, 256) and (Hf, Wf) == (Hf2, Wf2) == (16, 24)
+    assert bank_s.dtype == torch.int16 and bank_s.shape == (5, Hf * Wf, 4, 256) and (Hf, Wf) == (Hf2, Wf2) == (16, 24)
     cfg = model.engine_config()
-    assert cfg.pair_split_fmt == "f16f6"                               # an f16f8 trunk goes with the f16 + FP6 pair kernel (round 4)
+    assert cfg.pair_split_fmt == "f16f6" and cfg.bank_fmt == "f16f6x"  # an f16f8 / f16f6 trunk goes with the f16 + FP6 pair kernel (round 4) on 2 KiB rows: + the exact channels (round 5)
     assert torch.equal(ops.normalize_nhwc(y, True, split="f16f6"), ops.split_f16f6p(f))    # ... whose rows the same single pass writes
     assert float((ops.unsplit_f16f6p(ops.split_f16f6p(f)) - f).abs().max()) < 2.0 ** -12  # (their h part: 11 bits of 256 x, |x| <= 1)
-    assert torch.equal(ops.split_f16f6p(bank_f), bank_s)                # the hand-written trunk is deterministic call to call
+    assert torch.equal(ops.split_f16f6x(bank_f), bank_s)                # the hand-written trunk is deterministic call to call
+    assert torch.equal(ops.f32_of_f16f6x(bank_s), bank_f)               # ... and the bank's second KiB IS the f32 bank
     plan = engine.plan_clip(5, [0], cfg)
     a = engine.run_affinity(bank_s, Hf, Wf, plan, cfg)
     b = engine.run_affinity(bank_f, Hf, Wf, plan, cfg)                  # f32 form: split inside

@@ -1,0 +1,266 @@
+"""GPU parity of the refining merge (round 5): fgvc_split_f16f6x rows, fgvc_pair_topk_f16f6x and fgvc_merge_refine_topk_f32 -- the f16 + FP6
+pair kernel's approximate lists made index-exact again (csrc/refine.hip).
+
+Bars: rows are byte work -> BIT-EXACT (first KiB = fgvc_split_f16f6p's row, second KiB = the f32 channels); fgvc_pair_topk_f16f6x's lists
+equal fgvc_pair_topk_f16f6's bit for bit; the merged lists equal the float64 top-k EXACTLY on every query whose float64 ranks 1..k+1 are more
+than 1e-5 logit apart (SURVEY section 7's tie policy -- the bar the three-product kernel is held to), on smooth and on deliberately
+near-tied features; scores within 1e-3 logit (north_star; observed 1e-4); the assumed bound on the pair kernel's score error
+(ops.REFINE_EPS) holds with a factor of two on every case and at the 480p size.
+Reference: local_attention.py:318-371 (masked_attention_efficient), vanilla_tracker.py:345-394."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fgvc_oracle as O
+
+pytestmark = pytest.mark.gpu
+TAU = 0.07
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fgvc_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _feats(H, W, Tn, seed, kind):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(Tn, 256, H, W, generator=g)
+    if kind == "relu":
+        x = torch.relu(x)
+    elif kind == "smooth":
+        x = torch.nn.functional.avg_pool2d(torch.randn(Tn, 256, H + 6, W + 6, generator=g), 7, 1) + 0.05 * x
+    elif kind == "neartie":
+        # neighbouring key pixels that differ by ~1e-6 per channel: top-10 lists full of ranks 1e-5 .. 1e-4 logit apart
+        base = torch.randn(Tn, 256, (H + 1) // 2, (W + 1) // 2, generator=g)
+        x = base.repeat_interleave(2, 2).repeat_interleave(2, 3)[:, :, :H, :W] + 2e-5 * x
+    return x
+
+
+def test_f16f6x_rows_and_pair_kernel_on_them(dev):
+    """split_f16f6x rows = [split_f16f6p row | f32 channels]; the fused normalise pass writes the same bytes; fgvc_pair_topk_f16f6x on
+    them = fgvc_pair_topk_f16f6 on the 1 KiB rows, bit for bit."""
+    from fgvc_amd import engine, ops
+    f = ops.normalize_to_hwc(_feats(19, 33, 3, 5, "relu").to(dev))
+    rows = ops.split_f16f6x(f)
+    assert rows.shape == (3, 19 * 33, 4, 256) and rows.dtype == torch.int16 and ops.bank_format(rows) == "f16f6x"
+    assert torch.equal(rows[:, :, :2], ops.split_f16f6p(f))
+    assert torch.equal(ops.f32_of_f16f6x(rows), f)
+    y = torch.randn(2, 9, 13, 256, device=dev) * torch.rand(2, 9, 13, 1, device=dev)
+    for nrm in (True, False):
+        assert torch.equal(ops.normalize_nhwc(y, nrm, split="f16f6x"), ops.split_f16f6x(ops.normalize_nhwc(y, nrm)))
+    cfg = engine.TrackerConfig(pair_split_fmt="f16f6")
+    plan = engine.plan_clip(3, [0], cfg)
+    pairs = ops.make_pairs(plan.pairs, dev)
+    a = ops.pair_topk_split(rows, rows, pairs, 19, 33, 19, 33, cfg.mask, 10, all_masked=True, fmt="f16f6x")
+    p6 = ops.split_f16f6p(f)
+    b = ops.pair_topk_split(p6, p6, pairs, 19, 33, 19, 33, cfg.mask, 10, all_masked=True, fmt="f16f6")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not ops.pair_f16x3_timed_out()
+    with pytest.raises(AssertionError):                                # a bank of the other row size is refused, not misread
+        ops.pair_topk_split(p6, p6, pairs, 19, 33, 19, 33, cfg.mask, 10, all_masked=True, fmt="f16f6x")
+    with pytest.raises(ValueError):
+        engine.run_pairs(rows, 19, 33, plan, engine.TrackerConfig(pair_split_fmt="f16"))
+
+
+def _dense_rows(feats_cpu, plan, row, nr, mode, k=10):
+    """float64 masked slab (T * HW, HW) of plan row `row` from the normalised f32 rows (T, HW, C)"""
+    ks = plan.slot_frame[row][:sum(1 for p in plan.slot_pair[row] if p >= 0)]
+    qf = plan.pairs[[p for p in plan.slot_pair[row] if p >= 0][0]][0]
+    q = feats_cpu[qf].double()
+    kk = torch.cat([feats_cpu[f].double() for f in ks], 0)
+    return (kk @ q.t()) / TAU, ks
+
+
+@pytest.mark.parametrize("case", [(33, 70, 4, 30, "circle", 10, "gauss", 5), (37, 53, 4, 30, "circle", 10, "relu", 5),
+                                  (24, 40, 8, 30, "circle", 10, "smooth", 5), (30, 44, 8, 30, "circle", 10, "neartie", 5),
+                                  (17, 23, 3, 9, "square", 5, "neartie", 2), (8, 8, 3, 30, "circle", 10, "gauss", 5),
+                                  (5, 3, 2, 4, "circle", 5, "relu", 5), (26, 38, 3, 12, "circle", 7, "neartie", 1)])
+def test_refined_lists_equal_float64_topk(dev, case):
+    """run_pairs (f16f6x) + merge_refine against the float64 slab: every clear-gap query (1e-5 logit) equal index for index, in order; the
+    plain merge of the same lists for comparison (reported); the pair kernel's score error against ops.REFINE_EPS."""
+    from fgvc_amd import engine, ops
+    H, W, Tn, nr, mode, k, kind, pre = case
+    x = _feats(H, W, Tn, 11 + H, kind)
+    f = ops.normalize_to_hwc(x.to(dev))
+    cfg = engine.TrackerConfig(neighbor_range=nr, mask_mode=mode, topk=k, precede_frames=pre, pair_split_fmt="f16f6", pair_precision="split")
+    assert cfg.bank_fmt == "f16f6x"
+    plan = engine.plan_clip(Tn, [0], cfg)
+    pl = engine.run_pairs(f, H, W, plan, cfg)
+    assert pl.exact is not None and ops.bank_format(pl.exact) == "f16f6x"
+    tk = engine.merge_pairs(pl, cfg)
+    assert not ops.pair_f16x3_timed_out()
+    stats = tk.refine_stats.cpu().tolist()
+    plain = engine.merge_pairs(engine.PairLists(pl.plan, pl.idx, pl.score, pl.HW, pl.channels), cfg)
+    fc = f.cpu()
+    HW = H * W
+    tot = dict(queries=0, clear=0, exact=0, plain_exact=0, max_score_err=0.0)
+    for (s0, fr), row in plan.out_rows.items():
+        dense, ks = _dense_rows(fc, plan, row, nr, mode, k)
+        m = O.mask_slab(H, W, H, W, len(ks), torch.arange(HW), nr, mode)
+        dm = dense.masked_fill(~m, float("-inf"))
+        st = O.check_topk(dm, tk.idx[row].cpu().long(), tk.logit[row].cpu(), k, tol=1e-3, gap=1e-5)      # raises on a clear-gap mismatch
+        dv, di = O.topk_canonical(dm, k)
+        tot["plain_exact"] += int((plain.idx[row].cpu().long() == di.t()).all(1).sum())
+        for key in ("queries", "clear", "exact"):
+            tot[key] += st[key]
+        tot["max_score_err"] = max(tot["max_score_err"], st["max_score_err"])
+        # weights: the softmax of the logits written beside them
+        w = torch.softmax(tk.logit[row].cpu().double(), 1)
+        fin = torch.isfinite(tk.logit[row].cpu()).all(1)
+        assert float((w[fin] - tk.weight[row].cpu().double()[fin]).abs().max()) < 1e-6
+    # the pair kernel's own scores against float64, every listed candidate: the bound the refining merge assumes
+    err = 0.0
+    for pid, (qf, kf, _) in enumerate(plan.pairs):
+        ci = pl.idx[pid].long()
+        ex = torch.einsum("qc,qkc->qk", fc[qf].double().to(dev), f[kf].double()[ci.clamp(min=0)])
+        e = (pl.score[pid].double() - ex).abs()
+        err = max(err, float(e[ci >= 0].max()))
+    assert err < 0.5 * ops.REFINE_EPS, err
+    assert tot["exact"] >= tot["clear"] and tot["exact"] >= tot["plain_exact"]
+    print(f"{case}: {tot}, refine stats (queries, from scratch, candidates) {stats}, pair score error {err:.2e} (eps {ops.REFINE_EPS:.0e})")
+    if kind == "neartie":
+        assert stats[0] > 0 and tot["exact"] > tot["plain_exact"]      # the case exists to exercise the re-scoring: it must have happened and helped
+
+
+def test_refine_from_scratch_when_one_slot_owns_the_list(dev):
+    """One key slot per frame (no first-frame slot, one preceding frame): the merged list IS the pair's list, its last entry closes no
+    window -- every query is recomputed from every candidate under the mask, exactly: equal to the float64 top-k on every clear-gap query
+    and to fgvc_pair_topk_f32's lists wherever that kernel's own f32 sums do not tie."""
+    from fgvc_amd import engine, ops
+    H, W, Tn = 21, 27, 3
+    f = ops.normalize_to_hwc(_feats(H, W, Tn, 3, "neartie").to(dev))
+    for nr, mode in ((30, "circle"), (8, "square")):
+        cfg = engine.TrackerConfig(neighbor_range=nr, mask_mode=mode, precede_frames=1, with_first=False, pair_split_fmt="f16f6", pair_precision="split")
+        plan = engine.plan_clip(Tn, [0], cfg)
+        assert all(sum(1 for p in sp if p >= 0) == 1 for sp in plan.slot_pair)
+        tk = engine.run_affinity(f, H, W, plan, cfg)
+        stats = tk.refine_stats.cpu().tolist()
+        assert stats[0] == stats[1] == len(plan.slot_pair) * H * W and stats[3] == 0, stats
+        fc = f.cpu()
+        for (s0, fr), row in plan.out_rows.items():
+            dense, ks = _dense_rows(fc, plan, row, nr, mode)
+            m = O.mask_slab(H, W, H, W, len(ks), torch.arange(H * W), nr, mode)
+            st = O.check_topk(dense.masked_fill(~m, float("-inf")), tk.idx[row].cpu().long(), tk.logit[row].cpu(), 10, tol=1e-5, gap=1e-6)
+            assert st["max_score_err"] < 2e-6           # f64 products and sums, one rounding to f32, / tau in f32
+    assert not ops.pair_f16x3_timed_out()
+
+
+def test_refine_from_scratch_beyond_the_scan_queue(dev):
+    """More from-scratch queries than the scan queue holds (4096, or a 32nd of the queries): the rest are recomputed inside the refine kernel,
+    candidate by candidate -- slow, and exactly as right (the two paths sum the same f64 products in different orders: equal lists, scores
+    within an f32 ulp)."""
+    from fgvc_amd import engine, ops
+    H, W, Tn = 70, 72, 2
+    f = ops.normalize_to_hwc(_feats(H, W, Tn, 13, "gauss").to(dev))
+    cfg = engine.TrackerConfig(neighbor_range=12, precede_frames=1, with_first=False, pair_split_fmt="f16f6", pair_precision="split")
+    plan = engine.plan_clip(Tn, [0], cfg)
+    tk = engine.run_affinity(f, H, W, plan, cfg)
+    stats = tk.refine_stats.cpu().tolist()
+    assert stats[0] == stats[1] == H * W and stats[3] == H * W - 4096, stats
+    fc = f.cpu()
+    dense, ks = _dense_rows(fc, plan, 0, 12, "circle")
+    m = O.mask_slab(H, W, H, W, 1, torch.arange(H * W), 12, "circle")
+    st = O.check_topk(dense.masked_fill(~m, float("-inf")), tk.idx[0].cpu().long(), tk.logit[0].cpu(), 10, tol=1e-5, gap=1e-6)
+    assert st["max_score_err"] < 2e-6 and st["exact"] >= st["clear"] > 0.9 * H * W, st
+    assert not ops.pair_f16x3_timed_out()
+
+
+def test_refine_eps_zero_is_the_plain_merge_and_twins_keep_their_order(dev):
+    """eps = 0: only exact ties of the approximate scores are re-scored -- the lists equal the plain merge's wherever that has no tie; and a
+    frame that sits in two key slots (frame 0 while idx <= precede_frames) contributes every pixel twice, lower slot first."""
+    from fgvc_amd import engine, ops
+    H, W, Tn = 18, 26, 3
+    f = ops.normalize_to_hwc(_feats(H, W, Tn, 9, "gauss").to(dev))
+    cfg = engine.TrackerConfig(pair_split_fmt="f16f6", pair_precision="split", pair_refine_eps=0.0)
+    plan = engine.plan_clip(Tn, [0], cfg)
+    pl = engine.run_pairs(f, H, W, plan, cfg)
+    tk = engine.merge_pairs(pl, cfg)
+    plain = engine.merge_pairs(engine.PairLists(pl.plan, pl.idx, pl.score, pl.HW, pl.channels), cfg)
+    row = plan.out_rows[(0, 1)]
+    assert plan.slot_pair[row][:2] == [0, 0]                          # frame 0 twice
+    i = tk.idx[row].cpu().long()
+    HW = H * W
+    assert bool(((i[:, 0::2] + HW) == i[:, 1::2]).all())              # (pixel, slot 0), (pixel, slot 1), ...
+    same = (tk.idx == plain.idx).all(-1)
+    tie = (plain.logit[..., :-1] == plain.logit[..., 1:]).any(-1)
+    assert bool(same[~tie].all())
+    tk2 = engine.merge_pairs(pl, engine.TrackerConfig(pair_split_fmt="f16f6", pair_precision="split"))
+    i2 = tk2.idx[row].cpu().long()
+    assert bool(((i2[:, 0::2] + HW) == i2[:, 1::2]).all())
+    assert torch.equal(tk2.logit[row][:, 0::2], tk2.logit[row][:, 1::2])     # twins carry ONE score, re-scored or not
+
+
+def test_refine_at_480p_size_sampled(dev):
+    """BASELINE configs[1]'s grid (120 x 214, 8 frames, 27 pairs): the refined lists of 2 000 sampled queries of the last frame equal the
+    float64 top-10 on every clear-gap query; every listed score of every pair within half of ops.REFINE_EPS of float64 (sampled
+    queries of every pair); the share of queries re-scored and the (tiny) share recomputed from scratch are reported and bounded."""
+    from fgvc_amd import engine, ops
+    H, W, Tn = 120, 214, 8
+    g = torch.Generator().manual_seed(480)
+    x = torch.nn.functional.avg_pool2d(torch.randn(Tn, 256, H + 2, W + 2, generator=g), 3, 1) + 0.3 * torch.randn(Tn, 256, H, W, generator=g)
+    f = ops.normalize_to_hwc(torch.relu(x).to(dev))
+    cfg = engine.TrackerConfig(pair_split_fmt="f16f6", pair_precision="split")
+    plan = engine.plan_clip(Tn, [0], cfg)
+    assert len(plan.pairs) == 27
+    pl = engine.run_pairs(f, H, W, plan, cfg)
+    tk = engine.merge_pairs(pl, cfg)
+    assert not ops.pair_f16x3_timed_out()
+    stats = tk.refine_stats.cpu().tolist()
+    HW = H * W
+    sample = torch.randperm(HW, generator=g)[:2000].sort().values.to(dev)
+    row = plan.out_rows[(0, 7)]
+    ks = plan.slot_frame[row]
+    f64 = f.double()
+    dense = torch.cat([f64[kf] @ f64[7][sample].t() for kf in ks], 0) / TAU            # (6 HW, S)
+    m = O.mask_slab(H, W, H, W, len(ks), sample.cpu(), 30, "circle").to(dev)
+    st = O.check_topk(dense.masked_fill(~m, float("-inf")), tk.idx[row][sample].long(), tk.logit[row][sample], 10, tol=1e-3, gap=1e-5)
+    assert st["clear"] > 1500, st
+    err = 0.0
+    for pid, (qf, kf, _) in enumerate(plan.pairs):
+        ci = pl.idx[pid][sample].long()
+        ex = torch.einsum("qc,qkc->qk", f64[qf][sample], f64[kf][ci.clamp(min=0)])
+        err = max(err, float((pl.score[pid][sample].double() - ex).abs()[ci >= 0].max()))
+    assert err < 0.5 * ops.REFINE_EPS, err
+    n_q = len(plan.slot_pair) * HW
+    print(f"480p: {st}; re-scored {stats[0]} of {n_q} queries ({100.0 * stats[0] / n_q:.1f} %), from scratch {stats[1]}, candidates {stats[2]}; "
+          f"pair score error {err:.2e}")
+    assert stats[1] < 1e-3 * n_q and stats[0] < 0.3 * n_q              # (measured: 78 from scratch, 9.5 % re-scored)
+
+
+def test_encoder_writes_f16f6x_bank(dev):
+    """The trunk's last convolution writes split_f16f6x() rows itself (fgvc_conv_split_bank_f16f6x_f32): the first KiB byte for byte the
+    rows of the 1-KiB route, the second KiB the f32 channels whose split they are (split_f16f6p of the second KiB == the first), and
+    both equal to the two-kernel route (dense f32 output + normalise pass); in every encoder arithmetic, ragged tile edges included."""
+    from fgvc_amd import ops
+    from tests.test_gpu_api import _tracker
+    cfg = dict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, with_first=True, with_first_neighbor=True, batch_step=3)
+    model = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), cfg, 7)
+    g = torch.Generator().manual_seed(2)
+    frames = (torch.rand(5, 3, 74, 130, generator=g) * 4 - 2).to(dev)                # -> 37 x 65 features: ragged 8 x 32 tiles
+    for arith in model.backbone.supported_arith():
+        model.backbone.set_arith(arith)
+        ecfg = model.engine_config()
+        bank, Hf, Wf = model.get_feats_hwc(frames, split=True)
+        if ecfg.pair_split_fmt != "f16f6":
+            assert bank.shape[2] == 2
+            continue
+        assert ecfg.bank_fmt == "f16f6x" and bank.shape == (5, Hf * Wf, 4, 256) and (Hf, Wf) == (37, 65)
+        x = ops.f32_of_f16f6x(bank).contiguous()
+        assert torch.equal(ops.split_f16f6p(x), bank[:, :, :2].contiguous())
+        nrm = x.double().pow(2).sum(-1).sqrt()
+        assert float((nrm - 1).abs().max()) < 1e-6
+        model.backbone.fuse_bank = False                                             # the two-kernel route
+        try:
+            bank2, _, _ = model.get_feats_hwc(frames, split=True)
+        finally:
+            model.backbone.fuse_bank = True
+        assert torch.equal(bank, bank2)
+        model.test_cfg["pair_refine"] = False                                        # round 4's 1-KiB bank: the same first KiB
+        try:
+            bank1, _, _ = model.get_feats_hwc(frames, split=True)
+        finally:
+            model.test_cfg.pop("pair_refine")
+        assert bank1.shape == (5, Hf * Wf, 2, 256) and torch.equal(bank1, bank[:, :, :2].contiguous())
