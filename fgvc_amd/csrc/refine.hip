@@ -98,9 +98,10 @@ __device__ __forceinline__ void rf_write(const RefineParams& p, int row, int q, 
 
 __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
   const int HWq = p.Hq * p.Wq, HWk = p.Hk * p.Wk;
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int q_raw = blockIdx.x * 256 + threadIdx.x;
   const int f = blockIdx.y;
-  if (q >= HWq) return;
+  const bool valid = q_raw < HWq;                      // (no early exit: the wave-wide exchanges at the end want every lane's registers defined)
+  const int q = valid ? q_raw : HWq - 1;
   TopK<RF_KX> top;
   top.init();
   float drop_max = -INFINITY;         // best approximate score of a LISTED candidate that is not among the 16
@@ -119,8 +120,15 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
     return true;
   };
   if (p.kin == RF_KMAX) {
-    // full-length lists: a slot's 80 bytes by 8-byte loads, issued for slot t + 1 before slot t is merged (read entry by entry with an
-    // early exit, every load waited for the one before it: 60 dependent round trips per thread, 111 us per launch for 47 of the plain merge)
+    // Full-length lists: a slot's 80 bytes by 8-byte loads, issued for slot t + 1 before slot t is merged (read entry by entry with an
+    // early exit, every load waited for the one before it: 111 us per launch for 47 of the plain merge), and merged by a NETWORK on
+    // packed (score, ~index) keys instead of ten 16-step insertions: the 16 best of (16 sorted) U (10 sorted) are max(a[i], b[15 - i]) --
+    // a bitonic sequence -- and 32 compare-exchanges put them in order (~190 vector operations per slot for ~1 000: every lane of a
+    // wave walked every insertion as long as ANY lane's list still took candidates).
+    unsigned long long a[RF_KX];
+#pragma unroll
+    for (int j = 0; j < RF_KX; ++j) a[j] = 0ull;
+    unsigned long long dropk = 0ull;
     int2 ii[RF_KMAX / 2], ni[RF_KMAX / 2];
     float2 ss[RF_KMAX / 2], ns[RF_KMAX / 2];
     auto fetch = [&](int t, int2 (&I)[RF_KMAX / 2], float2 (&S)[RF_KMAX / 2]) -> int {
@@ -138,24 +146,55 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
     int pid = fetch(0, ii, ss);
     for (int t = 0; t < p.T; ++t) {
       const int npid = fetch(t + 1, ni, ns);
-      if (pid >= 0) {
-        if (ii[RF_KMAX / 2 - 1].y >= 0) {
-          tau_max = fmaxf(tau_max, ss[RF_KMAX / 2 - 1].y);
-#pragma unroll
-          for (int u = 0; u < 16; ++u) tau[u] = u == t ? ss[RF_KMAX / 2 - 1].y : tau[u];
-        }
-        bool more = true;
+      if (pid >= 0) {                                                    // (divergent only where a row's slots end: the same for a whole launch row)
+        unsigned long long bk[RF_KMAX];
 #pragma unroll
         for (int j = 0; j < RF_KMAX; ++j) {
           const int id = (j & 1) ? ii[j / 2].y : ii[j / 2].x;
           const float sv = (j & 1) ? ss[j / 2].y : ss[j / 2].x;
-          more = more && id >= 0;
-          if (more) more = take(t, id, sv);
+          bk[j] = id >= 0 ? TopK64<1>::make_key(sv, t * HWk + id) : 0ull;
         }
+        if (bk[RF_KMAX - 1] != 0ull) {
+          const float tv = ss[RF_KMAX / 2 - 1].y;
+          tau_max = fmaxf(tau_max, tv);
+#pragma unroll
+          for (int u = 0; u < 16; ++u) tau[u] = u == t ? tv : tau[u];
+        }
+#pragma unroll
+        for (int i = RF_KX - RF_KMAX; i < RF_KX; ++i) {                   // a[0 .. 5] stay: at most ten keys of b can pass them
+          const unsigned long long x = a[i], y = bk[RF_KX - 1 - i];
+          const bool g = x > y;
+          a[i] = g ? x : y;
+          const unsigned long long lo = g ? y : x;
+          dropk = lo > dropk ? lo : dropk;
+        }
+#pragma unroll
+        for (int d = RF_KX / 2; d >= 1; d >>= 1)
+#pragma unroll
+          for (int i = 0; i < RF_KX; ++i)
+            if ((i & d) == 0) {
+              const unsigned long long x = a[i], y = a[i + d];
+              const bool g = x > y;
+              a[i] = g ? x : y;
+              a[i + d] = g ? y : x;
+            }
       }
       pid = npid;
 #pragma unroll
       for (int j = 0; j < RF_KMAX / 2; ++j) { ii[j] = ni[j]; ss[j] = ns[j]; }
+    }
+    TopK64<RF_KX> dec;
+#pragma unroll
+    for (int j = 0; j < RF_KX; ++j) dec.k[j] = a[j];
+#pragma unroll
+    for (int j = 0; j < RF_KX; ++j) {
+      top.v[j] = dec.score(j);
+      top.ix[j] = a[j] == 0ull ? IDX_EMPTY : dec.index(j);
+    }
+    if (dropk != 0ull) {
+      TopK64<1> dd;
+      dd.k[0] = dropk;
+      drop_max = dd.score(0);
     }
   } else {
     for (int t = 0; t < p.T; ++t) {
@@ -208,18 +247,35 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
 #pragma unroll
   for (int j = RF_KX - 2; j >= 0; --j)
     if (((twins >> j) & 1u) && ((mask >> j) & 3u)) mask |= 3u << j;
-  if (!brute && mask == 0u) {
+  const bool flagged = valid && (brute || mask != 0u);
+  if (valid && !flagged) {
     float sc[RF_KMAX];
     int id[RF_KMAX];
 #pragma unroll
     for (int j = 0; j < RF_KMAX; ++j) { sc[j] = top.v[j]; id[j] = top.ix[j]; }
     rf_write(p, f, q, sc, id);
-    return;
   }
-  const int slot = atomicAdd(&p.counters[0], 1);
+  // queue slots by ONE atomic per wave and counter (a tenth of the queries are flagged: 17 000 atomics on one address otherwise)
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long bf = __ballot(flagged), bb = __ballot(flagged && brute);
+  if (bf == 0ull) return;                                                // (wave-uniform)
+  int base_f = 0, base_b = 0;
+  if (lane == __builtin_ctzll(bf)) base_f = atomicAdd(&p.counters[0], __popcll(bf));
+  base_f = __shfl(base_f, __builtin_ctzll(bf));
+  if (bb != 0ull) {
+    if (lane == __builtin_ctzll(bb)) base_b = atomicAdd(&p.counters[1], __popcll(bb));
+    base_b = __shfl(base_b, __builtin_ctzll(bb));
+  }
+  int n_resc = (flagged && !brute) ? __popc(mask) : 0;
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) n_resc += __shfl_xor(n_resc, mm);
+  if (lane == __builtin_ctzll(bf) && n_resc) atomicAdd(&p.counters[2], n_resc);
+  if (!flagged) return;
+  const int slot = base_f + __popcll(bf & lt);
   int flags = (int)mask;
   if (brute) {
-    const int b = atomicAdd(&p.counters[1], 1);
+    const int b = base_b + __popcll(bb & lt);
     // which slots must be scanned: those whose own last entry lies inside the window (an unlisted candidate of theirs may belong to the
     // list); every slot when more listed candidates lie inside the window than the 16 kept.  The other slots' contenders are among the 16.
     unsigned open = 0;
@@ -229,8 +285,6 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
     flags = RF_BRUTE | (int)open;
     if (b < p.scan_cap) p.scan_ids[b] = slot;
     else { flags |= RF_INLINE; atomicAdd(&p.counters[3], 1); }
-  } else {
-    atomicAdd(&p.counters[2], __popc(mask));
   }
   RefineItem* it = p.items + slot;
   it->row = f; it->q = q; it->flags = flags; it->m = m;
@@ -392,27 +446,13 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
 // parts and writes the item's final lists.  (One workgroup per item with one candidate per lane: 0.16 ms for 78 items -- 64 lanes x 64
 // cache lines per load instruction; one workgroup per item with coalesced rows: 0.20 ms -- a chain of HBM latencies, 90 passes long.)
 constexpr int RF_SCAN_WAVES = 8;
-constexpr int RF_SCAN_PARTS = 8;
-
-// the k largest of up to two keys per lane (hi >= lo; 0 = none; keys unique), in order, to every lane
-__device__ __forceinline__ void rf_wave_topk(unsigned long long hi, unsigned long long lo, unsigned long long (&out)[RF_KMAX]) {
-#pragma unroll 1
-  for (int r = 0; r < RF_KMAX; ++r) {
-    unsigned long long best = hi;
-#pragma unroll
-    for (int mm = 32; mm >= 1; mm >>= 1) {
-      const unsigned long long o = __shfl_xor(best, mm);
-      best = o > best ? o : best;
-    }
-    if (hi == best) { hi = lo; lo = 0ull; }
-#pragma unroll
-    for (int j = 0; j < RF_KMAX; ++j) out[j] = j == r ? best : out[j];
-  }
-}
+constexpr int RF_SCAN_PARTS = 4;
 
 __global__ __launch_bounds__(RF_SCAN_WAVES * 64) void refine_scan_kernel(RefineParams p) {
-  __shared__ unsigned long long wl[RF_SCAN_WAVES][RF_KMAX];
-  __shared__ unsigned long long w2[RF_SCAN_WAVES / 4][RF_KMAX];
+  __shared__ unsigned long long wk[RF_SCAN_WAVES][8 * RF_KMAX];      // a wave's eight lists
+  __shared__ unsigned long long wl[RF_SCAN_WAVES][RF_KMAX];          // its k best
+  __shared__ unsigned long long pl[RF_KMAX];                         // the workgroup's
+  __shared__ unsigned long long fk[RF_SCAN_PARTS * RF_KMAX], fl[RF_KMAX];   // the item's parts, its final list
   __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -524,45 +564,43 @@ __global__ __launch_bounds__(RF_SCAN_WAVES * 64) void refine_scan_kernel(RefineP
       }
       pass += npass;
     }
-    __syncthreads();                                                    // (the previous unit's readers of wl / w2 / s_last)
-    // this wave's k best: k rounds over the lanes' own sorted lists
-    for (int r = 0; r < RF_KMAX; ++r) {
-      const unsigned long long key = loc.ix[0] == IDX_EMPTY ? 0ull : TopK64<1>::make_key(loc.v[0], loc.ix[0]);
-      unsigned long long best = key;
+    // ---- the workgroup's k best.  Only the lanes (lane & 7) == 0 carry lists (eight per wave); selection by RANK (a key's rank = the
+    // number of larger keys; keys are unique) needs no chain of cross-lane exchanges: per wave over its 80 keys, then over the waves' 80.
+    // (Rounds of "largest head wins" -- ten rounds of six dependent 64-bit exchanges, three levels -- were most of a workgroup's 25 us.)
+    __syncthreads();                                                    // (the previous unit's readers of wk / wl / pl / s_last)
+    if ((lane & 7) == 0) {
 #pragma unroll
-      for (int mm = 32; mm >= 1; mm >>= 1) {
-        const unsigned long long o = __shfl_xor(best, mm);
-        best = o > best ? o : best;
+      for (int j = 0; j < RF_KMAX; ++j)
+        wk[wave][(lane >> 3) * RF_KMAX + j] = loc.ix[j] == IDX_EMPTY ? 0ull : TopK64<1>::make_key(loc.v[j], loc.ix[j]);
+    }
+    if (lane < RF_KMAX) wl[wave][lane] = 0ull;
+    if (threadIdx.x < RF_KMAX) pl[threadIdx.x] = 0ull;
+    {
+      // (the LDS serves a wave's operations in order: this wave's own stores above are visible to its loads below)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long ka = wk[wave][lane], kb2 = lane < 8 * RF_KMAX - 64 ? wk[wave][64 + lane] : 0ull;
+      int ra = 0, rb = 0;
+      for (int j = 0; j < 8 * RF_KMAX; ++j) {
+        const unsigned long long kj = wk[wave][j];
+        ra += kj > ka ? 1 : 0;
+        rb += kj > kb2 ? 1 : 0;
       }
-      const bool pop = best != 0ull && key == best;
-#pragma unroll
-      for (int j = 0; j + 1 < RF_KMAX; ++j) {
-        loc.v[j] = pop ? loc.v[j + 1] : loc.v[j];
-        loc.ix[j] = pop ? loc.ix[j + 1] : loc.ix[j];
-      }
-      if (pop) { loc.v[RF_KMAX - 1] = -INFINITY; loc.ix[RF_KMAX - 1] = IDX_EMPTY; }
-      if (lane == 0) wl[wave][r] = best;
+      if (ka != 0ull && ra < RF_KMAX) wl[wave][ra] = ka;
+      if (kb2 != 0ull && rb < RF_KMAX) wl[wave][rb] = kb2;
     }
     __syncthreads();
-    if (wave < RF_SCAN_WAVES / 4) {                                     // a wave merges four lists ...
-      unsigned long long o4[RF_KMAX];
-      rf_wave_topk(lane < 4 * RF_KMAX ? wl[4 * wave + lane / RF_KMAX][lane % RF_KMAX] : 0ull, 0ull, o4);
-      if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < RF_KMAX; ++j) w2[wave][j] = o4[j];
-      }
+    if (threadIdx.x < RF_SCAN_WAVES * RF_KMAX) {
+      const unsigned long long ka = wl[threadIdx.x / RF_KMAX][threadIdx.x % RF_KMAX];
+      int ra = 0;
+      for (int j = 0; j < RF_SCAN_WAVES * RF_KMAX; ++j) ra += wl[j / RF_KMAX][j % RF_KMAX] > ka ? 1 : 0;
+      if (ka != 0ull && ra < RF_KMAX) pl[ra] = ka;
     }
     __syncthreads();
-    if (wave == 0) {                                                    // ... wave 0 the merged ones: this workgroup's part
-      unsigned long long fin[RF_KMAX];
-      rf_wave_topk(lane < (RF_SCAN_WAVES / 4) * RF_KMAX ? w2[lane / RF_KMAX][lane % RF_KMAX] : 0ull, 0ull, fin);
+    if (wave == 0) {                                                    // this workgroup's part
       unsigned long long* dst = p.scan_parts + ((size_t)b * RF_SCAN_PARTS + part) * RF_KMAX;
-      if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < RF_KMAX; ++j) dst[j] = fin[j];
-        __threadfence();                                                // the part is visible before the count says so
-        s_last = atomicAdd(&p.scan_done[b], 1) == RF_SCAN_PARTS - 1;
-      }
+      if (lane < RF_KMAX) dst[lane] = pl[lane];
+      __threadfence();                                                  // the part is visible before the count says so
+      if (lane == 0) s_last = atomicAdd(&p.scan_done[b], 1) == RF_SCAN_PARTS - 1;
     }
     __syncthreads();
     if (s_last && wave == 0) {                                          // the item's last workgroup: all parts are written
@@ -571,21 +609,31 @@ __global__ __launch_bounds__(RF_SCAN_WAVES * 64) void refine_scan_kernel(RefineP
       constexpr int NE = RF_SCAN_PARTS * RF_KMAX;
       static_assert(NE <= 128, "two keys per lane");
       // (device-scope atomic loads: served by the L2, never by a line this CU's L1 may still hold)
-      unsigned long long hi = lane < NE ? __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-      unsigned long long lo = lane + 64 < NE ? __hip_atomic_load(src + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-      if (lo > hi) { const unsigned long long tmp = hi; hi = lo; lo = tmp; }
-      unsigned long long fin[RF_KMAX];
-      rf_wave_topk(hi, lo, fin);
+      const unsigned long long ka = lane < NE ? __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      const unsigned long long kb2 = lane + 64 < NE ? __hip_atomic_load(src + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      if (lane < NE) fk[lane] = ka;
+      if (lane + 64 < NE) fk[lane + 64] = kb2;
+      if (lane < RF_KMAX) fl[lane] = 0ull;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      int ra = 0, rb = 0;
+      for (int j = 0; j < NE; ++j) {
+        const unsigned long long kj = fk[j];
+        ra += kj > ka ? 1 : 0;
+        rb += kj > kb2 ? 1 : 0;
+      }
+      if (ka != 0ull && ra < RF_KMAX) fl[ra] = ka;
+      if (kb2 != 0ull && rb < RF_KMAX) fl[rb] = kb2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) {
         float osc[RF_KMAX];
         int oid[RF_KMAX];
         TopK64<RF_KMAX> dec;
 #pragma unroll
-        for (int j = 0; j < RF_KMAX; ++j) dec.k[j] = fin[j];
+        for (int j = 0; j < RF_KMAX; ++j) dec.k[j] = fl[j];
 #pragma unroll
         for (int j = 0; j < RF_KMAX; ++j) {
           osc[j] = dec.score(j);
-          oid[j] = fin[j] == 0ull ? IDX_EMPTY : dec.index(j);
+          oid[j] = dec.k[j] == 0ull ? IDX_EMPTY : dec.index(j);
         }
         rf_write(p, row, q, osc, oid);
       }
