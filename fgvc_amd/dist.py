@@ -277,7 +277,10 @@ class HipBackend:
         return engine.run_propagation(tk, start, pts, Hf, Wf, h, w, cfg)[1]
 
     def reset_calibration(self):
-        """Drop the encoder's per-tensor scales (and what was captured with them): the next encode calibrates afresh."""
+        """Called on EVERY rank when any rank's encoder overflowed: drop the per-tensor scales (and what was captured with them).  Under
+        the canonical calibration (scales = a function of the weights) the retry of this video runs with 2^4 more headroom per overflow
+        in a row -- the same number on every rank, whichever rank overflowed -- and `calibration_ok()` returns to the canonical scales
+        after the first call that succeeds; under `calibration = "first_batch"` the next encode calibrates on its own frames."""
         bb = getattr(self.model, "backbone", None)
         cache = getattr(bb, "__dict__", {}).get("_split_cache") if bb is not None else None
         if cache:
@@ -285,6 +288,17 @@ class HipBackend:
                 del cache[k]
             if hasattr(bb, "_drop_graphs"):
                 bb._drop_graphs()
+        if getattr(bb, "calibration", None) == "canonical":
+            self._overflows_in_a_row = getattr(self, "_overflows_in_a_row", 0) + 1
+            bb.__dict__["_headroom_extra"] = min(4 * self._overflows_in_a_row, 12)
+
+    def calibration_ok(self):
+        """A video went through without an overflow: the next one starts from the canonical scales again."""
+        if getattr(self, "_overflows_in_a_row", 0):
+            self._overflows_in_a_row = 0
+            bb = getattr(self.model, "backbone", None)
+            if hasattr(bb, "end_overflow_retry"):
+                bb.end_overflow_retry()
 
     def failure_flags(self) -> Tuple[bool, bool]:
         """(a bounded wait of the pair kernel's LDS protocol gave up, an activation left the encoder's calibrated f16 range) since the
@@ -607,6 +621,8 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
             t_out, ovf = (bool(v) for v in flags.tolist())
             if ovf and hasattr(backend, "reset_calibration"):
                 backend.reset_calibration()                 # on every rank, also those whose own flag was clear
+            if not ovf and hasattr(backend, "calibration_ok"):
+                backend.calibration_ok()
             if t_out or ovf:
                 raise RuntimeError("track_points_sharded: " + " and ".join(
                     m for m, f in (("a bounded wait of the pair kernel timed out on some rank", t_out),

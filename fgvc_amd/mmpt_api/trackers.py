@@ -49,12 +49,22 @@ class BaseModel(nn.Module):
         try:
             return self.forward_test(**kwargs)
         except EncoderOverflow:
-            # The f16 arithmetic of the encoder stores activations at scales calibrated on the FIRST batch these weights saw; a later
-            # video with larger activations overflows them.  The check that raised has dropped the scales: run the video once more --
-            # the encoder re-calibrates on this video's own frames.  A second overflow (a single video whose later frames exceed its
-            # first batch by more than the 2^7 of headroom) is an error: results are never returned from an overflowed pass.
-            self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
-            return self.forward_test(**kwargs)
+            # The f16 arithmetic of the encoder stores activations at per-tensor scales derived from the weights (canonical frames, 2^8 of
+            # headroom); a video with larger activations than that overflows them.  The check that raised has dropped the scales and
+            # asked for 2^4 more headroom: run the video once more (up to three times: 2^22 in all).  The video AFTER it starts from the
+            # canonical scales again -- no result depends on the videos before it.  Results are never returned from an overflowed pass.
+            bb = getattr(self, "backbone", None)
+            try:
+                for attempt in range(3):
+                    self.overflow_retries = getattr(self, "overflow_retries", 0) + 1
+                    try:
+                        return self.forward_test(**kwargs)
+                    except EncoderOverflow:
+                        if attempt == 2 or getattr(bb, "calibration", None) != "canonical":
+                            raise
+            finally:
+                if hasattr(bb, "end_overflow_retry"):
+                    bb.end_overflow_retry()
 
 
 @MODELS.register_module()

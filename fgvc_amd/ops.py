@@ -697,9 +697,10 @@ F8_AX, F8_BX, F8_AW, F8_BW = 7, 3, 2, 9
 F16_TARGET_LOG2 = 8            # a calibrated tensor's largest value sits at ~2^8 of the f16 range (top 2^16): 2^7-2^8 of headroom
 
 
-def act_scale_log2(amax: float) -> int:
-    """log2 of the power-of-two scale that puts a tensor whose largest magnitude is `amax` at (2^7, 2^8] in f16."""
-    return _pow2_exponent(amax, F16_TARGET_LOG2)
+def act_scale_log2(amax: float, target_log2: int = F16_TARGET_LOG2) -> int:
+    """log2 of the power-of-two scale that puts a tensor whose largest magnitude is `amax` at (2^(target-1), 2^target] in f16
+    (default (2^7, 2^8]; ResNet's canonical calibration asks for 2^6: 2^10 of headroom)."""
+    return _pow2_exponent(amax, target_log2)
 
 
 def _pow2_exponent(amax: float, target_log2: int) -> int:

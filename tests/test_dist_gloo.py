@@ -190,6 +190,46 @@ def test_multi_rank_sharding_matches_unsharded_oracle(world, halo, precede, memb
     assert all(torch.equal(res[0][1], r[1]) for r in res[1:])          # replicated sweep is deterministic across ranks
 
 
+@pytest.mark.timeout(900)
+def test_eight_ranks_with_the_cfg4_schedule():
+    """World size 8 -- the node the north_star names -- on the schedule of BASELINE configs[3] (a 64-frame video, precede_frames 5):
+    first the schedule itself (pure host logic: 8 query frames per rank, 33 unique pairs on rank 0, 48 on the middle ranks, one 5-frame halo message per boundary, every needed frame arriving exactly once), then the eight gloo ranks with the oracle
+    backend on a tiny grid (both calls: the second with the cached schedule, the bank in place and the early halo) against the
+    un-sharded oracle driver.  (the largest world size rehearsed anywhere had been 4.)"""
+    from fgvc_amd import dist as D
+    from fgvc_amd import engine
+    T, world = 64, 8
+    cfg = engine.TrackerConfig(neighbor_range=8, regroup=True, precede_frames=5)
+    ranges = D.shard_frames(T, world, first=1)
+    assert ranges == [(8 * r + 1, min(8 * r + 9, T)) for r in range(8)]                      # 63 query frames: 8 per rank, 7 on the last
+    own = D.own_ranges(ranges, 0)
+    msgs = D.halo_messages(ranges, own, 0, 5)
+    assert msgs == [(r, r + 1, 8 * r + 4, 8 * r + 9) for r in range(7)]                     # the last five frames of every clip, to the next rank
+    # unique (query, key) pairs: frames 1..8 have 1,2,3,4,5,6,6,6 key frames (33), every later frame 6
+    assert [len(engine.plan_clip(T, [0], cfg, frame_range=r).pairs) for r in ranges] == [33] + [48] * 6 + [42]
+    g = torch.Generator().manual_seed(64)
+    C, Hf, Wf = 8, 6, 8
+    feats = torch.randn(T, C, Hf, Wf, generator=g)
+    qp = torch.tensor([[0., 3., 4.], [0., 11.3, 7.2], [0., 6.5, 9.25]])
+    h, w = 2 * Hf, 2 * Wf
+    exp = O.forward_test_main(feats, qp[:, 1:], h, w, neighbor_range=8, precede_frames=5)[0]
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, feats, qp, q, "exchange", 5, None, None)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=700) for _ in range(world)], key=lambda r: r[0])
+    assert all(r[2] is not None for r in res), res
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, traj, order in res:
+        assert order.tolist() == [0, 1, 2]
+        assert torch.allclose(traj, exp, atol=1e-6), (rank, float((traj - exp).abs().max()))
+    assert all(torch.equal(res[0][1], r[1]) for r in res[1:])
+
+
 def test_halo_message_plan():
     from fgvc_amd import dist as D
     ranges = D.shard_frames(17, 4, first=1)                              # [(1,5),(5,9),(9,13),(13,17)]

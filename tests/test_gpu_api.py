@@ -168,7 +168,10 @@ def test_dense_softmax_branch_topk_none(dev, common, golden):
 # of near-tied lists (tools/experiments/ledger_matrix.py traj: up to 1.8e-3 px with ANY encoder in front of it, 5e-5 with an exact pair
 # kernel behind the same encoders); the refining merge re-scores those near-ties exactly.  Measured: bf16x3 2.4e-5, f16x3 1.1e-5,
 # f16f8 3.2e-5, f16f6 4.9e-5; on the 256 x 256 fixtures every arithmetic is within 3.1e-5 px (one f32 ulp of a coordinate).
-TRAJ_TOL_PX = {"bf16x3": 5e-5, "f16x3": 5e-5, "f16f8": 1e-4, "f16f6": 1e-4}
+# f16f8 (round 3's arithmetic, not the default): its e4m3 cross terms carry FIXED scales that assume a tensor's largest value near 2^8 of the
+# f16 range, so it feels where the (canonical, round 5) scales put a video's activations: 6.2e-5 px here (3.9e-5 with scales calibrated
+# on this very clip; 1.8e-3 when the canonical target was tried at 2^6).  The block-scaled FP6 forms of f16f6, the default, do not care.
+TRAJ_TOL_PX = {"bf16x3": 5e-5, "f16x3": 5e-5, "f16f8": 1.5e-4, "f16f6": 1e-4}
 _LEDGER = {}
 
 
@@ -351,7 +354,9 @@ def test_tracker_cfg0_geometry_indices_through_the_encoder(dev, golden):
         assert n_clear > 450
         # ten times tighter than the north_star asks: measured score errors are 2-4e-5 logit in every arithmetic, so the indices must
         # also agree on every query whose ranks are 1e-4 apart (510 of the 512), and the scores within 1e-4
-        n_tight, _ = _cfg0_compare_topk(g, tk.idx[0][sample].cpu().numpy(), tk.logit[0][sample].cpu().numpy(), gap=1e-4, score_tol=1e-4)
+        # (f16f6 / f16f8: the entries the refining merge does not re-score keep the pair kernel's ~7e-5 logit on top of the encoder's: 1.05e-4 measured)
+        n_tight, _ = _cfg0_compare_topk(g, tk.idx[0][sample].cpu().numpy(), tk.logit[0][sample].cpu().numpy(), gap=1e-4,
+                                        score_tol=2e-4 if arith in ("f16f6", "f16f8") else 1e-4)
         assert n_tight >= 505
         report[arith] = dict(traj_err_px=d, clear_queries_gap_1e_3=n_clear, clear_queries_gap_1e_4=n_tight, max_score_err=err,
                              pair_kernel=ecfg.pair_split_fmt, all_512=_cfg0_ledger(g, tk.idx[0][sample].cpu().numpy()))
@@ -501,38 +506,74 @@ def test_jhmdb_adapter_end_to_end(dev, tmp_path):
     assert pck["PCK@0.2"] > 80.0 and pck["PCK@0.1"] <= pck["PCK@0.2"] <= pck["PCK@0.5"], pck
 
 
-def test_tracker_recalibrates_after_an_encoder_overflow(dev):
-    """The f16 arithmetic of the encoder keeps per-tensor scales calibrated on the first batch a set of weights sees.  A later video
-    whose activations are 2^10 times larger leaves that range: the pass raises the device flag, its results are dropped
-    (EncoderOverflow inside forward), the scales are re-calibrated on the new video and the video runs once more -- the caller gets
-    the trajectories a freshly calibrated model gives, bit for bit, and `overflow_retries` counts the event.  (The reference has no
-    such failure mode; never returning numbers from an overflowed pass is the point.)"""
+def _scaled_tracker(dev):
     import fgvc_amd.mmpt_api as api
-    from oracle import fgvc_oracle as O
+    m = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
+                                                                   pool_type="none")), train_cfg=None,
+                        test_cfg=api.ConfigDict(precede_frames=3, topk=10, temperature=0.07, neighbor_range=12, with_first=True,
+                                                with_first_neighbor=True))
+    m.backbone.load_state_dict(O.seeded_resnet_state(31, (1, 2, 1, 1), "none"), strict=False)
+    return m.to(dev).eval()
 
-    def build():
-        m = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,),
-                                                                       pool_type="none")), train_cfg=None,
-                            test_cfg=api.ConfigDict(precede_frames=3, topk=10, temperature=0.07, neighbor_range=12, with_first=True,
-                                                    with_first_neighbor=True))
-        m.backbone.load_state_dict(O.seeded_resnet_state(31, (1, 2, 1, 1), "none"), strict=False)
-        return m.to(dev).eval()
+
+def test_results_do_not_depend_on_the_videos_before(dev):
+    """the f16 scales of the encoder are a function of the WEIGHTS (canonical frames through them, 2^8 of
+    headroom), not of the first batch the weights happened to see: model(B) is the same bits whether or not model(A) ran first, in
+    every f16 arithmetic -- and so are the feature banks two data-parallel ranks would build for B after different first videos.
+    (resnet.py:605-638: the reference's forward is stateless.)"""
     g = torch.Generator().manual_seed(31)
-    faint = (torch.randn(1, 4, 3, 64, 96, generator=g) * 2.0 ** -6).to(dev)
-    bright = (torch.randn(1, 4, 3, 64, 96, generator=g) * 2.0 ** 4).to(dev)
+    A = (torch.randn(1, 4, 3, 64, 96, generator=g) * 2.0 ** -5).to(dev)              # a faint video: round 4 calibrated tight scales on it
+    B = torch.randn(1, 4, 3, 64, 96, generator=g).to(dev)
+    C = (torch.rand(1, 4, 3, 64, 96, generator=g) * 5.2 - 2.6).to(dev)
     qp = torch.tensor([[[0., 20., 17.], [0., 70.5, 40.25], [1., 33., 50.]]]).to(dev)
     traj, vis = torch.zeros(1, 4, 3, 2, device=dev), torch.ones(1, 4, 3, device=dev)
-    model = build()
+    for arith in ("f16f6", "f16f8", "f16x3"):
+        alone = _scaled_tracker(dev)
+        alone.backbone.set_arith(arith)
+        want = alone(test_mode=True, rgbs=B, query_points=qp, trajectories=traj, visibilities=vis)
+        want_bank = alone.get_feats_hwc(B[0], split=True)[0].clone()
+        for first in (A, C):
+            m = _scaled_tracker(dev)
+            m.backbone.set_arith(arith)
+            m(test_mode=True, rgbs=first, query_points=qp, trajectories=traj, visibilities=vis)
+            got = m(test_mode=True, rgbs=B, query_points=qp, trajectories=traj, visibilities=vis)
+            assert torch.equal(got[2], want[2]) and torch.equal(got[4], want[4]), arith
+            assert torch.equal(m.get_feats_hwc(B[0], split=True)[0], want_bank), arith
+            assert getattr(m, "overflow_retries", 0) == 0
+        assert alone.backbone._scales(dev) is not None and alone.backbone.__dict__["_split_cache"][("scales_from", dev)] == "canonical"
+    # a calibration of the caller's own choice still pins the scales (and is then the caller's history to manage)
+    pinned = _scaled_tracker(dev)
+    pinned.backbone.calibrate(B[0])
+    assert pinned.backbone.__dict__["_split_cache"][("scales_from", dev)] == "frames"
+    out = pinned(test_mode=True, rgbs=B, query_points=qp, trajectories=traj, visibilities=vis)
+    assert float((out[2] - want[2]).abs().max()) < 1e-3
+
+
+def test_tracker_retries_after_an_encoder_overflow(dev):
+    """A video whose activations leave the f16 range of the canonical scales (2^8 of headroom: here frames 2^12 times the canonical
+    amplitude): the pass raises the device flag, its results are dropped (EncoderOverflow inside forward), the video runs once more with
+    2^4 more headroom -- the caller gets what a fresh model returns for this video, bit for bit, `overflow_retries` counts the event --
+    and the NEXT video starts from the canonical scales again: its result is what a fresh model gives.  (The reference has no such
+    failure mode; never returning numbers from an overflowed pass is the point.)"""
+    g = torch.Generator().manual_seed(31)
+    faint = (torch.randn(1, 4, 3, 64, 96, generator=g) * 2.0 ** -6).to(dev)
+    bright = (torch.randn(1, 4, 3, 64, 96, generator=g) * 2.0 ** 12).to(dev)
+    qp = torch.tensor([[[0., 20., 17.], [0., 70.5, 40.25], [1., 33., 50.]]]).to(dev)
+    traj, vis = torch.zeros(1, 4, 3, 2, device=dev), torch.ones(1, 4, 3, device=dev)
+    model = _scaled_tracker(dev)
     assert model.backbone.arith == "f16f6"
-    model(test_mode=True, rgbs=faint, query_points=qp, trajectories=traj, visibilities=vis)          # calibrates on the faint video
+    first = model(test_mode=True, rgbs=faint, query_points=qp, trajectories=traj, visibilities=vis)
     assert getattr(model, "overflow_retries", 0) == 0
-    out = model(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)   # overflows, re-calibrates, re-runs
-    assert model.overflow_retries == 1 and bool(torch.isfinite(out[2]).all())
-    fresh = build()(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)
-    assert torch.equal(out[2], fresh[2]) and torch.equal(out[4], fresh[4])
-    # ... and from then on the bright scales hold: no further retry for the same kind of video
-    model(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)
-    assert model.overflow_retries == 1
+    out = model(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)   # overflows, runs once more
+    assert model.overflow_retries >= 1 and bool(torch.isfinite(out[2]).all())
+    n1 = model.overflow_retries
+    fresh = _scaled_tracker(dev)
+    ref = fresh(test_mode=True, rgbs=bright, query_points=qp, trajectories=traj, visibilities=vis)
+    assert torch.equal(out[2], ref[2]) and torch.equal(out[4], ref[4]) and fresh.overflow_retries == n1
+    # the video after it: canonical scales again -- the same bits as before the bright video
+    again = model(test_mode=True, rgbs=faint, query_points=qp, trajectories=traj, visibilities=vis)
+    assert torch.equal(again[2], first[2]) and model.overflow_retries == n1
+    assert "_headroom_extra" not in model.backbone.__dict__
 
 
 def test_badja_adapter_end_to_end(dev, tmp_path):
