@@ -548,6 +548,12 @@ def main():
         kernels[tag_[0]] = {"kernel": "fgvc_merge_refine_topk_f32" if tag_[0] == "merge_refine" else "fgvc_merge_topk_f32", "ms_per_launch": ms_,
                             "launches_timed": n_, "pairs": tag_[1],
                             "note": "HIP events on the stream the merge runs on (the tail stream: overlaps the next step's encoder)"}
+    rs = getattr(backend, "refine_stats", None)
+    if "merge_refine" in kernels and rs is not None:
+        rs = rs.cpu().tolist()
+        n_q = (Tc - 1) * HW if a.mode == "video" and world == 1 else None
+        kernels["merge_refine"].update(queries_rescored=rs[0], of_them_from_scratch=rs[1], candidates_rescored=rs[2], beyond_scan_queue=rs[3],
+                                       queries=n_q, eps=cfg.pair_refine_eps)
     head = kernels.get("encoder_conv") or kernels.get("pair_topk")
     roofline = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "what", "executed_tflops",
                                      "frac_executed", "frac_of_f32_mfma_peak", "sustained_peak", "frac_executed_of_sustained", "sustained_note", "ms_per_launch", "mfma_util", "launch_note", "pmc_note")

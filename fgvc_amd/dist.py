@@ -258,6 +258,7 @@ class HipBackend:
     def affinity(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig, phases=None):
         """`phases` = (plan indices of the pairs to launch first, callable to run before the others): see engine.run_pairs."""
         tk = engine.run_affinity(bank, Hf, Wf, plan, cfg, phases=phases, channels=getattr(self.model, "feat_channels", None))
+        self.refine_stats = tk.refine_stats          # (device counters of the refining merge, None behind an exact pair kernel: bench.py reports them)
         return tk.idx, tk.weight
 
     def pairs(self, bank: torch.Tensor, Hf: int, Wf: int, plan: Plan, cfg: TrackerConfig, phases=None):

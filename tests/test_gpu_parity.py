@@ -1370,6 +1370,15 @@ def test_encoder_hip_graph_in_the_tracker_and_invalidation(dev):
             assert ovf
             ovf[0].fill_(1)
             assert net.check_overflow() and not graphs()
+            # (the retry after an overflow runs 2^4 further below the f16 top -- ResNet.check_overflow under the canonical calibration --:
+            # the same features up to the fixed-scale e4m3 cross terms of layer 1; end_overflow_retry() returns to the canonical scales)
+            from fgvc_amd import ops
+            for v, w in zip(vids[:2], want[:2]):
+                got = model.get_feats_hwc(v, split=True)[0]
+                assert float((ops.f32_of_f16f6x(got) - ops.f32_of_f16f6x(w)).abs().max()) < 2e-4
+            assert graphs()
+            net.end_overflow_retry()
+            assert not graphs() and "_headroom_extra" not in net.__dict__
             for v, w in zip(vids[:2], want[:2]):
                 assert torch.equal(model.get_feats_hwc(v, split=True)[0], w)
             assert graphs()
