@@ -636,7 +636,7 @@ def main():
 
     if a.mode == "video":
         # what this rank handed to the exchange steps per step, against the schedule's arithmetic (N = 1: nothing moves)
-        frame_bytes = HW * C * (8 if cfg.bank_fmt == "f16f6x" else 4)      # one frame of the bank: 1 KiB per pixel (f32 or 2 x 16-bit parts), 2 KiB for split_f16f6x() rows
+        frame_bytes = HW * C * 4                                           # one frame ON THE WIRE: 1 KiB per pixel (f32 or 2 x 16-bit parts; of split_f16f6x() rows only the f32 half travels)
         list_bytes = HW * cfg.topk * 8                                      # idx int32 + weight f32 of one frame's merged list
         rr = fdist.shard_frames(T, world, first=1)
         exp = {"broadcast": frame_bytes if world > 1 else 0,
@@ -758,6 +758,26 @@ def main():
                 if rnd:
                     res[name].append(sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs))
         med = lambda v: sorted(v)[len(v) // 2]
+        # the write stream by itself, measured HERE: (a) the kernel's own store sequence replayed without its loads
+        # and multiplies (same grid, row classes, lane swap, barriers; zeros written), (b) a linear sweep of 16-byte stores over the same bytes
+        def timed(fn, n=10, rounds=5):
+            out_ms = []
+            for _ in range(rounds):
+                fn()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+                for e0, e1 in evs:
+                    e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                out_ms.append(sum(e0.elapsed_time(e1) for e0, e1 in evs) / n)
+            return med(out_ms[1:])
+        ops.set_option("corr6_debug", 1024)
+        try:
+            replay_ms = timed(fns["f16f6"])
+        finally:
+            ops.set_option("corr6_debug", 0)
+        nfl = (HW * HW // 4) * 4
+        sweep_ms = {nt: timed(lambda nt=nt: _lib.call("fgvc_debug_store_sweep_f32", ops._ptr(vol), nfl, nt, ops._stream(vol))) for nt in (0, 1)}
+        vol_bytes = HW * HW * 4 / 1e9
         var = {k: {"ms": med(v), "ms_min": min(v), "ms_max": max(v), "rounds": len(v), "achieved": gbytes / (med(v) * 1e-3),
                    "frac": gbytes / (med(v) * 1e-3) / HBM_PEAK_GBPS} for k, v in res.items()}
         var["f16f6"]["max_abs_err_bound"] = "1e-3 logit (tests); measured 6e-5 on Gaussian rows, 8e-5 against bf16x3 at 720p"
@@ -772,9 +792,10 @@ def main():
             "roofline": {"kernel": "fgvc_corr_volume_f16f6", "bound": "hbm", "achieved": var["f16f6"]["achieved"],
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": var["f16f6"]["frac"],
                          "ceiling_gbps": STORE_CEILING_GBPS, "ceiling_frac": var["f16f6"]["achieved"] / STORE_CEILING_GBPS,
-                         "write_rate_ceiling_note": "pure stores over a 2.64 GB footprint run at 5.43 (nt) - 5.68 (plain) TB/s on MI355X, 7.2-7.4 "
-                                                    "TB/s while the footprint fits the 256 MB Infinity Cache (tools/micro/store_footprint.hip, "
-                                                    "profiles/r03_store_footprint.log): 0.68-0.71 of the 8 TB/s `frac` is priced against",
+                         "write_rate_ceiling_note": "dword stores over 2.64 GB: profiles/r03_store_footprint.log; measured live: store_replay / store_sweep",
+                         "store_replay_ms": replay_ms, "store_replay_gbps": vol_bytes / (replay_ms * 1e-3),
+                         "store_sweep_ms": sweep_ms[0], "store_sweep_gbps": vol_bytes / (sweep_ms[0] * 1e-3),
+                         "store_sweep_nt_gbps": vol_bytes / (sweep_ms[1] * 1e-3),
                          "traffic": pm.get("hbm_bytes_per_launch"), "mfma_util": pm.get("mfma_util"),
                          "bytes_per_launch": gbytes * 1e9,
                          "note": "median of 6 rounds x 10 launches (HIP events), round-robin with the other variants, first round dropped"},
@@ -783,7 +804,9 @@ def main():
         if out.get("roofline") is not None:      # the second half of BASELINE's metric, where the driver's record keeps it
             out["roofline"].update(corr_volume_kernel="fgvc_corr_volume_f16f6", ms_per_corr_volume=var["f16f6"]["ms"],
                                    corr_volume_frac=var["f16f6"]["frac"], corr_volume_gbps=var["f16f6"]["achieved"],
-                                   corr_volume_traffic=pm.get("hbm_bytes_per_launch"), corr_volume_peak_gbps=HBM_PEAK_GBPS)
+                                   corr_volume_traffic=pm.get("hbm_bytes_per_launch"), corr_volume_peak_gbps=HBM_PEAK_GBPS,
+                                   store_ceiling_gbps=vol_bytes / (min(sweep_ms.values()) * 1e-3),
+                                   corr_volume_store_replay_gbps=vol_bytes / (replay_ms * 1e-3))
         del vol
     if rank == 0 and world == 1 and not a.no_cpu_baseline:          # reported at N = 1 only (the other ranks would sit at the barrier)
         out["cpu_baseline"] = cpu_baseline(wl)

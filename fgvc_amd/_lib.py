@@ -73,6 +73,7 @@ SIGNATURES = {
     "fgvc_corr_volume_f16f8": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
     "fgvc_split_f16f6": (_i, [_p, _p, C.c_int64, _i, _p]),
     "fgvc_corr_volume_f16f6": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
+    "fgvc_debug_store_sweep_f32": (_i, [_p, C.c_int64, _i, _p]),
     "fgvc_dense_attend_splits": (_i, [_i, _i]),
     "fgvc_dense_attend_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "fgvc_dense_attend_finish_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),

@@ -77,6 +77,7 @@ void set_corr8_debug(int);
 int split_f16f6_launch(const float*, unsigned char*, long long, hipStream_t);
 int corr_volume_f16f6_launch(const unsigned char*, const unsigned char*, int, int, float, float*, hipStream_t);
 void set_corr6_debug(int);
+int store_sweep_launch(float*, long long, int, hipStream_t);
 int dense_attend_splits(int, int);
 int dense_attend_launch(const float*, const float*, int, int, int, int, int, int, int, int, int, int, int, float*, int, hipStream_t, const float*);
 int dense_kth_launch(const float*, int, int, int, float*, int, float*, hipStream_t);
@@ -412,6 +413,12 @@ int fgvc_split_f16f6(const float* feat, uint8_t* out, int64_t n_pixels, int C, v
   FGVC_REQUIRE(aligned16(feat) && aligned16(out), FGVC_ERR_INVALID_ARG, "fgvc_split_f16f6: 16-byte alignment required");
   if (n_pixels == 0) return FGVC_OK;
   return split_f16f6_launch(feat, out, n_pixels, (hipStream_t)stream);
+}
+
+int fgvc_debug_store_sweep_f32(float* buf, int64_t n_floats, int nontemporal, void* stream) {
+  FGVC_REQUIRE(buf && aligned16(buf) && n_floats >= 0 && n_floats % 4 == 0, FGVC_ERR_INVALID_ARG, "fgvc_debug_store_sweep_f32: a 16-byte aligned buffer of a multiple of 4 floats");
+  if (n_floats == 0) return FGVC_OK;
+  return store_sweep_launch(buf, n_floats, nontemporal, (hipStream_t)stream);
 }
 
 int fgvc_corr_volume_f16f6(const uint8_t* q, const uint8_t* k, int C, int HWq, int HWk, float temperature, float* vol,

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
     }
   };
   static_assert(2 * ROWS / NW == 16, "two DMA rows per multiply part of a staging wave: 2 tiles x 4 parts");
-  stage_load(kb0, 0);
+  if constexpr (!((DEBUG & 1024) != 0)) stage_load(kb0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the DMAs are inline assembly: the compiler's own wait at the barrier does not count them
   __syncthreads();
   if (probe) p_pro = __builtin_amdgcn_s_memtime() - p_start;
@@ -395,6 +395,9 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   // vmcnt(16): waits for the first tile's burst.)
   constexpr bool DMA_EARLY = !(DEBUG & 16);
   constexpr bool F_HALVES = !(DEBUG & 64);
+  // DEBUG & 1024: the kernel's STORES alone -- same grid, same row classes, same lane swap and address sequence, same barriers;
+  // no key-row DMA, no LDS reads, no MFMAs (zeros are stored): what the write stream by itself costs (bench.py: store_replay)
+  constexpr bool STORE_ONLY = (DEBUG & 1024) != 0;
   auto stage_rows = [&](int kb, int buf, int sb, int slot) {   // slot 0..3 of tile sb
     if constexpr (DMA_EARLY) {
       if (sb == 0) {
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
   for (int kb = kb0; kb < kb1; kb += SUB) {
     const bool more = kb + SUB < kb1;
     n_counted = 0;
-    load_F(&smem[buf * BUFB + r * LDB], 0);
+    if constexpr (!STORE_ONLY) load_F(&smem[buf * BUFB + r * LDB], 0);
     if (probe) c0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int sb = 0; sb < SUB; ++sb) {
@@ -426,9 +429,10 @@ __global__ __launch_bounds__(NW * 64, 2) void corr_volume_f16f6_kernel(const uns
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      load_S(ka);
+      if constexpr (!STORE_ONLY) load_S(ka);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
+        if constexpr (STORE_ONLY) continue;
         load_P(ka, u);                                 // lands during the F part
         if (more && stager) stage_rows(kb + SUB, buf ^ 1, sb, 2 * u);
         // the F fragments of the NEXT block: the first two K-32 steps are re-read as soon as their last reader has issued, the
@@ -570,6 +574,11 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
   const float out_scale = 1.0f / (temperature * F6_S * F6_S);
   const int mm = period > 1 ? m32 : 0;
 #define FGVC_C6(D) corr_volume_f16f6_kernel<8, D><<<grid, 512, 0, s>>>(q, k, HWq, HWk, out_scale, vol, s_tile, c_half, n_tiles, period, mm, g_corr6_skew)
+  if (g_corr6_debug & 1024) {          // the store stream alone (results: zeros)
+    FGVC_C6(1026);
+    FGVC_CHECK_LAUNCH("fgvc_corr_volume_f16f6");
+    return FGVC_OK;
+  }
   switch (g_corr6_debug & 1019) {
     case 128: FGVC_C6(128); break;
     case 32 + 256: FGVC_C6(288); break;      // probe, no f16 MFMAs (results wrong)
@@ -595,6 +604,25 @@ int corr_volume_f16f6_launch(const unsigned char* q, const unsigned char* k, int
   }
 #undef FGVC_C6
   FGVC_CHECK_LAUNCH("fgvc_corr_volume_f16f6");
+  return FGVC_OK;
+}
+
+// A linear sweep of 16-byte stores over `n` floats (the write stream of a kernel that has nothing else to do): the ceiling the volume
+// kernel's store pattern is measured against in bench.py (`roofline.store_ceiling_gbps`).  2048 workgroups x 256 threads, grid-stride.
+__global__ __launch_bounds__(256) void store_sweep_kernel(float* __restrict__ v, long long n4, int nt) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4* p = reinterpret_cast<f32x4*>(v);
+  if (nt) {
+    for (long long i = tid; i < n4; i += stride) __builtin_nontemporal_store(z, p + i);
+  } else {
+    for (long long i = tid; i < n4; i += stride) p[i] = z;
+  }
+}
+
+int store_sweep_launch(float* v, long long n_floats, int nontemporal, hipStream_t s) {
+  store_sweep_kernel<<<2048, 256, 0, s>>>(v, n_floats / 4, nontemporal);
+  FGVC_CHECK_LAUNCH("fgvc_debug_store_sweep_f32");
   return FGVC_OK;
 }
 

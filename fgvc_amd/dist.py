@@ -121,6 +121,23 @@ def _wire(t: torch.Tensor) -> torch.Tensor:
     return t.view(torch.uint8) if t.dtype == torch.int16 else t
 
 
+def _is_f16f6x(t: torch.Tensor) -> bool:
+    """Rows of ops.split_f16f6x(): 2 KiB per pixel = the pair kernel's f16 + FP6 row AND the f32 channels it was made from.  Only the
+    f32 half travels (1 KiB per pixel, what every other bank format moves); the receiver rebuilds the rows with the same kernel the
+    sender's encoder epilogue is held to byte for byte (fgvc_split_f16f6x)."""
+    return t.is_cuda and t.dtype == torch.int16 and t.dim() >= 3 and t.shape[-2] == 4 and t.shape[-1] == 256
+
+
+def _pack_f32(t: torch.Tensor) -> torch.Tensor:
+    from . import ops
+    return ops.f32_of_f16f6x(t).contiguous()
+
+
+def _unpack_f32(f32: torch.Tensor, into: torch.Tensor) -> None:
+    from . import ops
+    ops.split_f16f6x(f32.to(into.device), out=into)
+
+
 def _global_rank(group, r: int) -> int:
     """The schedule counts ranks inside `group` (enumerate(ranges)); torch.distributed's src / dst / peer arguments are GLOBAL ranks."""
     return r if group is None or group is dist.group.WORLD else dist.get_global_rank(group, r)
@@ -128,15 +145,20 @@ def _global_rank(group, r: int) -> int:
 
 def _broadcast(buf: torch.Tensor, src: int, group) -> None:
     """`src`: rank within `group`."""
+    rows = buf if _is_f16f6x(buf) else None
+    if rows is not None:
+        buf = _pack_f32(rows)            # (on every rank: the owner's channels, a buffer to receive into elsewhere)
     buf = _wire(buf)
-    src = _global_rank(group, src)
+    src_g = _global_rank(group, src)
     COMM_BYTES["broadcast"] += buf.numel() * buf.element_size()
     if _host_staged(buf, group):
         tmp = buf.cpu()
-        dist.broadcast(tmp, src=src, group=group)
+        dist.broadcast(tmp, src=src_g, group=group)
         buf.copy_(tmp)
     else:
-        dist.broadcast(buf, src=src, group=group)
+        dist.broadcast(buf, src=src_g, group=group)
+    if rows is not None and (dist.get_rank(group) != src):
+        _unpack_f32(buf, rows)
 
 
 def _all_gather(outs: List[torch.Tensor], t: torch.Tensor, group) -> None:
@@ -155,10 +177,10 @@ class _Messages:
     STREAM wait for the transfers (the host does not block), so kernels launched in between overlap them."""
 
     def __init__(self, group):
-        self.group, self.ops, self.keep, self.land, self.reqs = group, [], [], [], None
+        self.group, self.ops, self.keep, self.land, self.reqs, self.split = group, [], [], [], None, []
 
     def send(self, t: torch.Tensor, dst: int):            # dst / src: ranks within the group
-        t = _wire(t.contiguous())
+        t = _wire(_pack_f32(t) if _is_f16f6x(t) else t.contiguous())
         COMM_BYTES["halo_send"] += t.numel() * t.element_size()
         if _host_staged(t, self.group):
             t = t.cpu()
@@ -167,6 +189,9 @@ class _Messages:
 
     def recv(self, into: torch.Tensor, src: int):
         assert into.is_contiguous()
+        if _is_f16f6x(into):             # the f32 channels arrive in a buffer of their own; wait() splits them into the bank's rows
+            rows, into = into, torch.empty(tuple(into.shape[:-2]) + (256,), dtype=torch.float32, device=into.device)
+            self.split.append((rows, into))
         into = _wire(into)
         COMM_BYTES["halo_recv"] += into.numel() * into.element_size()
         if _host_staged(into, self.group):
@@ -199,7 +224,9 @@ class _Messages:
             req.wait()
         for into, tmp in self.land:
             into.copy_(tmp)
-        self.reqs, self.land, self.keep = None, [], []
+        for rows, f32 in self.split:
+            _unpack_f32(f32, rows)
+        self.reqs, self.land, self.keep, self.split = None, [], [], []
 
 
 class Timing:

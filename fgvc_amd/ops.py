@@ -380,14 +380,17 @@ def split_f16f6p(feat: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def split_f16f6x(feat: torch.Tensor) -> torch.Tensor:
+def split_f16f6x(feat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(…, 256) f32 L2-normalised rows -> (…, 4, 256) int16 = 2 KiB per pixel: [the row of split_f16f6p() | the 256 f32 channels
     themselves].  The bank of the default configuration (round 5): fgvc_pair_topk_f16f6x multiplies the first KiB, the refining merge
     (merge_refine_topk) re-scores near-ties exactly from the second; one tensor, sliced and sent like any other bank."""
     feat = _chk(feat, torch.float32, "feat")
     assert feat.shape[-1] == 256, "fgvc_split_f16f6x: 256 channels"
     n = feat.numel() // 256
-    out = torch.empty((*feat.shape[:-1], 4, 256), device=feat.device, dtype=torch.int16)
+    if out is None:
+        out = torch.empty((*feat.shape[:-1], 4, 256), device=feat.device, dtype=torch.int16)
+    else:       # rows of the caller's bank (clip sharding: a halo frame arrives as its f32 channels and is split into its bank rows here)
+        assert out.dtype == torch.int16 and tuple(out.shape) == (*feat.shape[:-1], 4, 256) and out.is_contiguous() and out.device == feat.device
     _lib.call("fgvc_split_f16f6x", _ptr(feat), _ptr(out), n, 256, _stream(feat))
     return out
 

@@ -233,6 +233,11 @@ int fgvc_split_f16f6(const float* feat, uint8_t* out, int64_t n_pixels, int C, v
 int fgvc_corr_volume_f16f6(const uint8_t* q_split, const uint8_t* k_split, int C, int HWq, int HWk,
                            float temperature, float* vol, void* stream);
 
+/* Measurement helper (no reference counterpart): zeros over `n_floats` floats by a linear sweep of 16-byte stores (plain or non-temporal) --
+ * the store ceiling bench.py prices fgvc_corr_volume_f16f6's write stream against; fgvc_set_option("corr6_debug", 1024) replays that
+ * kernel's own store sequence without its loads and multiplies (zeros are written). */
+int fgvc_debug_store_sweep_f32(float* buf, int64_t n_floats, int nontemporal, void* stream);
+
 /* ---- A5, topk=None branch: weights over EVERY unmasked key instead of the k best
  * replaces local_attention.py:376-383 (`cur_affinity.softmax(dim=1)` / `.clamp(min=0)**2` over the (T*HWk x step) slab and the
  * einsum with value_vec).  Called once per key slot t with that slot's dense volume vol[HWk][HWq] (fgvc_corr_volume_*, already

@@ -1,23 +1,12 @@
 #!/bin/bash
-# Four separate rocprofv3 --pmc passes of tools/run_kernels_once.py (counters are never combined with traces; the interpreter
-# sits directly after `--`), then tools/pmc_report.py -> profiles/<name>.  Run from the repository root on the GPU box:
-#     bash tools/pmc_passes.sh gpurun_out/pmc r04_pmc.json
+# The four rocprofv3 --pmc passes of tools/run_kernels_once.py (counters only: never combined with a trace; the interpreter directly
+# after `--`) and the report:   bash tools/pmc_passes.sh r05   ->   gpurun_out/r05_pmc.json
 set -e
-OUT=${1:-gpurun_out/pmc}
-NAME=${2:-r04_pmc.json}
-ROOT=$(pwd)
-export TMPDIR=/tmp
-mkdir -p "$OUT"
-run() {  # dir, counters...
-  local d="$ROOT/$OUT/$1"; shift
-  rm -rf "$d"
-  (cd /tmp && rocprofv3 --pmc "$@" -d "$d" -- python3 "$ROOT/tools/run_kernels_once.py") > "$ROOT/$OUT/pass_$(basename $d).log" 2>&1
-  echo "pass $(basename $d) done"
-}
+TAG=${1:-r05}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+run() { local d=$OUT/$1; shift; rm -rf $d; (cd /tmp && rocprofv3 --pmc "$@" -d $d -- python3 $ROOT/tools/run_kernels_once.py) > $OUT/log_$(basename $d).txt 2>&1; echo "pass $(basename $d) done"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum
 run mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
-python3 tools/pmc_report.py "$OUT/fetch" "$OUT/write" "$OUT/tcc" "$OUT/mfma" > "$OUT/$NAME"
-rm -rf "$OUT/fetch" "$OUT/write" "$OUT/tcc" "$OUT/mfma"     # raw databases: tens of MB each
-echo "wrote $OUT/$NAME"
+python3 tools/pmc_report.py $OUT/fetch $OUT/write $OUT/tcc $OUT/mfma > $ROOT/gpurun_out/${TAG}_pmc.json
+echo "wrote gpurun_out/${TAG}_pmc.json"

@@ -33,6 +33,8 @@ names = {"fgvc_pair_topk_f16f6": "pair_topk_kernel_v7", "fgvc_pair_topk_f16x3": 
          "fgvc_conv_split_fmt_f32[f16f6]": "conv_split_kernel<3, 256, 1, 3, 4, false, 3, 2, false, false",
          "fgvc_conv_split_proj_fmt_f32[f16f6]": "conv_split_kernel<3, 256, 1, 3, 4, false, 3, 2, false, true",
          "fgvc_conv_split_bank_f16f6p_f32[f16f6]": "conv_split_kernel<3, 256, 1, 3, 4, false, 3, 2, true, false",
+         "fgvc_merge_refine_topk_f32[mark]": "merge_mark_kernel", "fgvc_merge_refine_topk_f32[refine]": "refine_kernel",
+         "fgvc_merge_refine_topk_f32[scan]": "refine_scan_kernel",
          "fgvc_conv64_split_f32": "conv64_kernel",
          "fgvc_stem7_split_f32": "stem7_kernel", "fgvc_conv_s2_split_f32": "conv_s2_kernel<3>"}
 HW = 120 * 214

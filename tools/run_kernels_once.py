@@ -11,12 +11,16 @@ cfg = engine.TrackerConfig()
 plan = engine.plan_clip(T, [0], cfg)
 pairs = ops.make_pairs(plan.pairs, dev)
 h16_all = ops.split_f16x2(feats)
-h6_all = ops.split_f16f6p(feats)      # round 4: the rows of fgvc_pair_topk_f16f6 (the engine's default pair kernel)
+h6_all = ops.split_f16f6p(feats)      # round 4: the rows of fgvc_pair_topk_f16f6
+h6x_all = ops.split_f16f6x(feats)     # round 5: the 2 KiB rows of the default bank (fgvc_pair_topk_f16f6x + the refining merge)
+cfg6 = engine.TrackerConfig(pair_split_fmt="f16f6", pair_precision="split")
 hl = ops.split_bf16(feats[:2])
 sp = ops.split_f16f8(feats[:2])
 sp6 = ops.split_f16f6(feats[:2])
 vol = torch.empty((HW, HW), device=dev)
 for _ in range(3):
+    pl = engine.run_pairs(h6x_all, H, W, plan, cfg6)          # the default: fgvc_pair_topk_f16f6x on 2 KiB rows ...
+    engine.merge_pairs(pl, cfg6)                              # ... + fgvc_merge_refine_topk_f32 (merge_mark / refine / refine_scan kernels)
     ops.pair_topk_split(h6_all, h6_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16f6")
     ops.pair_topk_split(h16_all, h16_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16")
     ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False)
@@ -47,7 +51,7 @@ x2 = ops.alloc_split_nhwc(T, 128, H, W, dev)
 wq0, bq0 = ops.prepare_conv_split(torch.randn(128, 128, 3, 3, device=dev) * 0.03, torch.nn.BatchNorm2d(128).eval().to(dev))
 ops.conv_split(ops.nchw_to_split_nhwc(torch.relu(torch.randn(T, 128, H, W, device=dev))), wq0, bq0, H, W, True, out_split=x2, out_fmt=ops.ACT_F16F6, out_scale_log2=4, overflow=ovf)
 wp2, bs2, _ = ops.prepare_conv_split_f16(wt2, torch.nn.BatchNorm2d(256).eval().to(dev), ops.ACT_F16F6, force_exp=sw6)     # s_x2 s_w2 = s_x s_w (both inputs at 2^4)
-bank = torch.empty((T, H * W, 2, 256), dtype=torch.int16, device=dev)
+bank = torch.empty((T, H * W, 4, 256), dtype=torch.int16, device=dev)      # round 5: split_f16f6x rows (+ the f32 channels)
 idt = ops.alloc_nhwc(T, 256, H, W, dev); idt.normal_()
 for _ in range(3):
     ops.conv_split(xs6, wp6, bs6 + bs2, H, W, True, out_split=ys, out_f32=idt, in_fmt=ops.ACT_F16F6, in_scale_log2=4 + sw6, out_fmt=ops.ACT_F16F6, out_scale_log2=4,
