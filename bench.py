@@ -297,6 +297,8 @@ def main():
     ap.add_argument("--tail-from", default="sweep", choices=["sweep", "pairs"],
                     help="what runs on the side stream: the label sweep + read-out only, or everything after the encoder (pair top-k, "
                          "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
+    ap.add_argument("--merge-on-main", action="store_true", help="the slot merge (+ exact re-scoring) behind the pair kernel on the main stream instead of "
+                                                                 "on the side stream with the sweep (HipBackend.merge_on_tail = False; A/B)")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
     ap.add_argument("--conv64-f16f8", action="store_true", help="with --enc-arith f16f8: layer 1 and the stem's output in the f16 + fp8 form too (ResNet.conv64_f16f8; A/B)")
     ap.add_argument("--no-conv64-f16f8", action="store_true", help="layer 1 and the stem's output in the bf16 form also when the trunk computes in f16f8 (A/B)")
@@ -420,6 +422,7 @@ def main():
 
     tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
     backend = fdist.HipBackend(model, tail_stream=tail_stream, tail_from=a.tail_from)
+    backend.merge_on_tail = not a.merge_on_main
     if os.environ.get("FGVC_EARLY_HALO", "1") == "0":               # escape hatch: the halo posted after the whole encoder pass (round 2's order)
         backend.early_halo = False
     timing = fdist.Timing(dev)
@@ -550,10 +553,13 @@ def main():
                             "note": "HIP events on the stream the merge runs on (the tail stream: overlaps the next step's encoder)"}
     rs = getattr(backend, "refine_stats", None)
     if "merge_refine" in kernels and rs is not None:
+        worst = ops.refine_max_error(rs)
         rs = rs.cpu().tolist()
         n_q = (Tc - 1) * HW if a.mode == "video" and world == 1 else None
         kernels["merge_refine"].update(queries_rescored=rs[0], of_them_from_scratch=rs[1], candidates_rescored=rs[2], beyond_scan_queue=rs[3],
-                                       queries=n_q, eps=cfg.pair_refine_eps)
+                                       queries=n_q, eps=cfg.pair_refine_eps, max_pair_score_error_seen=worst)
+        if worst > cfg.pair_refine_eps:
+            raise SystemExit(f"bench.py: the pair kernel's score error reached {worst:.2e}, beyond the bound {cfg.pair_refine_eps:.2e} the exact re-scoring assumes")
     head = kernels.get("encoder_conv") or kernels.get("pair_topk")
     roofline = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "what", "executed_tflops",
                                      "frac_executed", "frac_of_f32_mfma_peak", "sustained_peak", "frac_executed_of_sustained", "sustained_note", "ms_per_launch", "mfma_util", "launch_note", "pmc_note")

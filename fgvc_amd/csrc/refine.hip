@@ -56,7 +56,8 @@ struct RefineParams {
   int32_t* idx_out;
   float* logit_out;
   float* weight_out;
-  int* counters;                      // [0] work items, [1] items recomputed from scratch, [2] candidates re-scored, [3] scan items beyond the queue
+  int* counters;                      // [0] work items, [1] items recomputed from scratch, [2] candidates re-scored, [3] scan items beyond the queue,
+                                      // [4] the largest |approximate - exact| score among the re-scored candidates (f32 bits)
   RefineItem* items;
   int* scan_ids;                      // [scan_cap] work-item index of every queued scan item
   int* scan_done;                     // [scan_cap] workgroups of the item that have written their part
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
     }
     const f32x4 qv = *reinterpret_cast<const f32x4*>(p.q_exact + (size_t)qf * p.q_frame_bytes + (size_t)q * p.q_row_bytes + 16 * lane);
     if (!(flags & RF_BRUTE)) {
+      float err = 0.f;
       const unsigned char* qrow = p.q_exact + (size_t)qf * p.q_frame_bytes + (size_t)q * p.q_row_bytes;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -375,9 +377,17 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
           const int e = 8 * half + v;
           const int src = ((v >> 2) & 1) * 32 + ((v >> 1) & 1) * 16 + (v & 1) * 8;
           const float got = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), src));
-          if (((flags >> e) & 1) && (lane & 15) == e) sc = got;
+          if (((flags >> e) & 1) && (lane & 15) == e) {
+            err = fmaxf(err, fabsf(got - sc));        // the pair kernel's error on this candidate: what `eps` is a bound of
+            sc = got;
+          }
         }
       }
+      // every re-scored candidate is a sample of |approximate - exact|: the largest one seen goes to counters[4] (positive floats order
+      // like their bit patterns), where the host holds it against eps -- the bound is measured on the run's own data, not assumed
+#pragma unroll
+      for (int mm = 8; mm >= 1; mm >>= 1) err = fmaxf(err, __shfl_xor(err, mm));
+      if (lane == 0 && err > 0.f) atomicMax(&p.counters[4], __builtin_bit_cast(int, err));
     } else {
       // every candidate of every slot, exactly
       TopK<RF_KMAX> ex;

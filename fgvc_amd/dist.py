@@ -275,7 +275,7 @@ class HipBackend:
         self.tail_stream = tail_stream
         self.tail_from = tail_from          # "pairs": everything after the encoder runs on the side stream
         self.tail_event = None
-        self.merge_on_tail = False          # True: the slot merge (pairs() / merge()) joins the sweep on the side stream
+        self.merge_on_tail = True           # the slot merge (pairs() / merge()) joins the sweep on the side stream (when there is one)
 
     def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None):
         # the bank in the form the pair kernel reads (the (h, l) f16 split where it applies): no second pass, same bytes to ship.
@@ -563,9 +563,9 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
 
         # the merge of the pair lists goes to the side stream with the sweep where the backend offers the two steps
         pl = None
-        # (`backend.merge_on_tail`; off by default: measured at 480p, N = 1 -- 4.76 ms per step with the merge on the side stream against
-        # 4.68 behind the pair kernel: its launches are latency-bound, but their workgroups keep the next video's convolutions off the CUs
-        # they sit on, and the encode phase grows by more than the 0.2 ms the merge takes alone)
+        # (`backend.merge_on_tail`, default on: measured at 480p, N = 1, A/B/A/B on one box -- 4.80 ms per step with the merge on the side
+        # stream against 4.86 behind the pair kernel.  Its launches are latency-bound, but their workgroups keep the next video's
+        # convolutions off the CUs they sit on: the encode phase grows by 0.23 ms where the affinity phase loses 0.30)
         split_merge = (getattr(backend, "tail_stream", None) is not None and not early and getattr(backend, "merge_on_tail", False)
                        and hasattr(backend, "pairs") and hasattr(backend, "merge"))
         with _span(timing, "affinity"):

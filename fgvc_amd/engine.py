@@ -365,11 +365,12 @@ def run_propagation_async(topk, start: int, points_xy: torch.Tensor, Hf: int, Wf
 
 
 def track_points(feats_hwc: torch.Tensor, Hf: int, Wf: int, h: int, w: int, query_points: torch.Tensor,
-                 cfg: TrackerConfig, channels: Optional[int] = None):
+                 cfg: TrackerConfig, channels: Optional[int] = None, stats_out: Optional[list] = None):
     """The whole post-encoder path for one clip.  query_points (P,3) = (t, x, y) (any device).
     Returns traj_pred (T, P', 2) f64 on the device with points re-ordered by query time (the
     reference's regrouping, vanilla_tracker.py:257-299) and `order` (P',) original indices.
-    `channels`: the encoder's channel count where the rows are zero-padded beyond it (read by sim_mode='l2-distance' only)."""
+    `channels`: the encoder's channel count where the rows are zero-padded beyond it (read by sim_mode='l2-distance' only).
+    `stats_out`: a list that receives the refining merge's counters (DeviceTopk.refine_stats) of every group."""
     T = feats_hwc.shape[0]
     dev = feats_hwc.device
     qp = query_points.detach().to("cpu")
@@ -384,6 +385,8 @@ def track_points(feats_hwc: torch.Tensor, Hf: int, Wf: int, h: int, w: int, quer
         sel = (times == s).nonzero().flatten() if cfg.regroup else torch.arange(qp.shape[0])
         pts = qp[sel, 1:].to(dev, torch.float32)
         topk = merge_pairs(pl, cfg, [plan.out_rows[(s, f)] for f in range(s + 1, T)])     # this group's rows only
+        if stats_out is not None and topk.refine_stats is not None:
+            stats_out.append(topk.refine_stats)                                          # (the refining merge's device counters, per group)
         _, coords = run_propagation(topk, s, pts, Hf, Wf, h, w, cfg)
         traj[s:, K:K + sel.numel()] = coords
         order.extend(sel.tolist())

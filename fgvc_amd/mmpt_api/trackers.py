@@ -169,6 +169,15 @@ class VanillaTracker(BaseTracker):
             return
         if ops.pair_f16x3_timed_out():
             raise RuntimeError("fgvc_pair_topk_f16x3: a bounded wait of the kernel's LDS protocol timed out; this video's results are invalid")
+        st = getattr(self, "_refine_stats", None)
+        if st is not None:
+            # the refining merge assumes |fgvc_pair_topk_f16f6 score - exact| <= pair_refine_eps; every candidate it re-scores is a sample
+            # of that error, and the largest one seen in this video is held against the bound (measured: 5e-6 of 2e-5)
+            self._refine_stats = None
+            worst, eps = max(ops.refine_max_error(s_) for s_ in st), float(self.engine_config().pair_refine_eps)
+            if worst > eps:
+                raise RuntimeError(f"fgvc_merge_refine_topk_f32: the pair kernel's score error reached {worst:.2e} on this video, beyond the bound "
+                                   f"{eps:.2e} the exact re-scoring assumes; raise test_cfg.pair_refine_eps or set pair_split_fmt='f16'")
         if hasattr(self.backbone, "check_overflow") and self.backbone.check_overflow():
             raise EncoderOverflow("fgvc_amd ResNet: an activation left the f16 range of its calibrated scale (f16 arithmetic of the encoder); "
                                "this video's results are invalid -- the scales were dropped and the next call re-calibrates on its own "
@@ -191,6 +200,7 @@ class VanillaTracker(BaseTracker):
             feats, Hf, Wf = self.get_feats_hwc(rgbs[0], split=True)
             plan = engine.plan_clip(T, [0], cfg)
             tk = engine.run_affinity(feats, Hf, Wf, plan, cfg, channels=self.feat_channels)
+            self._refine_stats = [tk.refine_stats] if tk.refine_stats is not None else None
             _, coords = engine.run_propagation(tk, 0, qp[:, 1:].to(dev, torch.float32), Hf, Wf, h, w, cfg)
             traj_pred = coords.unsqueeze(0)                                   # float64, like torch.from_numpy(...)
             self._check_kernels()
@@ -200,7 +210,9 @@ class VanillaTracker(BaseTracker):
         feats, Hf, Wf = self.get_feats_hwc(rgbs[0, t_min:], split=True)
         qp_rel = qp.clone()
         qp_rel[:, 0] -= t_min
-        traj, order = engine.track_points(feats, Hf, Wf, h, w, qp_rel, cfg, channels=self.feat_channels)   # (T-t_min, P, 2) f64, regrouped
+        stats = []
+        traj, order = engine.track_points(feats, Hf, Wf, h, w, qp_rel, cfg, channels=self.feat_channels, stats_out=stats)   # (T-t_min, P, 2) f64, regrouped
+        self._refine_stats = stats or None
         order = order.to(dev)
         traj_pred = torch.zeros_like(trajectories)
         traj_pred[0, t_min:] = traj.to(traj_pred.dtype)
@@ -216,6 +228,7 @@ class VanillaTracker(BaseTracker):
         feats, Hf, Wf = self.get_feats_hwc(rgbs[0], split=True)
         plan = engine.plan_clip(T, [0], cfg)
         tk = engine.run_affinity(feats, Hf, Wf, plan, cfg, channels=self.feat_channels)
+        self._refine_stats = [tk.refine_stats] if tk.refine_stats is not None else None
         pts = query_points[0, :, 1:].to(rgbs.device, torch.float32)
         _, coords = engine.run_propagation(tk, 0, pts, Hf, Wf, h, w, cfg)
         self._check_kernels()

@@ -443,8 +443,9 @@ def merge_refine_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pai
     2 eps of a neighbour are re-scored from the exact rows of `q_bank` / `k_bank` (f32 (frames, HW, 256), or split_f16f6x() banks),
     queries whose window the pair lists do not close are recomputed from every candidate under `mask`.
     Returns idx, logit, weight as merge_topk(), and the int32 statistics {queries re-scored, of them from scratch, candidates re-scored,
-    from-scratch queries beyond the scan queue (slow path)} as a device tensor (4,) (a view of the workspace: read it before the next
-    call that uses the same workspace)."""
+    from-scratch queries beyond the scan queue (slow path), f32 bits of the largest |approximate - exact| score among the re-scored
+    candidates} as a device tensor (5,) (a view of the workspace: read it before the next call that uses the same workspace;
+    refine_max_error() decodes the last word)."""
     pair_idx, pair_score = _chk(pair_idx, torch.int32, "pair_idx"), _chk(pair_score, torch.float32, "pair_score")
     slot_pair, pairs = _chk(slot_pair, torch.int32, "slot_pair"), _chk(pairs, torch.int32, "pairs")
     assert pair_idx.shape == pair_score.shape and pair_idx.shape[2] == topk and pair_idx.shape[1] == Hq * Wq and pairs.shape[0] == pair_idx.shape[0]
@@ -464,7 +465,13 @@ def merge_refine_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pai
               C.c_void_p(qb.data_ptr() + qo), C.c_int64(qfb), qrb, C.c_void_p(kb.data_ptr() + ko), C.c_int64(kfb), krb,
               n_out, T, Hq, Wq, Hk, Wk, 256, topk, float(temperature), wm, float(eps), mask.r2max, mask.ry, mask.rx,
               _ptr(idx), _ptr(logit), _ptr(weight), _ptr(workspace), _stream(pair_idx))
-    return idx, logit, weight, workspace.view(torch.int32)[:4]
+    return idx, logit, weight, workspace.view(torch.int32)[:5]
+
+
+def refine_max_error(stats: torch.Tensor) -> float:
+    """The largest |approximate - exact| score (dot-product units) the refining merge saw among the candidates it re-scored: `eps` as
+    measured on that call's data.  Synchronises (reads the device counters)."""
+    return float(stats[4:5].cpu().view(torch.float32)[0])
 
 
 def unsplit_f16f6p(split: torch.Tensor) -> torch.Tensor:

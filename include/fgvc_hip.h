@@ -176,8 +176,10 @@ int fgvc_merge_topk_f32(const int32_t* pair_idx, const float* pair_score, const 
  *   pairs [n_pairs][4] int32 as the pair kernel took them; slot_pair, outputs, weight modes as fgvc_merge_topk_f32; 1 <= topk <= 10 = the
  *   length of the pair lists; C == 256.  Two slots fed by ONE pair (frame 0 twice while idx <= precede_frames,
  *   vanilla_tracker.py:353-362) are exact twins: the lower slot first, as equal scores are ordered everywhere.
- *   workspace: fgvc_merge_refine_workspace_bytes(n_out, HWq) bytes, 16-byte aligned; after the call its first four int32 hold
- *   {queries re-scored, of them recomputed from scratch, candidates re-scored, from-scratch queries beyond the scan queue}. */
+ *   workspace: fgvc_merge_refine_workspace_bytes(n_out, HWq) bytes, 16-byte aligned; after the call its first five 32-bit words hold
+ *   {queries re-scored, of them recomputed from scratch, candidates re-scored, from-scratch queries beyond the scan queue, the largest
+ *   |approximate - exact| score among the re-scored candidates as f32 bits}: the last one is `eps` MEASURED on the call's own data --
+ *   a caller that finds it above the eps it passed must not trust the lists (fgvc_amd raises). */
 size_t fgvc_merge_refine_workspace_bytes(int n_out, int HWq);
 int fgvc_merge_refine_topk_f32(const int32_t* pair_idx, const float* pair_score, const int32_t* slot_pair, const int32_t* pairs,
                                const void* q_exact, int64_t q_frame_bytes, int q_row_bytes, const void* k_exact, int64_t k_frame_bytes,

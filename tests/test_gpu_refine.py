@@ -119,6 +119,8 @@ def test_refined_lists_equal_float64_topk(dev, case):
         e = (pl.score[pid].double() - ex).abs()
         err = max(err, float(e[ci >= 0].max()))
     assert err < 0.5 * ops.REFINE_EPS, err
+    seen = ops.refine_max_error(tk.refine_stats)                          # the kernel's own measurement of the same error (re-scored candidates only)
+    assert seen <= err + 1e-7 and (stats[2] == 0 or seen > 0), (seen, err)
     assert tot["exact"] >= tot["clear"] and tot["exact"] >= tot["plain_exact"]
     print(f"{case}: {tot}, refine stats (queries, from scratch, candidates) {stats}, pair score error {err:.2e} (eps {ops.REFINE_EPS:.0e})")
     if kind == "neartie":
@@ -264,3 +266,21 @@ def test_encoder_writes_f16f6x_bank(dev):
         finally:
             model.test_cfg.pop("pair_refine")
         assert bank1.shape == (5, Hf * Wf, 2, 256) and torch.equal(bank1, bank[:, :, :2].contiguous())
+
+
+def test_tracker_holds_the_measured_score_error_against_eps(dev):
+    """Fail closed: the refining merge reports the largest |approximate - exact| score among the candidates it re-scored; the tracker
+    reads it per video (where the reference synchronises anyway, vanilla_tracker.py:404) and raises when it exceeds the bound the exact
+    re-scoring assumes -- here provoked by a bound (1e-7) far below the f16 + FP6 arithmetic's ~5e-6."""
+    from tests.test_gpu_api import _tracker
+    cfg = dict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, with_first=True, with_first_neighbor=True)
+    g = torch.Generator().manual_seed(3)
+    rgbs = (torch.rand(1, 4, 3, 96, 128, generator=g) * 4 - 2).to(dev)
+    qp = torch.tensor([[[0., 20., 17.], [0., 70.5, 40.25], [1., 33., 50.]]]).to(dev)
+    traj, vis = torch.zeros(1, 4, 3, 2, device=dev), torch.ones(1, 4, 3, device=dev)
+    ok = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), cfg, 5)
+    out = ok(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
+    assert bool(torch.isfinite(out[2]).all()) and ok._refine_stats is None          # (read and cleared by the per-video check)
+    tight = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), dict(cfg, pair_refine_eps=1e-7), 5)
+    with pytest.raises(RuntimeError, match="beyond the bound"):
+        tight(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
