@@ -481,6 +481,130 @@ def gen_tracker_8f():
          feats_sub=feats[:, ::16, ::8, ::8], feats_abs_sum=float(feats.double().abs().sum()))
 
 
+def _lift_methods(relpath, cls_name, names, ns):
+    """The named methods of a reference class, lifted out of their module by AST (the modules import cv2 / mmcv / tensorboard, absent
+    here) into a bare class of the same name: the methods' own statements run unchanged, on the stand-ins `ns` gives their globals."""
+    import ast
+    src = open(os.path.join(ref_import.REF_ROOT, relpath)).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == cls_name][0]
+    body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names), [n.name for n in body]
+    new = ast.ClassDef(name=cls_name, bases=[], keywords=[], body=body, decorator_list=[])
+    mod = ast.Module([new], [])
+    ast.fix_missing_locations(mod)
+    exec(compile(mod, "ref:" + relpath, "exec"), ns)
+    return ns[cls_name]
+
+
+class _NP:
+    """numpy as the reference's numpy 1.x: `np.float` still exists"""
+    float = float
+
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+
+def gen_jhmdb_pck():
+    """tests/golden/jhmdb_pck.npz: the genuine jhmdb_dataset_rgb.pck_evaluate / compute_pck (jhmdb_dataset.py:144-256), lifted by AST,
+    on three synthetic videos: ground-truth joints from .mat files written here (`pos_img`, 1-based, as the dataset ships them),
+    predictions = ground truth + noise with some joints marked invisible (x <= 0) and one clip longer than its annotation.
+    Stand-ins (no arithmetic): mmcv.imread / imwrite / ProgressBar, cv2.line, terminal_is_available."""
+    import tempfile
+    import types
+    import scipy.io as sio
+    mm = types.SimpleNamespace(imread=lambda p_: np.zeros((8, 8, 3), np.uint8), imwrite=lambda *a, **k: True, ProgressBar=lambda n: None)
+    ns = {"np": _NP(), "sio": sio, "os": os, "osp": os.path, "mmcv": mm, "cv2": types.SimpleNamespace(line=lambda *a, **k: None),
+          "terminal_is_available": lambda: False}
+    Cls = _lift_methods("mmpt/datasets/jhmdb_dataset.py", "jhmdb_dataset_rgb", ["compute_pck", "pck_evaluate", "vis_pose"], ns)
+    Cls.NUM_KEYPOINTS = 15
+    Cls.PALETTE = [[0, 0, 0]] * 16
+    rng = np.random.default_rng(15)
+    with tempfile.TemporaryDirectory() as tmp:
+        ds = Cls.__new__(Cls)
+        ds.video_dir, ds.filename_tmpl, ds.samples = tmp, "{:05}.png", []
+        gts, preds = [], []
+        for v, (T_gt, T_pred) in enumerate(((9, 9), (14, 17), (6, 6))):
+            gt = rng.random((2, 15, T_gt)) * 180 + 15
+            if v == 2:
+                gt[:, :, :] = gt[:, :, :1] + rng.normal(0, 2, gt.shape)          # a nearly still pose: a small box, a large normalised error
+            sio.savemat(os.path.join(tmp, f"v{v}.mat"), {"pos_img": gt + 1.0})
+            pred = np.zeros((2, 15, T_pred))
+            pred[:, :, :T_gt] = gt + rng.normal(0, 30, gt.shape)
+            pred[:, :, T_gt:] = 50.0
+            hide = rng.random((15, T_pred)) < 0.15
+            pred[:, hide] = -1.0                                                   # img2coord's mark of an empty label map (:170)
+            ds.samples.append(dict(anno_path=os.path.join(tmp, f"v{v}.mat"), num_frames=T_pred, video_path=os.path.join(tmp, f"v{v}"),
+                                   frames_path=[os.path.join(tmp, f"v{v}", f"{i:05}.png") for i in range(T_pred)]))
+            gts.append(gt)
+            preds.append(pred)
+        out = os.path.join(tmp, "out")
+        os.makedirs(out)
+        res = ds.pck_evaluate([p_.copy() for p_ in preds], out)
+    arrs = {}
+    for v in range(3):
+        arrs[f"gt{v}"], arrs[f"pred{v}"] = gts[v], preds[v]
+    save("jhmdb_pck", n_videos=3, **arrs, **{k.replace("@", "_at_"): np.float64(v_) for k, v_ in res.items()})
+
+
+def gen_badja_pck():
+    """tests/golden/badja_pck.npz: the genuine BadjaDataset.pck_evaluate (badja_dataset.py:438-583), lifted by AST, on two synthetic
+    animals (silhouettes, (y, x) joints, visibility flags, unlabelled frames).  Stand-ins (no arithmetic): SummaryWriter /
+    pips_vis.Summ_writer (never used: vis_traj is off), mmcv.imresize at the identity size, torch's .cuda(), get_video."""
+    import math
+    import tempfile
+    import types
+    mm = types.SimpleNamespace(imresize=lambda x, size, interpolation=None: (x if (x.shape[1], x.shape[0]) == tuple(size) else 1 / 0),
+                               ProgressBar=lambda n: None)
+    ns = {"np": _NP(), "os": os, "osp": os.path, "mmcv": mm, "math": math, "torch": torch, "terminal_is_available": lambda: False,
+          "SummaryWriter": lambda *a, **k: None, "pips_vis": types.SimpleNamespace(Summ_writer=lambda **k: None)}
+    Cls = _lift_methods("mmpt/datasets/badja_dataset.py", "BadjaDataset", ["pck_evaluate"], ns)
+    rng = np.random.default_rng(20)
+    H, W, J = 48, 64, 20
+    videos = []
+    for v, T in enumerate((7, 5)):
+        frames = [rng.integers(0, 255, (H, W, 3)).astype(np.uint8) for _ in range(T)]
+        segs, joints, vis = [], [], []
+        for t in range(T):
+            sg = np.zeros((H, W), np.uint8)
+            sg[8 + v:30 + t, 10:40 + 2 * t] = 255
+            segs.append(sg)
+            unlabelled = (t == 3 and v == 0)
+            joints.append(None if unlabelled else np.stack([rng.random(J) * (H - 1), rng.random(J) * (W - 1)], 1))
+            vis.append(None if unlabelled else (rng.random(J) < 0.7).astype(np.int64))
+        if joints[0] is None:
+            raise AssertionError
+        videos.append((frames, segs, joints, vis))
+    preds = []
+    for frames, segs, joints, vis in videos:
+        T = len(frames)
+        p_ = np.zeros((2, J, T))
+        for t in range(T):
+            j = joints[t] if joints[t] is not None else np.zeros((J, 2))
+            p_[0, :, t] = j[:, 1] + rng.normal(0, 4, J)
+            p_[1, :, t] = j[:, 0] + rng.normal(0, 4, J)
+        preds.append(p_)
+    with tempfile.TemporaryDirectory() as tmp, ref_import.cuda_as_cpu():
+        ds = Cls.__new__(Cls)
+        ds.size, ds.length, ds.vis_traj = (H, W), -1, False
+        ds.get_video = lambda i: ([f.copy() for f in videos[i][0]], [s_.copy() for s_ in videos[i][1]],
+                                  [None if j is None else j.copy() for j in videos[i][2]],
+                                  [None if q is None else q.copy() for q in videos[i][3]], f"v{i}")
+        Cls.__len__ = lambda self: 2
+        res = ds.pck_evaluate([p_.copy() for p_ in preds], tmp)
+        txt = open(os.path.join(tmp, "result.txt")).read()
+    avg = float(txt.split("PCK@0.1 AVG:")[1].strip())                # (the per-video mean of PCK@0.2, written under this label: :552-557, :578)
+    arrs = {}
+    for v, (frames, segs, joints, vis) in enumerate(videos):
+        T = len(frames)
+        arrs[f"pred{v}"] = preds[v]
+        arrs[f"segs{v}"] = np.stack(segs, 0)
+        arrs[f"labelled{v}"] = np.array([j is not None for j in joints])
+        arrs[f"joints{v}"] = np.stack([j if j is not None else np.zeros((J, 2)) for j in joints], 0)
+        arrs[f"visible{v}"] = np.stack([q if q is not None else np.zeros(J, np.int64) for q in vis], 0)
+    save("badja_pck", n_videos=2, per_video_mean_pck02=np.float64(avg), **arrs,
+         **{k.replace("@", "_at_"): np.float64(v_) for k, v_ in res.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate single fixtures: python gen_golden.py gen_hr_tracker ...
         for name in sys.argv[1:]:
@@ -494,3 +618,5 @@ if __name__ == "__main__":
         gen_tracker_cfg0()
         gen_dense_api()
         gen_tracker_8f()
+        gen_jhmdb_pck()
+        gen_badja_pck()

@@ -32,6 +32,39 @@ def test_summary_known_answers():
         assert abs(s[k] - 100 * v) < 1e-9, (k, s[k])
 
 
+def test_jhmdb_pck_matches_reference_golden(golden):
+    """F3: metrics.jhmdb_pck against what the GENUINE jhmdb_dataset_rgb.pck_evaluate returned (jhmdb_dataset.py:174-256, lifted by AST in
+    tests/golden/gen_golden.py: gen_jhmdb_pck) for three synthetic videos -- joints marked invisible by the prediction, a clip longer
+    than its annotation, a nearly still pose.  PCK@0.1 is the accuracy figure BASELINE.json names."""
+    g = golden("jhmdb_pck")
+    n = int(g["n_videos"])
+    got = M.jhmdb_pck([g[f"pred{v}"] for v in range(n)], [g[f"gt{v}"] for v in range(n)])
+    assert set(got) == {f"PCK@{a}" for a in (0.1, 0.2, 0.3, 0.4, 0.5)}
+    for a in (0.1, 0.2, 0.3, 0.4, 0.5):
+        assert abs(got[f"PCK@{a}"] - float(g[f"PCK_at_{a}"])) < 1e-9, (a, got[f"PCK@{a}"], float(g[f"PCK_at_{a}"]))
+    assert 5.0 < got["PCK@0.1"] < got["PCK@0.5"] < 100.0                                # (a fixture that discriminates)
+
+
+def test_badja_pck_matches_reference_golden(golden):
+    """F3: metrics.badja_pck against the GENUINE BadjaDataset.pck_evaluate (badja_dataset.py:438-583, lifted by AST: gen_badja_pck) on two
+    synthetic animals: silhouette-area thresholds, (y, x) joints, visibility flags, an unlabelled frame; and the per-video mean of
+    PCK@0.2 that the reference writes out as 'PCK@0.1 AVG'."""
+    g = golden("badja_pck")
+    n = int(g["n_videos"])
+    preds, joints, vis, segs = [], [], [], []
+    for v in range(n):
+        lab = g[f"labelled{v}"]
+        preds.append(g[f"pred{v}"])
+        joints.append([g[f"joints{v}"][t] if lab[t] else None for t in range(len(lab))])
+        vis.append([g[f"visible{v}"][t] if lab[t] else None for t in range(len(lab))])
+        segs.append(list(g[f"segs{v}"]))
+    got = M.badja_pck(preds, joints, vis, segs)
+    for r in (0.1, 0.2, 0.3, 0.4):
+        assert abs(got[f"PCK@{r}"] - float(g[f"PCK_at_{r}"])) < 1e-9, (r, got[f"PCK@{r}"], float(g[f"PCK_at_{r}"]))
+    assert abs(got["PCK@0.2 per-video mean"] - float(g["per_video_mean_pck02"])) < 1e-9
+    assert 5.0 < got["PCK@0.1"] < got["PCK@0.4"] < 100.0
+
+
 def test_jhmdb_pck():
     rng = np.random.default_rng(1)
     gt = [rng.random((2, 15, 9)) * 100 + 10 for _ in range(3)]
