@@ -252,6 +252,11 @@ def _collect_worker(rank, world, port, q):
     # rank r ran videos r, r + world, ... (mmpt/datasets/samplers/distributed_sampler.py:53); video i's result carries i
     mine = [tuple(torch.full((1, 2, 3), float(i)) for _ in range(5)) for i in range(rank, 7, world)]
     out = apis.collect_results(mine, size=7)
+    # ... and the reference's default: part_{rank}.pkl files in a directory rank 0 makes (mmpt/apis/test.py:131-189)
+    out_f = apis.collect_results_cpu(mine, size=7)
+    assert (out is None) == (out_f is None)
+    if out is not None:
+        assert [float(r[2].flatten()[0]) for r in out_f] == [float(r[2].flatten()[0]) for r in out]
     q.put((rank, None if out is None else [float(r[2].flatten()[0]) for r in out]))
     dist.barrier()
     dist.destroy_process_group()
