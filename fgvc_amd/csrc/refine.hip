@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
   const int n_waves = (int)gridDim.x * 4;
   const int n_items = __builtin_amdgcn_readfirstlane(p.counters[0]);
   const int HWk = p.Hk * p.Wk;
+  float wave_err = 0.f;
   for (int it = wave; it < n_items; it += n_waves) {
     const RefineItem* I = p.items + it;
     const int row = __builtin_amdgcn_readfirstlane(I->row), q = __builtin_amdgcn_readfirstlane(I->q);
@@ -383,11 +384,10 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
           }
         }
       }
-      // every re-scored candidate is a sample of |approximate - exact|: the largest one seen goes to counters[4] (positive floats order
-      // like their bit patterns), where the host holds it against eps -- the bound is measured on the run's own data, not assumed
-#pragma unroll
-      for (int mm = 8; mm >= 1; mm >>= 1) err = fmaxf(err, __shfl_xor(err, mm));
-      if (lane == 0 && err > 0.f) atomicMax(&p.counters[4], __builtin_bit_cast(int, err));
+      // every re-scored candidate is a sample of |approximate - exact|: the largest one this wave sees goes to counters[4] when the wave
+      // is done (positive floats order like their bit patterns; ONE atomic per wave -- one per item was 62 000 atomics on one address:
+      // 0.7 ms), where the host holds it against eps -- the bound is measured on the run's own data, not assumed
+      wave_err = fmaxf(wave_err, err);
     } else {
       // every candidate of every slot, exactly
       TopK<RF_KMAX> ex;
@@ -448,6 +448,9 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
     }
     if (lane == 0) rf_write(p, row, q, osc, oid);
   }
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) wave_err = fmaxf(wave_err, __shfl_xor(wave_err, mm));
+  if (lane == 0 && wave_err > 0.f) atomicMax(&p.counters[4], __builtin_bit_cast(int, wave_err));
 }
 
 // ---- scan: RF_SCAN_PARTS workgroups of 8 waves per item.  The passes (8 box positions of one slot each: eight coalesced 1 KiB rows,
