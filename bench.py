@@ -299,6 +299,7 @@ def main():
                          "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
     ap.add_argument("--merge-on-main", action="store_true", help="the slot merge (+ exact re-scoring) behind the pair kernel on the main stream instead of "
                                                                  "on the side stream with the sweep (HipBackend.merge_on_tail = False; A/B)")
+    ap.add_argument("--no-layer1-whole-batch", action="store_true", help="the stem and layer 1 per stream lane instead of once over the whole batch (ResNet.layer1_whole_batch; A/B)")
     ap.add_argument("--no-conv64", action="store_true", help="64-channel layers on the generic fgvc_conv_split_f32 (A/B)")
     ap.add_argument("--conv64-f16f8", action="store_true", help="with --enc-arith f16f8: layer 1 and the stem's output in the f16 + fp8 form too (ResNet.conv64_f16f8; A/B)")
     ap.add_argument("--no-conv64-f16f8", action="store_true", help="layer 1 and the stem's output in the bf16 form also when the trunk computes in f16f8 (A/B)")
@@ -367,6 +368,8 @@ def main():
         ResNet.split_lanes = a.encoder_lanes
     if a.no_conv64:
         ResNet.use_conv64 = False
+    if a.no_layer1_whole_batch:
+        ResNet.layer1_whole_batch = False
     if a.encoder_graph:
         ResNet.use_graph = True
     if a.no_fuse_bank:

@@ -161,6 +161,7 @@ class ResNet(nn.Module):
     fold_projection = True         # a block's stride-1 1 x 1 projection shortcut rides in the sums of the block's second convolution
                                    # (fgvc_conv_split_proj_fmt_f32: 256 output channels, 3 x 3; not in the f16f8 arithmetic, whose e4m3
                                    # forms cannot take a forced weight scale): no projection launch, no dense f32 identity (False: A/B)
+    layer1_whole_batch = True      # the stem and layer 1 once over the whole batch, the stream lanes fork behind them (see _trunk)
     fuse_bank = True               # the trunk's last convolution writes the pair kernel's feature bank itself (fgvc_conv_split_bank_f16f6p_f32)
                                    # when the caller asks for f16f6 rows of a 256-channel stage: no dense f32 output, no normalise pass;
                                    # byte-identical rows (False: the two-kernel route, kept for A/B and as the reference of the tests)
@@ -677,9 +678,16 @@ class ResNet(nn.Module):
                     s.wait_stream(main)
             else:
                 streams = [main]
+            # Layer 1 runs on fgvc_conv64_split_fmt_f32 -- one wave per SIMD owns the whole register file (the weights live there), so two
+            # lanes' launches cannot share a CU: they take turns, and each pays its own prologue (147 KB of weights per workgroup) and its
+            # own ragged last round of tiles.  With `layer1_whole_batch` the stem and layer 1 therefore run ONCE over the whole batch on
+            # the caller's stream and the lanes fork behind them (measured: bench.py --no-layer1-whole-batch).
+            whole = bool(n_lanes > 1 and self.layer1_whole_batch and last >= 1 and calib is None and 0 not in fresh
+                         and all(self._is_conv64(b.conv1) and self._is_conv64(b.conv2) for b in stages[0]))
+            lane_streams = [main] if whole else streams
             lanes = []
-            for li, s in enumerate(streams):
-                lo, hi = li * N // n_lanes, (li + 1) * N // n_lanes
+            for li, s in enumerate(lane_streams):
+                lo, hi = (0, N) if whole else (li * N // n_lanes, (li + 1) * N // n_lanes)
                 with torch.cuda.stream(s):
                     if stem7:                                                   # stem on the bf16 pipe, from the NCHW frames
                         H, W, C0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1, 64
@@ -709,6 +717,16 @@ class ResNet(nn.Module):
                     nb = stages[i + 1][0]
                     st = nb.conv1.conv.stride
                     need_f32 = nb.downsample is None or not (st == (1, 1) or (st == (2, 2) and self.use_s2_conv))
+                if whole and i == 0:
+                    one = self._stage_split(0, dict(lanes[0], need_split=True, need_f32=need_f32), call)     # the whole batch, on `main`
+                    fulls.append(one["full"])
+                    for s in streams:
+                        s.wait_stream(main)
+                    lanes = []
+                    for li in range(n_lanes):                                    # ... and the lanes take their slices of its output
+                        lo, hi = li * N // n_lanes, (li + 1) * N // n_lanes
+                        lanes.append(dict(one, split=one["split"][lo:hi], f32=None if one["f32"] is None else one["f32"][lo:hi], lo=lo, hi=hi))
+                    continue
                 for li, s in enumerate(streams):                                 # lanes interleaved stage by stage
                     with torch.cuda.stream(s):
                         lanes[li] = self._stage_split(i, dict(lanes[li], need_split=i < last, need_f32=need_f32), call)
@@ -762,7 +780,7 @@ class ResNet(nn.Module):
         cache = self.__dict__.setdefault("_split_cache", {})
         # (everything a captured pass bakes in besides the input: the class-level switches tests and A/B runs flip between calls)
         sig = (self.arith, self.split_lanes, self.use_conv64, self.use_stem7, self.use_s2_conv, self.conv64_f16f8, self.res_from_split,
-               self.use_split_conv, self.fuse_bank, self.fold_projection, tuple(self.out_indices))
+               self.use_split_conv, self.fuse_bank, self.fold_projection, self.layer1_whole_batch, tuple(self.out_indices))
         key = ("graph", tuple(x.shape), x.device, bool(normalize), split_fmt, split_if is not None, sig)
         ent = cache.get(key)
         if ent is None:                                        # first call of this shape: eager (it may calibrate and allocate)

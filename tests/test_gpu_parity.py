@@ -1753,3 +1753,32 @@ def test_encoder_projection_rides_in_the_second_convolution(dev):
             assert float((got - ref).abs().max()) <= tol * top + 1e-6, (arith, float((got - ref).abs().max()), top)
             assert float((got - sep).abs().max()) <= tol * top + 1e-6
             assert (arith == "f16f8") == bool(torch.equal(got, sep))          # (the fold did change the arithmetic where it applies)
+
+
+@pytest.mark.gpu
+def test_encoder_layer1_whole_batch_equals_lanes(dev):
+    """ResNet.layer1_whole_batch (round 5): the stem and layer 1 once over the whole batch on the caller's stream, the stream lanes forking
+    behind them (layer 1's register-resident kernel cannot share a CU between lanes) -- the same bank bit for bit as with every stage in
+    lanes, in every arithmetic, for an odd batch (lanes of 2 and 3 frames)."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd.mmpt_api.backbones import ResNet
+    net = api.build_backbone(dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none"))
+    net.load_state_dict(O.seeded_resnet_state(9, (1, 2, 1, 1), "none"))
+    net = net.to(dev).eval()
+    x = torch.randn(5, 3, 72, 104, generator=torch.Generator().manual_seed(4)).to(dev)
+    yes = lambda C, H, W: True
+    assert ResNet.layer1_whole_batch
+    with torch.no_grad():
+        for arith in net.supported_arith():
+            net.set_arith(arith)
+            fmt = "f16f6x" if arith in ("f16f6", "f16f8") else "f16"
+            a = net.forward_hwc(x, True, split_if=yes, split_fmt=fmt)[0].clone()
+            try:
+                ResNet.layer1_whole_batch = False
+                b = net.forward_hwc(x, True, split_if=yes, split_fmt=fmt)[0].clone()
+            finally:
+                ResNet.layer1_whole_batch = True
+            assert torch.equal(a, b), arith
+            f32 = net.forward_hwc(x, True)[0]
+            assert f32.dtype == torch.float32 and bool(torch.isfinite(f32).all())
+    assert not net.check_overflow()
