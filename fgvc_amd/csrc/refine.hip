@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
 // (eight coalesced 1 KiB loads in flight), products and sums in f64; the eight partial sums per lane are reduced across the wave by a
 // transposing butterfly -- each of the first three exchanges halves the values a lane carries -- in 10 exchanges instead of 48.
 // Returns the total of row ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1): rf_mine(lane).  Exact products, a fixed
-// order of sums: the same bits wherever a row is scored (re-scoring and the from-scratch scan share this routine).
+// order of sums (the from-scratch scan and the slow path use this routine; the refine kernel's 16-lane groups sum the same exact
+// products in another order: the two agree to the last bit except where an f64 sum sits on an f32 rounding boundary).
 __device__ __forceinline__ int rf_mine(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
 __device__ __forceinline__ void rf_load8(const unsigned char* const (&krow)[8], int lane, f32x4 (&b)[8]) {
 #pragma unroll
@@ -331,18 +332,14 @@ __device__ __forceinline__ double rf_dot8(const f32x4& a, const unsigned char* c
   return rf_reduce8(a, b, lane);
 }
 
-__global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  const int n_waves = (int)gridDim.x * 4;
-  const int n_items = __builtin_amdgcn_readfirstlane(p.counters[0]);
+// One work item on a whole wave (round 5's first form of the refine kernel).  Since the items went four to a wave (refine_kernel below) this
+// serves the from-scratch items that found the scan queue full: every candidate of every slot, exactly, candidate by candidate.
+__device__ __forceinline__ void refine_item_wave(const RefineParams& p, const RefineItem* I, int lane, float& wave_err) {
   const int HWk = p.Hk * p.Wk;
-  float wave_err = 0.f;
-  for (int it = wave; it < n_items; it += n_waves) {
-    const RefineItem* I = p.items + it;
+  {
     const int row = __builtin_amdgcn_readfirstlane(I->row), q = __builtin_amdgcn_readfirstlane(I->q);
     const int flags = __builtin_amdgcn_readfirstlane(I->flags);
-    if ((flags & RF_BRUTE) && !(flags & RF_INLINE)) continue;            // queued for the scan kernels
+    if ((flags & RF_BRUTE) && !(flags & RF_INLINE)) return;              // queued for the scan kernel
     int m = __builtin_amdgcn_readfirstlane(I->m);
     int gid = I->gid[lane & 15];
     float sc = I->sc[lane & 15];
@@ -448,9 +445,127 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
     }
     if (lane == 0) rf_write(p, row, q, osc, oid);
   }
+}
+
+
+// The refine kernel: FOUR work items per wave, 16 lanes each.  An item's chain -- its record, the frames of its entries, their rows, the
+// reduction, the lists -- is a handful of dependent round trips; one item per wave left 48 lanes of every step idle and 62 000 items of a
+// noise clip took 0.12 ms.  Lane `sub` of a group holds entry `sub` of its item's 16 and resolves that entry's row address itself; a
+// 1 KiB row is 16 lanes x 64 bytes; sums in f64 over the lane's 16 products, then four exchanges inside the group.
+__global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, g0 = lane & 48;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const int n_waves = (int)gridDim.x * 4;
+  const int n_items = __builtin_amdgcn_readfirstlane(p.counters[0]);
+  const int HWk = p.Hk * p.Wk;
+  float wave_err = 0.f;
+  for (int base = 4 * wave; base < n_items; base += 4 * n_waves) {
+    const int it = base + (lane >> 4);
+    const bool active = it < n_items;
+    const RefineItem* I = p.items + (active ? it : base);
+    const int row = I->row, q = I->q, flags = I->flags, m = I->m;
+    int gid = I->gid[sub];
+    float sc = I->sc[sub];
+    const bool mine = active && !(flags & RF_BRUTE);                     // (from-scratch items: the scan kernel's, or refine_inline_kernel's)
+    const unsigned mask = mine ? ((unsigned)flags & 0xffffu) : 0u;
+    // this lane's entry: its key frame and row; the query frame is the same for every slot of the row
+    const bool ent = mine && gid != IDX_EMPTY && sub < m;
+    const int t_ = ent ? gid / HWk : 0, pix = ent ? gid - t_ * HWk : 0;
+    const int pid = ent ? p.slot_pair[row * p.T + t_] : -1;
+    const int4 pr = pid >= 0 ? p.pairs[pid] : int4{0, 0, 0, 0};
+    const unsigned char* my_row = p.k_exact + (size_t)pr.y * p.k_frame_bytes + (size_t)pix * p.k_row_bytes;
+    const int qf = __shfl(pr.x, g0);                                     // entry 0 is valid whenever the item has a window
+    const unsigned char* qrow = p.q_exact + (size_t)qf * p.q_frame_bytes + (size_t)(mine ? q : 0) * p.q_row_bytes + 64 * sub;
+    f32x4 qv[4];
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const f32x4*>(qrow + 16 * j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float err = 0.f;
+    // the entries any of the wave's four items re-scores, four at a time: their 16 row loads are in flight together (one entry per
+    // pass waited for a row's round trip 6-8 times per wave: 66 us per launch where one item per wave had taken 43)
+    unsigned um = mask;
+    um |= __shfl_xor(um, 16);
+    um |= __shfl_xor(um, 32);
+    um = (unsigned)__builtin_amdgcn_readfirstlane((int)um);
+    while (um) {
+      int ev[4];
+      bool nd[4];
+      f32x4 kv[4][4];
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) {
+        ev[b4] = um ? __builtin_ctz(um) : -1;                              // wave-uniform
+        if (um) um &= um - 1;
+        nd[b4] = ev[b4] >= 0 && ((mask >> ev[b4]) & 1u);
+        const unsigned long long ra = __shfl((unsigned long long)(size_t)my_row, g0 + (ev[b4] >= 0 ? ev[b4] : 0));
+        const unsigned char* kr = nd[b4] ? reinterpret_cast<const unsigned char*>((size_t)ra) + 64 * sub : qrow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kv[b4][j] = *reinterpret_cast<const f32x4*>(kr + 16 * j);
+      }
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) {
+        if (ev[b4] < 0) continue;                                         // wave-uniform
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sacc = fma((double)qv[j].x, (double)kv[b4][j].x, sacc);
+          sacc = fma((double)qv[j].y, (double)kv[b4][j].y, sacc);
+          sacc = fma((double)qv[j].z, (double)kv[b4][j].z, sacc);
+          sacc = fma((double)qv[j].w, (double)kv[b4][j].w, sacc);
+        }
+#pragma unroll
+        for (int mm = 8; mm >= 1; mm >>= 1) sacc += __shfl_xor(sacc, mm);
+        if (nd[b4] && sub == ev[b4]) {
+          const float got = (float)sacc;
+          err = fmaxf(err, fabsf(got - sc));          // the pair kernel's error on this candidate: what `eps` is a bound of
+          sc = got;
+        }
+      }
+    }
+    wave_err = fmaxf(wave_err, err);
+    // rank of this lane's entry among the m entries of its item's window: (score desc, index asc)
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < RF_KX; ++j) {
+      const float sj = __shfl(sc, g0 + j);
+      const int gj = __shfl(gid, g0 + j);
+      rank += (j < m && (sj > sc || (sj == sc && gj < gid))) ? 1 : 0;
+    }
+    const bool inwin = mine && sub < m;
+    float osc[RF_KMAX];
+    int oid[RF_KMAX];
+#pragma unroll
+    for (int r = 0; r < RF_KMAX; ++r) {
+      const unsigned long long bal = __ballot(inwin && rank == r);
+      const unsigned grp = (unsigned)(bal >> g0) & 0xffffu;
+      const int src = g0 + (grp ? __builtin_ctz(grp) : 0);
+      const float v = __shfl(sc, src);
+      const int gi = __shfl(gid, src);
+      osc[r] = grp ? v : -INFINITY;
+      oid[r] = grp ? gi : IDX_EMPTY;
+    }
+    if (mine && sub == 0) rf_write(p, row, q, osc, oid);
+  }
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) wave_err = fmaxf(wave_err, __shfl_xor(wave_err, mm));
   if (lane == 0 && wave_err > 0.f) atomicMax(&p.counters[4], __builtin_bit_cast(int, wave_err));
+}
+
+// ... and the from-scratch items that found the scan queue full, one per wave (a launch that ends at once when there are none)
+__global__ __launch_bounds__(256) void refine_inline_kernel(RefineParams p) {
+  if (p.counters[3] == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const int n_waves = (int)gridDim.x * 4;
+  const int n_items = __builtin_amdgcn_readfirstlane(p.counters[0]);
+  float wave_err = 0.f;
+  for (int it = wave; it < n_items; it += n_waves) {
+    const int flags = __builtin_amdgcn_readfirstlane(p.items[it].flags);
+    if ((flags & RF_BRUTE) && (flags & RF_INLINE)) refine_item_wave(p, p.items + it, lane, wave_err);
+  }
 }
 
 // ---- scan: RF_SCAN_PARTS workgroups of 8 waves per item.  The passes (8 box positions of one slot each: eight coalesced 1 KiB rows,
@@ -679,6 +794,8 @@ int merge_refine_launch(const RefineParams& p_in, int n_out, void* workspace, hi
   FGVC_CHECK_LAUNCH("fgvc_merge_refine_topk_f32 (merge)");
   refine_kernel<<<1024, 256, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_merge_refine_topk_f32 (refine)");
+  refine_inline_kernel<<<1024, 256, 0, s>>>(p);
+  FGVC_CHECK_LAUNCH("fgvc_merge_refine_topk_f32 (inline)");
   refine_scan_kernel<<<1024, RF_SCAN_WAVES * 64, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_merge_refine_topk_f32 (scan)");
   return FGVC_OK;
