@@ -39,7 +39,7 @@ struct Conv64Params {
   float out_scale;         // out_fmt 1: s_y of the split output
   int out_fmt;             // split output: 0 = (hi, lo) bf16, 1 = f16 + fp8 (FGVC_ACT_F16F8)
   int* overflow;           // out_fmt 1: OR-ed with 1 when |s_y y| leaves the f16 range
-  int variant;             // option "conv64_variant": 8 = s_memtime probe of workgroup 77 (fgvc_conv64_probe)
+  int variant;             // option "conv64_variant": 8 = s_memtime probe of workgroup 77 (fgvc_conv64_probe), 16 = the f16 + fp8 form on conv64_kernel<1>
 };
 
 __device__ __forceinline__ void c64_lds_dma_16(const void* src_lane, uint32_t lds_uniform) {
@@ -436,6 +436,352 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(Conv64Params p) {
   }
 }
 
+// ---- round 5: the f16 + fp8 form with the K dimension split across the waves ------------------------------------------------------
+// conv64_kernel's wave (ct, rg) multiplies 32 output channels x 2 pixel rows over the whole K = 576: every activation operand it reads
+// from the LDS feeds ONE matrix instruction, the two waves of a row pair read the same bytes, and a patch row is read again for every
+// kernel row it serves: 576 KiB of LDS reads per tile = 4608 cycles at 128 B/clock -- exactly the tile's 4608 MFMA cycles, on top of
+// the patch DMA (60 KiB) and the epilogue's transposition (128 KiB).  The LDS, not the matrix pipe, paced the multiply loop
+// (11 000 of its 14 500 cycles per tile).  Here wave (kh, rg) owns ALL 64 output channels x 2 pixel rows over ONE 32-channel chunk of the input
+// (the same 288 weight registers), and walks the 4 patch rows x 3 column shifts of its row pair once: an operand (4 reads) feeds up
+// to 12 matrix instructions -- both channel tiles, and both pixel rows it is a kernel-row neighbour of.  48 KiB of reads per wave and
+// tile instead of 144.  The two chunk halves of an accumulator meet through the LDS: each wave hands the channel tile it does not
+// finish to its partner (8 KiB), adds what it receives (f32 addition commutes: the sum does not depend on who adds) and runs the old
+// epilogue on channel tile kh.  Accumulation order: per chunk as before (taps ascending; f16 k-steps, then the fp8 cross terms), the two
+// chunk sums added last (conv64_kernel interleaves the chunks tap by tap: last-bit differences, both within the test bounds).
+constexpr int C64_XCH = 8192;                              // per wave: 2 pixel rows x 16 accumulator registers x 64 lanes x 4 B
+
+__global__ __launch_bounds__(256, 1) void conv64k_kernel(Conv64Params p) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) unsigned char patches[2 * C64_PATCHB];
+  __shared__ __attribute__((aligned(16))) unsigned char xch[4 * C64_XCH];     // exchange of partial sums, then the epilogue's tiles
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave & 1, rg = wave >> 1;                  // input chunk of the multiplies = output channel tile of the epilogue; row pair
+  const int n = lane & 31, h = lane >> 5;
+  const int d_row = lane >> 3, d_slot = lane & 7;
+
+  // weights: index 0 of the channel-tile dimension = the tile this wave FINISHES (ct = kh), index 1 = the one it hands to its partner
+  f16x8 wf[9][2][2];                                        // [tap][own | other][k-step]
+  i32x8 wx[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint16_t* wp = p.w + ((((size_t)(j ^ kh) * 9 + t) * 2 + kh) * 4) * 512;
+      wf[t][j][0] = *reinterpret_cast<const f16x8*>(wp + lane * 8);
+      wf[t][j][1] = *reinterpret_cast<const f16x8*>(wp + 512 + lane * 8);
+      wx[t][j] = *reinterpret_cast<const i32x8*>(wp + 1024 + lane * 16);
+    }
+  const uint32_t sa_ = h ? (uint32_t)(127 - F8_BW) : (uint32_t)(127 + F8_AW), sb_ = h ? (uint32_t)(127 + F8_AX) : (uint32_t)(127 - F8_BX);
+  const int scale_a = (int)(sa_ * 0x01010101u), scale_b = (int)(sb_ * 0x01010101u);
+  if (tid < 64) bias_s[tid] = p.bias[tid];
+
+  // The patch DMA.  A wave issues ONE instruction per four cycles (the sequencer visits a SIMD every fourth cycle and this wave is the
+  // SIMD's only one), so every scalar instruction of the address arithmetic costs what a vector instruction costs: conv64_kernel's
+  // per-piece origin arithmetic (divisions by constants, 64-bit multiplies: ~27 instructions x 15 pieces) was 1 600 of a tile's 14 500
+  // cycles.  Here lane k of one register holds what piece wave + 4 k needs -- lanes 0-14 the byte offset of its 8 pixels from the
+  // tile's first patch pixel, lanes 16-30 its LDS offset in a patch buffer, lanes 32-46 its swizzle key (0 or 64: the XOR of the lanes'
+  // source offsets) --, three v_readlane per piece.
+  const uint32_t lane_off0 = (uint32_t)(d_row * 256 + ((d_slot ^ (d_row >> 1)) << 4));
+  int piece_tab;
+  {
+    const int k = lane & 15, i = wave + 4 * k;              // (k = 15: unused)
+    const int chunk = i / ((C64_TR + 2) * 5), r2 = i - chunk * ((C64_TR + 2) * 5);
+    const int prow = r2 / 5, pc0 = (r2 - prow * 5) * 8;
+    const int goff = (prow * p.Wp + pc0) * 256 + chunk * 128;
+    const int ldst = chunk * C64_CHUNKB + (prow * C64_PW + pc0) * 128;
+    const int key = (((prow * C64_PW + pc0) >> 1) & 4) << 4;
+    piece_tab = lane < 16 ? goff : lane < 32 ? ldst : key;
+  }
+  const uint32_t patches_lds = c64_lds_addr(patches);
+  auto stage_piece = [&](const unsigned char* tile_base, int buf, int k) {     // k: compile-time
+    const uint32_t goff = (uint32_t)__builtin_amdgcn_readlane(piece_tab, k);
+    const uint32_t dst = patches_lds + (uint32_t)(buf * C64_PATCHB) + (uint32_t)__builtin_amdgcn_readlane(piece_tab, 16 + k);
+    const uint32_t off = lane_off0 ^ (uint32_t)__builtin_amdgcn_readlane(piece_tab, 32 + k);
+    const unsigned char* base = tile_base + goff;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
+  };
+  const int G = gridDim.x;
+  auto tile_at = [&](int k) { return k * G + (int)blockIdx.x; };
+  auto tile_origin = [&](int tile, int& nimg, int& y0, int& x0) {
+    nimg = tile / (p.n_ty * p.n_tx);
+    const int rem = tile - nimg * p.n_ty * p.n_tx;
+    const int ty = rem / p.n_tx;
+    y0 = ty * C64_TR;
+    x0 = (rem - ty * p.n_tx) * 32;
+  };
+  auto patch_base = [&](int nimg, int y0, int x0) {
+    return reinterpret_cast<const unsigned char*>(p.x) + (((size_t)nimg * p.Hp + y0) * p.Wp + x0) * 256;
+  };
+  // lane part of the operand addresses: pixel n + dx of a patch row, slot h of its 128-byte row in this wave's chunk; [dx][patch row
+  // parity].  Slots 2 + h (f16 k-step 1), 4 + h (l8), 6 + h (h8) are this address with bits 5 / 6 / 5-6 flipped (everything else in it is
+  // a multiple of 128).
+  uint32_t lane_b[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const uint32_t key = (uint32_t)((((n + dx) >> 1) & 7) ^ (4 * par));
+      lane_b[dx][par] = (uint32_t)((n + dx) * 128 + kh * C64_CHUNKB) + ((((uint32_t)h) ^ key) << 4);
+    }
+  // the f32 residual as a raw buffer (range-checked: conv64_launch keeps this kernel to tensors below 4 GiB)
+  const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.residual), 0, p.residual ? (int)((unsigned)p.N * (unsigned)p.H * (unsigned)p.W * 256u) : 0, 0x00020000);
+  const int res_voff = (lane >> 3) * 256 + (lane & 7) * 16;
+  const bool probe = (p.variant & 8) && blockIdx.x == 77;
+  long long pb = 0, pm = 0, pw = 0, pe = 0, pn = 0;
+  int it = 0, tile = tile_at(0), buf = 0;
+  if (tile < p.n_tiles) {
+    int ni, ya, xa;
+    tile_origin(tile, ni, ya, xa);
+    const unsigned char* tb = patch_base(ni, ya, xa);
+#pragma unroll
+    for (int k = 0; k < 15; ++k) stage_piece(tb, 0, k);
+  }
+  // (the BUILTIN, not an assembly statement: the compiler's own wait-count pass must see that the weight loads above are complete.  It
+  // did not see conv64_kernel's assembly wait, guarded the first use of every weight register INSIDE the tile loop with a counted
+  // vmcnt(N) of its own -- needed in the first tile only, executed in all -- and, blind to the assembly DMAs in flight, each of those
+  // waited for recent DMA pieces to land: most of what the residual's loads seemed to cost, 2 800-7 000 cycles per tile)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+  for (; tile < p.n_tiles; tile = tile_at(++it), buf ^= 1) {
+    int nimg, y0, x0;
+    tile_origin(tile, nimg, y0, x0);
+    const long long t0 = probe ? __builtin_amdgcn_s_memtime() : 0;
+    lds_barrier();                                          // patch `buf` complete, buffer buf ^ 1 and the exchange region free
+    const long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0;
+    const int next = tile_at(it + 1);
+    const bool has_next = next < p.n_tiles;
+    int nimg_n = 0, y0_n = 0, x0_n = 0;
+    if (has_next) tile_origin(next, nimg_n, y0_n, x0_n);
+    const unsigned char* next_base = patch_base(nimg_n, y0_n, x0_n);
+
+    i32x4 res[2][4];                                       // residual rows in the STORE layout: [pixel row b][pixels 8 i + lane / 8], 16 B at (lane & 7) * 16
+    f32x16 acc[2][2];                                       // [own | other channel tile][pixel row of the pair]
+    const uint32_t pbase = patches_lds + (uint32_t)(buf * C64_PATCHB) + (uint32_t)(2 * rg * C64_PW * 128);
+    f16x8 fc[2], fn[2];
+    i32x4 xc[2], xn[2];
+    auto load_b = [&](f16x8* df, i32x4* dxp, int g) {       // group g = (patch row r of the wave's four, column shift dx)
+      const int r = g / 3, dx = g % 3;
+      const uint32_t rowbase = pbase + (uint32_t)(r * C64_PW * 128);
+      uint32_t a0;
+      C64_ADDR(a0, rowbase, lane_b[dx][r & 1]);
+      const uint32_t a1 = a0 ^ 32u, a2 = a0 ^ 64u, a3 = a0 ^ 96u;
+      C64_READ(df[0], a0, 0); C64_READ(df[1], a1, 0); C64_READ(dxp[0], a2, 0); C64_READ(dxp[1], a3, 0);
+    };
+    // What rides in the shadow of matrix instruction j of group g (a 32x32x16 f16 product covers 7 more issue slots, the fp8 one 15):
+    // the next group's operand reads behind the first, the next patch's DMA pieces (15 per wave) behind the first two fp8 products,
+    // the residual rows' loads late in the tile.
+    auto side = [&](int g, int j, int M) {
+      if (j == 0 && g + 1 < 12) load_b(fn, xn, g + 1);
+      if (has_next) {
+        if (j == M - 2 && 2 * g < 15) stage_piece(next_base, buf ^ 1, 2 * g);
+        if (j == M - 1 && 2 * g + 1 < 15) stage_piece(next_base, buf ^ 1, 2 * g + 1);
+      }
+      if (p.residual && (g == 7 || g == 8) && j >= 2 && j < 6) {
+        // eight loads of 8 pixels x 128 B: scalar row origin + the lane's (pixel, 16-byte column) + an immediate; pixels beyond the row's end
+        // read what follows in the tensor (never stored), beyond the tensor's end the buffer's range check returns zeros
+        const int b = g - 7, i = j - 2;
+        const int y = imin(y0 + 2 * rg + b, p.H - 1);
+        const int soff = ((nimg * p.H + y) * p.W + x0) * 256 + kh * 128;
+        res[b][i] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_voff + i * 2048, soff, 0);
+      }
+    };
+    load_b(fc, xc, 0);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      const int r = g / 3, dx = g % 3;
+      const int M = (r == 0 || r == 3) ? 6 : 12;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this group's operands (read during the group before)
+      const i32x8 xv = __builtin_shufflevector(xc[0], xc[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      int j = 0;
+      // pixel row b of the pair sees patch row r as kernel row dy = r - b
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int dy = r - b;
+          if (dy < 0 || dy > 2) continue;
+          const int t = dy * 3 + dx;
+          const bool first = (dy == 0 && dx == 0 && part == 0);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            if (part < 2) {
+              if (first) C64_MFMA_F0(acc[ct][b], wf[t][ct][part], fc[part]);
+              else C64_MFMA_F(acc[ct][b], wf[t][ct][part], fc[part]);
+            } else if (t < 7) {
+              C64_MFMA_XA(acc[ct][b], wx[t][ct], xv, scale_a, scale_b);
+            } else {
+              C64_MFMA_XV(acc[ct][b], wx[t][ct], xv, scale_a, scale_b);
+            }
+            side(g, j, M);
+            ++j;
+          }
+        }
+      fc[0] = fn[0]; fc[1] = fn[1]; xc[0] = xn[0]; xc[1] = xn[1];
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results before vector instructions read them
+    const long long t2 = probe ? __builtin_amdgcn_s_memtime() : 0;
+    // ---- the other channel tile's partial sums to the partner wave (same row pair, other chunk)
+    {
+      unsigned char* xw = xch + wave * C64_XCH + lane * 16;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(xw + (b * 4 + q) * 1024) = f32x4{acc[1][b][4 * q + 0], acc[1][b][4 * q + 1], acc[1][b][4 * q + 2], acc[1][b][4 * q + 3]};
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): the next patch's DMAs and the residual loads (older than anything the epilogue issues)
+    const long long t3 = probe ? __builtin_amdgcn_s_memtime() : 0;
+    lds_barrier();
+    unsigned char* tw = xch + (wave ^ 1) * C64_XCH;         // what the partner left; afterwards this wave's transposition tile (only this wave
+                                                            // reads the region, and the partner writes it again behind the next tile's barrier)
+    f32x4 fin[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(tw + lane * 16 + (b * 4 + q) * 1024);
+        fin[b][q] = f32x4{acc[0][b][4 * q + 0], acc[0][b][4 * q + 1], acc[0][b][4 * q + 2], acc[0][b][4 * q + 3]} + o;
+      }
+    wave_sync();
+
+    // ---- epilogue on channel tile kh: scale + bias (+ residual) (+ ReLU), the output formats, 128-byte rows per pixel through the wave's
+    // LDS tile.  Without a residual (a block's first convolution) conv64_kernel's order: everything in the accumulator layout (pixel on the
+    // lane), the finished rows transposed.  With one: the sums are transposed FIRST and the rest happens in the store layout (8 lanes per
+    // pixel, 4 channels each) -- there the residual's loads are the coalesced ones prefetched above.  In the accumulator layout they were
+    // 64 lanes x 16 B from 32 cache lines per instruction, eight per tile: 2 800 cycles of a tile's 17 000 (the wave waits at the ISSUE of
+    // such a load, and nothing else runs on its SIMD).
+    const int mv_row = lane >> 3, mv_col = (lane & 7) * 16;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int y = y0 + 2 * rg + b;
+      if (y >= p.H) continue;                               // wave-uniform
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + kh * 32 + 8 * g + 4 * h);
+        v[g] = {fmaf(fin[b][g].x, p.acc_scale, bv.x), fmaf(fin[b][g].y, p.acc_scale, bv.y), fmaf(fin[b][g].z, p.acc_scale, bv.z),
+                fmaf(fin[b][g].w, p.acc_scale, bv.w)};
+      }
+      const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
+      unsigned char* dst_s = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * 2 + kh) * 128;
+      unsigned char* dst_f = reinterpret_cast<unsigned char*>(p.y_f32 + (((size_t)nimg * p.H + y) * p.W + x0) * 64 + kh * 32);
+      if (p.residual) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(tw + n * C64_RS + (8 * g + 4 * h) * 4) = v[g];
+        wave_sync();
+        f32x4 u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const f32x4*>(tw + (i * 8 + mv_row) * C64_RS + mv_col);
+        wave_sync();
+        bool ovf = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + mv_row;
+          u[i] += __builtin_bit_cast(f32x4, res[b][i]);
+          if (p.relu) {
+            u[i].x = fmaxf(u[i].x, 0.f); u[i].y = fmaxf(u[i].y, 0.f); u[i].z = fmaxf(u[i].z, 0.f); u[i].w = fmaxf(u[i].w, 0.f);
+          }
+          if (p.y_f32 && x0 + row < p.W) *reinterpret_cast<f32x4*>(dst_f + (size_t)row * 256 + mv_col) = u[i];
+          if (p.y_split) {                                  // this lane's 4 channels of the pixel's split row: [h 64 B | l8 32 B | h8 32 B] or (hi, lo) bf16
+            unsigned char* o = tw + row * C64_RS;
+            if (p.out_fmt == 0) {
+              ushort4 hv, lv;
+              split_bf16_4(u[i], hv, lv);
+              *reinterpret_cast<ushort4*>(o + (mv_col >> 1)) = hv;
+              *reinterpret_cast<ushort4*>(o + 64 + (mv_col >> 1)) = lv;
+            } else {
+              uint2 hw, lw;
+              uint32_t l8, h8;
+              bool of1 = false;
+              split_f16_4(u[i], p.out_scale, hw, l8, h8, lw, of1);
+              ovf |= of1 && x0 + row < p.W;
+              *reinterpret_cast<uint2*>(o + (mv_col >> 1)) = hw;
+              *reinterpret_cast<uint32_t*>(o + 64 + (mv_col >> 2)) = l8;
+              *reinterpret_cast<uint32_t*>(o + 96 + (mv_col >> 2)) = h8;
+            }
+          }
+        }
+        if (p.y_split) {
+          if (p.out_fmt != 0 && __builtin_amdgcn_ballot_w64(ovf) != 0ull && lane == 0) atomicOr(p.overflow, 1);
+          wave_sync();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + mv_row;
+            if (x0 + row < p.W)
+              *reinterpret_cast<uint4*>(dst_s + (size_t)row * 256 + mv_col) = *reinterpret_cast<const uint4*>(tw + row * C64_RS + mv_col);
+          }
+          wave_sync();
+        }
+        continue;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f);
+        }
+      }
+      if (p.y_f32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(tw + n * C64_RS + (8 * g + 4 * h) * 4) = v[g];
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + mv_row;
+          if (x0 + row < p.W)
+            *reinterpret_cast<uint4*>(dst_f + (size_t)row * 256 + mv_col) = *reinterpret_cast<const uint4*>(tw + row * C64_RS + mv_col);
+        }
+        wave_sync();
+      }
+      if (p.y_split) {
+        if (p.out_fmt == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            ushort4 hv, lv;
+            split_bf16_4(v[g], hv, lv);
+            unsigned char* o = tw + n * C64_RS + (8 * g + 4 * h) * 2;
+            *reinterpret_cast<ushort4*>(o) = hv;
+            *reinterpret_cast<ushort4*>(o + 64) = lv;
+          }
+        } else {
+          bool ovf = false;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hw, lw;
+            uint32_t l8, h8;
+            split_f16_4(v[g], p.out_scale, hw, l8, h8, lw, ovf);
+            unsigned char* o = tw + n * C64_RS;
+            *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw;
+            *reinterpret_cast<uint32_t*>(o + 64 + 8 * g + 4 * h) = l8;
+            *reinterpret_cast<uint32_t*>(o + 96 + 8 * g + 4 * h) = h8;
+          }
+          if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.W) != 0ull && lane == 0) atomicOr(p.overflow, 1);
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + mv_row;
+          if (x0 + row < p.W)
+            *reinterpret_cast<uint4*>(dst_s + (size_t)row * 256 + mv_col) = *reinterpret_cast<const uint4*>(tw + row * C64_RS + mv_col);
+        }
+        wave_sync();
+      }
+    }
+    if (probe) {
+      const long long t4 = __builtin_amdgcn_s_memtime();
+      pb += t1 - t0; pm += t2 - t1; pw += t3 - t2; pe += t4 - t3; pn += 1;
+    }
+  }
+  if (probe && lane == 0) {
+    g_c64_probe[wave * 8 + 0] = pb; g_c64_probe[wave * 8 + 1] = pm; g_c64_probe[wave * 8 + 2] = pw; g_c64_probe[wave * 8 + 3] = pe;
+    g_c64_probe[wave * 8 + 4] = pn;
+  }
+}
+
 int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, const uint16_t* res_split,
                   uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, int in_fmt, int in_scale_log2,
                   int out_fmt, int out_scale_log2, int* overflow, hipStream_t s) {
@@ -452,7 +798,9 @@ int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const
   p.n_tiles = (int)tiles;
   p.variant = g_conv64_variant;
   const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
-  if (in_fmt == 1) conv64_kernel<1><<<grid, 256, 0, s>>>(p);
+  const bool res_fits = !residual || (unsigned long long)N * H * W * 256ull < (1ull << 32);      // conv64k_kernel reads the residual as a 32-bit raw buffer
+  if (in_fmt == 1 && !(p.variant & 16) && res_fits) conv64k_kernel<<<grid, 256, 0, s>>>(p);      // option conv64_variant & 16: round 3's kernel (A/B)
+  else if (in_fmt == 1) conv64_kernel<1><<<grid, 256, 0, s>>>(p);
   else conv64_kernel<0><<<grid, 256, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32");
   return FGVC_OK;
