@@ -782,6 +782,448 @@ __global__ __launch_bounds__(256, 1) void conv64k_kernel(Conv64Params p) {
   }
 }
 
+// ---- round 5: the f16 + fp8 form as ONE instruction stream per tile ---------------------------------------------------------------
+// What the s_memtime probes of conv64_kernel<1> and of the K-split experiment above showed: the LDS was never the limit.  A wave that
+// owns its SIMD issues one instruction per ~4 cycles, in order; a matrix instruction occupies the pipe for 32 (f16 32x32x16) or 64
+// cycles (fp8 32x32x64) and only what is issued RIGHT BEHIND it -- ~5 resp. ~13 instructions -- is free.  conv64_kernel put the
+// operand reads, the DMA's address arithmetic (27 scalar instructions per piece) and the residual's loads BETWEEN its groups of six
+// matrix instructions and the whole epilogue behind the last: ~2 400 of a tile's ~3 600 instructions ran with the pipe idle, 14 500
+// cycles per tile against 4 608 of matrix work.  The compiler's own s_waitcnt vmcnt(N) -- counted without the assembly DMAs, guarding
+// the first use of each weight register INSIDE the loop because it had not seen the assembly wait in front of it -- stalled on recent
+// DMA pieces on top of that.
+// Here: conv64_kernel's decomposition (wave = 32 output channels x 2 pixel rows, all of K; the same accumulation order, bit for bit),
+// but (1) an operand read from the LDS once per patch row serves both pixel rows it is a kernel-row neighbour of (96 reads per tile
+// instead of 144); (2) the DMA reads its per-piece constants from a lane table (10 instructions per piece); (3) the residual rows are
+// loaded in the STORE layout (8 lanes x 16 B per pixel: coalesced) and every global access of the loop is a raw-buffer instruction whose
+// descriptor ends where the tile's row ends -- no predicates, no branches, and every one is issued every tile, so (4) each s_waitcnt
+// vmcnt(N) is exact; (5) the epilogue of tile i - 1 runs in the gaps of tile i's matrix instructions, step by step, in the order
+// tools/gen_conv64p_sched.py deals out (conv64p_sched_*.inc).
+#define C64P_SB __builtin_amdgcn_sched_barrier(0);
+#define C64P_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <bool RES, bool F32OUT, int OUT_FMT>
+__global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) unsigned char patches[2 * C64_PATCHB];
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[4 * 32 * C64_RS];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 1, rg = wave >> 1;
+  const int n = lane & 31, h = lane >> 5;
+  const int d_row = lane >> 3, d_slot = lane & 7;
+
+  f16x8 wf[9][2][2];                                        // [tap][chunk][k-step]
+  i32x8 wx[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint16_t* wp = p.w + ((((size_t)ct * 9 + t) * 2 + c) * 4) * 512;
+      wf[t][c][0] = *reinterpret_cast<const f16x8*>(wp + lane * 8);
+      wf[t][c][1] = *reinterpret_cast<const f16x8*>(wp + 512 + lane * 8);
+      wx[t][c] = *reinterpret_cast<const i32x8*>(wp + 1024 + lane * 16);
+    }
+  const uint32_t sa_ = h ? (uint32_t)(127 - F8_BW) : (uint32_t)(127 + F8_AW), sb_ = h ? (uint32_t)(127 + F8_AX) : (uint32_t)(127 - F8_BX);
+  const int scale_a = (int)(sa_ * 0x01010101u), scale_b = (int)(sb_ * 0x01010101u);
+  if (tid < 64) bias_s[tid] = p.bias[tid];
+
+  // DMA: lane k of piece_tab holds what piece wave + 4 k needs (conv64k_kernel)
+  const uint32_t lane_off0 = (uint32_t)(d_row * 256 + ((d_slot ^ (d_row >> 1)) << 4));
+  int piece_tab;
+  {
+    const int k = lane & 15, i = wave + 4 * k;
+    const int chunk = i / ((C64_TR + 2) * 5), r2 = i - chunk * ((C64_TR + 2) * 5);
+    const int prow = r2 / 5, pc0 = (r2 - prow * 5) * 8;
+    const int goff = (prow * p.Wp + pc0) * 256 + chunk * 128;
+    const int ldst = chunk * C64_CHUNKB + (prow * C64_PW + pc0) * 128;
+    const int key = (((prow * C64_PW + pc0) >> 1) & 4) << 4;
+    piece_tab = lane < 16 ? goff : lane < 32 ? ldst : key;
+  }
+  const uint32_t patches_lds = c64_lds_addr(patches);
+  auto stage_piece = [&](const unsigned char* tile_base, uint32_t buf_lds, int k) {
+    const uint32_t goff = (uint32_t)__builtin_amdgcn_readlane(piece_tab, k);
+    const uint32_t dst = buf_lds + (uint32_t)__builtin_amdgcn_readlane(piece_tab, 16 + k);
+    const uint32_t off = lane_off0 ^ (uint32_t)__builtin_amdgcn_readlane(piece_tab, 32 + k);
+    const unsigned char* base = tile_base + goff;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
+  };
+  const int G = gridDim.x;
+  auto tile_origin = [&](int tile, int& nimg, int& y0, int& x0) {
+    nimg = tile / (p.n_ty * p.n_tx);
+    const int rem = tile - nimg * p.n_ty * p.n_tx;
+    const int ty = rem / p.n_tx;
+    y0 = ty * C64_TR;
+    x0 = (rem - ty * p.n_tx) * 32;
+  };
+  auto patch_base = [&](int nimg, int y0, int x0) {
+    return reinterpret_cast<const unsigned char*>(p.x) + (((size_t)nimg * p.Hp + y0) * p.Wp + x0) * 256;
+  };
+  // operand addresses: [dx][patch row parity][f16 k-step 0 | k-step 1 | l8 | h8] in the CURRENT patch buffer, rows of this wave's pair;
+  // patch row r and chunk c are immediates of the reads, the buffer is flipped (flip()) behind an address's last read of a tile
+  uint32_t lane_a[3][2][4];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const uint32_t key = (uint32_t)((((n + dx) >> 1) & 7) ^ (4 * par));
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        lane_a[dx][par][k] = patches_lds + (uint32_t)(2 * rg * C64_PW * 128 + (n + dx) * 128) + ((((uint32_t)(2 * k + h)) ^ key) << 4);
+    }
+  int flip_delta = C64_PATCHB;                              // added to an address when the tile behind this one reads the other buffer
+  // epilogue constants
+  unsigned char* tw = tiles + wave * (32 * C64_RS);
+  const int mv_row = lane >> 3, mv_col = (lane & 7) * 16;
+  const int st_goff = mv_row * 256 + mv_col, st_goff2 = st_goff + 4096;
+  const float relu_lo = p.relu ? 0.f : -INFINITY;
+  const float acc_scale = p.acc_scale, out_scale = p.out_scale;
+  constexpr int RSRC3 = 0x00020000;
+
+  // ---- state carried from tile to tile
+  f32x4 fin[2][4];                                          // the previous tile's sums, accumulator layout
+  i32x4 res[2][4];                                          // its residual rows, store layout
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { fin[b][g] = f32x4{0.f, 0.f, 0.f, 0.f}; res[b][g] = i32x4{0, 0, 0, 0}; }
+  int nimg_p = 0, y0_p = 0, x0_p = p.W;                     // ... and where it lies (x0 = W: nothing of it is stored -- the first tile has no predecessor)
+  i32x4 d_f32[2], d_spl[2], d_res[2];                       // raw-buffer descriptors of the rows: previous tile's outputs, this tile's residual
+  f32x4 bv[4], u[4];
+  i32x4 rw[4];
+  float amax[4];
+  f32x4 sp_c, sp_hf, sp_lf, sp_t;
+  uint2 sp_hw, sp_lw;
+  uint32_t sp_h8, sp_l8;
+
+  const bool probe = (p.variant & 8) && blockIdx.x == 77;
+  long long pb = 0, pm = 0, pw = 0, pe = 0, pn = 0;
+  int tile = (int)blockIdx.x, buf = 0;
+  int nimg, y0, x0;
+  tile_origin(tile, nimg, y0, x0);
+  {
+    const unsigned char* tb = patch_base(nimg, y0, x0);
+#pragma unroll
+    for (int k = 0; k < 15; ++k) stage_piece(tb, patches_lds, k);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as the BUILTIN: the compiler's wait-count pass must know the weights have landed
+  lds_barrier();
+
+  auto row_desc = [&](const void* base, size_t byte_off, int nrec) {
+    const size_t a = (size_t)base + byte_off;               // (64-bit products run on the vector unit: back into scalar registers, where a descriptor lives)
+    return i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)a), __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)),
+                 __builtin_amdgcn_readfirstlane(nrec), RSRC3};
+  };
+  auto buf_store = [&](const i32x4& d, int voff, const i32x4& v, int imm) {   // imm: 0 or 2048
+    if (imm == 0) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(d) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:2048\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(d) : "memory");
+  };
+
+  // ---- the steps of the previous tile's epilogue (called from the generated schedule with literal arguments)
+  // raw-buffer descriptors of the rows [pixel x0 .. min(x0 + 32, W)) of image row y: the previous tile's outputs, this tile's residual
+  auto row_records = [&](int x0_, int y) {
+    const int nv = imin(imax(p.W - x0_, 0), 32);
+    return (y < p.H && nv > 0) ? nv * 256 - 128 : 0;
+  };
+  auto e_desc_s = [&](int b) {
+    const int y = y0_p + 2 * rg + b;
+    d_spl[b] = row_desc(p.y_split, ((((size_t)nimg_p * p.Hp + (y + 1)) * p.Wp + (x0_p + 1)) * 2 + ct) * 128, row_records(x0_p, y));
+  };
+  auto e_desc_f = [&](int b) {
+    const int y = y0_p + 2 * rg + b;
+    if (F32OUT) d_f32[b] = row_desc(p.y_f32, ((((size_t)nimg_p * p.H + y) * p.W + x0_p) * 2 + ct) * 128, row_records(x0_p, y));
+  };
+  auto e_desc_r = [&](int b) {                              // (loaded late in this tile, used in the next)
+    const int y = y0 + 2 * rg + b;
+    if (RES) d_res[b] = row_desc(p.residual, ((((size_t)nimg * p.H + y) * p.W + x0) * 2 + ct) * 128, row_records(x0, y));
+  };
+  auto resload = [&](int b, int i) {
+    if (!RES) return;
+#define C64P_RL(B, I, REG, VOFF, IMM) \
+  if (b == B && i == I) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" IMM : "=" REG(res[B][I]) : "v"(VOFF), "s"(d_res[B]) : "memory");
+    C64P_RL(0, 0, "{v[64:67]}", st_goff, "") C64P_RL(0, 1, "{v[68:71]}", st_goff, " offset:2048")
+    C64P_RL(0, 2, "{v[72:75]}", st_goff2, "") C64P_RL(0, 3, "{v[76:79]}", st_goff2, " offset:2048")
+    C64P_RL(1, 0, "{v[80:83]}", st_goff, "") C64P_RL(1, 1, "{v[84:87]}", st_goff, " offset:2048")
+    C64P_RL(1, 2, "{v[88:91]}", st_goff2, "") C64P_RL(1, 3, "{v[92:95]}", st_goff2, " offset:2048")
+#undef C64P_RL
+  };
+  auto e_bias = [&]() {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(bias_s + ct * 32 + 8 * g + 4 * h);
+  };
+  auto e_fma = [&](int b, int g) {
+    const f32x4 f = fin[b][g];
+    f32x4 v = {fmaf(f.x, acc_scale, bv[g].x), fmaf(f.y, acc_scale, bv[g].y), fmaf(f.z, acc_scale, bv[g].z), fmaf(f.w, acc_scale, bv[g].w)};
+    if (RES) *reinterpret_cast<f32x4*>(tw + n * C64_RS + (8 * g + 4 * h) * 4) = v;
+    else u[g] = v;
+  };
+  auto e_uread = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const f32x4*>(tw + (i * 8 + mv_row) * C64_RS + mv_col);
+  };
+  auto e_res = [&](int b, int i) { u[i] += __builtin_bit_cast(f32x4, res[b][i]); };
+  auto e_relu = [&](int i) {
+    u[i] = f32x4{fmaxf(u[i].x, relu_lo), fmaxf(u[i].y, relu_lo), fmaxf(u[i].z, relu_lo), fmaxf(u[i].w, relu_lo)};
+  };
+  auto e_stf = [&](int b, int i) {
+    if (F32OUT) buf_store(d_f32[b], i < 2 ? st_goff : st_goff2, __builtin_bit_cast(i32x4, u[i]), (i & 1) * 2048);
+  };
+  // split_f16_4 / split_bf16_4 (common.hpp) on u[j], the same operations in the same order, in pieces of 4-6 instructions (what fits
+  // behind an f16 matrix instruction)
+  auto e_sp1 = [&](int j) {
+    if (OUT_FMT == 0) {
+      const uint32_t h0 = f2bf_pk(u[j].x, u[j].y), h1 = f2bf_pk(u[j].z, u[j].w);
+      sp_hw = uint2{h0, h1};
+    } else {
+      sp_c = u[j] * out_scale;
+    }
+  };
+  auto e_sp2 = [&](int j) {
+    if (OUT_FMT == 0) {
+      sp_hf = f32x4{__builtin_bit_cast(float, sp_hw.x << 16), __builtin_bit_cast(float, sp_hw.x & 0xFFFF0000u), __builtin_bit_cast(float, sp_hw.y << 16),
+                    __builtin_bit_cast(float, sp_hw.y & 0xFFFF0000u)};
+    } else {
+      amax[j] = fmaxf(fmaxf(fabsf(sp_c.x), fabsf(sp_c.y)), fmaxf(fabsf(sp_c.z), fabsf(sp_c.w)));
+    }
+  };
+  auto e_sp3 = [&](int j) {
+    if (OUT_FMT == 0) {
+      sp_lf = u[j] - sp_hf;
+    } else {
+      sp_c = f32x4{__builtin_amdgcn_fmed3f(sp_c.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(sp_c.y, -65504.f, 65504.f),
+                   __builtin_amdgcn_fmed3f(sp_c.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(sp_c.w, -65504.f, 65504.f)};
+    }
+  };
+  auto e_sp4 = [&](int j) {
+    if (OUT_FMT == 0) {
+      sp_lw = uint2{f2bf_pk(sp_lf.x, sp_lf.y), f2bf_pk(sp_lf.z, sp_lf.w)};
+    } else {
+      const f16x4 hh = {(_Float16)sp_c.x, (_Float16)sp_c.y, (_Float16)sp_c.z, (_Float16)sp_c.w};
+      sp_hw = __builtin_bit_cast(uint2, hh);
+    }
+  };
+  auto e_sp5 = [&](int j) {
+    const f16x4 hh = __builtin_bit_cast(f16x4, sp_hw);
+    sp_hf = f32x4{(float)hh.x, (float)hh.y, (float)hh.z, (float)hh.w};
+  };
+  auto e_sp6 = [&](int j) { sp_lf = sp_c - sp_hf; };
+  auto e_sp7 = [&](int j) {
+    constexpr float SA = 1.0f / (float)(1 << F8_AX);
+    sp_t = sp_hf * SA;
+  };
+  auto e_sp8 = [&](int j) {
+    int a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(sp_t.x, -448.f, 448.f), __builtin_amdgcn_fmed3f(sp_t.y, -448.f, 448.f), 0, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(sp_t.z, -448.f, 448.f), __builtin_amdgcn_fmed3f(sp_t.w, -448.f, 448.f), a, true);
+    sp_h8 = (uint32_t)a;
+  };
+  auto e_sp9 = [&](int j) {
+    constexpr float SBX = (float)(1 << F8_BX);
+    const f32x4 t = sp_lf * SBX;
+    int bq = __builtin_amdgcn_cvt_pk_fp8_f32(t.x, t.y, 0, false);
+    bq = __builtin_amdgcn_cvt_pk_fp8_f32(t.z, t.w, bq, true);
+    sp_l8 = (uint32_t)bq;
+  };
+  auto e_spw = [&](int j) {                               // RES: j = pixel group i of the store layout; else: j = channel group g of the accumulator layout
+    unsigned char* o;
+    int c16;                                              // first of the lane's 4 channels within the 32-channel tile
+    if (RES) { o = tw + (j * 8 + mv_row) * C64_RS; c16 = mv_col >> 2; }
+    else { o = tw + n * C64_RS; c16 = 8 * j + 4 * h; }
+    if (OUT_FMT == 0) {
+      *reinterpret_cast<uint2*>(o + c16 * 2) = sp_hw;
+      *reinterpret_cast<uint2*>(o + 64 + c16 * 2) = sp_lw;
+    } else {
+      *reinterpret_cast<uint2*>(o + c16 * 2) = sp_hw;
+      *reinterpret_cast<uint32_t*>(o + 64 + c16) = sp_l8;
+      *reinterpret_cast<uint32_t*>(o + 96 + c16) = sp_h8;
+    }
+  };
+  auto e_ovf = [&](int b) {
+    if (OUT_FMT == 0) return;
+    const int nv = p.W - x0_p;
+    bool of;
+    if (RES) of = (amax[0] > 57344.f && mv_row < nv) || (amax[1] > 57344.f && 8 + mv_row < nv) || (amax[2] > 57344.f && 16 + mv_row < nv) ||
+                  (amax[3] > 57344.f && 24 + mv_row < nv);
+    else of = fmaxf(fmaxf(amax[0], amax[1]), fmaxf(amax[2], amax[3])) > 57344.f && n < nv;
+    of = of && (y0_p + 2 * rg + b < p.H);
+    if (__builtin_amdgcn_ballot_w64(of) != 0ull && lane == 0) atomicOr(p.overflow, 1);
+  };
+  auto e_rread = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rw[i] = *reinterpret_cast<const i32x4*>(tw + (i * 8 + mv_row) * C64_RS + mv_col);
+  };
+  auto e_sts = [&](int b, int i) { buf_store(d_spl[b], i < 2 ? st_goff : st_goff2, rw[i], (i & 1) * 2048); };
+
+
+  for (;;) {
+    const long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0;
+    int nimg_n, y0_n, x0_n;
+    const unsigned char* next_base;
+    const uint32_t pbuf = (uint32_t)(buf * C64_PATCHB);     // (only the DMA target needs it: the operand addresses carry the buffer)
+    const uint32_t next_lds = patches_lds + (uint32_t)((buf ^ 1) * C64_PATCHB);
+    (void)pbuf;
+    f32x16 acc[2];
+    f16x8 fa0, fa1, fb0, fb1;
+    i32x4 xa0, xa1, xb0, xb1;
+
+    // ---- the steps (called from the generated schedule with literal arguments)
+    // Everything an assembly statement writes ASYNCHRONOUSLY -- the accumulators, the operand buffers, the residual rows -- sits in NAMED
+    // registers: to the compiler an assembly output is complete when the statement ends, and a copy it makes afterwards (it moved one
+    // accumulator to other registers between two matrix instructions of the first build, under register pressure) reads what has not
+    // landed yet.  A value that every statement wants in the same physical registers is never moved.
+    //   acc[0] v[0:15]  acc[1] v[16:31]   buffer a: f16 k-steps v[32:35] v[36:39], fp8 operand v[40:47]   buffer b: v[48:51] v[52:55] v[56:63]
+    //   residual rows v[64:79] (b = 0), v[80:95] (b = 1)
+    auto opread = [&](int q) {
+      const int r = q / 6, dx = (q % 6) / 2, c = q % 2;
+      const uint32_t* a = lane_a[dx][r & 1];
+      // (offsets: patch row r, chunk c -- at most 3 * 5120 + 30720 < 65536)
+      if ((q & 1) == 0) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[32:35]}"(fa0) : "v"(a[0]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[36:39]}"(fa1) : "v"(a[1]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[40:43]}"(xa0) : "v"(a[2]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[44:47]}"(xa1) : "v"(a[3]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+      } else {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[48:51]}"(fb0) : "v"(a[0]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[52:55]}"(fb1) : "v"(a[1]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[56:59]}"(xb0) : "v"(a[2]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "={v[60:63]}"(xb1) : "v"(a[3]), "i"(r * C64_PW * 128 + c * C64_CHUNKB) : "memory");
+      }
+    };
+    auto tilenext_a = [&]() {                               // the tile behind this one -- or this one again (its patch is loaded a second
+      const int next = tile + G;                            // time, into the free buffer, and never read: every tile issues the same instructions)
+      const int tn = next < p.n_tiles ? next : tile;
+      tile_origin(tn, nimg_n, y0_n, x0_n);
+    };
+    auto tilenext_b = [&]() { next_base = patch_base(nimg_n, y0_n, x0_n); };
+    const unsigned char* dma_base;
+    uint32_t dma_dst, dma_off;
+    auto dma_a = [&](int k) {
+      dma_base = next_base + (uint32_t)__builtin_amdgcn_readlane(piece_tab, k);
+      dma_dst = next_lds + (uint32_t)__builtin_amdgcn_readlane(piece_tab, 16 + k);
+      dma_off = lane_off0 ^ (uint32_t)__builtin_amdgcn_readlane(piece_tab, 32 + k);
+    };
+    auto dma_b = [&](int k) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_off), "s"(dma_base), "s"(dma_dst) : "memory");
+    };
+    auto flip = [&](int dx, int par, int k) { lane_a[dx][par][k] += (uint32_t)flip_delta; };
+#define GB(Q) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define C64P_RACC_0 "{v[0:15]}"
+#define C64P_RACC_1 "{v[16:31]}"
+#define C64P_RF_a0 "{v[32:35]}"
+#define C64P_RF_a1 "{v[36:39]}"
+#define C64P_RF_b0 "{v[48:51]}"
+#define C64P_RF_b1 "{v[52:55]}"
+#define C64P_RX_a "{v[40:47]}"
+#define C64P_RX_b "{v[56:63]}"
+#define MF_F0(B, T, C, P, BUF) \
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&" C64P_RACC_##B(acc[B]) : "a"(wf[T][C][P]), C64P_RF_##BUF##P(f##BUF##P));
+#define MF_F(B, T, C, P, BUF) \
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+" C64P_RACC_##B(acc[B]) : "a"(wf[T][C][P]), C64P_RF_##BUF##P(f##BUF##P));
+#define MF_XA(B, T, C, P, BUF)                                                                                                    \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"                                          \
+               : "+" C64P_RACC_##B(acc[B])                                                                                          \
+               : "a"(wx[T][C]), C64P_RX_##BUF(__builtin_shufflevector(x##BUF##0, x##BUF##1, 0, 1, 2, 3, 4, 5, 6, 7)), "v"(scale_a), "v"(scale_b));
+#define MF_XV(B, T, C, P, BUF)                                                                                                    \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"                                          \
+               : "+" C64P_RACC_##B(acc[B])                                                                                          \
+               : "v"(wx[T][C]), C64P_RX_##BUF(__builtin_shufflevector(x##BUF##0, x##BUF##1, 0, 1, 2, 3, 4, 5, 6, 7)), "v"(scale_a), "v"(scale_b));
+// the last matrix instructions' results before vector instructions read them.  The accumulators are OPERANDS of the pause: the copy into
+// `fin` below cannot be scheduled in front of it (hoisted to the accumulator's last matrix instruction it read sums still in the pipe)
+#define C64P_ACC_DONE asm volatile("s_nop 15\n\ts_nop 15" : "+{v[0:15]}"(acc[0]), "+{v[16:31]}"(acc[1])::"memory");
+#define SB C64P_SB
+#define LB asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define C64P_N(A, F) ((A) + (F32OUT ? (F) : 0))
+// (the residual registers are operands of the wait: what reads them cannot be scheduled in front of it)
+#define WAITRES(B)                                                                                                                  \
+  if ((B) == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+{v[64:67]}"(res[0][0]), "+{v[68:71]}"(res[0][1]), "+{v[72:75]}"(res[0][2]), "+{v[76:79]}"(res[0][3]) : "n"(C64P_VM_RES0) : "memory"); \
+  else asm volatile("s_waitcnt vmcnt(%4)" : "+{v[80:83]}"(res[1][0]), "+{v[84:87]}"(res[1][1]), "+{v[88:91]}"(res[1][2]), "+{v[92:95]}"(res[1][3]) : "n"(C64P_VM_RES1) : "memory");
+    opread(0);
+    if constexpr (!RES) {
+#define C64P_SECTION 0
+#include "conv64p_sched_plain.inc"
+#undef C64P_SECTION
+#define C64P_SECTION 1
+#include "conv64p_sched_plain.inc"
+#undef C64P_SECTION
+      C64P_ACC_DONE
+      C64P_WAIT_VM(C64P_VM_END);                            // the next patch has landed (this wave's pieces)
+#undef C64P_VM_END
+    } else if constexpr (OUT_FMT == 1) {
+#define C64P_SECTION 0
+#include "conv64p_sched_res.inc"
+#undef C64P_SECTION
+#define C64P_SECTION 1
+#include "conv64p_sched_res.inc"
+#undef C64P_SECTION
+      C64P_ACC_DONE
+      C64P_WAIT_VM(C64P_VM_END);
+#undef C64P_VM_END
+#undef C64P_VM_RES0
+#undef C64P_VM_RES1
+    } else {
+#define C64P_SECTION 0
+#include "conv64p_sched_res_bf16.inc"
+#undef C64P_SECTION
+#define C64P_SECTION 1
+#include "conv64p_sched_res_bf16.inc"
+#undef C64P_SECTION
+      C64P_ACC_DONE
+      C64P_WAIT_VM(C64P_VM_END);
+#undef C64P_VM_END
+#undef C64P_VM_RES0
+#undef C64P_VM_RES1
+    }
+    const long long t2 = probe ? __builtin_amdgcn_s_memtime() : 0;
+    // this tile becomes the previous one
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fin[b][g] = f32x4{acc[b][4 * g + 0], acc[b][4 * g + 1], acc[b][4 * g + 2], acc[b][4 * g + 3]};
+    nimg_p = nimg; y0_p = y0; x0_p = x0;
+    flip_delta = -flip_delta;
+    buf ^= 1;
+    if (probe) { pm += t2 - t1; pn += 1; }
+    tile += G;
+    if (tile >= p.n_tiles) break;
+    nimg = nimg_n; y0 = y0_n; x0 = x0_n;
+    const long long t3 = probe ? __builtin_amdgcn_s_memtime() : 0;
+    lds_barrier();                                          // every wave's pieces of the next patch have landed; the other buffer is free
+    if (probe) pb += __builtin_amdgcn_s_memtime() - t3;
+  }
+  // ---- the last tile's epilogue
+  {
+    const long long t3 = probe ? __builtin_amdgcn_s_memtime() : 0;
+#define DRAIN_BEGIN __builtin_amdgcn_s_waitcnt(0x0F70);
+#define C64P_SECTION 2
+    if constexpr (!RES) {
+#include "conv64p_sched_plain.inc"
+    } else if constexpr (OUT_FMT == 1) {
+#include "conv64p_sched_res.inc"
+    } else {
+#include "conv64p_sched_res_bf16.inc"
+    }
+#undef C64P_SECTION
+    if (probe) pe += __builtin_amdgcn_s_memtime() - t3;
+  }
+#undef GB
+#undef MF_F0
+#undef MF_F
+#undef MF_XA
+#undef MF_XV
+#undef SB
+#undef C64P_ACC_DONE
+#undef LB
+#undef C64P_N
+#undef WAITRES
+#undef DRAIN_BEGIN
+  if (probe && lane == 0) {
+    g_c64_probe[wave * 8 + 0] = pb; g_c64_probe[wave * 8 + 1] = pm; g_c64_probe[wave * 8 + 2] = pw; g_c64_probe[wave * 8 + 3] = pe;
+    g_c64_probe[wave * 8 + 4] = pn;
+  }
+}
+
 int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const float* residual, const uint16_t* res_split,
                   uint16_t* y_split, float* y_f32, int N, int H, int W, int Hp, int Wp, int relu, int in_fmt, int in_scale_log2,
                   int out_fmt, int out_scale_log2, int* overflow, hipStream_t s) {
@@ -798,8 +1240,16 @@ int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const
   p.n_tiles = (int)tiles;
   p.variant = g_conv64_variant;
   const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
+  // conv64p_kernel: the forms the encoder launches (a block's first convolution; its second with the f32 residual, + f32 out and the f16 + fp8
+  // split out, or the bf16 split out alone); every other combination runs on conv64_kernel.  option conv64_variant & 32: conv64k_kernel.
+  if (in_fmt == 1 && !(p.variant & (16 | 32)) && y_split && !res_split) {
+    if (!residual && !y_f32 && out_fmt == 1) { conv64p_kernel<false, false, 1><<<grid, 256, 0, s>>>(p); FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32"); return FGVC_OK; }
+    if (residual && y_f32 && out_fmt == 1) { conv64p_kernel<true, true, 1><<<grid, 256, 0, s>>>(p); FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32"); return FGVC_OK; }
+    if (residual && !y_f32 && out_fmt == 1) { conv64p_kernel<true, false, 1><<<grid, 256, 0, s>>>(p); FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32"); return FGVC_OK; }
+    if (residual && !y_f32 && out_fmt == 0) { conv64p_kernel<true, false, 0><<<grid, 256, 0, s>>>(p); FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32"); return FGVC_OK; }
+  }
   const bool res_fits = !residual || (unsigned long long)N * H * W * 256ull < (1ull << 32);      // conv64k_kernel reads the residual as a 32-bit raw buffer
-  if (in_fmt == 1 && !(p.variant & 16) && res_fits) conv64k_kernel<<<grid, 256, 0, s>>>(p);      // option conv64_variant & 16: round 3's kernel (A/B)
+  if (in_fmt == 1 && (p.variant & 32) && res_fits) conv64k_kernel<<<grid, 256, 0, s>>>(p);      // option conv64_variant & 16: round 3's kernel (A/B)
   else if (in_fmt == 1) conv64_kernel<1><<<grid, 256, 0, s>>>(p);
   else conv64_kernel<0><<<grid, 256, 0, s>>>(p);
   FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32");
