@@ -799,6 +799,7 @@ __global__ __launch_bounds__(256, 1) void conv64k_kernel(Conv64Params p) {
 // vmcnt(N) is exact; (5) the epilogue of tile i - 1 runs in the gaps of tile i's matrix instructions, step by step, in the order
 // tools/gen_conv64p_sched.py deals out (conv64p_sched_*.inc).
 #define C64P_SB __builtin_amdgcn_sched_barrier(0);
+#define MARK(S) __builtin_amdgcn_sched_barrier(0); asm volatile("; @@" S); __builtin_amdgcn_sched_barrier(0);      // (a comment in the ISA: tools/conv64p_costs.py counts a step's instructions between two of them)
 #define C64P_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 template <bool RES, bool F32OUT, int OUT_FMT>
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
     x0 = (rem - ty * p.n_tx) * 32;
   };
   auto patch_base = [&](int nimg, int y0, int x0) {
-    return reinterpret_cast<const unsigned char*>(p.x) + (((size_t)nimg * p.Hp + y0) * p.Wp + x0) * 256;
+    return reinterpret_cast<const unsigned char*>(p.x) + (uint32_t)(((nimg * p.Hp + y0) * p.Wp + x0) * 256);
   };
   // operand addresses: [dx][patch row parity][f16 k-step 0 | k-step 1 | l8 | h8] in the CURRENT patch buffer, rows of this wave's pair;
   // patch row r and chunk c are immediates of the reads, the buffer is flipped (flip()) behind an address's last read of a tile
@@ -902,8 +903,10 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
   const bool probe = (p.variant & 8) && blockIdx.x == 77;
   long long pb = 0, pm = 0, pw = 0, pe = 0, pn = 0;
   int tile = (int)blockIdx.x, buf = 0;
+  const int g_img = G / (p.n_ty * p.n_tx), g_rem = G - g_img * (p.n_ty * p.n_tx), g_ty = g_rem / p.n_tx, g_tx = g_rem - g_ty * p.n_tx;
   int nimg, y0, x0;
   tile_origin(tile, nimg, y0, x0);
+  uint32_t tx_c = (uint32_t)x0 / 32u, ty_c = (uint32_t)y0 / (uint32_t)C64_TR;
   {
     const unsigned char* tb = patch_base(nimg, y0, x0);
 #pragma unroll
@@ -912,8 +915,10 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
   __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as the BUILTIN: the compiler's wait-count pass must know the weights have landed
   lds_barrier();
 
-  auto row_desc = [&](const void* base, size_t byte_off, int nrec) {
-    const size_t a = (size_t)base + byte_off;               // (64-bit products run on the vector unit: back into scalar registers, where a descriptor lives)
+  // (byte offsets within a tensor fit 32 bits: conv64_launch keeps larger tensors on conv64_kernel -- scalar arithmetic throughout; a
+  // 64-bit product would run on the vector unit)
+  auto row_desc = [&](const void* base, uint32_t byte_off, int nrec) {
+    const size_t a = (size_t)base + byte_off;
     return i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)a), __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)),
                  __builtin_amdgcn_readfirstlane(nrec), RSRC3};
   };
@@ -930,15 +935,15 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
   };
   auto e_desc_s = [&](int b) {
     const int y = y0_p + 2 * rg + b;
-    d_spl[b] = row_desc(p.y_split, ((((size_t)nimg_p * p.Hp + (y + 1)) * p.Wp + (x0_p + 1)) * 2 + ct) * 128, row_records(x0_p, y));
+    d_spl[b] = row_desc(p.y_split, (uint32_t)((((nimg_p * p.Hp + (y + 1)) * p.Wp + (x0_p + 1)) * 2 + ct) * 128), row_records(x0_p, y));
   };
   auto e_desc_f = [&](int b) {
     const int y = y0_p + 2 * rg + b;
-    if (F32OUT) d_f32[b] = row_desc(p.y_f32, ((((size_t)nimg_p * p.H + y) * p.W + x0_p) * 2 + ct) * 128, row_records(x0_p, y));
+    if (F32OUT) d_f32[b] = row_desc(p.y_f32, (uint32_t)((((nimg_p * p.H + y) * p.W + x0_p) * 2 + ct) * 128), row_records(x0_p, y));
   };
   auto e_desc_r = [&](int b) {                              // (loaded late in this tile, used in the next)
     const int y = y0 + 2 * rg + b;
-    if (RES) d_res[b] = row_desc(p.residual, ((((size_t)nimg * p.H + y) * p.W + x0) * 2 + ct) * 128, row_records(x0, y));
+    if (RES) d_res[b] = row_desc(p.residual, (uint32_t)((((nimg * p.H + y) * p.W + x0) * 2 + ct) * 128), row_records(x0, y));
   };
   auto resload = [&](int b, int i) {
     if (!RES) return;
@@ -1043,11 +1048,14 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
   auto e_ovf = [&](int b) {
     if (OUT_FMT == 0) return;
     const int nv = p.W - x0_p;
-    bool of;
-    if (RES) of = (amax[0] > 57344.f && mv_row < nv) || (amax[1] > 57344.f && 8 + mv_row < nv) || (amax[2] > 57344.f && 16 + mv_row < nv) ||
-                  (amax[3] > 57344.f && 24 + mv_row < nv);
-    else of = fmaxf(fmaxf(amax[0], amax[1]), fmaxf(amax[2], amax[3])) > 57344.f && n < nv;
-    of = of && (y0_p + 2 * rg + b < p.H);
+    const float m = fmaxf(fmaxf(amax[0], amax[1]), fmaxf(amax[2], amax[3]));
+    bool of = m > 57344.f;
+    if (nv < 32) {                                          // (the image's last tile column: pixels beyond the row's end do not count)
+      if (RES) of = (amax[0] > 57344.f && mv_row < nv) || (amax[1] > 57344.f && 8 + mv_row < nv) || (amax[2] > 57344.f && 16 + mv_row < nv) ||
+                    (amax[3] > 57344.f && 24 + mv_row < nv);
+      else of = of && n < nv;
+    }
+    if (y0_p + 2 * rg + b >= p.H) of = false;
     if (__builtin_amdgcn_ballot_w64(of) != 0ull && lane == 0) atomicOr(p.overflow, 1);
   };
   auto e_rread = [&](int b) {
@@ -1060,6 +1068,7 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
   for (;;) {
     const long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0;
     int nimg_n, y0_n, x0_n;
+    uint32_t tx_n, ty_n;
     const unsigned char* next_base;
     const uint32_t pbuf = (uint32_t)(buf * C64_PATCHB);     // (only the DMA target needs it: the operand addresses carry the buffer)
     const uint32_t next_lds = patches_lds + (uint32_t)((buf ^ 1) * C64_PATCHB);
@@ -1092,9 +1101,18 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
       }
     };
     auto tilenext_a = [&]() {                               // the tile behind this one -- or this one again (its patch is loaded a second
-      const int next = tile + G;                            // time, into the free buffer, and never read: every tile issues the same instructions)
-      const int tn = next < p.n_tiles ? next : tile;
-      tile_origin(tn, nimg_n, y0_n, x0_n);
+      // time, into the free buffer, and never read: every tile issues the same instructions).  G tiles further = (g_img, g_ty, g_tx)
+      // further with carries: no division in the loop (tile_origin's two cost 45 scalar instructions)
+      uint32_t txn = tx_c + (uint32_t)g_tx, tyn = ty_c + (uint32_t)g_ty, nin = (uint32_t)nimg + (uint32_t)g_img;
+      const uint32_t c1 = txn >= (uint32_t)p.n_tx ? 1u : 0u;
+      txn -= c1 ? (uint32_t)p.n_tx : 0u;
+      tyn += c1;
+      const uint32_t c2 = tyn >= (uint32_t)p.n_ty ? 1u : 0u;
+      tyn -= c2 ? (uint32_t)p.n_ty : 0u;
+      nin += c2;
+      const bool has = tile + G < p.n_tiles;
+      tx_n = has ? txn : tx_c; ty_n = has ? tyn : ty_c; nimg_n = has ? (int)nin : nimg;
+      y0_n = (int)(ty_n * C64_TR); x0_n = (int)(tx_n * 32);
     };
     auto tilenext_b = [&]() { next_base = patch_base(nimg_n, y0_n, x0_n); };
     const unsigned char* dma_base;
@@ -1105,6 +1123,7 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
       dma_off = lane_off0 ^ (uint32_t)__builtin_amdgcn_readlane(piece_tab, 32 + k);
     };
     auto dma_b = [&](int k) {
+      if (p.variant & 64) return;                           // (timing experiment: no patch DMA -- wrong results)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_off), "s"(dma_base), "s"(dma_dst) : "memory");
     };
     auto flip = [&](int dx, int par, int k) { lane_a[dx][par][k] += (uint32_t)flip_delta; };
@@ -1187,7 +1206,7 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
     if (probe) { pm += t2 - t1; pn += 1; }
     tile += G;
     if (tile >= p.n_tiles) break;
-    nimg = nimg_n; y0 = y0_n; x0 = x0_n;
+    nimg = nimg_n; y0 = y0_n; x0 = x0_n; tx_c = tx_n; ty_c = ty_n;
     const long long t3 = probe ? __builtin_amdgcn_s_memtime() : 0;
     lds_barrier();                                          // every wave's pieces of the next patch have landed; the other buffer is free
     if (probe) pb += __builtin_amdgcn_s_memtime() - t3;
@@ -1242,7 +1261,8 @@ int conv64_launch(const uint16_t* x, const uint16_t* w, const float* bias, const
   const int grid = (int)(tiles < 256 ? tiles : 256);        // persistent: one workgroup per CU (a wave owns a SIMD's registers)
   // conv64p_kernel: the forms the encoder launches (a block's first convolution; its second with the f32 residual, + f32 out and the f16 + fp8
   // split out, or the bf16 split out alone); every other combination runs on conv64_kernel.  option conv64_variant & 32: conv64k_kernel.
-  if (in_fmt == 1 && !(p.variant & (16 | 32)) && y_split && !res_split) {
+  const bool fits32 = (unsigned long long)N * Hp * Wp * 256ull < (1ull << 32);      // conv64p_kernel: 32-bit byte offsets within a tensor
+  if (in_fmt == 1 && !(p.variant & (16 | 32)) && y_split && !res_split && fits32) {
     if (!residual && !y_f32 && out_fmt == 1) { conv64p_kernel<false, false, 1><<<grid, 256, 0, s>>>(p); FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32"); return FGVC_OK; }
     if (residual && y_f32 && out_fmt == 1) { conv64p_kernel<true, true, 1><<<grid, 256, 0, s>>>(p); FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32"); return FGVC_OK; }
     if (residual && !y_f32 && out_fmt == 1) { conv64p_kernel<true, false, 1><<<grid, 256, 0, s>>>(p); FGVC_CHECK_LAUNCH("fgvc_conv64_split_f32"); return FGVC_OK; }

@@ -101,7 +101,7 @@ for rep in range(7):
             t[(v, k)].append(ms)
 for (v, k), ms in t.items():
     print(f"{'conv64p_kernel' if v == 0 else 'conv64_kernel '}  {k:42s} {statistics.median(ms):.4f} ms", flush=True)
-for v in (8,):
+for v in (8, 8 | 64):
     for k, form in FORMS.items():
         for _ in range(3):
             call(v, form)
@@ -110,5 +110,5 @@ for v in (8,):
         _lib.call("fgvc_conv64_probe", ctypes.cast(buf, ctypes.c_void_p))
         pb, pm, pw, pe, pn = list(buf)[0:5]
         if pn:
-            print(f"probe {k}: wave 0, {pn} tiles; cycles per tile: barrier {pb / pn:.0f}  tile loop body {pm / pn:.0f}  drain (once) {pe:.0f}", flush=True)
+            print(f"probe (variant {v}) {k}: wave 0, {pn} tiles; cycles per tile: barrier {pb / pn:.0f}  tile loop body {pm / pn:.0f}  drain (once) {pe:.0f}", flush=True)
 ops.set_option("conv64_variant", 0)

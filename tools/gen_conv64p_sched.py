@@ -21,7 +21,7 @@ import sys
 
 CAP_F16, CAP_FP8 = 5, 13
 LDS_GAP = 3
-OPREAD_SITE = 1        # the next group's operand reads ride behind this matrix instruction of a group (see conv64.hip: 0 overwrote operands in use)
+OPREAD_SITE = 0        # the next group's operand reads ride behind this matrix instruction of a group (see conv64.hip: 0 overwrote operands in use)
 
 
 def groups():
@@ -86,15 +86,41 @@ def epilogue_stream(res, fmt1):
     return s
 
 
+COSTS = {}
+DYNAMIC = {"e_ovf(0)": 10, "e_ovf(1)": 10}          # steps whose static instruction count contains a rarely taken path
+
+
+def load_costs(forms):
+    """measured instruction counts of the steps (tools/conv64p_costs.py), the maximum over the kernel forms that share a schedule"""
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv64p_costs.json")
+    COSTS.clear()
+    if os.path.exists(path):
+        data = json.load(open(path))
+        for f in forms:
+            for k, v in data.get(f, {}).items():
+                COSTS[k] = max(COSTS.get(k, 0), v)
+    COSTS.update(DYNAMIC)
+
+
+def measured(step):
+    key = step.text.rstrip(";")
+    if key.startswith(("flip", "opread")):
+        key = key.split("(")[0]
+    if key in COSTS:
+        step.cost = max(1, COSTS[key])
+    return step
+
+
 def build(res, fmt1=True):
     G = groups()
-    epi = epilogue_stream(res, fmt1)
+    epi = [measured(e) for e in epilogue_stream(res, fmt1)]
     dma = []
     for k in range(15):
-        dma += [Step(f"dma_a({k});", 6), Step(f"dma_b({k});", 4, vmem=1, fp8=True, tag=("dma", k))]
+        dma += [measured(Step(f"dma_a({k});", 6)), measured(Step(f"dma_b({k});", 4, vmem=1, fp8=True, tag=("dma", k)))]
     flips0 = [Step(f"flip({dx}, 0, {k});", 1, min_group=17) for dx in range(3) for k in range(4)]
     flips1 = [Step(f"flip({dx}, 1, {k});", 1, min_group=23) for dx in range(3) for k in range(4)]
-    misc = [Step("tilenext_a();", 14), Step("tilenext_b();", 12)] + flips0 + flips1
+    misc = [measured(Step("tilenext_a();", 14)), measured(Step("tilenext_b();", 12))] + flips0 + flips1
     lines, order = [], []          # order: every emitted step with vmem counts, for the wait arithmetic
     ei = di = mi = 0
     site_no, epi_ready = 0, 0      # a step behind a boundary starts at least LDS_GAP matrix instructions later (the LDS round trip)
@@ -122,23 +148,24 @@ def build(res, fmt1=True):
                 e = epi[ei]
                 if site_no < epi_ready:
                     break
-                if e.cost > left + 1 and not (left >= st['cap'] - 1 and e.cost <= st['cap'] + 4):
-                    break
+                if e.cost > left + 1 and not (st['fp8'] and left >= st['cap'] - 4 and e.cost > CAP_F16 + 1):
+                    break      # (a step too long for any gap goes behind an fp8 instruction that has little else)
                 here.append(e); left -= e.cost; ei += 1
                 if e.boundary:
                     epi_ready = site_no + LDS_GAP
                     break
             for e in here:
-                lines.append(f"    {e.text}")
+                lines.append(f"    MARK(\"{e.text.rstrip(';')}\") {e.text}")
                 order.append(e)
-            lines.append("  SB")
+            lines.append("  MARK(\"end\") SB")
     assert di == len(dma) and mi == len(misc), (di, mi)
     leftover = epi[ei:]
     if leftover:                                           # what did not fit rides behind the last matrix instruction, exposed
         lines.append(f"  // {len(leftover)} steps beyond the last gap")
         for e in leftover:
-            lines.append(f"    {e.text}" + ("  LB" if e.boundary else ""))
+            lines.append(f"    MARK(\"{e.text.rstrip(';')}\") {e.text}" + ("  LB" if e.boundary else ""))
             order.append(e)
+        lines.append("  MARK(\"end\")")
     # ---- the wait arithmetic: all vector-memory instructions of the loop are issued unconditionally, in this order, every tile
     def vm_after(idx_from, idx_to_wrapped):
         """(always, f32-only) counts of vector-memory instructions issued after order[idx_from] up to (not including) the step at
@@ -169,7 +196,8 @@ def drain(res, fmt1=True):
 
 def main():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fgvc_amd", "csrc")
-    for name, res, fmt1 in (("plain", False, True), ("res", True, True), ("res_bf16", True, False)):
+    for name, res, fmt1, forms in (("plain", False, True, ["plain"]), ("res", True, True, ["res", "res_nof32"]), ("res_bf16", True, False, ["res_bf16"])):
+        load_costs(forms)
         lines, defs, total, left = build(res, fmt1)
         path = os.path.join(root, f"conv64p_sched_{name}.inc")
         with open(path, "w") as f:
