@@ -1009,6 +1009,227 @@ void set_conv_narrow(int v) { g_conv_narrow = v; }
 static int g_conv_cot_cap = 0;     // tuning knob: cap the output channels per workgroup (0 = widest that divides Cout)
 void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 
+// ---- round 5: the 256 -> 256 channel 3 x 3 convolution (f16 + FP6) with ONE wave per SIMD, a fixed instruction stream per stage ------
+// conv_split_kernel runs this layer with two waves per SIMD, 24 matrix instructions per wave and stage.  Round 4's s_memtime probe
+// (profiles/r04_probe_conv_stage.log) had the older wave of a SIMD spend 1 600 cycles on them and the younger 2 150, one after the other:
+// 768 cycles of matrix pipe each -- a wave's own stream is instruction-bound (~200 instructions beside the 24), and the second wave
+// does not hide that, it queues behind it.  Round 5's conv64p_kernel (conv64.hip) showed what a wave that owns its SIMD does when its
+// stream is laid out by hand: one instruction issues per ~4 cycles, a matrix instruction covers ~6 of them.
+// Here: 4 waves per workgroup, the same 8 x 32 pixel x 256 channel tile, LDS layout, patch and weight ring; wave (ch, pr) owns output
+// channels 128 ch ..+128 (four 32-channel tiles) x pixel rows 4 pr ..+4: 16 accumulator tiles = the 256 accumulation registers.  A stage
+// (one tap of one 32-channel input chunk) = 48 matrix instructions = 1 536 cycles of pipe, in conv_split_kernel's order per accumulator
+// (f16 k-step 0, 1, then the FP6 cross terms: bit-identical sums); beside them 16 weight-fragment reads (tile a + 1 during tile a),
+// 16 pixel-fragment reads (the NEXT tap's, into the other buffer), 8 weight DMA pieces of the stage two ahead, and -- taps 5-7 of a
+// chunk -- the next chunk's patch into registers, written to the LDS during tap 8 (whose own pixel fragments were read during tap 7).
+// ~120 instructions per 48: every gap has room.  tools/gen_conv256p_sched.py deals them out and counts the vmcnt waits
+// (conv256p_sched.inc).  Everything an assembly statement writes asynchronously sits in NAMED registers (conv64.hip has the story):
+//   accumulators a[0:255] = [tile a][row r] x 16;  pixel fragments v[0:63] / v[64:127] (buffer x row x [f16 k0 | k1 | FP6 16 B | 16 B]);
+//   weight fragments v[128:143] / v[144:159];  the patch in flight v[160:211].
+__global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
+  constexpr int TROWS = 8, PATCHB = (TROWS + 2) * CV_PW * 128, SLOTB = 256 * 128, NPIECE = (TROWS + 2) * 5;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PATCHB + 3 * SLOTB];
+  unsigned char* patch = smem;
+  unsigned char* wring = smem + PATCHB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = wave & 1, pr = wave >> 1;
+  const int n = lane & 31, h = lane >> 5;
+  const int d_row = lane >> 3, d_slot = lane & 7;
+  int bid = blockIdx.x;
+  const int nimg = bid / (p.n_ty * p.n_tx);
+  bid -= nimg * p.n_ty * p.n_tx;
+  const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
+  const int y0 = ty * TROWS, x0 = tx * 32;
+  const int co_base = blockIdx.y * 256;
+  const int nchunk = p.Cin / 32;
+  const uint32_t pixb = (uint32_t)nchunk * 128u;
+
+  // ---- lane parts and loop-invariant scalars
+  const uint32_t w_lane_off = (uint32_t)(d_row * 128 + ((d_slot ^ (d_row >> 1)) << 4));
+  const uint32_t wo[2] = {w_lane_off, w_lane_off ^ 64u};                     // piece j: first channel 8 (8 wave + j), swizzle key 4 (j & 1)
+  const uint32_t ring_lds = lds_addr(wring), patch_lds = lds_addr(patch);
+  const uint32_t wl = ring_lds + (uint32_t)((ch * 128 + n) * 128) + ((((uint32_t)h) ^ (uint32_t)((n >> 1) & 7)) << 4);
+  uint32_t pl[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const uint32_t key = (uint32_t)((((n + dx) >> 1) & 7) ^ (4 * par));
+      pl[dx][par] = patch_lds + (uint32_t)((4 * pr * CV_PW + n + dx) * 128) + ((((uint32_t)h) ^ key) << 4);
+    }
+  const uint32_t pf_lane_off = (uint32_t)d_row * pixb + (uint32_t)((d_slot ^ (d_row >> 1)) << 4);
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  int ptab;                                                 // lane k: patch piece wave + 4 k of this wave: source offset | LDS offset | swizzle key
+  {
+    const int k = lane & 15, i = imin(wave + 4 * k, NPIECE - 1);
+    const int prow = i / 5, pc0 = (i - prow * 5) * 8;
+    const int goff = (int)((uint32_t)(prow * p.Wp + pc0) * pixb);
+    const int ldst = (prow * CV_PW + pc0) * 128;
+    const int key = ((prow + (pc0 >> 3)) & 1) << 6;
+    ptab = lane < 16 ? goff : lane < 32 ? ldst : key;
+  }
+  const unsigned char* xb_tile = reinterpret_cast<const unsigned char*>(p.x) + (uint32_t)((nimg * p.Hp + y0) * p.Wp + x0) * pixb;
+  const unsigned char* wb_tile = reinterpret_cast<const unsigned char*>(p.w) + (uint32_t)(co_base * 128);
+  const uint32_t piece_off = (uint32_t)(wave * 8 * 8 * 128);                // this wave's 8 pieces = output channels 64 wave ..+64 of a slab
+  auto weight_base = [&](int chunk, int tap) { return wb_tile + (uint32_t)((tap * nchunk + chunk) * p.Cout * 128); };
+  auto weight_piece = [&](const unsigned char* base, uint32_t dst, int j) {
+    const unsigned char* src = base + piece_off + (uint32_t)(j * 1024);
+    const uint32_t d = dst + piece_off + (uint32_t)(j * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(wo[j & 1]), "s"(src), "s"(d) : "memory");
+  };
+
+  // ---- prologue: the first chunk's patch (LDS-DMA), the weights of stages 0 and 1
+  for (int i = wave; i < NPIECE; i += 4) {
+    const int prow = i / 5, pc0 = (i - prow * 5) * 8;
+    const int P = prow * CV_PW + pc0 + d_row;
+    const int sl = d_slot ^ ((P >> 1) & 7);
+    const size_t gpix = ((size_t)nimg * p.Hp + (y0 + prow)) * p.Wp + (x0 + pc0 + d_row);
+    conv_lds_dma_16(reinterpret_cast<const unsigned char*>(p.x) + gpix * pixb + sl * 16, lds_addr(patch + (prow * CV_PW + pc0) * 128));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) weight_piece(weight_base(0, 0), ring_lds, j);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) weight_piece(weight_base(0, 1), ring_lds + SLOTB, j);
+
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as the builtin (conv64.hip): prologue DMAs landed (this wave's)
+
+  // ---- the main loop: one assembly statement (tools/gen_conv256p_sched.py has the register map and the reasons)
+  {
+    const size_t wb64 = (size_t)wb_tile, xb64 = (size_t)xb_tile;
+    const int s_tap = __builtin_amdgcn_readfirstlane(nchunk * p.Cout * 128), s_chunk = __builtin_amdgcn_readfirstlane(p.Cout * 128);
+    const int s_nchunk = __builtin_amdgcn_readfirstlane(nchunk), s_ring = __builtin_amdgcn_readfirstlane((int)ring_lds);
+    const int s_patch = __builtin_amdgcn_readfirstlane((int)patch_lds), s_piece = __builtin_amdgcn_readfirstlane((int)piece_off);
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2 s_wb = {__builtin_amdgcn_readfirstlane((int)(uint32_t)wb64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(wb64 >> 32))};
+    const i32x2 s_xb = {__builtin_amdgcn_readfirstlane((int)(uint32_t)xb64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(xb64 >> 32))};
+#define C256P_INPUTS                                                                                                              \
+  "{v232}"(wl), "{v233}"(pl[0][0]), "{v234}"(pl[0][1]), "{v235}"(pl[1][0]), "{v236}"(pl[1][1]), "{v237}"(pl[2][0]), "{v238}"(pl[2][1]),     \
+      "{v239}"(wo[0]), "{v240}"(wo[1]), "{v241}"(pf_lane_off), "{v242}"(lane16), "{v243}"(ptab), "{s[20:21]}"(s_wb), "{s22}"(s_tap),       \
+      "{s23}"(s_chunk), "{s[24:25]}"(s_xb), "{s26}"(s_nchunk), "{s27}"(s_ring), "{s28}"(s_patch), "{s29}"(s_piece)
+#include "conv256p_loop.inc"
+#undef C256P_INPUTS
+  }
+  f32x16 acc[4][4];
+  asm volatile(""
+               : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), "={a[64:79]}"(acc[1][0]),
+                 "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]), "={a[128:143]}"(acc[2][0]),
+                 "={a[144:159]}"(acc[2][1]), "={a[160:175]}"(acc[2][2]), "={a[176:191]}"(acc[2][3]), "={a[192:207]}"(acc[3][0]),
+                 "={a[208:223]}"(acc[3][1]), "={a[224:239]}"(acc[3][2]), "={a[240:255]}"(acc[3][3]));
+
+  // ---- epilogue (conv_split_kernel's, for 4 tiles x 4 rows per wave): + bias [+ residual] [ReLU], pixel rows through a wave-private LDS tile
+  constexpr int NA = 4, RPW = 4, CW = 128, RB = CW * 4, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;
+  static_assert(4 * 32 * RS <= PATCHB + 3 * SLOTB, "epilogue staging");
+  __syncthreads();
+  unsigned char* tile = smem + wave * (32 * RS);
+  const int co_w = co_base + ch * CW;
+  const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+#pragma unroll
+  for (int b = 0; b < RPW; ++b) {
+    const int y = y0 + RPW * pr + b;
+    if (y >= p.H) continue;                       // wave-uniform
+    const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
+    const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;
+    if (p.residual) {
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + mv_row;
+        if (x0 + row < p.W)
+          *reinterpret_cast<uint4*>(tile + row * RS + mv_col) = *reinterpret_cast<const uint4*>(src + (size_t)row * p.Cout * 4 + mv_col);
+      }
+      wave_sync();
+    }
+    f32x4 v[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cw = a * 32 + 8 * g + 4 * h;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
+        v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
+                   fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
+        if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
+        if (p.relu) {
+          v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
+          v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
+        }
+      }
+    if (p.y_f32) {
+      wave_sync();
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(tile + n * RS + (a * 32 + 8 * g + 4 * h) * 4) = v[a][g];
+      wave_sync();
+      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_f32 + fpix0 * p.Cout + co_w);
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + mv_row;
+        if (x0 + row < p.W)
+          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) = *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
+      }
+    }
+    if (p.y_split) {
+      wave_sync();
+      if (p.out_fmt == 0) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            ushort4 hv, lv;
+            split_bf16_4(v[a][g], hv, lv);
+            unsigned char* o = tile + n * RS + a * 128 + (8 * g + 4 * h) * 2;
+            *reinterpret_cast<ushort4*>(o) = hv;
+            *reinterpret_cast<ushort4*>(o + 64) = lv;
+          }
+      } else if (p.out_fmt == 3) {
+        bool ovf = false;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          uint2 hw[4];
+          i32x4 main6, tail6;
+          split_f16f6_chunk(v[a], p.out_scale, h, hw, main6, tail6, ovf);
+          unsigned char* o = tile + n * RS + a * 128;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw[g];
+          *reinterpret_cast<i32x4*>(o + 80 - 16 * h) = main6;
+          *reinterpret_cast<i32x4*>(o + 112 - 16 * h) = tail6;
+        }
+        if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.W) != 0ull && lane == 0) atomicOr(p.overflow, 1);
+      } else {
+        bool ovf = false;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hw, lw;
+            uint32_t l8, h8;
+            split_f16_4(v[a][g], p.out_scale, hw, l8, h8, lw, ovf);
+            unsigned char* o = tile + n * RS + a * 128;
+            *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw;
+            if (p.out_fmt == 1) {
+              *reinterpret_cast<uint32_t*>(o + 64 + 8 * g + 4 * h) = l8;
+              *reinterpret_cast<uint32_t*>(o + 96 + 8 * g + 4 * h) = h8;
+            } else {
+              *reinterpret_cast<uint2*>(o + 64 + (8 * g + 4 * h) * 2) = lw;
+            }
+          }
+        if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.W) != 0ull && lane == 0) atomicOr(p.overflow, 1);
+      }
+      wave_sync();
+      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * (p.Cout / 32) + (co_w >> 5)) * 128;
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + mv_row;
+        if (x0 + row < p.W)
+          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) = *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
+      }
+    }
+    wave_sync();
+  }
+}
+
 template <int ARITH>
 static void conv_split_dispatch(const ConvSplitParams& p, dim3 grid, int KS, int cot_eff, bool narrow, hipStream_t s) {
   if (KS == 3) {
@@ -1045,6 +1266,13 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.n_ty = cdiv(H, narrow ? 4 : 8); p.n_tx = cdiv(W, 32);
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
+  // conv256p_kernel: the plain 256-channel-tile 3 x 3 form of the f16 + FP6 arithmetic (option conv_debug & 1024: conv_split_kernel)
+  const bool fits32 = (unsigned long long)N * Hp * Wp * (Cin / 32) * 128ull < (1ull << 32) && (unsigned long long)9 * Cin * Cout * 4ull < (1ull << 32);
+  if (in_fmt == 3 && KS == 3 && cot_eff == 256 && !narrow && !y_bank && !x2 && Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
+    conv256p_kernel<<<grid, 256, 0, s>>>(p);
+    FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
+    return FGVC_OK;
+  }
   if (in_fmt == 1) conv_split_dispatch<1>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 3) conv_split_dispatch<3>(p, grid, KS, cot_eff, narrow, s);
   else if (in_fmt == 2) conv_split_dispatch<2>(p, grid, KS, cot_eff, narrow, s);
