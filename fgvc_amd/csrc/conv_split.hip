@@ -1025,11 +1025,16 @@ void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 // (conv256p_sched.inc).  Everything an assembly statement writes asynchronously sits in NAMED registers (conv64.hip has the story):
 //   accumulators a[0:255] = [tile a][row r] x 16;  pixel fragments v[0:63] / v[64:127] (buffer x row x [f16 k0 | k1 | FP6 16 B | 16 B]);
 //   weight fragments v[128:143] / v[144:159];  the patch in flight v[160:211].
+// OUT_FMT / RES / F32OUT: the epilogue's form at compile time (-1 / the runtime fields when GENERIC).  With every form in one body, unrolled
+// over the wave's four pixel rows, the epilogue was 13 000 instructions -- more than the instruction cache -- and took 88 000 cycles per tile
+// beside the loop's 140 000.
+template <int OUT_FMT, bool RES, bool F32OUT, bool GENERIC>
 __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   constexpr int TROWS = 8, PATCHB = (TROWS + 2) * CV_PW * 128, SLOTB = 256 * 128, NPIECE = (TROWS + 2) * 5;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PATCHB + 3 * SLOTB];
   unsigned char* patch = smem;
   unsigned char* wring = smem + PATCHB;
+  const long long t_begin = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = wave & 1, pr = wave >> 1;
@@ -1093,6 +1098,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
 
   __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as the builtin (conv64.hip): prologue DMAs landed (this wave's)
 
+  const long long t_loop0 = __builtin_amdgcn_s_memtime();
   // ---- the main loop: one assembly statement (tools/gen_conv256p_sched.py has the register map and the reasons)
   {
     const size_t wb64 = (size_t)wb_tile, xb64 = (size_t)xb_tile;
@@ -1102,12 +1108,20 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     const i32x2 s_wb = {__builtin_amdgcn_readfirstlane((int)(uint32_t)wb64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(wb64 >> 32))};
     const i32x2 s_xb = {__builtin_amdgcn_readfirstlane((int)(uint32_t)xb64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(xb64 >> 32))};
+    typedef int i32x2_t __attribute__((ext_vector_type(2)));
+    i32x2_t loop_cycles;
 #define C256P_INPUTS                                                                                                              \
   "{v232}"(wl), "{v233}"(pl[0][0]), "{v234}"(pl[0][1]), "{v235}"(pl[1][0]), "{v236}"(pl[1][1]), "{v237}"(pl[2][0]), "{v238}"(pl[2][1]),     \
       "{v239}"(wo[0]), "{v240}"(wo[1]), "{v241}"(pf_lane_off), "{v242}"(lane16), "{v243}"(ptab), "{s[20:21]}"(s_wb), "{s22}"(s_tap),       \
       "{s23}"(s_chunk), "{s[24:25]}"(s_xb), "{s26}"(s_nchunk), "{s27}"(s_ring), "{s28}"(s_patch), "{s29}"(s_piece)
 #include "conv256p_loop.inc"
 #undef C256P_INPUTS
+    if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {    // option conv_debug & 8: s_memtime of workgroup 300's loop (as conv_split_kernel)
+      long long* o = reinterpret_cast<long long*>(p.y_split) + wave * 8;
+      o[4] = (long long)(uint32_t)loop_cycles.x | ((long long)loop_cycles.y << 32);
+      o[5] = nchunk * 9;
+      o[0] = t_loop0 - t_begin;
+    }
   }
   f32x16 acc[4][4];
   asm volatile(""
@@ -1120,17 +1134,24 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   constexpr int NA = 4, RPW = 4, CW = 128, RB = CW * 4, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;
   static_assert(4 * 32 * RS <= PATCHB + 3 * SLOTB, "epilogue staging");
   __syncthreads();
+  long long ts0 = __builtin_amdgcn_s_memtime(), ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
   unsigned char* tile = smem + wave * (32 * RS);
   const int co_w = co_base + ch * CW;
   const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  // the lane's 16 bias vectors, once for the wave's four rows (read row by row, each row waited ~3 000 cycles for them)
+  f32x4 bvv[NA][4];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bvv[a][g] = *reinterpret_cast<const f32x4*>(p.bias + co_w + a * 32 + 8 * g + 4 * h);
 #pragma unroll
   for (int b = 0; b < RPW; ++b) {
     const int y = y0 + RPW * pr + b;
     if (y >= p.H) continue;                       // wave-uniform
     const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
     const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;
-    if (p.residual) {
+    if (GENERIC ? p.residual != nullptr : RES) {
       const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
 #pragma unroll
       for (int i = 0; i < 32 / RPI; ++i) {
@@ -1146,16 +1167,17 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cw = a * 32 + 8 * g + 4 * h;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
+        const f32x4 bv = bvv[a][g];
         v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
                    fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
-        if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
+        if (GENERIC ? p.residual != nullptr : RES) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
         if (p.relu) {
           v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
           v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
         }
       }
-    if (p.y_f32) {
+    if (b == 1) { asm volatile("s_nop 0" ::"v"(v[0][0]), "v"(v[3][3])); ts1 = __builtin_amdgcn_s_memtime(); }
+    if (GENERIC ? p.y_f32 != nullptr : F32OUT) {
       wave_sync();
 #pragma unroll
       for (int a = 0; a < NA; ++a)
@@ -1172,7 +1194,8 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     }
     if (p.y_split) {
       wave_sync();
-      if (p.out_fmt == 0) {
+      const int out_fmt = GENERIC ? p.out_fmt : OUT_FMT;
+      if (out_fmt == 0) {
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -1183,7 +1206,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
             *reinterpret_cast<ushort4*>(o) = hv;
             *reinterpret_cast<ushort4*>(o + 64) = lv;
           }
-      } else if (p.out_fmt == 3) {
+      } else if (out_fmt == 3) {
         bool ovf = false;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -1208,7 +1231,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
             split_f16_4(v[a][g], p.out_scale, hw, l8, h8, lw, ovf);
             unsigned char* o = tile + n * RS + a * 128;
             *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw;
-            if (p.out_fmt == 1) {
+            if (out_fmt == 1) {
               *reinterpret_cast<uint32_t*>(o + 64 + 8 * g + 4 * h) = l8;
               *reinterpret_cast<uint32_t*>(o + 96 + 8 * g + 4 * h) = h8;
             } else {
@@ -1218,6 +1241,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
         if (__builtin_amdgcn_ballot_w64(ovf && x0 + n < p.W) != 0ull && lane == 0) atomicOr(p.overflow, 1);
       }
       wave_sync();
+      if (b == 1) ts2 = __builtin_amdgcn_s_memtime();
       unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * (p.Cout / 32) + (co_w >> 5)) * 128;
 #pragma unroll
       for (int i = 0; i < 32 / RPI; ++i) {
@@ -1227,6 +1251,14 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
       }
     }
     wave_sync();
+    if (b == 0) ts4 = __builtin_amdgcn_s_memtime();
+    if (b == 1) ts3 = __builtin_amdgcn_s_memtime();
+  }
+  if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {
+    long long* o_ = reinterpret_cast<long long*>(p.y_split) + wave * 8;
+    o_[2] = ts4 - ts0; o_[3] = ts1 - ts4; o_[6] = ts2 - ts1; o_[7] = ts3 - ts2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    reinterpret_cast<long long*>(p.y_split)[wave * 8 + 1] = __builtin_amdgcn_s_memtime() - t_begin;
   }
 }
 
@@ -1269,7 +1301,9 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   // conv256p_kernel: the plain 256-channel-tile 3 x 3 form of the f16 + FP6 arithmetic (option conv_debug & 1024: conv_split_kernel)
   const bool fits32 = (unsigned long long)N * Hp * Wp * (Cin / 32) * 128ull < (1ull << 32) && (unsigned long long)9 * Cin * Cout * 4ull < (1ull << 32);
   if (in_fmt == 3 && KS == 3 && cot_eff == 256 && !narrow && !y_bank && !x2 && Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
-    conv256p_kernel<<<grid, 256, 0, s>>>(p);
+    if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<3, false, false, false><<<grid, 256, 0, s>>>(p);
+    else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<3, true, true, false><<<grid, 256, 0, s>>>(p);
+    else conv256p_kernel<-1, false, false, true><<<grid, 256, 0, s>>>(p);
     FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
     return FGVC_OK;
   }

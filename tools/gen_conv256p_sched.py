@@ -181,20 +181,21 @@ def main():
         idx = next(i for i, f in enumerate(flat) if f[1] == "p" and f[2] == k)
         subst[f"@PWN{k}@"] = str(sum(1 for i in range(idx + 1, n_all) if flat[i][0] < 8))
     out = ["; zero the accumulators"] + [f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)]
-    out += ["s_mov_b32 s30, 0", "s_mov_b64 s[38:39], s[24:25]", "1:"]
+    out += ["s_mov_b32 s30, 0", "s_mov_b64 s[38:39], s[24:25]", "s_memtime s[42:43]", "1:"]
     for t in range(9):
         out += bodies[t]
-    out += ["s_add_i32 s30, s30, 1", "s_cmp_lt_i32 s30, s26", "s_cbranch_scc1 1b", "s_nop 15", "s_nop 15", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    out += ["s_add_i32 s30, s30, 1", "s_cmp_lt_i32 s30, s26", "s_cbranch_scc1 1b", "s_nop 15", "s_nop 15", "s_memtime s[44:45]",
+            "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_sub_u32 s42, s44, s42", "s_subb_u32 s43, s45, s43"]          # s[42:43] = cycles of the loop
     text = "\n".join(out)
     for k, v in subst.items():
         text = text.replace(k, v)
-    clob = [f"v{i}" for i in range(0, 222)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(30, 42)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(0, 222)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(30, 42)] + ["s44", "s45"] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(root, "conv256p_loop.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_conv256p_sched.py -- do not edit.  The main loop of conv256p_kernel: one assembly statement.\n")
         f.write("asm volatile(\n")
         for line in text.split("\n"):
             f.write(f'    "{line}\\n\\t"\n')
-        f.write("    :\n    : C256P_INPUTS\n    : " + ", ".join(f'"{c}"' for c in clob) + ");\n")
+        f.write("    : \"={s[42:43]}\"(loop_cycles)\n    : C256P_INPUTS\n    : " + ", ".join(f'"{c}"' for c in clob) + ");\n")
     n_instr = sum(1 for line in text.split("\n") if line and not line.startswith(";") and not line.endswith(":"))
     print("instructions", n_instr, "tops", [subst[f"@TOPN{t}@"] for t in range(9)], "writes", [subst[f"@PWN{k}@"] for k in range(13)], file=sys.stderr)
 
