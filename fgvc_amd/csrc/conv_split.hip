@@ -1028,9 +1028,12 @@ void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 // OUT_FMT / RES / F32OUT: the epilogue's form at compile time (-1 / the runtime fields when GENERIC).  With every form in one body, unrolled
 // over the wave's four pixel rows, the epilogue was 13 000 instructions -- more than the instruction cache -- and took 88 000 cycles per tile
 // beside the loop's 140 000.
-template <int OUT_FMT, bool RES, bool F32OUT, bool GENERIC>
+// COT: output channels per workgroup, 256 (four 32-channel tiles per wave, 16 accumulators) or 128 (two tiles, 8 accumulators: the 128 -> 128
+// layers; conv128p_loop.inc -- a stage has 24 matrix instructions there).
+template <int COT, int OUT_FMT, bool RES, bool F32OUT, bool GENERIC>
 __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
-  constexpr int TROWS = 8, PATCHB = (TROWS + 2) * CV_PW * 128, SLOTB = 256 * 128, NPIECE = (TROWS + 2) * 5;
+  constexpr int NA = COT / 64, PPW = NA * 2;
+  constexpr int TROWS = 8, PATCHB = (TROWS + 2) * CV_PW * 128, SLOTB = COT * 128, NPIECE = (TROWS + 2) * 5;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PATCHB + 3 * SLOTB];
   unsigned char* patch = smem;
   unsigned char* wring = smem + PATCHB;
@@ -1045,7 +1048,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   bid -= nimg * p.n_ty * p.n_tx;
   const int ty = bid / p.n_tx, tx = bid - ty * p.n_tx;
   const int y0 = ty * TROWS, x0 = tx * 32;
-  const int co_base = blockIdx.y * 256;
+  const int co_base = blockIdx.y * COT;
   const int nchunk = p.Cin / 32;
   const uint32_t pixb = (uint32_t)nchunk * 128u;
 
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   const uint32_t w_lane_off = (uint32_t)(d_row * 128 + ((d_slot ^ (d_row >> 1)) << 4));
   const uint32_t wo[2] = {w_lane_off, w_lane_off ^ 64u};                     // piece j: first channel 8 (8 wave + j), swizzle key 4 (j & 1)
   const uint32_t ring_lds = lds_addr(wring), patch_lds = lds_addr(patch);
-  const uint32_t wl = ring_lds + (uint32_t)((ch * 128 + n) * 128) + ((((uint32_t)h) ^ (uint32_t)((n >> 1) & 7)) << 4);
+  const uint32_t wl = ring_lds + (uint32_t)((ch * (COT / 2) + n) * 128) + ((((uint32_t)h) ^ (uint32_t)((n >> 1) & 7)) << 4);
   uint32_t pl[3][2];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
@@ -1075,7 +1078,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   }
   const unsigned char* xb_tile = reinterpret_cast<const unsigned char*>(p.x) + (uint32_t)((nimg * p.Hp + y0) * p.Wp + x0) * pixb;
   const unsigned char* wb_tile = reinterpret_cast<const unsigned char*>(p.w) + (uint32_t)(co_base * 128);
-  const uint32_t piece_off = (uint32_t)(wave * 8 * 8 * 128);                // this wave's 8 pieces = output channels 64 wave ..+64 of a slab
+  const uint32_t piece_off = (uint32_t)(wave * PPW * 1024);                 // this wave's PPW pieces = output channels 8 PPW wave ..+8 PPW of a slab
   auto weight_base = [&](int chunk, int tap) { return wb_tile + (uint32_t)((tap * nchunk + chunk) * p.Cout * 128); };
   auto weight_piece = [&](const unsigned char* base, uint32_t dst, int j) {
     const unsigned char* src = base + piece_off + (uint32_t)(j * 1024);
@@ -1092,9 +1095,9 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     conv_lds_dma_16(reinterpret_cast<const unsigned char*>(p.x) + gpix * pixb + sl * 16, lds_addr(patch + (prow * CV_PW + pc0) * 128));
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) weight_piece(weight_base(0, 0), ring_lds, j);
+  for (int j = 0; j < PPW; ++j) weight_piece(weight_base(0, 0), ring_lds, j);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) weight_piece(weight_base(0, 1), ring_lds + SLOTB, j);
+  for (int j = 0; j < PPW; ++j) weight_piece(weight_base(0, 1), ring_lds + SLOTB, j);
 
   __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as the builtin (conv64.hip): prologue DMAs landed (this wave's)
 
@@ -1114,7 +1117,11 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   "{v232}"(wl), "{v233}"(pl[0][0]), "{v234}"(pl[0][1]), "{v235}"(pl[1][0]), "{v236}"(pl[1][1]), "{v237}"(pl[2][0]), "{v238}"(pl[2][1]),     \
       "{v239}"(wo[0]), "{v240}"(wo[1]), "{v241}"(pf_lane_off), "{v242}"(lane16), "{v243}"(ptab), "{s[20:21]}"(s_wb), "{s22}"(s_tap),       \
       "{s23}"(s_chunk), "{s[24:25]}"(s_xb), "{s26}"(s_nchunk), "{s27}"(s_ring), "{s28}"(s_patch), "{s29}"(s_piece)
+    if constexpr (COT == 256) {
 #include "conv256p_loop.inc"
+    } else {
+#include "conv128p_loop.inc"
+    }
 #undef C256P_INPUTS
     if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {    // option conv_debug & 8: s_memtime of workgroup 300's loop (as conv_split_kernel)
       long long* o = reinterpret_cast<long long*>(p.y_split) + wave * 8;
@@ -1123,15 +1130,20 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
       o[0] = t_loop0 - t_begin;
     }
   }
-  f32x16 acc[4][4];
-  asm volatile(""
-               : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), "={a[64:79]}"(acc[1][0]),
-                 "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]), "={a[128:143]}"(acc[2][0]),
-                 "={a[144:159]}"(acc[2][1]), "={a[160:175]}"(acc[2][2]), "={a[176:191]}"(acc[2][3]), "={a[192:207]}"(acc[3][0]),
-                 "={a[208:223]}"(acc[3][1]), "={a[224:239]}"(acc[3][2]), "={a[240:255]}"(acc[3][3]));
+  f32x16 acc[NA][4];
+  if constexpr (NA == 4)
+    asm volatile(""
+                 : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), "={a[64:79]}"(acc[1][0]),
+                   "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]), "={a[128:143]}"(acc[NA - 2][0]),
+                   "={a[144:159]}"(acc[NA - 2][1]), "={a[160:175]}"(acc[NA - 2][2]), "={a[176:191]}"(acc[NA - 2][3]), "={a[192:207]}"(acc[NA - 1][0]),
+                   "={a[208:223]}"(acc[NA - 1][1]), "={a[224:239]}"(acc[NA - 1][2]), "={a[240:255]}"(acc[NA - 1][3]));
+  else
+    asm volatile(""
+                 : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), "={a[64:79]}"(acc[1][0]),
+                   "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]));
 
   // ---- epilogue (conv_split_kernel's, for 4 tiles x 4 rows per wave): + bias [+ residual] [ReLU], pixel rows through a wave-private LDS tile
-  constexpr int NA = 4, RPW = 4, CW = 128, RB = CW * 4, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;
+  constexpr int RPW = 4, CW = COT / 2, RB = CW * 4, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;
   static_assert(4 * 32 * RS <= PATCHB + 3 * SLOTB, "epilogue staging");
   __syncthreads();
   long long ts0 = __builtin_amdgcn_s_memtime(), ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
@@ -1300,10 +1312,16 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   // conv256p_kernel: the plain 256-channel-tile 3 x 3 form of the f16 + FP6 arithmetic (option conv_debug & 1024: conv_split_kernel)
   const bool fits32 = (unsigned long long)N * Hp * Wp * (Cin / 32) * 128ull < (1ull << 32) && (unsigned long long)9 * Cin * Cout * 4ull < (1ull << 32);
-  if (in_fmt == 3 && KS == 3 && cot_eff == 256 && !narrow && !y_bank && !x2 && Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
-    if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<3, false, false, false><<<grid, 256, 0, s>>>(p);
-    else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<3, true, true, false><<<grid, 256, 0, s>>>(p);
-    else conv256p_kernel<-1, false, false, true><<<grid, 256, 0, s>>>(p);
+  if (in_fmt == 3 && KS == 3 && (cot_eff == 256 || cot_eff == 128) && !narrow && !y_bank && !x2 && Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
+    if (cot_eff == 256) {
+      if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<256, 3, false, false, false><<<grid, 256, 0, s>>>(p);
+      else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<256, 3, true, true, false><<<grid, 256, 0, s>>>(p);
+      else conv256p_kernel<256, -1, false, false, true><<<grid, 256, 0, s>>>(p);
+    } else {
+      if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<128, 3, false, false, false><<<grid, 256, 0, s>>>(p);
+      else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<128, 3, true, true, false><<<grid, 256, 0, s>>>(p);
+      else conv256p_kernel<128, -1, false, false, true><<<grid, 256, 0, s>>>(p);
+    }
     FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
     return FGVC_OK;
   }

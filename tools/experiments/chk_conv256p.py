@@ -48,8 +48,8 @@ def run(debug, xs, wp, bias, sw, sx, H, W, Cout, res, f32, fmt, so, relu=True):
 
 
 bad = 0
-for (N, Cin, H, W) in [(1, 256, 8, 32), (1, 32, 5, 7), (2, 256, 21, 50), (1, 128, 33, 70), (2, 256, 120, 214)]:
-    Cout = 256
+for (N, Cin, Cout, H, W) in [(1, 256, 256, 8, 32), (1, 32, 256, 5, 7), (2, 256, 256, 21, 50), (1, 128, 256, 33, 70), (2, 256, 256, 120, 214),
+                             (1, 128, 128, 8, 32), (1, 32, 128, 5, 7), (2, 128, 128, 21, 50), (1, 64, 128, 33, 70), (2, 128, 128, 120, 214), (1, 128, 512, 16, 40)]:
     wp, bias, sw, x, sx = operands(N, Cin, Cout, H, W, N * 100 + H + W + Cin)
     xs = pack_f16f6(x, sx)
     res = torch.randn(N, H, W, Cout, device=dev)
@@ -61,40 +61,41 @@ for (N, Cin, H, W) in [(1, 256, 8, 32), (1, 32, 5, 7), (2, 256, 21, 50), (1, 128
             bad += 1
             print(f"MISMATCH {N}x{Cin}x{H}x{W} res={r is not None} f32={f32} fmt={fmt}: split words {(a[0] != b[0]).sum().item()}, "
                   f"f32 words {(a[1] != b[1]).sum().item() if f32 else 0}, overflow {a[2]} vs {b[2]}", flush=True)
-    print(f"{N} x {Cin} -> 256 x {H} x {W}: checked", flush=True)
+    print(f"{N} x {Cin} -> {Cout} x {H} x {W}: checked", flush=True)
 print("all identical" if bad == 0 else f"{bad} mismatching cases", flush=True)
 if bad:
     sys.exit(1)
-N, Cin, Cout, H, W = 8, 256, 256, 120, 214
-wp, bias, sw, x, sx = operands(N, Cin, Cout, H, W, 1)
-xs = pack_f16f6(x, sx)
-res = torch.randn(N, H, W, Cout, device=dev)
-o_s, o_f = ops.alloc_split_nhwc(N, Cout, H, W, dev), ops.alloc_nhwc(N, Cout, H, W, dev)
-ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+for (Cin, Cout) in ((256, 256), (128, 128)):
+  N, H, W = 8, 120, 214
+  wp, bias, sw, x, sx = operands(N, Cin, Cout, H, W, 1)
+  xs = pack_f16f6(x, sx)
+  res = torch.randn(N, H, W, Cout, device=dev)
+  o_s, o_f = ops.alloc_split_nhwc(N, Cout, H, W, dev), ops.alloc_nhwc(N, Cout, H, W, dev)
+  ovf = torch.zeros(1, dtype=torch.int32, device=dev)
 
 
-def call(debug, with_res):
-    ops.set_option("conv_debug", debug)
-    ops.conv_split(xs, wp, bias, H, W, True, residual=res if with_res else None, out_split=o_s, out_f32=o_f if with_res else None, in_fmt=F6,
-                   in_scale_log2=sx + sw, out_fmt=F6, out_scale_log2=4, overflow=ovf)
+  def call(debug, with_res):
+      ops.set_option("conv_debug", debug)
+      ops.conv_split(xs, wp, bias, H, W, True, residual=res if with_res else None, out_split=o_s, out_f32=o_f if with_res else None, in_fmt=F6,
+                     in_scale_log2=sx + sw, out_fmt=F6, out_scale_log2=4, overflow=ovf)
 
 
-def timeit(fn, n=10):
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
+  def timeit(fn, n=10):
+      a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      a.record()
+      for _ in range(n):
+          fn()
+      b.record()
+      torch.cuda.synchronize()
+      return a.elapsed_time(b) / n
 
 
-t = {(d, r): [] for d in (0, 1024) for r in (False, True)}
-for rep in range(6):
-    for k in t:
-        ms = timeit(lambda: call(*k))
-        if rep:
-            t[k].append(ms)
-ops.set_option("conv_debug", 0)
-for (d, r), ms in t.items():
-    print(f"{'conv256p_kernel  ' if d == 0 else 'conv_split_kernel'} 256 -> 256 @ 8 x 120 x 214 {'+ residual + f32 out' if r else 'split out only      '} {statistics.median(ms):.4f} ms", flush=True)
+  t = {(d, r): [] for d in (0, 1024) for r in (False, True)}
+  for rep in range(6):
+      for k in t:
+          ms = timeit(lambda: call(*k))
+          if rep:
+              t[k].append(ms)
+  ops.set_option("conv_debug", 0)
+  for (d, r), ms in t.items():
+      print(f"{'conv256p_kernel  ' if d == 0 else 'conv_split_kernel'} {Cin} -> {Cout} @ 8 x 120 x 214 {'+ residual + f32 out' if r else 'split out only      '} {statistics.median(ms):.4f} ms", flush=True)

@@ -32,6 +32,7 @@ import os
 import sys
 
 CAP = 6
+NA = 4                      # output-channel tiles per wave (4: 256 channels per workgroup, 2: 128)
 SLOTB = 256 * 128
 
 
@@ -84,8 +85,6 @@ def WB(t):
 
 
 def WP(j):
-    if os.environ.get("GEN_NO_WDMA"):                      # timing experiment: no weight DMA (wrong results)
-        return []
     return [f"s_add_i32 s36, s29, {j * 1024}", "s_add_u32 s34, s32, s36", "s_addc_u32 s35, s33, 0", "s_add_i32 m0, s36, s40", "s_nop 0",
             f"global_load_lds_dwordx4 v{239 + (j & 1)}, s[34:35]"]
 
@@ -104,30 +103,34 @@ def PW(k, n):
             f"ds_write_b128 v221, {v4(160 + 4 * k)}"]
 
 
-def main():
+def generate(na, fname):
+    global NA, SLOTB
+    NA, SLOTB = na, na * 64 * 128
+    NS = NA * 12                                            # matrix instructions per stage
+    PPW = NA * 2                                            # weight DMA pieces per wave and stage
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fgvc_amd", "csrc")
     bodies, vm_seq = [], []
     for t in range(9):
         cur, nxt = t & 1, (t + 1) & 1
-        sites = [(kind, a, r) for a in range(4) for kind in ("F0", "F1", "X") for r in range(4)]
+        sites = [(kind, a, r) for a in range(NA) for kind in ("F0", "F1", "X") for r in range(4)]
         side = []                                           # (earliest site, instructions, vector-memory tag)
-        for a in range(3):
+        for a in range(NA - 1):
             side.append((a * 12, RA(a + 1, (a + 1) & 1), None))
         if t < 8:
             for r in range(4):
-                side.append((r * 12 + 1, RB(r, nxt, t + 1), None))
+                side.append((r * (NS // 4) + 1, RB(r, nxt, t + 1), None))
         side.append((2, WB(t), None))
-        for j in range(8):
-            side.append((4 + j * 5, WP(j), ("w", t)))
+        for j in range(PPW):
+            side.append((4 + j * ((NS - 8) // PPW), WP(j), ("w", t)))
         if t in (5, 6, 7):
             ks = {5: range(0, 5), 6: range(5, 9), 7: range(9, 13)}[t]
             if t == 5:
-                side.append((20, PB(), None))
+                side.append((NS // 3, PB(), None))
             for i, k in enumerate(ks):
-                side.append((24 + i * 5, PL(k), ("p", k)))
+                side.append((NS // 2 + i * (NS // 12 + 1), PL(k), ("p", k)))
         if t == 8:
             for k in range(13):
-                side.append((4 + k * 3, PW(k, f"@PWN{k}@"), None))
+                side.append((2 + k * max(1, (NS - 6) // 13), PW(k, f"@PWN{k}@"), None))
         side.sort(key=lambda x: x[0])
         lines = [f"; ---- tap {t}", f"s_waitcnt vmcnt(@TOPN{t}@)", "s_waitcnt lgkmcnt(0)", "s_barrier",
                  f"v_add_u32 v212, {(t % 3) * SLOTB}, v232", "v_xor_b32 v213, 32, v212", "v_xor_b32 v214, 64, v212", "v_xor_b32 v215, 0x60, v212"]
@@ -180,7 +183,7 @@ def main():
     for k in range(13):
         idx = next(i for i, f in enumerate(flat) if f[1] == "p" and f[2] == k)
         subst[f"@PWN{k}@"] = str(sum(1 for i in range(idx + 1, n_all) if flat[i][0] < 8))
-    out = ["; zero the accumulators"] + [f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)]
+    out = ["; zero the accumulators"] + [f"v_accvgpr_write_b32 a{i}, 0" for i in range(NA * 64)]
     out += ["s_mov_b32 s30, 0", "s_mov_b64 s[38:39], s[24:25]", "s_memtime s[42:43]", "1:"]
     for t in range(9):
         out += bodies[t]
@@ -189,15 +192,20 @@ def main():
     text = "\n".join(out)
     for k, v in subst.items():
         text = text.replace(k, v)
-    clob = [f"v{i}" for i in range(0, 222)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(30, 42)] + ["s44", "s45"] + ["m0", "vcc", "scc", "memory"]
-    with open(os.path.join(root, "conv256p_loop.inc"), "w") as f:
+    clob = [f"v{i}" for i in range(0, 222)] + [f"a{i}" for i in range(NA * 64)] + [f"s{i}" for i in range(30, 42)] + ["s44", "s45"] + ["m0", "vcc", "scc", "memory"]
+    with open(os.path.join(root, fname), "w") as f:
         f.write("// GENERATED by tools/gen_conv256p_sched.py -- do not edit.  The main loop of conv256p_kernel: one assembly statement.\n")
         f.write("asm volatile(\n")
         for line in text.split("\n"):
             f.write(f'    "{line}\\n\\t"\n')
         f.write("    : \"={s[42:43]}\"(loop_cycles)\n    : C256P_INPUTS\n    : " + ", ".join(f'"{c}"' for c in clob) + ");\n")
     n_instr = sum(1 for line in text.split("\n") if line and not line.startswith(";") and not line.endswith(":"))
-    print("instructions", n_instr, "tops", [subst[f"@TOPN{t}@"] for t in range(9)], "writes", [subst[f"@PWN{k}@"] for k in range(13)], file=sys.stderr)
+    print(fname, "instructions", n_instr, "tops", [subst[f"@TOPN{t}@"] for t in range(9)], "writes", [subst[f"@PWN{k}@"] for k in range(13)], file=sys.stderr)
+
+
+def main():
+    generate(4, "conv256p_loop.inc")
+    generate(2, "conv128p_loop.inc")
 
 
 if __name__ == "__main__":
