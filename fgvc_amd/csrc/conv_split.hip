@@ -1113,10 +1113,26 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     const i32x2 s_xb = {__builtin_amdgcn_readfirstlane((int)(uint32_t)xb64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(xb64 >> 32))};
     typedef int i32x2_t __attribute__((ext_vector_type(2)));
     i32x2_t loop_cycles;
+    // the second input (p.x2 / p.w2: a block's 1 x 1 projection shortcut folded into this convolution): its chunks follow the main loop's
+    const int nchunk2 = p.x2 ? p.Cin2 / 32 : 0;
+    const uint32_t pixb2 = (uint32_t)nchunk2 * 128u;
+    const uint32_t pf_lane_off2 = (uint32_t)d_row * pixb2 + (uint32_t)((d_slot ^ (d_row >> 1)) << 4);
+    int ptab2;
+    {
+      const int k2 = lane & 15, i2 = imin(wave + 4 * k2, NPIECE - 1);
+      const int prow = i2 / 5, pc0 = (i2 - prow * 5) * 8;
+      const int goff = (int)((uint32_t)(prow * p.Wp + pc0) * pixb2);
+      ptab2 = lane < 16 ? goff : lane < 32 ? (prow * CV_PW + pc0) * 128 : (((prow + (pc0 >> 3)) & 1) << 6);
+    }
+    const size_t w2b64 = (size_t)p.w2 + (uint32_t)(co_base * 128), x2b64 = (size_t)p.x2 + (size_t)((uint32_t)((nimg * p.Hp + y0) * p.Wp + x0) * pixb2);
+    const i32x2 s_w2b = {__builtin_amdgcn_readfirstlane((int)(uint32_t)w2b64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(w2b64 >> 32))};
+    const i32x2 s_x2b = {__builtin_amdgcn_readfirstlane((int)(uint32_t)x2b64), __builtin_amdgcn_readfirstlane((int)(uint32_t)(x2b64 >> 32))};
+    const int s_last2 = __builtin_amdgcn_readfirstlane(nchunk2 ? nchunk - 1 : -1), s_nchunk2 = __builtin_amdgcn_readfirstlane(nchunk2);
 #define C256P_INPUTS                                                                                                              \
   "{v232}"(wl), "{v233}"(pl[0][0]), "{v234}"(pl[0][1]), "{v235}"(pl[1][0]), "{v236}"(pl[1][1]), "{v237}"(pl[2][0]), "{v238}"(pl[2][1]),     \
-      "{v239}"(wo[0]), "{v240}"(wo[1]), "{v241}"(pf_lane_off), "{v242}"(lane16), "{v243}"(ptab), "{s[20:21]}"(s_wb), "{s22}"(s_tap),       \
-      "{s23}"(s_chunk), "{s[24:25]}"(s_xb), "{s26}"(s_nchunk), "{s27}"(s_ring), "{s28}"(s_patch), "{s29}"(s_piece)
+      "{v239}"(wo[0]), "{v240}"(wo[1]), "{v241}"(pf_lane_off), "{v242}"(lane16), "{v243}"(ptab), "{v244}"(pf_lane_off2), "{v245}"(ptab2),  \
+      "{s[20:21]}"(s_wb), "{s22}"(s_tap), "{s23}"(s_chunk), "{s[24:25]}"(s_xb), "{s26}"(s_nchunk), "{s27}"(s_ring), "{s28}"(s_patch),      \
+      "{s29}"(s_piece), "{s46}"(s_last2), "{s[48:49]}"(s_w2b), "{s[50:51]}"(s_x2b), "{s52}"(s_nchunk2)
     if constexpr (COT == 256) {
 #include "conv256p_loop.inc"
     } else {
@@ -1126,7 +1142,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {    // option conv_debug & 8: s_memtime of workgroup 300's loop (as conv_split_kernel)
       long long* o = reinterpret_cast<long long*>(p.y_split) + wave * 8;
       o[4] = (long long)(uint32_t)loop_cycles.x | ((long long)loop_cycles.y << 32);
-      o[5] = nchunk * 9;
+      o[5] = nchunk * 9 + nchunk2;
       o[0] = t_loop0 - t_begin;
     }
   }
@@ -1312,9 +1328,11 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   // conv256p_kernel: the plain 256-channel-tile 3 x 3 form of the f16 + FP6 arithmetic (option conv_debug & 1024: conv_split_kernel)
   const bool fits32 = (unsigned long long)N * Hp * Wp * (Cin / 32) * 128ull < (1ull << 32) && (unsigned long long)9 * Cin * Cout * 4ull < (1ull << 32);
-  if (in_fmt == 3 && KS == 3 && (cot_eff == 256 || cot_eff == 128) && !narrow && !y_bank && !x2 && Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
+  if (in_fmt == 3 && KS == 3 && (cot_eff == 256 || cot_eff == 128) && !narrow && !y_bank && (!x2 || (cot_eff == 256 && Cin2 >= 32)) && Cin >= 32 && fits32 &&
+      !(g_conv_debug & 1024)) {
     if (cot_eff == 256) {
       if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<256, 3, false, false, false><<<grid, 256, 0, s>>>(p);
+      else if (y_split && out_fmt == 3 && !residual && y_f32) conv256p_kernel<256, 3, false, true, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<256, 3, true, true, false><<<grid, 256, 0, s>>>(p);
       else conv256p_kernel<256, -1, false, false, true><<<grid, 256, 0, s>>>(p);
     } else {

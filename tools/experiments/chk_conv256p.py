@@ -62,6 +62,32 @@ for (N, Cin, Cout, H, W) in [(1, 256, 256, 8, 32), (1, 32, 256, 5, 7), (2, 256, 
             print(f"MISMATCH {N}x{Cin}x{H}x{W} res={r is not None} f32={f32} fmt={fmt}: split words {(a[0] != b[0]).sum().item()}, "
                   f"f32 words {(a[1] != b[1]).sum().item() if f32 else 0}, overflow {a[2]} vs {b[2]}", flush=True)
     print(f"{N} x {Cin} -> {Cout} x {H} x {W}: checked", flush=True)
+# ---- the second input (a block's 1 x 1 projection folded in: fgvc_conv_split_proj_fmt_f32)
+for (N, Cin, Cin2, H, W) in [(1, 256, 128, 8, 32), (2, 256, 128, 21, 50), (1, 64, 32, 9, 40), (1, 256, 96, 33, 70), (2, 256, 128, 120, 214)]:
+    g = torch.Generator().manual_seed(N + Cin + Cin2 + H + W)
+    wp, bias, sw, x, sx = operands(N, Cin, 256, H, W, 7 * N + Cin + H + W)
+    xs = pack_f16f6(x, sx)
+    x2 = (torch.randn(N, Cin2, H, W, generator=g).abs() ** 1.3 * 3.0).to(dev)
+    sx2 = ops.act_scale_log2(float(x2.abs().max()))
+    xs2 = pack_f16f6(x2, sx2)
+    wt2 = (torch.randn(256, Cin2, 1, 1, generator=g) * 0.08).to(dev)
+    bn2 = torch.nn.BatchNorm2d(256).eval().to(dev)
+    wp2, bias2, sw2 = ops.prepare_conv_split_f16(wt2, bn2, F6, force_exp=sx + sw - sx2)
+    outs = {}
+    for dbg in (0, 1024):
+        ops.set_option("conv_debug", dbg)
+        o_s, o_f = ops.alloc_split_nhwc(N, 256, H, W, dev), ops.alloc_nhwc(N, 256, H, W, dev)
+        ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.conv_split(xs, wp, bias + bias2, H, W, True, out_split=o_s, out_f32=o_f, in_fmt=F6, in_scale_log2=sx + sw, out_fmt=F6, out_scale_log2=4,
+                       overflow=ovf, x2_split=xs2, w2=wp2)
+        torch.cuda.synchronize()
+        outs[dbg] = (o_s, o_f, int(ovf.item()))
+    ops.set_option("conv_debug", 0)
+    a, b = outs[0], outs[1024]
+    if not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]):
+        bad += 1
+        print(f"MISMATCH second input {N}x{Cin}+{Cin2}x{H}x{W}: split words {(a[0] != b[0]).sum().item()}, f32 words {(a[1] != b[1]).sum().item()}", flush=True)
+    print(f"{N} x ({Cin} 3x3 + {Cin2} 1x1) -> 256 x {H} x {W}: checked", flush=True)
 print("all identical" if bad == 0 else f"{bad} mismatching cases", flush=True)
 if bad:
     sys.exit(1)

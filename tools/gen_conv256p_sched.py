@@ -24,8 +24,10 @@ Register map
   v[128:143]  weight fragments, buffer 0 (same four pieces); v[144:159] buffer 1
   v[160:211]  the next chunk's patch in flight (13 pieces of 4)
   v[212:215]  weight-fragment addresses of the stage (slot variants), v[216:218] pixel-fragment slot variants, v220 / v221 temporaries
+  v222 / v223 patch lane offset and piece table in use (copies of v241 / v243; the second input's v244 / v245 from its first prefetch on)
   v232 wl  v[233:238] pl[dx][par]  v239 / v240 DMA lane offsets  v241 patch lane offset  v242 16 lane  v243 piece table      (inputs)
   s[20:21] weight base  s22 tap stride  s23 chunk stride  s[24:25] patch base  s26 chunks  s27 ring  s28 patch  s29 piece offset (inputs)
+  s46 the last chunk's index when a second input follows (else -1)  s[48:49] its weights  s[50:51] its patch base  s52 its chunks  (inputs)
   s30 chunk  s[32:33] slab base  s[34:35] / s36 / s37 temporaries  s[38:39] next patch base  s40 ring slot of the DMA
 """
 import os
@@ -78,9 +80,12 @@ def WB(t):
     out = []
     if t < 7:
         out += [f"s_mul_i32 s36, s22, {t + 2}", "s_mul_i32 s37, s23, s30"]
-    else:                                   # the next chunk's tap t - 7 (the last chunk: its own again)
+    else:                                   # the next chunk's tap t - 7 (the last chunk: its own again, or the second input's slab t - 7)
         out += ["s_add_i32 s37, s30, 1", "s_sub_i32 s36, s26, 1", "s_min_i32 s37, s37, s36", "s_mul_i32 s37, s23, s37", f"s_mul_i32 s36, s22, {t - 7}"]
     out += ["s_add_i32 s36, s36, s37", "s_add_u32 s32, s20, s36", "s_addc_u32 s33, s21, 0", f"s_add_i32 s40, s27, {((t + 2) % 3) * SLOTB}"]
+    if t >= 7:
+        out += ["s_cmp_eq_u32 s30, s46", f"s_cbranch_scc0 7{t}f", "s_sub_i32 s36, s52, 1", f"s_min_i32 s36, s36, {t - 7}", "s_mul_i32 s36, s36, s23",
+                "s_add_u32 s32, s48, s36", "s_addc_u32 s33, s49, 0", f"7{t}:"]
     return out
 
 
@@ -90,16 +95,17 @@ def WP(j):
 
 
 def PB():
-    return ["s_add_i32 s37, s30, 1", "s_sub_i32 s36, s26, 1", "s_min_i32 s37, s37, s36", "s_lshl_b32 s37, s37, 7", "s_add_u32 s38, s24, s37", "s_addc_u32 s39, s25, 0"]
+    return ["s_add_i32 s37, s30, 1", "s_sub_i32 s36, s26, 1", "s_min_i32 s37, s37, s36", "s_lshl_b32 s37, s37, 7", "s_add_u32 s38, s24, s37", "s_addc_u32 s39, s25, 0",
+            "s_cmp_eq_u32 s30, s46", "s_cbranch_scc0 75f", "s_mov_b64 s[38:39], s[50:51]", "v_mov_b32 v222, v244", "v_mov_b32 v223, v245", "75:"]
 
 
 def PL(k):
-    return [f"v_readlane_b32 s36, v243, {k}", f"v_readlane_b32 s37, v243, {32 + k}", "s_add_u32 s34, s38, s36", "s_addc_u32 s35, s39, 0",
-            "v_xor_b32 v220, s37, v241", f"global_load_dwordx4 {v4(160 + 4 * k)}, v220, s[34:35]"]
+    return [f"v_readlane_b32 s36, v223, {k}", f"v_readlane_b32 s37, v223, {32 + k}", "s_add_u32 s34, s38, s36", "s_addc_u32 s35, s39, 0",
+            "v_xor_b32 v220, s37, v222", f"global_load_dwordx4 {v4(160 + 4 * k)}, v220, s[34:35]"]
 
 
 def PW(k, n):
-    return [f"s_waitcnt vmcnt({n})", f"v_readlane_b32 s36, v243, {16 + k}", "s_add_i32 s36, s36, s28", "v_add_u32 v221, s36, v242",
+    return [f"s_waitcnt vmcnt({n})", f"v_readlane_b32 s36, v223, {16 + k}", "s_add_i32 s36, s36, s28", "v_add_u32 v221, s36, v242",
             f"ds_write_b128 v221, {v4(160 + 4 * k)}"]
 
 
@@ -184,15 +190,55 @@ def generate(na, fname):
         idx = next(i for i, f in enumerate(flat) if f[1] == "p" and f[2] == k)
         subst[f"@PWN{k}@"] = str(sum(1 for i in range(idx + 1, n_all) if flat[i][0] < 8))
     out = ["; zero the accumulators"] + [f"v_accvgpr_write_b32 a{i}, 0" for i in range(NA * 64)]
-    out += ["s_mov_b32 s30, 0", "s_mov_b64 s[38:39], s[24:25]", "s_memtime s[42:43]", "1:"]
+    out += ["s_mov_b32 s30, 0", "s_mov_b64 s[38:39], s[24:25]", "v_mov_b32 v222, v241", "v_mov_b32 v223, v243", "s_memtime s[42:43]", "1:"]
     for t in range(9):
         out += bodies[t]
-    out += ["s_add_i32 s30, s30, 1", "s_cmp_lt_i32 s30, s26", "s_cbranch_scc1 1b", "s_nop 15", "s_nop 15", "s_memtime s[44:45]",
+    out += ["s_add_i32 s30, s30, 1", "s_cmp_lt_i32 s30, s26", "s_cbranch_scc1 1b"]
+    # ---- the second input (the block's projection shortcut folded in): one stage per 32-channel chunk, its only tap the centre one.  The
+    # patch changes with every stage: a second barrier behind the operand reads frees it, the next chunk's pieces are loaded early in
+    # the stage and written late.  (s30 = chunk of the second input, s41 = its ring slot's offset, s[38:39] = its patch base.)
+    x2 = ["s_cmp_eq_u32 s52, 0", "s_cbranch_scc1 3f", "s_mov_b32 s30, 0", "s_mov_b32 s41, 0", "2:",
+          "s_waitcnt vmcnt(9)", "s_waitcnt lgkmcnt(0)", "s_barrier",
+          "v_add_u32 v212, s41, v232", "v_xor_b32 v213, 32, v212", "v_xor_b32 v214, 64, v212", "v_xor_b32 v215, 0x60, v212"]
+    x2 += RA(0, 0)
+    for r in range(4):
+        x2 += RB(r, 0, 4)
+    x2 += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    sites = [(kind, a, r) for a in range(NA) for kind in ("F0", "F1", "X") for r in range(4)]
+    side = [(a * 12, RA(a + 1, (a + 1) & 1)) for a in range(NA - 1)]
+    # next chunk of the second input (the last: itself again): patch base, then the 13 pieces; weights of the stage two ahead
+    side.append((1, ["s_add_i32 s37, s30, 1", "s_sub_i32 s36, s52, 1", "s_min_i32 s37, s37, s36", "s_lshl_b32 s37, s37, 7", "s_add_u32 s38, s50, s37",
+                     "s_addc_u32 s39, s51, 0"]))
+    for k in range(13):
+        side.append((2 + k, PL(k)))
+    side.append((16, ["s_add_i32 s37, s30, 2", "s_sub_i32 s36, s52, 1", "s_min_i32 s37, s37, s36", "s_mul_i32 s36, s37, s23", "s_add_u32 s32, s48, s36",
+                      "s_addc_u32 s33, s49, 0", "s_add_i32 s40, s41, {0}".format(2 * SLOTB), "s_cmp_ge_u32 s40, {0}".format(3 * SLOTB),
+                      "s_cselect_b32 s37, {0}, 0".format(3 * SLOTB), "s_sub_i32 s40, s40, s37", "s_add_i32 s40, s40, s27"]))
+    for j in range(NA * 2):
+        side.append((18 + j * 2, WP(j)))
+    for k in range(13):
+        side.append((NS - 14 + k, PW(k, 8 + 12 - k)))
+    side.sort(key=lambda x: x[0])
+    si = 0
+    for n, (kind, a, r) in enumerate(sites):
+        if n % 12 == 0 and n > 0:
+            x2.append("s_waitcnt lgkmcnt(0)")
+        x2.append(M(kind, a, r, a & 1, 0))
+        while si < len(side) and side[si][0] <= n:
+            x2 += side[si][1]
+            si += 1
+    while si < len(side):
+        x2 += side[si][1]
+        si += 1
+    x2 += ["s_add_i32 s41, s41, {0}".format(SLOTB), "s_cmp_ge_u32 s41, {0}".format(3 * SLOTB), "s_cselect_b32 s37, {0}, 0".format(3 * SLOTB), "s_sub_i32 s41, s41, s37",
+           "s_add_i32 s30, s30, 1", "s_cmp_lt_i32 s30, s52", "s_cbranch_scc1 2b", "3:"]
+    out += x2
+    out += ["s_nop 15", "s_nop 15", "s_memtime s[44:45]",
             "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_sub_u32 s42, s44, s42", "s_subb_u32 s43, s45, s43"]          # s[42:43] = cycles of the loop
     text = "\n".join(out)
     for k, v in subst.items():
         text = text.replace(k, v)
-    clob = [f"v{i}" for i in range(0, 222)] + [f"a{i}" for i in range(NA * 64)] + [f"s{i}" for i in range(30, 42)] + ["s44", "s45"] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(0, 224)] + [f"a{i}" for i in range(NA * 64)] + [f"s{i}" for i in range(30, 42)] + ["s44", "s45"] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(root, fname), "w") as f:
         f.write("// GENERATED by tools/gen_conv256p_sched.py -- do not edit.  The main loop of conv256p_kernel: one assembly statement.\n")
         f.write("asm volatile(\n")
