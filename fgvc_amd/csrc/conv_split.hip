@@ -1030,7 +1030,7 @@ void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 // beside the loop's 140 000.
 // COT: output channels per workgroup, 256 (four 32-channel tiles per wave, 16 accumulators) or 128 (two tiles, 8 accumulators: the 128 -> 128
 // layers; conv128p_loop.inc -- a stage has 24 matrix instructions there).
-template <int COT, int OUT_FMT, bool RES, bool F32OUT, bool GENERIC>
+template <int COT, int OUT_FMT, bool RES, bool F32OUT, bool GENERIC, bool BANK = false>
 __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   constexpr int NA = COT / 64, PPW = NA * 2;
   constexpr int TROWS = 8, PATCHB = (TROWS + 2) * CV_PW * 128, SLOTB = COT * 128, NPIECE = (TROWS + 2) * 5;
@@ -1167,6 +1167,178 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   const int co_w = co_base + ch * CW;
   const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  if constexpr (BANK) {
+    {
+      // ---- the feature bank straight from the accumulators (conv_split_kernel's BANK epilogue, here for 4 rows per wave and two row groups): what normalize_f16f6p_kernel makes of this convolution's dense
+      // f32 output, bit for bit, without that output ever reaching memory.  A workgroup holds all 256 channels of its pixels: wave
+      // (pr, ch) channels 128 ch ..+128 of pixel rows 2 pr, 2 pr + 1.  Per pixel row: (1) the sum of squares in that kernel's own
+      // association -- lane L of its wave-per-pixel layout holds channels 4 L ..+4 = here group (ch, a, g, h) with L = 32 ch + 8 a +
+      // 2 g + h, and its xor-shuffle tree adds partners 32, 16, 8, 4, 2, 1 apart: the other wave's partial through LDS, then a ^ 2,
+      // a ^ 1, g ^ 2, g ^ 1 in registers, then the other lane half; (2) x = v / |v|, h = f16(256 x), residual 256 (256 x - h);
+      // (3) a scale block of the row format = channels 64 v + 16 m + 8 hi + i = groups a = 2 (v & 1) + (m >> 1), g = hi + 2 (m & 1) of
+      // BOTH lane halves: the halves trade registers (v_permlane32_swap) so that lane (n, 0) holds the block's 32 h values and
+      // lane (n, 1) its 32 residuals, one v_cvt_scalef32_2xpk16_fp6_f32 each (position 2 e <- S0[e], 2 e + 1 <- S1[e], round to nearest
+      // even from f32: tools/micro/probe_cvt_fp6_f32.hip); (4) the pair of waves assembles the 1-KiB rows in LDS and stores them whole.
+      constexpr int BK_RS = 1024 + 16;
+      static_assert(COT == 256 && 2 * 32 * BK_RS <= PATCHB + 3 * SLOTB, "bank staging");
+      unsigned char* rows = smem + pr * (32 * BK_RS);
+      float* part = reinterpret_cast<float*>(rows);                 // [ch][a * 4 + g][lane]: aliases the rows, used before them
+#pragma unroll
+      for (int b = 0; b < RPW; ++b) {
+        const int y = y0 + RPW * pr + b;
+        const bool row_ok = y < p.H;                                // wave-uniform, the same for both waves of a pair; barriers are taken by all
+        const size_t fpix0 = ((size_t)nimg * p.H + imin(y, p.H - 1)) * p.W + x0;
+        if (p.residual) {
+          const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
+#pragma unroll
+          for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = i * RPI + mv_row;
+            if (x0 + row < p.W)
+              *reinterpret_cast<uint4*>(tile + row * RS + mv_col) = *reinterpret_cast<const uint4*>(src + (size_t)row * p.Cout * 4 + mv_col);
+          }
+          wave_sync();
+        }
+        f32x4 v[NA][4];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cw = a * 32 + 8 * g + 4 * h;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
+            v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
+                         fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
+            if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
+            if (p.relu) {
+              v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
+              v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
+            }
+          }
+        __syncthreads();                                            // (1) the private residual tiles are read: the region becomes the pairs' buffers
+        float pp[NA][4];
+        {
+#pragma clang fp contract(off)                                       // four rounded squares and three adds, as normalize_nhwc_kernel compiles
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float xx = v[a][g].x * v[a][g].x, yy = v[a][g].y * v[a][g].y, zz = v[a][g].z * v[a][g].z, ww = v[a][g].w * v[a][g].w;
+              pp[a][g] = ((xx + yy) + zz) + ww;
+              part[(ch * 16 + a * 4 + g) * 64 + lane] = pp[a][g];
+            }
+        }
+        __syncthreads();                                            // (2)
+        float ss;
+        {
+          float t[NA][4];
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t[a][g] = pp[a][g] + part[((ch ^ 1) * 16 + a * 4 + g) * 64 + lane];       // partner 32 lanes away
+          float u[2][4], w4[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { u[0][g] = t[0][g] + t[2][g]; u[1][g] = t[1][g] + t[3][g]; }                // 16
+#pragma unroll
+          for (int g = 0; g < 4; ++g) w4[g] = u[0][g] + u[1][g];                                                 // 8
+          const float z0 = w4[0] + w4[2], z1 = w4[1] + w4[3];                                                     // 4
+          const float s1 = z0 + z1;                                                                               // 2
+          ss = s1 + __shfl_xor(s1, 32);                                                                           // 1: the other lane half
+        }
+        __syncthreads();                                            // (3) the partials are read: rows may be written
+        const float inv = p.bank_normalize ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+        unsigned char* row = rows + n * BK_RS;
+#pragma unroll
+        for (int vl = 0; vl < 2; ++vl)
+#pragma unroll
+          for (int hi = 0; hi < 2; ++hi) {
+            unsigned A_[16], B_[16];
+            float mh = 0.f, ml = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const int a = 2 * vl + (m >> 1), g = hi + 2 * (m & 1);          // (every (a, g) group belongs to exactly one block)
+              f32x4 x = v[a][g];
+              x *= inv;
+              typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+              f16x4 hv;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float xs = x[k] * 256.f;
+                const _Float16 hh_ = (_Float16)xs;
+                hv[k] = hh_;
+                const float fh = (float)hh_, fl = (xs - fh) * 256.f;
+                mh = fmaxf(mh, fabsf(fh)); ml = fmaxf(ml, fabsf(fl));
+                A_[4 * m + k] = __builtin_bit_cast(unsigned, fh);
+                B_[4 * m + k] = __builtin_bit_cast(unsigned, fl);
+              }
+              *reinterpret_cast<f16x4*>(row + 2 * (128 * ch + 32 * a + 8 * g + 4 * h)) = hv;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {        // upper lanes of A_ <-> lower lanes of B_: A_ = the values of lane half 0, B_ of half 1
+              const auto t2 = __builtin_amdgcn_permlane32_swap(A_[j], B_[j], false, false);
+              A_[j] = t2[0]; B_[j] = t2[1];
+            }
+            const auto tm = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mh), __builtin_bit_cast(unsigned, ml), false, false);
+            const unsigned mb = tm[0] > tm[1] ? tm[0] : tm[1];     // (as unsigned integers: see split_f16f6_chunk)
+            int sexp = (int)(mb >> 23) - 129 + ((mb & 0x7fffffu) > 0x700000u ? 1 : 0);     // m / 2^s in (3.75, 7.5]: n6_scale_exp
+            sexp = (mb == 0u || sexp < -40) ? -40 : sexp;
+            fgvc_i32x16 S0, S1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              S0[4 * m + 0] = (int)A_[4 * m + 0]; S0[4 * m + 1] = (int)A_[4 * m + 2]; S0[4 * m + 2] = (int)B_[4 * m + 0]; S0[4 * m + 3] = (int)B_[4 * m + 2];
+              S1[4 * m + 0] = (int)A_[4 * m + 1]; S1[4 * m + 1] = (int)A_[4 * m + 3]; S1[4 * m + 2] = (int)B_[4 * m + 1]; S1[4 * m + 3] = (int)B_[4 * m + 3];
+            }
+            fgvc_i32x6 c6;
+            const unsigned sc_bits = (unsigned)(sexp + 127) << 23;
+            asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(c6) : "v"(S0), "v"(S1), "v"(sc_bits));
+            const int vg = 2 * ch + vl;
+            *reinterpret_cast<i32x4*>(row + (h ? 704 : 512) + 32 * vg + 16 * hi) = i32x4{c6[0], c6[1], c6[2], c6[3]};
+            *reinterpret_cast<uint2*>(row + (h ? 832 : 640) + 32 * (vg >> 1) + 16 * hi + 8 * (vg & 1)) = uint2{(unsigned)c6[4], (unsigned)c6[5]};
+            row[896 + 16 * hi + 4 * h + vg] = (unsigned char)(sexp + 127 - 4);
+          }
+        if (ch == 0) {                                              // the pads of the scale area and the row's zero tail
+          if (h == 0) {
+            *reinterpret_cast<unsigned long long*>(row + 904) = 0ull;
+            *reinterpret_cast<unsigned long long*>(row + 920) = 0ull;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) *reinterpret_cast<i32x4*>(row + 928 + 16 * i) = i32x4{0, 0, 0, 0};
+          }
+        }
+        __syncthreads();                                            // (4) the rows are whole
+        if (row_ok) {
+          unsigned char* dst = p.y_bank + fpix0 * p.bank_row_bytes;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int r = 16 * ch + i;
+            if (x0 + r < p.W)
+              *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+          }
+        }
+        __syncthreads();                                            // (5) before the next pixel row's residual tiles
+        if (p.bank_row_bytes > 1024) {                              // (uniform) round 5: the exact channels x themselves, second KiB of every row
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x4 x = v[a][g];
+              x *= inv;
+              *reinterpret_cast<f32x4*>(row + 4 * (128 * ch + 32 * a + 8 * g + 4 * h)) = x;
+            }
+          __syncthreads();
+          if (row_ok) {
+            unsigned char* dst = p.y_bank + fpix0 * p.bank_row_bytes + 1024;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int r = 16 * ch + i;
+              if (x0 + r < p.W)
+                *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+            }
+          }
+          __syncthreads();
+        }
+      }
+      return;
+    }
+  }
   // the lane's 16 bias vectors, once for the wave's four rows (read row by row, each row waited ~3 000 cycles for them)
   f32x4 bvv[NA][4];
 #pragma unroll
@@ -1328,9 +1500,10 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   // conv256p_kernel: the plain 256-channel-tile 3 x 3 form of the f16 + FP6 arithmetic (option conv_debug & 1024: conv_split_kernel)
   const bool fits32 = (unsigned long long)N * Hp * Wp * (Cin / 32) * 128ull < (1ull << 32) && (unsigned long long)9 * Cin * Cout * 4ull < (1ull << 32);
-  if (in_fmt == 3 && KS == 3 && (cot_eff == 256 || cot_eff == 128) && !narrow && !y_bank && (!x2 || (cot_eff == 256 && Cin2 >= 32)) && Cin >= 32 && fits32 &&
-      !(g_conv_debug & 1024)) {
-    if (cot_eff == 256) {
+  if (in_fmt == 3 && KS == 3 && (cot_eff == 256 || cot_eff == 128) && !narrow && (!y_bank || (cot_eff == 256 && !x2)) && (!x2 || (cot_eff == 256 && Cin2 >= 32)) &&
+      Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
+    if (y_bank) conv256p_kernel<256, -1, false, false, true, true><<<grid, 256, 0, s>>>(p);
+    else if (cot_eff == 256) {
       if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<256, 3, false, false, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && !residual && y_f32) conv256p_kernel<256, 3, false, true, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<256, 3, true, true, false><<<grid, 256, 0, s>>>(p);
