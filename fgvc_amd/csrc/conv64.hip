@@ -902,11 +902,25 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
 
   const bool probe = (p.variant & 8) && blockIdx.x == 77;
   long long pb = 0, pm = 0, pw = 0, pe = 0, pn = 0;
-  int tile = (int)blockIdx.x, buf = 0;
-  const int g_img = G / (p.n_ty * p.n_tx), g_rem = G - g_img * (p.n_ty * p.n_tx), g_ty = g_rem / p.n_tx, g_tx = g_rem - g_ty * p.n_tx;
+  // Tile order.  The layer is bound by HBM now (624 MB per 8-frame launch at 5 TB/s), a third of it patch rows that vertical neighbours
+  // share -- fetched twice when the neighbours run on different XCDs (raster order: tiles t and t + n_tx on workgroups 14 apart, L2 hit
+  // rate 0.30).  With the full grid of 256 persistent workgroups (dispatched round-robin over the 8 XCDs) the tiles are walked COLUMN-major
+  // (y fastest) and the 32 workgroups of an XCD take 32 consecutive ones of a round: one image column's strip in one L2.
+  // (option conv64_variant & 128: raster order.  conv64_kernel tried this order in round 3, issue-bound then: 0.7 % slower.)
+  const bool colmajor = G == 256 && !(p.variant & 128);
+  int tile = colmajor ? ((int)blockIdx.x & 7) * 32 + ((int)blockIdx.x >> 3) : (int)blockIdx.x, buf = 0;
+  const int n_fast = colmajor ? p.n_ty : p.n_tx, n_slow = colmajor ? p.n_tx : p.n_ty;
+  const int g_img = G / (p.n_ty * p.n_tx), g_rem = G - g_img * (p.n_ty * p.n_tx), g_slow = g_rem / n_fast, g_fast = g_rem - g_slow * n_fast;
   int nimg, y0, x0;
-  tile_origin(tile, nimg, y0, x0);
-  uint32_t tx_c = (uint32_t)x0 / 32u, ty_c = (uint32_t)y0 / (uint32_t)C64_TR;
+  uint32_t f_c, s_c;                                        // the tile's coordinates along the fast and the slow axis of the walk
+  {
+    nimg = tile / (p.n_ty * p.n_tx);
+    const int rem = tile - nimg * p.n_ty * p.n_tx;
+    s_c = (uint32_t)(rem / n_fast);
+    f_c = (uint32_t)rem - s_c * (uint32_t)n_fast;
+    y0 = (int)(colmajor ? f_c : s_c) * C64_TR;
+    x0 = (int)(colmajor ? s_c : f_c) * 32;
+  }
   {
     const unsigned char* tb = patch_base(nimg, y0, x0);
 #pragma unroll
@@ -1068,7 +1082,7 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
   for (;;) {
     const long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0;
     int nimg_n, y0_n, x0_n;
-    uint32_t tx_n, ty_n;
+    uint32_t f_n, s_n;
     const unsigned char* next_base;
     const uint32_t pbuf = (uint32_t)(buf * C64_PATCHB);     // (only the DMA target needs it: the operand addresses carry the buffer)
     const uint32_t next_lds = patches_lds + (uint32_t)((buf ^ 1) * C64_PATCHB);
@@ -1103,16 +1117,16 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
     auto tilenext_a = [&]() {                               // the tile behind this one -- or this one again (its patch is loaded a second
       // time, into the free buffer, and never read: every tile issues the same instructions).  G tiles further = (g_img, g_ty, g_tx)
       // further with carries: no division in the loop (tile_origin's two cost 45 scalar instructions)
-      uint32_t txn = tx_c + (uint32_t)g_tx, tyn = ty_c + (uint32_t)g_ty, nin = (uint32_t)nimg + (uint32_t)g_img;
-      const uint32_t c1 = txn >= (uint32_t)p.n_tx ? 1u : 0u;
-      txn -= c1 ? (uint32_t)p.n_tx : 0u;
-      tyn += c1;
-      const uint32_t c2 = tyn >= (uint32_t)p.n_ty ? 1u : 0u;
-      tyn -= c2 ? (uint32_t)p.n_ty : 0u;
+      uint32_t fn = f_c + (uint32_t)g_fast, sn = s_c + (uint32_t)g_slow, nin = (uint32_t)nimg + (uint32_t)g_img;
+      const uint32_t c1 = fn >= (uint32_t)n_fast ? 1u : 0u;
+      fn -= c1 ? (uint32_t)n_fast : 0u;
+      sn += c1;
+      const uint32_t c2 = sn >= (uint32_t)n_slow ? 1u : 0u;
+      sn -= c2 ? (uint32_t)n_slow : 0u;
       nin += c2;
       const bool has = tile + G < p.n_tiles;
-      tx_n = has ? txn : tx_c; ty_n = has ? tyn : ty_c; nimg_n = has ? (int)nin : nimg;
-      y0_n = (int)(ty_n * C64_TR); x0_n = (int)(tx_n * 32);
+      f_n = has ? fn : f_c; s_n = has ? sn : s_c; nimg_n = has ? (int)nin : nimg;
+      y0_n = (int)((colmajor ? f_n : s_n) * C64_TR); x0_n = (int)((colmajor ? s_n : f_n) * 32);
     };
     auto tilenext_b = [&]() { next_base = patch_base(nimg_n, y0_n, x0_n); };
     const unsigned char* dma_base;
@@ -1123,7 +1137,6 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
       dma_off = lane_off0 ^ (uint32_t)__builtin_amdgcn_readlane(piece_tab, 32 + k);
     };
     auto dma_b = [&](int k) {
-      if (p.variant & 64) return;                           // (timing experiment: no patch DMA -- wrong results)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_off), "s"(dma_base), "s"(dma_dst) : "memory");
     };
     auto flip = [&](int dx, int par, int k) { lane_a[dx][par][k] += (uint32_t)flip_delta; };
@@ -1206,7 +1219,7 @@ __global__ __launch_bounds__(256, 1) void conv64p_kernel(Conv64Params p) {
     if (probe) { pm += t2 - t1; pn += 1; }
     tile += G;
     if (tile >= p.n_tiles) break;
-    nimg = nimg_n; y0 = y0_n; x0 = x0_n; tx_c = tx_n; ty_c = ty_n;
+    nimg = nimg_n; y0 = y0_n; x0 = x0_n; f_c = f_n; s_c = s_n;
     const long long t3 = probe ? __builtin_amdgcn_s_memtime() : 0;
     lds_barrier();                                          // every wave's pieces of the next patch have landed; the other buffer is free
     if (probe) pb += __builtin_amdgcn_s_memtime() - t3;

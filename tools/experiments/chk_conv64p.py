@@ -93,15 +93,15 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n
 
 
-t = {(v, k): [] for v in (0, 16) for k in FORMS}
+t = {(v, k): [] for v in (0, 128, 16) for k in FORMS}
 for rep in range(7):
     for (v, k) in t:
         ms = timeit(lambda: call(v, FORMS[k]))
         if rep:
             t[(v, k)].append(ms)
 for (v, k), ms in t.items():
-    print(f"{'conv64p_kernel' if v == 0 else 'conv64_kernel '}  {k:42s} {statistics.median(ms):.4f} ms", flush=True)
-for v in (8, 8 | 64):
+    print(f"{'conv64p_kernel' if v == 0 else 'conv64p, raster' if v == 128 else 'conv64_kernel '}  {k:42s} {statistics.median(ms):.4f} ms", flush=True)
+for v in (8, 8 | 128):
     for k, form in FORMS.items():
         for _ in range(3):
             call(v, form)
@@ -110,5 +110,5 @@ for v in (8, 8 | 64):
         _lib.call("fgvc_conv64_probe", ctypes.cast(buf, ctypes.c_void_p))
         pb, pm, pw, pe, pn = list(buf)[0:5]
         if pn:
-            print(f"probe (variant {v}) {k}: wave 0, {pn} tiles; cycles per tile: barrier {pb / pn:.0f}  tile loop body {pm / pn:.0f}  drain (once) {pe:.0f}", flush=True)
+            print(f"probe ({'raster order' if v & 128 else 'XCD-aware column-major order'}) {k}: wave 0, {pn} tiles; cycles per tile: barrier {pb / pn:.0f}  tile loop body {pm / pn:.0f}  drain (once) {pe:.0f}", flush=True)
 ops.set_option("conv64_variant", 0)

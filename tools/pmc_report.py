@@ -30,12 +30,13 @@ names = {"fgvc_pair_topk_f16f6": "pair_topk_kernel_v7", "fgvc_pair_topk_f16x3": 
          "fgvc_corr_volume_f16f6": "corr_volume_f16f6_kernel", "fgvc_corr_volume_f16f8": "corr_volume_f16f8_v2_kernel", "fgvc_corr_volume_bf16x3": "corr_volume_bf16_kernel<256, 3",
          "fgvc_corr_volume_bf16": "corr_volume_bf16_kernel<256, 1", "fgvc_corr_volume_f32": "corr_volume_f32_kernel",
          "fgvc_conv_split_f32": "conv_split_kernel<3, 256, 1, 3, 4, true, 0, 2, false, false", "fgvc_conv_split_fmt_f32[f16f8]": "conv_split_kernel<3, 256, 1, 3, 4, false, 1, 2, false, false",
-         "fgvc_conv_split_fmt_f32[f16f6]": "conv_split_kernel<3, 256, 1, 3, 4, false, 3, 2, false, false",
-         "fgvc_conv_split_proj_fmt_f32[f16f6]": "conv_split_kernel<3, 256, 1, 3, 4, false, 3, 2, false, true",
-         "fgvc_conv_split_bank_f16f6p_f32[f16f6]": "conv_split_kernel<3, 256, 1, 3, 4, false, 3, 2, true, false",
+         "fgvc_conv_split_fmt_f32[f16f6]": "conv256p_kernel<256, 3, false, false, false",          # (round 5: the one-wave-per-SIMD stream kernel)
+         "fgvc_conv_split_proj_fmt_f32[f16f6]": "conv256p_kernel<256, 3, false, true, false",
+         "fgvc_conv_split_bank_f16f6p_f32[f16f6]": "conv256p_kernel<256, -1, false, false, true, true",
          "fgvc_merge_refine_topk_f32[mark]": "merge_mark_kernel", "fgvc_merge_refine_topk_f32[refine]": "refine_kernel",
          "fgvc_merge_refine_topk_f32[scan]": "refine_scan_kernel",
-         "fgvc_conv64_split_f32": "conv64_kernel",
+         "fgvc_conv64_split_f32": "conv64_kernel", "fgvc_conv64_split_fmt_f32[conv1]": "conv64p_kernel<false, false, 1>",
+         "fgvc_conv64_split_fmt_f32[conv2]": "conv64p_kernel<true, true, 1>",
          "fgvc_stem7_split_f32": "stem7_kernel", "fgvc_conv_s2_split_f32": "conv_s2_kernel<3>"}
 HW = 120 * 214
 tiles = -(-HW // 32) * -(-HW // 32)

@@ -66,8 +66,18 @@ w64, b64 = ops.prepare_conv64(torch.randn(64, 64, 3, 3, device=dev) * 0.05, torc
 y64 = ops.alloc_split_nhwc(T, 64, 240, 427, dev)
 w2, b2 = ops.prepare_conv_s2(torch.randn(128, 64, 3, 3, device=dev) * 0.05, torch.nn.BatchNorm2d(128).eval().to(dev))
 s2_out = ops.alloc_split_nhwc(T, 128, 120, 214, dev)
+# (round 5) layer 1 as the encoder runs it: f16 + fp8 operands -- a block's first convolution (split out) and its second (f32 residual,
+# f32 + split out) on conv64p_kernel
+w64f, b64f, sw64 = ops.prepare_conv64_f16(torch.randn(64, 64, 3, 3, device=dev) * 0.05, torch.nn.BatchNorm2d(64).eval().to(dev))
+st8 = ops.alloc_split_nhwc(T, 64, 240, 427, dev)
+y64f = ops.alloc_nhwc(T, 64, 240, 427, dev)
 for _ in range(3):
     ops.stem7_split(frames, sw, sb, True, out_split=st_s, out_f32=st_f)
     ops.conv64_split(st_s, w64, b64, 240, 427, True, out_split=y64)
     ops.conv_s2_split(st_s, w2, b2, 240, 427, True, out_split=s2_out)
+    ops.stem7_split(frames, sw, sb, True, out_split=st8, out_f32=st_f, out_fmt=ops.ACT_F16F8, out_scale_log2=4, overflow=ovf)
+    ops.conv64_split(st8, w64f, b64f, 240, 427, True, out_split=y64, in_fmt=ops.ACT_F16F8, in_scale_log2=4 + sw64, out_fmt=ops.ACT_F16F8, out_scale_log2=4,
+                     overflow=ovf)
+    ops.conv64_split(st8, w64f, b64f, 240, 427, True, residual=st_f, out_split=y64, out_f32=y64f, in_fmt=ops.ACT_F16F8, in_scale_log2=4 + sw64,
+                     out_fmt=ops.ACT_F16F8, out_scale_log2=4, overflow=ovf)
 torch.cuda.synchronize()
