@@ -60,6 +60,12 @@ const char* fgvc_last_error(void);
  *                        the 128-channel 3x3 layers (bit 1).
  *   "readout_prune"      fgvc_softargmax_top5_f32: 1 (default) = pruned read-out, full scan only for the maps it hands back;
  *                        0 = full scan of every map.  Identical results.
+ *   "conv64_variant"     fgvc_conv64_split_fmt_f32 (f16 + fp8 operands): 0 (default) = conv64p_kernel, round 5's one-stream-per-tile kernel, for the
+ *                        forms the encoder launches; 16 = conv64_kernel<1> (round 3's: the kernel every other form runs on), 32 = the K-split
+ *                        experiment, 128 = conv64p_kernel in raster tile order; 8 = s_memtime probe of one workgroup (fgvc_conv64_probe).
+ *                        16 and 128 give identical results (A/B switches); the tests hold 0 against 16 bit for bit.
+ *   "conv_debug" 1024    fgvc_conv_split_* with f16 + FP6 operands, 3 x 3, 128 / 256-channel tiles: conv_split_kernel (rounds 2-4) instead of
+ *                        conv256p_kernel (round 5: one wave per SIMD, main loop one assembly statement).  Identical results (A/B switch).
  *   "pair_debug", "pair_f16_debug", "corr_debug", "conv_debug", "conv_s2_debug": profiling ablations (skip selection / MFMA / staging /
  *                        epilogue, s_memtime probes); results are WRONG when non-zero -- tools/experiments/ablate_*.py, tools/experiments/time_*.py. */
 int fgvc_set_option(const char* name, int value);
