@@ -1167,6 +1167,32 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   const int co_w = co_base + ch * CW;
   const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  // ---- the f32 residual rows come by LDS-DMA, one pixel row of the wave ahead of their use.  (Read through registers where they are needed,
+  // every load under its own predicate, the compiler waited for each by itself -- 16 memory latencies per pixel row, 18 000 of a row's
+  // 26 000 cycles; batched into registers they do not fit beside 256 accumulators: scratch memory.)  Region: behind the four staging tiles,
+  // 32 pixels x RB bytes per wave, 16-byte slot s of pixel p at slot s ^ (p mod slots): the reads in the accumulator layout (one pixel
+  // per lane, the same logical slot) then fall on different banks.
+  constexpr int RSLOTS = RB / 16, RPIECES = 32 * RB / 1024, RPPP = 1024 / RB;       // slots per pixel row, 1-KiB pieces per wave row, pixels per piece
+  static_assert(4 * 32 * RS + 4 * 32 * RB <= PATCHB + 3 * SLOTB, "residual tiles");
+  unsigned char* rtile = smem + 4 * (32 * RS) + wave * (32 * RB);
+  const bool has_res = GENERIC || BANK ? p.residual != nullptr : RES;
+  auto residual_dma = [&](int b_) {
+    const int y_ = y0 + RPW * pr + b_;
+    if (!has_res || b_ >= RPW || y_ >= p.H) return;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + (((size_t)nimg * p.H + y_) * p.W + x0) * p.Cout + co_w);
+    const int pmax = p.W - 1 - x0;                          // (pixels beyond the row's end read its last pixel: never stored)
+#pragma unroll
+    for (int j = 0; j < RPIECES; ++j) {
+      const int pp = j * RPPP + (lane * 16) / RB, ps = ((lane * 16) % RB) / 16;
+      const uint32_t voff = (uint32_t)(imin(pp, pmax) * p.Cout * 4 + ((ps ^ (pp & (RSLOTS - 1))) << 4));
+      conv_lds_dma_16s(voff, src, lds_addr(rtile + j * 1024));
+    }
+  };
+  auto residual_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto residual_at = [&](int cw) {                          // the lane's pixel n, channels cw ..+4 of the wave's CW
+    return *reinterpret_cast<const f32x4*>(rtile + n * RB + ((((cw * 4) >> 4) ^ (n & (RSLOTS - 1))) << 4));
+  };
+  residual_dma(0);
   if constexpr (BANK) {
     {
       // ---- the feature bank straight from the accumulators (conv_split_kernel's BANK epilogue, here for 4 rows per wave and two row groups): what normalize_f16f6p_kernel makes of this convolution's dense
@@ -1188,16 +1214,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
         const int y = y0 + RPW * pr + b;
         const bool row_ok = y < p.H;                                // wave-uniform, the same for both waves of a pair; barriers are taken by all
         const size_t fpix0 = ((size_t)nimg * p.H + imin(y, p.H - 1)) * p.W + x0;
-        if (p.residual) {
-          const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
-#pragma unroll
-          for (int i = 0; i < 32 / RPI; ++i) {
-            const int row = i * RPI + mv_row;
-            if (x0 + row < p.W)
-              *reinterpret_cast<uint4*>(tile + row * RS + mv_col) = *reinterpret_cast<const uint4*>(src + (size_t)row * p.Cout * 4 + mv_col);
-          }
-          wave_sync();
-        }
+        if (has_res && row_ok) residual_wait();
         f32x4 v[NA][4];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -1207,12 +1224,13 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
             v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
                          fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
-            if (p.residual) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
+            if (has_res && row_ok) v[a][g] += residual_at(cw);
             if (p.relu) {
               v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
               v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
             }
           }
+        if (has_res) { wave_sync(); residual_dma(b + 1); }
         __syncthreads();                                            // (1) the private residual tiles are read: the region becomes the pairs' buffers
         float pp[NA][4];
         {
@@ -1351,16 +1369,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     if (y >= p.H) continue;                       // wave-uniform
     const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
     const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;
-    if (GENERIC ? p.residual != nullptr : RES) {
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual + fpix0 * p.Cout + co_w);
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int row = i * RPI + mv_row;
-        if (x0 + row < p.W)
-          *reinterpret_cast<uint4*>(tile + row * RS + mv_col) = *reinterpret_cast<const uint4*>(src + (size_t)row * p.Cout * 4 + mv_col);
-      }
-      wave_sync();
-    }
+    if (has_res) residual_wait();
     f32x4 v[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -1370,12 +1379,13 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
         const f32x4 bv = bvv[a][g];
         v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
                    fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
-        if (GENERIC ? p.residual != nullptr : RES) v[a][g] += *reinterpret_cast<const f32x4*>(tile + n * RS + cw * 4);
+        if (has_res) v[a][g] += residual_at(cw);
         if (p.relu) {
           v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
           v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
         }
       }
+    if (has_res) { wave_sync(); residual_dma(b + 1); }                  // this row's residual is in registers: the next row's may land
     if (b == 1) { asm volatile("s_nop 0" ::"v"(v[0][0]), "v"(v[3][3])); ts1 = __builtin_amdgcn_s_memtime(); }
     if (GENERIC ? p.y_f32 != nullptr : F32OUT) {
       wave_sync();

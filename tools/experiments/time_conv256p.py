@@ -41,9 +41,11 @@ for w in range(4):
     print(f"loop {int(v[w, 4])} cycles, {int(v[w, 5])} stages -> {int(v[w, 4]) / max(int(v[w, 5]), 1):.0f} per stage (48 matrix instructions = 1536 cycles of pipe)")
 # epilogue forms: whole-workgroup cycles of workgroup 300 minus the loop
 o_f = ops.alloc_nhwc(N, Cout, H, W, dev)
+res_t = torch.randn(N, H, W, Cout, device=dev)
 for name, kw in (("split f16f6 out", dict(out_split=o_s, out_fmt=F6, out_scale_log2=4)), ("split bf16 out", dict(out_split=o_s, out_fmt=ops.ACT_BF16X2)),
                  ("split f16f8 out", dict(out_split=o_s, out_fmt=ops.ACT_F16F8, out_scale_log2=4)),
-                 ("split f16f6 + f32 out", dict(out_split=o_s, out_f32=o_f, out_fmt=F6, out_scale_log2=4))):
+                 ("split f16f6 + f32 out", dict(out_split=o_s, out_f32=o_f, out_fmt=F6, out_scale_log2=4)),
+                 ("residual, f16f6 + f32 out", dict(out_split=o_s, out_f32=o_f, residual=res_t, out_fmt=F6, out_scale_log2=4))):
     for dbg in (8, 8 | 1024):
         ops.set_option("conv_debug", dbg)
         for _ in range(2):
