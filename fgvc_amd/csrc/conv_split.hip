@@ -1509,7 +1509,8 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
   p.debug = g_conv_debug;
   dim3 grid(p.n_ty * p.n_tx * N, Cout / cot_eff);
   // conv256p_kernel: the plain 256-channel-tile 3 x 3 form of the f16 + FP6 arithmetic (option conv_debug & 1024: conv_split_kernel)
-  const bool fits32 = (unsigned long long)N * Hp * Wp * (Cin / 32) * 128ull < (1ull << 32) && (unsigned long long)9 * Cin * Cout * 4ull < (1ull << 32);
+  const bool fits32 = (unsigned long long)N * Hp * Wp * (Cin / 32) * 128ull < (1ull << 32) && (unsigned long long)9 * Cin * Cout * 4ull < (1ull << 32) &&
+                      (!x2 || ((unsigned long long)N * Hp * Wp * (Cin2 / 32) * 128ull < (1ull << 32) && (unsigned long long)Cin2 * Cout * 4ull < (1ull << 32)));
   if (in_fmt == 3 && KS == 3 && (cot_eff == 256 || cot_eff == 128) && !narrow && (!y_bank || (cot_eff == 256 && !x2)) && (!x2 || (cot_eff == 256 && Cin2 >= 32)) &&
       Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
     if (y_bank) conv256p_kernel<256, -1, false, false, true, true><<<grid, 256, 0, s>>>(p);
