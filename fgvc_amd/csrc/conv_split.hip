@@ -1193,6 +1193,21 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     return *reinterpret_cast<const f32x4*>(rtile + n * RB + ((((cw * 4) >> 4) ^ (n & (RSLOTS - 1))) << 4));
   };
   residual_dma(0);
+  // the staged pixel rows to global memory; a tile that lies wholly inside the image row (all but the last tile column) stores without
+  // per-pixel predicates
+  const bool tile_full = x0 + 32 <= p.W;
+  auto store_rows = [&](unsigned char* dst) {
+    unsigned char* d0 = dst + (size_t)mv_row * p.Cout * 4 + mv_col;
+    const unsigned char* t0 = tile + mv_row * RS + mv_col;
+    if (tile_full) {
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) *reinterpret_cast<uint4*>(d0 + (size_t)(i * RPI) * p.Cout * 4) = *reinterpret_cast<const uint4*>(t0 + i * RPI * RS);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i)
+        if (x0 + i * RPI + mv_row < p.W) *reinterpret_cast<uint4*>(d0 + (size_t)(i * RPI) * p.Cout * 4) = *reinterpret_cast<const uint4*>(t0 + i * RPI * RS);
+    }
+  };
   if constexpr (BANK) {
     {
       // ---- the feature bank straight from the accumulators (conv_split_kernel's BANK epilogue, here for 4 rows per wave and two row groups): what normalize_f16f6p_kernel makes of this convolution's dense
@@ -1394,13 +1409,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(tile + n * RS + (a * 32 + 8 * g + 4 * h) * 4) = v[a][g];
       wave_sync();
-      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_f32 + fpix0 * p.Cout + co_w);
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int row = i * RPI + mv_row;
-        if (x0 + row < p.W)
-          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) = *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
-      }
+      store_rows(reinterpret_cast<unsigned char*>(p.y_f32 + fpix0 * p.Cout + co_w));
     }
     if (p.y_split) {
       wave_sync();
@@ -1452,13 +1461,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
       }
       wave_sync();
       if (b == 1) ts2 = __builtin_amdgcn_s_memtime();
-      unsigned char* dst = reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * (p.Cout / 32) + (co_w >> 5)) * 128;
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int row = i * RPI + mv_row;
-        if (x0 + row < p.W)
-          *reinterpret_cast<uint4*>(dst + (size_t)row * p.Cout * 4 + mv_col) = *reinterpret_cast<const uint4*>(tile + row * RS + mv_col);
-      }
+      store_rows(reinterpret_cast<unsigned char*>(p.y_split) + (pix0 * (p.Cout / 32) + (co_w >> 5)) * 128);
     }
     wave_sync();
     if (b == 0) ts4 = __builtin_amdgcn_s_memtime();
