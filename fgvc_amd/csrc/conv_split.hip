@@ -1339,11 +1339,19 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
         __syncthreads();                                            // (4) the rows are whole
         if (row_ok) {
           unsigned char* dst = p.y_bank + fpix0 * p.bank_row_bytes;
+          if (x0 + 32 <= p.W) {                                     // (a tile inside the image row: no per-pixel predicates)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int r = 16 * ch + i;
-            if (x0 + r < p.W)
+            for (int i = 0; i < 16; ++i) {
+              const int r = 16 * ch + i;
               *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int r = 16 * ch + i;
+              if (x0 + r < p.W)
+                *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+            }
           }
         }
         __syncthreads();                                            // (5) before the next pixel row's residual tiles
@@ -1359,11 +1367,19 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
           __syncthreads();
           if (row_ok) {
             unsigned char* dst = p.y_bank + fpix0 * p.bank_row_bytes + 1024;
+            if (x0 + 32 <= p.W) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int r = 16 * ch + i;
-              if (x0 + r < p.W)
+              for (int i = 0; i < 16; ++i) {
+                const int r = 16 * ch + i;
                 *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const int r = 16 * ch + i;
+                if (x0 + r < p.W)
+                  *reinterpret_cast<uint4*>(dst + (size_t)r * p.bank_row_bytes + 16 * lane) = *reinterpret_cast<const uint4*>(rows + r * BK_RS + 16 * lane);
+              }
             }
           }
           __syncthreads();
