@@ -1034,9 +1034,11 @@ template <int COT, int OUT_FMT, bool RES, bool F32OUT, bool GENERIC, bool BANK =
 __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   constexpr int NA = COT / 64, PPW = NA * 2;
   constexpr int TROWS = 8, PATCHB = (TROWS + 2) * CV_PW * 128, SLOTB = COT * 128, NPIECE = (TROWS + 2) * 5;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PATCHB + 3 * SLOTB];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PATCHB + 3 * SLOTB + COT * 4];
   unsigned char* patch = smem;
   unsigned char* wring = smem + PATCHB;
+  float* bias_lds = reinterpret_cast<float*>(smem + PATCHB + 3 * SLOTB);      // the workgroup's COT bias values (written here, read in the epilogue:
+                                                                              // as global loads under register pressure they were waited for one by one)
   const long long t_begin = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1086,6 +1088,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(wo[j & 1]), "s"(src), "s"(d) : "memory");
   };
 
+  if (tid < COT / 4) reinterpret_cast<f32x4*>(bias_lds)[tid] = reinterpret_cast<const f32x4*>(p.bias + co_base)[tid];
   // ---- prologue: the first chunk's patch (LDS-DMA), the weights of stages 0 and 1
   for (int i = wave; i < NPIECE; i += 4) {
     const int prow = i / 5, pc0 = (i - prow * 5) * 8;
@@ -1139,7 +1142,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
 #include "conv128p_loop.inc"
     }
 #undef C256P_INPUTS
-    if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {    // option conv_debug & 8: s_memtime of workgroup 300's loop (as conv_split_kernel)
+    if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0 && p.y_split) {    // option conv_debug & 8: s_memtime of workgroup 300's loop (as conv_split_kernel)
       long long* o = reinterpret_cast<long long*>(p.y_split) + wave * 8;
       o[4] = (long long)(uint32_t)loop_cycles.x | ((long long)loop_cycles.y << 32);
       o[5] = nchunk * 9 + nchunk2;
@@ -1188,7 +1191,13 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
       conv_lds_dma_16s(voff, src, lds_addr(rtile + j * 1024));
     }
   };
-  auto residual_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  // the row's DMA pieces are older than the previous row's stores (issued behind them): a counted wait lets those stores drain on their
+  // own -- when the tile is interior, i.e. every store instruction was issued (a predicated one whose pixels are all outside is skipped)
+  auto residual_wait = [&](int stores_behind) {
+    if (x0 + 32 > p.W || stores_behind == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (stores_behind == 32 / RPI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(32 / RPI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (32 / RPI)) : "memory");
+  };
   auto residual_at = [&](int cw) {                          // the lane's pixel n, channels cw ..+4 of the wave's CW
     return *reinterpret_cast<const f32x4*>(rtile + n * RB + ((((cw * 4) >> 4) ^ (n & (RSLOTS - 1))) << 4));
   };
@@ -1224,19 +1233,22 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
       static_assert(COT == 256 && 2 * 32 * BK_RS <= PATCHB + 3 * SLOTB, "bank staging");
       unsigned char* rows = smem + pr * (32 * BK_RS);
       float* part = reinterpret_cast<float*>(rows);                 // [ch][a * 4 + g][lane]: aliases the rows, used before them
+      long long bts[6] = {}, bt_begin = 0;
 #pragma unroll
       for (int b = 0; b < RPW; ++b) {
         const int y = y0 + RPW * pr + b;
         const bool row_ok = y < p.H;                                // wave-uniform, the same for both waves of a pair; barriers are taken by all
+        if (b == 1) bt_begin = __builtin_amdgcn_s_memtime();
+        if (b == 2) bts[4] = __builtin_amdgcn_s_memtime();
         const size_t fpix0 = ((size_t)nimg * p.H + imin(y, p.H - 1)) * p.W + x0;
-        if (has_res && row_ok) residual_wait();
+        if (has_res && row_ok) residual_wait(b == 0 || 32 / RPI != 16 ? 0 : (p.bank_row_bytes > 1024 ? 32 : 16));
         f32x4 v[NA][4];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int cw = a * 32 + 8 * g + 4 * h;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + cw);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + ch * CW + cw);
             v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
                          fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
             if (has_res && row_ok) v[a][g] += residual_at(cw);
@@ -1246,6 +1258,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
             }
           }
         if (has_res) { wave_sync(); residual_dma(b + 1); }
+        if (b == 1) bts[0] = __builtin_amdgcn_s_memtime();
         __syncthreads();                                            // (1) the private residual tiles are read: the region becomes the pairs' buffers
         float pp[NA][4];
         {
@@ -1277,6 +1290,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
           ss = s1 + __shfl_xor(s1, 32);                                                                           // 1: the other lane half
         }
         __syncthreads();                                            // (3) the partials are read: rows may be written
+        if (b == 1) bts[1] = __builtin_amdgcn_s_memtime();
         const float inv = p.bank_normalize ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
         unsigned char* row = rows + n * BK_RS;
 #pragma unroll
@@ -1336,6 +1350,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
             for (int i = 0; i < 6; ++i) *reinterpret_cast<i32x4*>(row + 928 + 16 * i) = i32x4{0, 0, 0, 0};
           }
         }
+        if (b == 1) bts[2] = __builtin_amdgcn_s_memtime();
         __syncthreads();                                            // (4) the rows are whole
         if (row_ok) {
           unsigned char* dst = p.y_bank + fpix0 * p.bank_row_bytes;
@@ -1355,6 +1370,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
           }
         }
         __syncthreads();                                            // (5) before the next pixel row's residual tiles
+        if (b == 1) bts[3] = __builtin_amdgcn_s_memtime();
         if (p.bank_row_bytes > 1024) {                              // (uniform) round 5: the exact channels x themselves, second KiB of every row
 #pragma unroll
           for (int a = 0; a < NA; ++a)
@@ -1385,29 +1401,36 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
           __syncthreads();
         }
       }
+      if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {
+        long long* o_ = reinterpret_cast<long long*>(p.y_bank) + wave * 8;
+        o_[0] = bts[0] - bt_begin; o_[1] = bts[1] - bts[0]; o_[2] = bts[2] - bts[1]; o_[3] = bts[3] - bts[2]; o_[4] = bts[4] - bts[3]; o_[5] = __builtin_amdgcn_s_memtime() - t_begin;
+      }
       return;
     }
   }
   // the lane's 16 bias vectors, once for the wave's four rows (read row by row, each row waited ~3 000 cycles for them)
-  f32x4 bvv[NA][4];
+  constexpr bool HOIST_BIAS = !GENERIC && !RES;                // (with residual rows or unknown forms: no 64 registers to spare -- from the LDS copy)
+  f32x4 bvv[HOIST_BIAS ? NA : 1][4];
+  if constexpr (HOIST_BIAS) {
 #pragma unroll
-  for (int a = 0; a < NA; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bvv[a][g] = *reinterpret_cast<const f32x4*>(p.bias + co_w + a * 32 + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g) bvv[a][g] = *reinterpret_cast<const f32x4*>(bias_lds + ch * CW + a * 32 + 8 * g + 4 * h);
+  }
 #pragma unroll
   for (int b = 0; b < RPW; ++b) {
     const int y = y0 + RPW * pr + b;
     if (y >= p.H) continue;                       // wave-uniform
     const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
     const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;
-    if (has_res) residual_wait();
+    if (has_res) residual_wait(b == 0 ? 0 : ((GENERIC ? p.y_f32 != nullptr : F32OUT) ? 32 / RPI : 0) + (p.y_split ? 32 / RPI : 0));
     f32x4 v[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cw = a * 32 + 8 * g + 4 * h;
-        const f32x4 bv = bvv[a][g];
+        const f32x4 bv = HOIST_BIAS ? bvv[HOIST_BIAS ? a : 0][g] : *reinterpret_cast<const f32x4*>(bias_lds + ch * CW + cw);
         v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
                    fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
         if (has_res) v[a][g] += residual_at(cw);
@@ -1483,7 +1506,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     if (b == 0) ts4 = __builtin_amdgcn_s_memtime();
     if (b == 1) ts3 = __builtin_amdgcn_s_memtime();
   }
-  if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {
+  if ((p.debug & 8) && blockIdx.x == 300 && blockIdx.y == 0 && lane == 0 && p.y_split) {
     long long* o_ = reinterpret_cast<long long*>(p.y_split) + wave * 8;
     o_[2] = ts4 - ts0; o_[3] = ts1 - ts4; o_[6] = ts2 - ts1; o_[7] = ts3 - ts2;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
