@@ -149,3 +149,47 @@ def test_conv256p_second_input_and_bank(dev, shape):
         assert torch.equal(a[3], b[3])
     finally:
         ops.set_option("conv_debug", 0)
+
+
+def test_stream_kernels_soak(dev):
+    """200 launches of each stream kernel on the same operands, other work in flight on a second stream: every output bit-identical to the
+    first launch's (their waits are hand-counted: a wait that is one short shows up as a rare wrong tile, not as a failing parity test)."""
+    from fgvc_amd import ops
+    F6, F8 = ops.ACT_F16F6, ops.ACT_F16F8
+    N, H, W = 2, 120, 214
+    wt, bn, x = _conv_operands(N, 256, 256, H, W, 77, dev)
+    wp, bias, sw = ops.prepare_conv_split_f16(wt, bn, F6)
+    sx = ops.act_scale_log2(float(x.abs().max()))
+    xs = _pack_f16f6(x, sx, dev)
+    res = torch.randn(N, H, W, 256, device=dev)
+    g = torch.Generator().manual_seed(5)
+    wt64 = (torch.randn(64, 64, 3, 3, generator=g) * 0.06).to(dev)
+    w64, b64, sw64 = ops.prepare_conv64_f16(wt64, torch.nn.BatchNorm2d(64).eval().to(dev))
+    x64 = (torch.randn(2, 64, 240, 427, generator=g).abs() ** 1.5).to(dev)
+    sx64 = ops.act_scale_log2(float(x64.abs().max()))
+    xs64 = _pack_f16f8(x64, sx64, dev)
+    r64 = torch.randn(2, 240, 427, 64, generator=g).to(dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    noise = torch.randn(4096, 4096, device=dev)
+
+    def launch():
+        o_s, o_f = ops.alloc_split_nhwc(N, 256, H, W, dev), ops.alloc_nhwc(N, 256, H, W, dev)
+        ops.conv_split(xs, wp, bias, H, W, True, residual=res, out_split=o_s, out_f32=o_f, in_fmt=F6, in_scale_log2=sx + sw, out_fmt=F6, out_scale_log2=4,
+                       overflow=ovf)
+        y_s, y_f = ops.alloc_split_nhwc(2, 64, 240, 427, dev), ops.alloc_nhwc(2, 64, 240, 427, dev)
+        ops.conv64_split(xs64, w64, b64, 240, 427, True, residual=r64, out_split=y_s, out_f32=y_f, in_fmt=F8, in_scale_log2=sx64 + sw64, out_fmt=F8,
+                         out_scale_log2=3, overflow=ovf)
+        return o_s, o_f, y_s, y_f
+    first = launch()
+    torch.cuda.synchronize()
+    for it in range(200):
+        with torch.cuda.stream(side):
+            noise = noise @ noise * 1e-4                    # memory and matrix traffic beside the kernels under test
+        got = launch()
+        if it % 20 == 19:
+            torch.cuda.synchronize()
+            for a, b in zip(first, got):
+                assert torch.equal(a, b), it
+    torch.cuda.synchronize()
+    assert int(ovf.item()) == 0
