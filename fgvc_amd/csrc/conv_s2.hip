@@ -89,6 +89,11 @@ __global__ __launch_bounds__(64 * S2_NW, 2) void conv_s2_kernel(ConvS2Params p) 
   // operand is ONE contiguous KiB
   const int n_ct = p.Cout / 32;
   const uint16_t* wlane = p.w + (size_t)(active ? (co_w >> 5) : 0) * 2048 + lane * 8;   // + (t * nchunk + chunk) * n_ct * 2048
+  // the lane's four bias vectors, loaded up front (read in the epilogue's row loop every load was followed by its own wait: eight L2 round
+  // trips in a row per workgroup)
+  f32x4 bias_v[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bias_v[g] = *reinterpret_cast<const f32x4*>(p.bias + (active ? co_w : 0) + 8 * g + 4 * h);
 
   for (int cg = 0; cg < nchunk; cg += S2_CPG) {
     const int ncg = imin(S2_CPG, nchunk - cg);
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(64 * S2_NW, 2) void conv_s2_kernel(ConvS2Params p) 
     f32x4 v[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co_w + 8 * g + 4 * h);
+      const f32x4 bv = bias_v[g];
       v[g] = {acc[b][4 * g + 0] + bv.x, acc[b][4 * g + 1] + bv.y, acc[b][4 * g + 2] + bv.z, acc[b][4 * g + 3] + bv.w};
       if (p.relu) {
         v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f);
