@@ -1560,10 +1560,12 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
       if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<256, 3, false, false, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && !residual && y_f32) conv256p_kernel<256, 3, false, true, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<256, 3, true, true, false><<<grid, 256, 0, s>>>(p);
+      else if (y_split && out_fmt == 3 && residual && !y_f32) conv256p_kernel<256, 3, true, false, false><<<grid, 256, 0, s>>>(p);
       else conv256p_kernel<256, -1, false, false, true><<<grid, 256, 0, s>>>(p);
     } else {
       if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<128, 3, false, false, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<128, 3, true, true, false><<<grid, 256, 0, s>>>(p);
+      else if (y_split && out_fmt == 3 && residual && !y_f32) conv256p_kernel<128, 3, true, false, false><<<grid, 256, 0, s>>>(p);
       else conv256p_kernel<128, -1, false, false, true><<<grid, 256, 0, s>>>(p);
     }
     FGVC_CHECK_LAUNCH("fgvc_conv_split_f32");
