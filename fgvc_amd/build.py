@@ -20,7 +20,7 @@ OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "lib", "libfgvc_hip.so")
 SOURCES = ["capi.hip", "pair_topk.hip", "pair_topk_v5.hip", "conv_split.hip", "conv_s2.hip", "conv64.hip", "stem7.hip", "post.hip", "corr_volume.hip", "corr_volume_f8.hip", "corr_volume_f6.hip", "local.hip", "dense_attend.hip", "refine.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "pair_common.hpp"), os.path.join(CSRC, "sortnet.hpp"), os.path.join(ROOT, "include", "fgvc_hip.h"),
-           os.path.join(CSRC, "pair_topk_v7.hpp"), os.path.join(CSRC, "pair_v7.inc"), os.path.join(CSRC, "pair_v5_chain.inc")]
+           os.path.join(CSRC, "pair_topk_v7.hpp"), os.path.join(CSRC, "pair_v7.inc"), os.path.join(CSRC, "pair_topk_v8.hpp"), os.path.join(CSRC, "pair_v8.inc"), os.path.join(CSRC, "pair_v5_chain.inc")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # pair_topk_v5.hip unrolls a 48-MFMA chain with one slice of a sorting network behind every MFMA: beyond clang's default budget for
 # `#pragma unroll` (the loop would stay rolled and the register-resident operands would go to scratch)

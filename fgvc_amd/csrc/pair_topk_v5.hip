@@ -936,4 +936,5 @@ int pair_topk_v5_launch(const uint16_t* q_hl, const uint16_t* k_hl, const int32_
 
 }  // namespace fgvc
 
-#include "pair_topk_v7.hpp"      // fgvc_pair_topk_f16f6: the same protocol at 1.5 pipe units (shares the helpers above)
+#include "pair_topk_v7.hpp"
+#include "pair_topk_v8.hpp"      // round 6: the same arithmetic as ONE kind of wave, a key block staged once for eight query blocks      // fgvc_pair_topk_f16f6: the same protocol at 1.5 pipe units (shares the helpers above)

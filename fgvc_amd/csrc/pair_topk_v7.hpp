@@ -703,6 +703,8 @@ static int pair_v7_blocks_reached(int r2max, int ry, int rx, int reach_y, int re
   return count;
 }
 
+int pair_topk_v8_launch(const PairParamsB& p0, int n_pairs, int n_groups, int topk, hipStream_t s);      // pair_topk_v8.hpp
+
 int pair_topk_v7_launch(const uint16_t* q_sp, const uint16_t* k_sp, const int32_t* pairs, int n_pairs, int Hq, int Wq, int Hk, int Wk,
                         int r2max, int ry, int rx, int topk, const int32_t* groups, int n_groups, int32_t* idx_out, float* score_out,
                         int row_bytes, hipStream_t s) {
@@ -723,6 +725,11 @@ int pair_topk_v7_launch(const uint16_t* q_sp, const uint16_t* k_sp, const int32_
     set_error("fgvc_pair_topk_f16f6: the mask reaches more than %d key blocks per query tile; use fgvc_pair_topk_f16x3", V7_MAX_BLOCKS);
     return FGVC_ERR_UNSUPPORTED;
   }
+  // round 6: the one-role kernel (pair_topk_v8.hpp: a key block staged once for EIGHT query blocks, every wave multiplies and selects
+  // for itself) is bit-identical and moves 0.65 of the bytes, but 4-7 % SLOWER at every BASELINE shape (profiles/r06_pair_v8.log): it
+  // is kept behind pair_f16_debug & 4194304 (tests hold the two kernels against each other), this kernel stays the default
+  if ((p.debug & 4194304) && p.reach_y <= 16 && p.reach_x <= 16 && (long long)Hk * Wk * row_bytes < (1ll << 31))
+    return pair_topk_v8_launch(p, n_pairs, n_groups, topk, s);
   dim3 grid(p.n_ty * p.n_tx, groups ? n_groups : n_pairs);
   if (topk <= 5) pair_topk_kernel_v7<5, false><<<grid, 768, 0, s>>>(p);
   else if (p.debug & 256) pair_topk_kernel_v7<10, true><<<grid, 768, 0, s>>>(p);

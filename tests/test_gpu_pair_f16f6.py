@@ -277,3 +277,61 @@ def test_pair_f16f6_work_order_over_many_runs(dev, shape):
     fin = torch.isfinite(s3)
     assert bool((torch.isfinite(sa) == fin).all()) and float((sa[fin] - s3[fin]).abs().max()) < 1.2e-5
     assert float((~(ia == i3).all(-1)).float().mean()) < 2e-2
+
+
+V8 = 4194304          # pair_f16_debug bit: pair_topk_kernel_v8 (csrc/pair_topk_v8.hpp) takes the launch instead of pair_topk_kernel_v7
+
+
+@pytest.mark.parametrize("case", [(33, 70, 4, 30, "circle", 10), (37, 53, 3, 30, "circle", 5), (17, 23, 3, 9, "square", 5),
+                                  (8, 8, 3, 30, "circle", 10), (5, 3, 2, 4, "circle", 5), (64, 48, 7, 30, "circle", 10),
+                                  (40, 72, 3, 32, "square", 10)])
+def test_pair_v8_equals_v7(dev, case):
+    """The one-role kernel of round 6 (a key block staged once for eight query blocks, one kind of wave; opt-in, not the default) against
+    the three-role kernel: the same instructions on the same operands in the same order -> scores BIT-IDENTICAL; indices equal except
+    where a score ties across the K-th place (v8's selection keys are canonical: the lower pixel index wins; v7's resolve by the order its
+    blocks were visited in); ragged grids, frames smaller than a tile, disc and square windows (reach 2 .. 16), runs of 1 .. 6 pairs,
+    2 KiB rows; no timed-out wait; then against float64 like every other pair kernel."""
+    from fgvc_amd import ops
+    H, W, Tn, nr, mm, k = case
+    feats = _pairs_case(dev, H, W, Tn, seed=H * 131 + W, kind="smooth" if H == 64 else "gauss")
+    mask = ops.MaskSpec.from_neighbor_range(nr, mm)
+    rows = [(q, kk, True) for q in range(1, Tn) for kk in range(max(0, q - 6), q)]
+    pairs = ops.make_pairs(rows, dev)
+    for fmt, sp in (("f16f6", ops.split_f16f6p(feats)), ("f16f6x", ops.split_f16f6x(feats))):
+        i7, s7 = ops.pair_topk_split(sp, sp, pairs, H, W, H, W, mask, k, all_masked=True, fmt=fmt)
+        ops.set_option("pair_f16_debug", V8)
+        try:
+            i8, s8 = ops.pair_topk_split(sp, sp, pairs, H, W, H, W, mask, k, all_masked=True, fmt=fmt)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_option("pair_f16_debug", 0)
+        assert not ops.pair_f16x3_timed_out()
+        assert torch.equal(s7, s8), f"{fmt}: {int((s7 != s8).sum())} scores differ"
+        differ = (i7 != i8).any(-1)
+        for a, b, s in zip(i7[differ].tolist(), i8[differ].tolist(), s7[differ].tolist()):
+            gone = [x for x in a if x not in b]
+            assert (all(s[a.index(x)] == s[-1] for x in gone) if gone else len(set(s)) < len(s)), (a, b, s)
+    for pi, (q, kk, _) in enumerate(rows[:3]):
+        dense = (feats[kk].double().cpu() @ feats[q].double().cpu().T) / TAU
+        m = O.mask_slab(H, W, H, W, 1, torch.arange(H * W), nr, mm)
+        st = O.check_topk(dense.masked_fill(~m, float("-inf")), i8[pi].cpu().long(), s8[pi].cpu() / TAU, k, tol=1e-3, gap=GAP)
+        assert st["exact"] >= st["clear"] and st["max_score_err"] < 2e-4
+
+
+def test_pair_v8_fail_closed(dev):
+    """the injected protocol fault (pair_f16_debug & 4096) poisons v8's lists as it does v7's, and raises the flag"""
+    from fgvc_amd import ops
+    H, W, Tn = 24, 40, 3
+    feats = _pairs_case(dev, H, W, Tn, seed=11)
+    sp = ops.split_f16f6p(feats)
+    pairs = ops.make_pairs([(1, 0, True), (2, 0, True), (2, 1, True)], dev)
+    mask = ops.MaskSpec.from_neighbor_range(30)
+    ops.set_option("pair_f16_debug", V8 + 4096)
+    try:
+        idx, score = ops.pair_topk_split(sp, sp, pairs, H, W, H, W, mask, 10, all_masked=True, fmt="f16f6")
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("pair_f16_debug", 0)
+    assert ops.pair_f16x3_timed_out()
+    assert bool((idx == 0).all()) and bool(torch.isinf(score).all()) and bool((score > 0).all())
+    assert not ops.pair_f16x3_timed_out()
