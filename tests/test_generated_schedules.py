@@ -27,6 +27,22 @@ def test_conv64p_schedules_are_current(tmp_path):
     _regen(tmp_path, "gen_conv64p_sched.py", ["conv64p_sched_plain.inc", "conv64p_sched_res.inc", "conv64p_sched_res_bf16.inc"])
 
 
+def test_pair_v8_statements_are_current(tmp_path):
+    """pair_v8.inc (the one-statement tiles of the opt-in pair kernel): tools/gen_pair_v8.py reads the comparator lists of csrc/sortnet.hpp
+    through tools/gen_pair_v5_chain.py, verifies its register allocation on 300 random tiles per K, and must write the file byte for byte
+    on every run (its allocator once iterated a set of tuples: the statement changed from run to run)"""
+    work = tmp_path / "repo"
+    (work / "tools").mkdir(parents=True)
+    (work / "fgvc_amd" / "csrc").mkdir(parents=True)
+    for f in ("gen_pair_v8.py", "gen_pair_v5_chain.py"):
+        shutil.copy(os.path.join(ROOT, "tools", f), work / "tools" / f)
+    shutil.copy(os.path.join(ROOT, "fgvc_amd", "csrc", "sortnet.hpp"), work / "fgvc_amd" / "csrc" / "sortnet.hpp")
+    have = open(os.path.join(ROOT, "fgvc_amd", "csrc", "pair_v8.inc")).read()
+    for seed in ("0", "12345"):
+        subprocess.run([sys.executable, str(work / "tools" / "gen_pair_v8.py")], check=True, capture_output=True, env={**os.environ, "PYTHONHASHSEED": seed})
+        assert (work / "fgvc_amd" / "csrc" / "pair_v8.inc").read_text() == have, "pair_v8.inc is not what tools/gen_pair_v8.py writes: regenerate it"
+
+
 def test_conv256p_loops_are_current(tmp_path):
     _regen(tmp_path, "gen_conv256p_sched.py", ["conv256p_loop.inc", "conv128p_loop.inc"])
 

@@ -614,6 +614,13 @@ def test_bench_launches_its_own_ranks(dev, two_ranks):
     assert "rehearsal" in res and sum(res["config"]["query_frames_per_rank"]) == 15      # a 16-frame video: frame 0 + 15 query frames over two ranks
     c = res["comm_bytes_per_step_rank0"]
     assert c["broadcast"] == c["expected"]["broadcast"] > 0
+    # what the driver's record keeps (round 6): world size, backend, library version and the count of distinct devices inside `config`;
+    # a `roofline` of at most 24 keys, numbers and kernel names only
+    cfgd = res["config"]
+    assert cfgd["world_size"] == 2 and cfgd["backend"] == "gloo" and "rccl_version" in cfgd and "distinct_devices" in cfgd
+    rf = res["roofline"]
+    assert len(rf) <= 24 and {"frac", "achieved", "peak", "ms_per_launch", "pair_topk_ms", "pair_topk_frac", "step_ms_min", "step_ms_max"} <= set(rf)
+    assert all(isinstance(v, (int, float, type(None))) or k in ("kernel", "bound", "unit", "corr_volume_kernel") for k, v in rf.items()), rf
 
 
 def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):

@@ -36,11 +36,11 @@ import gen_pair_v5_chain as g5          # noqa: E402  (net: the comparator lists
 OUT = os.path.join(os.path.dirname(HERE), "fgvc_amd", "csrc", "pair_v8.inc")
 # row format (fgvc_split_f16f6p), byte offsets inside a pixel row; a lane (n, hi) adds 16 hi to every one of them
 OFF_H, OFF_H6M, OFF_H6T, OFF_L6M, OFF_L6T, OFF_SC = 0, 512, 640, 704, 832, 896
-RING = int(os.environ.get('V8_RING', '4'))                                 # key fragments in flight
+RING = int(os.environ.get('V8_RING', '2'))                                 # key fragments in flight
 N_MFMA = 24
 
 # ---- physical registers that live inside a statement only (clobbers): the chain's buffers, then the selection's temporaries
-ONE6 = os.environ.get('V8_ONE6', '0') == '1'      # one buffer for the key block's two FP6 operands
+ONE6 = os.environ.get('V8_ONE6', '1') == '1'      # one buffer for the key block's two FP6 operands
 T_KSC = 254          # scale bytes: v[254:255]
 T_Y6 = 248           # key l6 operand: v[248:253]
 T_X6 = T_Y6 if ONE6 else 242           # key h6 operand
