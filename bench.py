@@ -279,7 +279,8 @@ def main():
     ap.add_argument("--mode", default="video", choices=["video", "clips"],
                     help="video = one N x T-frame video per step, sharded by clip over the ranks (broadcast + halo message + "
                          "all_gather in the data path); clips = an independent T-frame clip per rank per step (no collective)")
-    ap.add_argument("--halo", default="exchange", choices=["exchange", "recompute"])
+    ap.add_argument("--halo", default="exchange", choices=["exchange", "recompute", "auto"],
+                    help="auto: exchange or recompute from the schedule's byte and pair counts and a 16 MB link ping at start-up (fgvc_amd.dist.choose_halo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr-volume", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="MIOpen immediate mode (clean profiles)")
@@ -395,6 +396,13 @@ def main():
     cfg.pair_precision = a.pair_precision
     cfg.regroup = False                                              # all points are given at frame 0 of the video
 
+    halo_why = None
+    if a.halo == "auto" and a.mode == "video":                       # resolved once, from numbers every rank holds (the link figure is broadcast)
+        halo_why = fdist.choose_halo(T, world, [0], cfg, fdist.halo_cost_model(h, w),
+                                     fdist.measure_link_gbps(None, dev) if world > 1 else fdist.LINK_GBPS_ASSUMED)
+        a.halo = halo_why["mode"]
+    elif a.halo == "auto":
+        a.halo = "exchange"
     # the same video on every rank (seeded): a rank only ever touches its own frames of it
     g = torch.Generator(device="cpu").manual_seed(1000 if a.mode == "video" else 1000 + rank)
     lo, hi = (fdist.shard_frames(T, world, first=1)[rank] if a.mode == "video" else (1, T))
@@ -819,6 +827,9 @@ def main():
         del vol
     if rank == 0 and world == 1 and not a.no_cpu_baseline:          # reported at N = 1 only (the other ranks would sit at the barrier)
         out["cpu_baseline"] = cpu_baseline(wl)
+    if halo_why is not None:
+        out["halo_auto"] = {"mode": halo_why["mode"], "link_gbps": halo_why["link_gbps"],
+                            "worst_boundary": max(halo_why["boundaries"], key=lambda d: d["exposed_s"]) if halo_why["boundaries"] else None}
     _driver_view(out)
     if rank == 0:
         print(json.dumps(out), flush=True)

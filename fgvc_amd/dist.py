@@ -101,6 +101,84 @@ def halo_messages(ranges: List[Tuple[int, int]], own: List[Tuple[int, int]], s_m
 
 
 # bytes this rank handed to each exchange step since the last reset (bench.py checks them against the schedule's arithmetic)
+# ---- halo="auto": exchange or recompute, from the schedule's own byte and pair counts (round 6) ----------------------------------
+LINK_GBPS_ASSUMED = 77.0        # one direction of one xGMI link between two GPUs of a node; replaced by `measure_link_gbps()` where it ran
+_LINK_GBPS = {}                 # per process group: what the 16 MB ping measured
+
+
+def halo_cost_model(h: int, w: int, stride: int = 4, channels: int = 256) -> dict:
+    """What the decision needs to know about a frame, scaled from the 480p measurements of DESIGN section 6 (an MI355X: the encoder
+    0.36 ms per 480 x 854 frame, the pair kernel 43 us per 120 x 214 pair) by pixel count; `frame_bytes` = what travels of a bank frame
+    (the f32 half of a row: 4 bytes per channel and feature pixel).  A backend may carry its own `cost_model(h, w)`."""
+    hf, wf = -(-h // stride), -(-w // stride)
+    return {"enc_frame_s": 0.36e-3 * (h * w) / (480.0 * 854.0), "pair_s": 43e-6 * (hf * wf) / (120.0 * 214.0),
+            "frame_bytes": hf * wf * channels * 4}
+
+
+def choose_halo(T: int, world: int, starts, cfg: TrackerConfig, cost: dict, link_gbps: float = LINK_GBPS_ASSUMED, early_halo: bool = True) -> dict:
+    """A pure function of the schedule (identical on every rank: it fixes the order of the communication calls).  Per boundary between
+    two clips: the halo message is `p` frames of `frame_bytes` over one link direction; it is posted before the pair launch (after the
+    sender's last p frames with the early halo: the receiver's remaining encoder frames also cover it) and awaited in front of the first
+    pair that touches a halo frame, so what it can hide behind is the receiver's halo-free pairs (+ its front frames' encode); what is
+    left over is EXPOSED.  Recomputing costs p encoder frames on the receiver and no message.  One mode for the whole video -- the clips
+    are equal, so are the boundaries; the worst boundary decides.  Returns the mode and the numbers it was chosen from."""
+    s_min = min(starts)
+    p = cfg.precede_frames
+    ranges = shard_frames(T, world, first=s_min + 1)
+    rows = []
+    for r, (lo, hi) in enumerate(ranges):
+        if r == 0 or hi <= lo:
+            continue
+        n_halo = min(p, lo - s_min - 1) if lo - 1 > s_min else 0           # frames in front of the clip that another rank encodes (frame s_min comes by broadcast)
+        if n_halo <= 0:
+            continue
+        plan = engine.plan_clip(T, list(starts), cfg, frame_range=(lo, hi))
+        halo_frames = set(range(lo - n_halo, lo))
+        free = sum(1 for (q, kf, _) in plan.pairs if q not in halo_frames and kf not in halo_frames)
+        t_x = n_halo * cost["frame_bytes"] / (link_gbps * 1e9)
+        cover = free * cost["pair_s"] + (max(0, (hi - lo) - p) * cost["enc_frame_s"] if early_halo else 0.0)
+        rows.append(dict(rank=r, halo_frames=n_halo, message_bytes=n_halo * cost["frame_bytes"], transfer_s=t_x, halo_free_pairs=free,
+                         cover_s=cover, exposed_s=max(0.0, t_x - cover), recompute_s=n_halo * cost["enc_frame_s"]))
+    if not rows:
+        return dict(mode="exchange", link_gbps=link_gbps, boundaries=[])
+    worst = max(rows, key=lambda d: d["exposed_s"] - d["recompute_s"])
+    return dict(mode="exchange" if worst["exposed_s"] <= worst["recompute_s"] else "recompute", link_gbps=link_gbps, boundaries=rows)
+
+
+def measure_link_gbps(group=None, device: Optional[torch.device] = None, nbytes: int = 16 << 20, reps: int = 3) -> float:
+    """The one constant `choose_halo` assumes, measured once per process group: rank 0 sends `nbytes` to rank 1 (`reps` times after a
+    warm-up, the fastest counts) and the figure is broadcast, so that every rank decides from the same number.  World size 1: the
+    assumed constant."""
+    key = id(group)
+    if key in _LINK_GBPS:
+        return _LINK_GBPS[key]
+    if not dist.is_initialized() or dist.get_world_size(group) < 2:
+        return LINK_GBPS_ASSUMED
+    import time
+    rank = dist.get_rank(group)
+    r0, r1 = _global_rank(group, 0), _global_rank(group, 1)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    best = float("inf")
+    for i in range(reps + 1):
+        dist.barrier(group=group)
+        if buf.is_cuda:
+            torch.cuda.synchronize(buf.device)
+        t0 = time.perf_counter()
+        if rank == 0:
+            dist.send(buf, r1, group=group)
+        elif rank == 1:
+            dist.recv(buf, r0, group=group)
+            if buf.is_cuda:
+                torch.cuda.synchronize(buf.device)
+        dt = time.perf_counter() - t0
+        if i and rank == 1:
+            best = min(best, dt)
+    t = torch.tensor([nbytes / best / 1e9 if rank == 1 else 0.0], dtype=torch.float64, device=device)
+    dist.broadcast(t, r1, group=group)
+    _LINK_GBPS[key] = float(t.item())
+    return _LINK_GBPS[key]
+
+
 COMM_BYTES = {"broadcast": 0, "halo_send": 0, "halo_recv": 0, "all_gather_send": 0}
 
 
@@ -365,7 +443,7 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
     rank (`backend.reset_calibration()`: the ranks re-calibrate together instead of drifting apart), then raise RuntimeError.  Costs
     a device synchronisation per video; drivers that pipeline videos (bench.py) pass check=False and check once per loop.
     The device flags are process-wide words (read-and-clear): one consumer per process -- two trackers sharing a process also share them."""
-    if halo not in ("exchange", "recompute"):
+    if halo not in ("exchange", "recompute", "auto"):
         raise ValueError(f"halo={halo!r}")
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -378,6 +456,13 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
         starts = sorted(set(times.tolist())) if cfg.regroup else [0]
         s_min = min(starts)
         ranges = shard_frames(T, world, first=s_min + 1)
+        halo_why = None
+        if halo == "auto":                      # from the schedule's own byte and pair counts and ONE measured constant: the same on every rank
+            cm = getattr(backend, "cost_model", None)
+            cost = cm(h, w) if cm is not None else halo_cost_model(h, w)
+            halo_why = choose_halo(T, world, starts, cfg, cost, measure_link_gbps(group, dev) if world > 1 else LINK_GBPS_ASSUMED,
+                                   early_halo=getattr(backend, "early_halo", True))
+            halo = halo_why["mode"]
         if halo == "exchange" and world > 1:
             enc = own_ranges(ranges, s_min)
             msgs = halo_messages(ranges, enc, s_min, cfg.precede_frames)
@@ -401,10 +486,12 @@ def track_points_sharded(backend, rgbs: torch.Tensor, query_points: torch.Tensor
         sc = dict(starts=starts, s_min=s_min, ranges=ranges, enc=enc, msgs=msgs, plan=plan, rows=[len(pp.slot_pair) for pp in plans],
                   gplan=Plan(T, starts, [], out_rows, [], slot_frame, plan.t_max),
                   slot_frame_dev=torch.tensor(slot_frame, dtype=torch.int32, device=dev).reshape(len(slot_frame), plan.t_max),
-                  groups=groups, order=torch.tensor(order, dtype=torch.int64), n_points=qp.shape[0], lplan=None, geom=None)
+                  groups=groups, order=torch.tensor(order, dtype=torch.int64), n_points=qp.shape[0], lplan=None, geom=None,
+                  halo=halo, halo_why=halo_why)
         if cache is not None:
             cache["schedule"] = sc
     starts, ranges, enc, msgs, plan = sc["starts"], sc["ranges"], sc["enc"], sc["msgs"], sc["plan"]
+    halo = sc.get("halo", halo)                 # ("auto" was resolved when the schedule was built)
     lo, hi = ranges[rank]
     e_lo, e_hi = enc[rank]
 

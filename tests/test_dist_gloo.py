@@ -109,6 +109,10 @@ def _worker(rank, world, port, feats, qp, q, halo="exchange", precede=5, members
         traj2, order2 = _run(D, be, feats, qp, cfg, h, w, halo=halo, timing=timing, group=group, cache=cache)
         assert torch.equal(traj2, traj) and torch.equal(order2, order)
         assert cache["schedule"].get("bank_in_place", 0) == 1
+        if halo == "auto":               # resolved when the schedule was built, from one measured constant that every rank holds
+            why = cache["schedule"]["halo_why"]
+            assert cache["schedule"]["halo"] == why["mode"] and why["link_gbps"] > 0 and D.measure_link_gbps(group) == why["link_gbps"]
+            halo = cache["schedule"]["halo"]
         assert cache["schedule"].get("halo_early", 0) == (1 if halo == "exchange" else 0)
         rep = timing.report()
         rank = dist.get_rank(group) if group is not None else rank
@@ -147,7 +151,7 @@ def _run(D, backend, feats, qp, cfg, h, w, **kw):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,halo,precede,members,T,p2p", [(2, "exchange", 5, None, 11, None), (2, "recompute", 5, None, 11, None),
+@pytest.mark.parametrize("world,halo,precede,members,T,p2p", [(2, "exchange", 5, None, 11, None), (2, "recompute", 5, None, 11, None), (2, "auto", 5, None, 11, None),
                                                                 (3, "exchange", 5, None, 11, None), (3, "exchange", 5, [1, 2], 11, None),
                                                                 (3, "exchange", 5, None, 3, None), (4, "exchange", 5, [0, 2, 3], 3, "posted"),
                                                                 (3, "exchange", 2, None, 11, "posted")])
@@ -228,6 +232,31 @@ def test_eight_ranks_with_the_cfg4_schedule():
         assert order.tolist() == [0, 1, 2]
         assert torch.allclose(traj, exp, atol=1e-6), (rank, float((traj - exp).abs().max()))
     assert all(torch.equal(res[0][1], r[1]) for r in res[1:])
+
+
+def test_halo_auto_decision():
+    """halo="auto" (round 6) as a pure function of the schedule: at the shapes of BASELINE configs[1] x 8 ranks (a 64-frame 480p video,
+    8 query frames per rank) the 131 MB halo message takes 1.7 ms over one xGMI direction and hides behind the receiver's 33 halo-free
+    pairs + its three front frames -> exchange; without the early halo 0.3 ms of it is exposed, still cheaper than five encoder frames;
+    over a 10 GB/s link the exposed 11 ms lose to 1.8 ms of recompute; at world size 1 there is no boundary."""
+    from fgvc_amd import dist as D
+    from fgvc_amd.engine import TrackerConfig
+    cfg = TrackerConfig()
+    cost = D.halo_cost_model(480, 854)
+    assert cost["frame_bytes"] == 120 * 214 * 256 * 4 and abs(cost["enc_frame_s"] - 0.36e-3) < 1e-9
+    d = D.choose_halo(64, 8, [0], cfg, cost, link_gbps=77.0)
+    assert d["mode"] == "exchange" and len(d["boundaries"]) == 7
+    b = d["boundaries"][0]
+    assert b["halo_frames"] == 5 and b["message_bytes"] == 5 * cost["frame_bytes"] and b["halo_free_pairs"] == 33
+    assert 1.6e-3 < b["transfer_s"] < 1.8e-3 and b["exposed_s"] == 0.0
+    d2 = D.choose_halo(64, 8, [0], cfg, cost, link_gbps=77.0, early_halo=False)
+    assert d2["mode"] == "exchange" and 0.2e-3 < d2["boundaries"][0]["exposed_s"] < 0.4e-3
+    d3 = D.choose_halo(64, 8, [0], cfg, cost, link_gbps=10.0)
+    assert d3["mode"] == "recompute" and d3["boundaries"][0]["exposed_s"] > d3["boundaries"][0]["recompute_s"]
+    assert D.choose_halo(8, 1, [0], cfg, cost)["boundaries"] == []
+    # query groups that start later: the frames in front of a clip that another rank encodes never reach below the first start
+    d4 = D.choose_halo(16, 4, [3], cfg, cost)
+    assert all(bd["halo_frames"] <= 5 for bd in d4["boundaries"])
 
 
 def test_halo_message_plan():
