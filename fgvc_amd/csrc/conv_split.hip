@@ -1162,13 +1162,24 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
                    "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]));
 
   // ---- epilogue (conv_split_kernel's, for 4 tiles x 4 rows per wave): + bias [+ residual] [ReLU], pixel rows through a wave-private LDS tile
+  // The loop's statement clobbers every vector register but ten: whatever per-lane value the epilogue needs and the compiler had computed
+  // BEFORE the loop (lane, pixel, lane half and what it derives from them: staging addresses, store columns) went to scratch around it --
+  // 16-18 registers of the two hottest instances (round-5 review).  The lane id is taken again here, by an instruction the compiler cannot
+  // move above the loop, and the epilogue derives its values from that.
+  int lane_e;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+  {
+  int lane = lane_e, n = lane & 31, h = lane >> 5;      // (not const: re-taken per pixel row below -- `row_fence`)
   constexpr int RPW = 4, CW = COT / 2, RB = CW * 4, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;
   static_assert(4 * 32 * RS <= PATCHB + 3 * SLOTB, "epilogue staging");
   __syncthreads();
   long long ts0 = __builtin_amdgcn_s_memtime(), ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
   unsigned char* tile = smem + wave * (32 * RS);
   const int co_w = co_base + ch * CW;
-  const int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
+  int mv_row = lane / LPR, mv_col = (lane % LPR) * 16;
+  // per pixel row: the lane's values are taken as new (an empty statement that 'writes' them), so that the compiler computes a row's
+  // addresses in that row instead of all four rows' up front -- 20 registers of the plain instances went to scratch for those
+  auto row_fence = [&]() { asm volatile("" : "+v"(n), "+v"(h), "+v"(mv_row), "+v"(mv_col)); };
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
   // ---- the f32 residual rows come by LDS-DMA, one pixel row of the wave ahead of their use.  (Read through registers where they are needed,
   // every load under its own predicate, the compiler waited for each by itself -- 16 memory latencies per pixel row, 18 000 of a row's
@@ -1236,6 +1247,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
       long long bts[6] = {}, bt_begin = 0;
 #pragma unroll
       for (int b = 0; b < RPW; ++b) {
+        row_fence();
         const int y = y0 + RPW * pr + b;
         const bool row_ok = y < p.H;                                // wave-uniform, the same for both waves of a pair; barriers are taken by all
         if (b == 1) bt_begin = __builtin_amdgcn_s_memtime();
@@ -1408,8 +1420,10 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
       return;
     }
   }
-  // the lane's 16 bias vectors, once for the wave's four rows (read row by row, each row waited ~3 000 cycles for them)
-  constexpr bool HOIST_BIAS = !GENERIC && !RES;                // (with residual rows or unknown forms: no 64 registers to spare -- from the LDS copy)
+  // (Round 5 kept the lane's 16 bias vectors in 64 registers across the wave's four rows where no residual needs the room.  With them the
+  // plain instances spill 36-45 registers into scratch inside the rows; from the LDS copy (16 ds_read_b128 per row) they spill none, at
+  // +0.3 % of the launch -- tools/ab_bench.sh, same box.  Off.)
+  constexpr bool HOIST_BIAS = false;
   f32x4 bvv[HOIST_BIAS ? NA : 1][4];
   if constexpr (HOIST_BIAS) {
 #pragma unroll
@@ -1419,6 +1433,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   }
 #pragma unroll
   for (int b = 0; b < RPW; ++b) {
+    row_fence();
     const int y = y0 + RPW * pr + b;
     if (y >= p.H) continue;                       // wave-uniform
     const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
@@ -1512,6 +1527,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     reinterpret_cast<long long*>(p.y_split)[wave * 8 + 1] = __builtin_amdgcn_s_memtime() - t_begin;
   }
+  }      // (the epilogue's scope: its own lane, n, h)
 }
 
 template <int ARITH>

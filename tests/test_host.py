@@ -418,3 +418,27 @@ def test_f16f6_weight_rows_agree_with_the_oracle_model():
     assert torch.equal(ha, hb * 4.0)                                               # the same weights, two binades lower
     with pytest.raises(AssertionError):
         ops.prepare_conv_split_f16(wt, bn, ops.ACT_F16F6, force_exp=ea + 8)        # would leave the f16 range
+
+
+def test_stream_kernels_use_no_scratch():
+    """What the compiler actually allocated, read from the code-object notes of the built library (tools/kernel_notes.py; LLVM tools only,
+    no GPU): every instance of conv256p_kernel -- the one-wave-per-SIMD convolutions whose main loop is one assembly statement that names
+    s32 and m0 among its clobbers -- has NO scratch memory (private_segment_fixed_size == 0: no stack, so s32 is no stack pointer) and no
+    spilled vector register (round-5 review: the two hottest instances carried 68 / 76 bytes); likewise conv64p_kernel, and the shipped
+    instances of both pair kernels (the s_memtime probe instances aside)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("kernel_notes", os.path.join(root, "tools", "kernel_notes.py"))
+    kn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kn)
+    notes = kn.kernel_notes()
+    c256 = {k: v for k, v in notes.items() if "conv256p_kernel" in k}
+    assert len(c256) >= 10, sorted(notes)[:5]
+    for fam, want in (("conv256p_kernel", 10), ("conv64p_kernel", 3), ("pair_topk_kernel_v7ILi10ELb0", 1), ("pair_topk_kernel_v7ILi5ELb0", 1),
+                      ("pair_topk_kernel_v8ILi10ELb0", 1), ("pair_topk_kernel_v8ILi5ELb0", 1)):
+        ks = {k: v for k, v in notes.items() if fam in k}
+        assert len(ks) >= want, (fam, len(ks))
+        for k, v in ks.items():
+            assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
+    for k, v in c256.items():                                   # one wave per SIMD: the whole register file, all accumulators in it
+        assert v["vgpr_count"] in (376, 512) and v["agpr_count"] in (128, 256), (k, v)
