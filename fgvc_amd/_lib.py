@@ -5,6 +5,7 @@ There is NO fallback: if the shared library is missing or a call fails, this rai
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -114,6 +115,32 @@ def load() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
+
+
+ABLATIONS_PATH = os.path.join(_HERE, "lib", "libfgvc_hip_ablations.so")
+_ablations = None
+
+
+@contextlib.contextmanager
+def ablations():
+    """Inside the block every call goes to libfgvc_hip_ablations.so -- the same kernels, whose fgvc_set_option also accepts the profiling
+    ablations that give WRONG results (the production library refuses them).  For measurements only (bench.py's store-stream replay,
+    tools/experiments); each library has its own option words.  Raises FgvcHipError when that library was not built."""
+    global _lib, _ablations
+    prod = load()
+    if _ablations is None:
+        if not os.path.exists(ABLATIONS_PATH):
+            raise FgvcHipError(f"{ABLATIONS_PATH} is missing: `python -m fgvc_amd.build` makes it beside the production library")
+        lib = C.CDLL(ABLATIONS_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _ablations = lib
+    _lib = _ablations
+    try:
+        yield _ablations
+    finally:
+        _lib = prod
 
 
 def call(name: str, *args) -> None:

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "lib", "libfgvc_hip.so")
+LIB_ABLATIONS = os.path.join(HERE, "lib", "libfgvc_hip_ablations.so")      # the same objects, fgvc_set_option accepts the results-wrong profiling switches
 SOURCES = ["capi.hip", "pair_topk.hip", "pair_topk_v5.hip", "conv_split.hip", "conv_s2.hip", "conv64.hip", "stem7.hip", "post.hip", "corr_volume.hip", "corr_volume_f8.hip", "corr_volume_f6.hip", "local.hip", "dense_attend.hip", "refine.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "pair_common.hpp"), os.path.join(CSRC, "sortnet.hpp"), os.path.join(ROOT, "include", "fgvc_hip.h"),
            os.path.join(CSRC, "pair_topk_v7.hpp"), os.path.join(CSRC, "pair_v7.inc"), os.path.join(CSRC, "pair_topk_v8.hpp"), os.path.join(CSRC, "pair_v8.inc"), os.path.join(CSRC, "pair_v5_chain.inc")]
@@ -65,6 +66,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    # the experiment library: capi.hip once more with -DFGVC_ABLATIONS, every other object shared (identical kernels: A/B timings carry over)
+    capi_ab = os.path.join(OBJ, "capi_ablations.o")
+    if force or _stale(capi_ab, [os.path.join(CSRC, "capi.hip")] + HEADERS):
+        run([hipcc, *FLAGS, "-DFGVC_ABLATIONS", "-c", os.path.join(CSRC, "capi.hip"), "-o", capi_ab])
+    objs_ab = [capi_ab if o.endswith(os.sep + "capi.o") else o for o in objs]
+    if force or jobs or _stale(LIB_ABLATIONS, objs_ab):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_ABLATIONS, *objs_ab])
     return LIB
 
 

@@ -94,8 +94,28 @@ extern "C" {
 const char* fgvc_version(void) { return "fgvc_hip 0.1 (gfx950)"; }
 const char* fgvc_last_error(void) { return g_err; }
 
+// The profiling ablations (a kernel without its stores, its matrix chain, its selection ...) return WRONG results.  The production
+// library refuses to switch them on: the bits below are accepted only by the build with -DFGVC_ABLATIONS (libfgvc_hip_ablations.so,
+// `python -m fgvc_amd.build` makes both from the same objects but this file; tools/experiments select it with FGVC_HIP_LIB).  What
+// the production library still takes are A/B switches between forms with IDENTICAL results, the s_memtime probes, and the fault
+// injection of the fail-closed test (poison lists + the device flag: not a result anybody can mistake for one).
+static int ablation_bits(const char* name, int value) {
+  if (strcmp(name, "corr_debug") == 0 || strcmp(name, "pair_debug") == 0 || strcmp(name, "conv_s2_debug") == 0) return value;
+  if (strcmp(name, "corr8_debug") == 0) return value & (1 | 2);
+  if (strcmp(name, "corr6_debug") == 0) return value & (1 | 2 | 256 | 512 | 1024);
+  if (strcmp(name, "conv_debug") == 0) return value & (1 | 2 | 4);
+  if (strcmp(name, "pair_f16_debug") == 0)
+    return value & ((value & 4194304) ? (1 | 2 | 524288 | 1048576) : (1 | 2 | 4 | 8 | 16 | 32 | 64 | 2048 | 524288 | 1048576));
+  return 0;
+}
+
 int fgvc_set_option(const char* name, int value) {
   FGVC_REQUIRE(name != nullptr, FGVC_ERR_INVALID_ARG, "fgvc_set_option: null name");
+#ifndef FGVC_ABLATIONS
+  FGVC_REQUIRE(ablation_bits(name, value) == 0, FGVC_ERR_UNSUPPORTED,
+               "fgvc_set_option: %s = %d switches a profiling ablation on (bits %d: results would be wrong); this library is built without them -- "
+               "use libfgvc_hip_ablations.so (FGVC_HIP_LIB)", name, value, ablation_bits(name, value));
+#endif
   if (strcmp(name, "corr_debug") == 0) {   // profiling ablation: 1 = bf16 volume kernels skip their stores
     set_corr_debug(value);
     return FGVC_OK;

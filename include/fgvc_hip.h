@@ -66,8 +66,13 @@ const char* fgvc_last_error(void);
  *                        16 and 128 give identical results (A/B switches); the tests hold 0 against 16 bit for bit.
  *   "conv_debug" 1024    fgvc_conv_split_* with f16 + FP6 operands, 3 x 3, 128 / 256-channel tiles: conv_split_kernel (rounds 2-4) instead of
  *                        conv256p_kernel (round 5: one wave per SIMD, main loop one assembly statement).  Identical results (A/B switch).
- *   "pair_debug", "pair_f16_debug", "corr_debug", "conv_debug", "conv_s2_debug": profiling ablations (skip selection / MFMA / staging /
- *                        epilogue, s_memtime probes); results are WRONG when non-zero -- tools/experiments/ablate_*.py, tools/experiments/time_*.py. */
+ *   "pair_f16_debug" 4194304   fgvc_pair_topk_f16f6[x]: pair_topk_kernel_v8 (round 6: one kind of wave, a key block staged once for eight query
+ *                        blocks) instead of pair_topk_kernel_v7.  Identical scores, lists equal up to exact score ties across the K-th place.
+ *   "pair_debug", "pair_f16_debug", "corr_debug", "corr6_debug", "corr8_debug", "conv_debug", "conv_s2_debug": besides such A/B bits and
+ *                        the s_memtime probes these words carry PROFILING ABLATIONS (a kernel without its stores / matrix chain / selection /
+ *                        staging): results are WRONG.  libfgvc_hip.so REFUSES them (FGVC_ERR_UNSUPPORTED); libfgvc_hip_ablations.so -- the
+ *                        same objects, this one function compiled with -DFGVC_ABLATIONS -- accepts them (fgvc_amd._lib.ablations(),
+ *                        FGVC_HIP_LIB; tools/experiments/ablate_*.py, time_*.py). */
 int fgvc_set_option(const char* name, int value);
 
 /* Largest integer d2 such that sqrtf((float)d2) < radius, -1 if none (host helper). */

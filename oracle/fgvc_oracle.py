@@ -548,9 +548,12 @@ class ResNet18(nn.Module):
         return x
 
 
-def seeded_resnet_state(seed: int = 0, strides=(1, 1, 1, 4), pool_type="none"):
+def seeded_resnet_state(seed: int = 0, strides=(1, 1, 1, 4), pool_type="none", trained_like: bool = False):
     """Synthetic weights per SURVEY.md section 8d: kaiming-normal(fan_out) convs, BN gamma=1 beta=0,
-    running stats (0,1); the last BN of each block is NOT zeroed."""
+    running stats (0,1); the last BN of each block is NOT zeroed.
+    trained_like (round 6): BatchNorm layers as a trained checkpoint has them -- gamma in [0.5, 1.5], beta ~ N(0, 0.1), running_mean
+    ~ N(0, 0.2), running_var in [0.5, 2] -- drawn AFTER the convolutions from the same generator (the convolution weights of a seed do
+    not change with the flag)."""
     g = torch.Generator().manual_seed(seed)
     net = ResNet18(strides, 3, pool_type)
     sd = net.state_dict()
@@ -558,6 +561,16 @@ def seeded_resnet_state(seed: int = 0, strides=(1, 1, 1, 4), pool_type="none"):
         if k.endswith("conv.weight"):
             fan_out = v.shape[0] * v.shape[2] * v.shape[3]
             sd[k] = torch.randn(v.shape, generator=g) * math.sqrt(2.0 / fan_out)
+    if trained_like:
+        for k, v in sd.items():
+            if k.endswith("bn.weight"):
+                sd[k] = 0.5 + torch.rand(v.shape, generator=g)
+            elif k.endswith("bn.bias"):
+                sd[k] = 0.1 * torch.randn(v.shape, generator=g)
+            elif k.endswith("bn.running_mean"):
+                sd[k] = 0.2 * torch.randn(v.shape, generator=g)
+            elif k.endswith("bn.running_var"):
+                sd[k] = 0.5 + 1.5 * torch.rand(v.shape, generator=g)
     return sd
 
 

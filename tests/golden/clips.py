@@ -41,3 +41,12 @@ def moving_texture(T, h, w, seed, drift=(3, -2), cell=8, amp=96, noise=8):
             nz = ((hsh * (c + 1) * 2246822519) >> 7) % (2 * noise + 1) - noise
             out[t, c] = canvas[c, oy:oy + h, ox:ox + w] + nz
     return np.clip(out, -128, 127).astype(np.int8)
+
+
+def lab_like(T, h, w, seed, drift=(3, -2)):
+    """(T, 3, h, w) int8 on a 1/32 grid inside the range of the reference's input pipeline (configs/eval/base_data.py:1-7: RGB -> Lab ->
+    (x - [50, 0, 0]) / [50, 127, 127]): channel 0 (L) within [-1, 1], channels 1, 2 (a, b) within [-0.45, 0.45]; the moving texture above
+    at a smaller amplitude."""
+    x = moving_texture(T, h, w, seed, drift=drift, amp=29, noise=3).astype(np.int64)
+    x[:, 1:] = (x[:, 1:] * 7) >> 4
+    return x.astype(np.int8)

@@ -481,6 +481,67 @@ def gen_tracker_8f():
          feats_sub=feats[:, ::16, ::8, ::8], feats_abs_sum=float(feats.double().abs().sum()))
 
 
+def gen_tracker_all_queries(trained: bool):
+    """tests/golden/tracker_8x256x256_all.npz / tracker_trained_8x256x256.npz (round 6): the genuine VanillaTracker.forward_test on eight
+    256 x 256 frames, as gen_tracker_8f, with what the reference's own `topk` returned for ALL 16 384 queries of frame 7 (key pixel as
+    (slot, pixel): uint8 + uint16), the float64 top-10 of the same rows from the REFERENCE's features, and per query the smallest
+    distance between float64 ranks 1 .. 11 -- the number that says at which resolution a list is decidable.
+    trained = False: the weights and clip of tracker_8x256x256.npz (kaiming convolutions, unit BatchNorm statistics, a texture in [-4, 4)).
+    trained = True: BatchNorm layers as a trained checkpoint has them (gamma in [0.5, 1.5], beta, running mean and variance: oracle
+    seeded_resnet_state(trained_like=True)) and frames inside the range of the reference's Lab normalisation (clips.lab_like)."""
+    from tests.golden import clips
+    ref = ref_import.load()
+    cfg = ref.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30, step=512,
+                         with_first=True, with_first_neighbor=True)
+    model = ref.builder.build_model(
+        dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 1, 1, 4),
+                                                  out_indices=(2,), pool_type="none")),
+        train_cfg=None, test_cfg=cfg)
+    seed, clip_seed = (23, 2300) if trained else (17, 1700)
+    sd = O.seeded_resnet_state(seed=seed, strides=(1, 1, 1, 4), pool_type="none", trained_like=trained)
+    model.backbone.load_state_dict(sd, strict=True)
+    model.eval()
+    Tn, h, w, P = 8, 256, 256, 8
+    clip = clips.lab_like(Tn, h, w, seed=clip_seed) if trained else clips.moving_texture(Tn, h, w, seed=clip_seed)
+    rgbs = (torch.from_numpy(clip).float() / 32.0).unsqueeze(0)
+    g = torch.Generator().manual_seed(clip_seed)
+    qp = torch.cat([torch.zeros(P, 1), torch.rand(P, 2, generator=g) * 180 + 38], 1).unsqueeze(0)
+    traj_gt = torch.rand(1, Tn, P, 2, generator=g) * 256
+    vis_gt = (torch.rand(1, Tn, P, generator=g) > 0.3).float()
+    with ref_import.cuda_as_cpu(), torch.no_grad(), TopkSpy() as spy:
+        outs = model(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj_gt, visibilities=vis_gt)
+    with torch.no_grad():
+        feats = model.backbone(rgbs[0])                                   # (8, 256, 128, 128)
+    HW, k = 128 * 128, 10
+    calls = [c for c in spy.calls if c[0].shape[1] == k]
+    per_frame = HW // 512
+    assert len(calls) == (Tn - 1) * per_frame, len(calls)
+    last = calls[-per_frame:]
+    tv = torch.cat([c[0][0] for c in last], dim=1).t().contiguous()      # (HW, k)
+    ti = torch.cat([c[1][0] for c in last], dim=1).t().contiguous()
+    slots = [0, 2, 3, 4, 5, 6]
+    fn = torch.nn.functional.normalize(feats.double(), dim=1).flatten(2)  # (8, C, HW)
+    keys = torch.stack([fn[s] for s in slots], 0)                          # (6, C, HW)
+    ky, kx = torch.arange(HW) // 128, torch.arange(HW) % 128
+    f64_idx = torch.empty(HW, k, dtype=torch.int64)
+    gap = torch.empty(HW, dtype=torch.float64)
+    for q0 in range(0, HW, 512):
+        qs = torch.arange(q0, q0 + 512)
+        inside = ((ky.view(-1, 1) - ky[qs].view(1, -1)) ** 2 + (kx.view(-1, 1) - kx[qs].view(1, -1)) ** 2).double().sqrt() < 15
+        aff = (torch.einsum("sck,cq->skq", keys, fn[7][:, qs]) / 0.07).masked_fill(~inside.unsqueeze(0), float("-inf")).reshape(6 * HW, 512)
+        dv, di = aff.topk(k + 1, dim=0)
+        f64_idx[qs] = di[:k].t()
+        gap[qs] = (dv[:-1] - dv[1:]).min(0).values
+    wsum = float(sum(v.double().abs().sum() for kk, v in sd.items() if v.dtype.is_floating_point))
+    name = "tracker_trained_8x256x256" if trained else "tracker_8x256x256_all"
+    extra = dict(query_points=qp, trajectories=traj_gt, visibilities=vis_gt, out_traj_pred=outs[2], out_query_points=outs[4],
+                 feats_sub=feats[:, ::16, ::8, ::8]) if trained else {}
+    save(name, clip_seed=clip_seed, seed=seed, trained_like=int(trained), weight_abs_sum=wsum, feats_abs_sum=float(feats.double().abs().sum()),
+         ref_slot=(ti // HW).to(torch.uint8), ref_pix=(ti % HW).to(torch.int32).numpy().astype("uint16"), ref_val=tv,
+         f64_slot=(f64_idx // HW).to(torch.uint8), f64_pix=(f64_idx % HW).to(torch.int32).numpy().astype("uint16"),
+         gap=gap.float(), **extra)
+
+
 def _lift_methods(relpath, cls_name, names, ns):
     """The named methods of a reference class, lifted out of their module by AST (the modules import cv2 / mmcv / tensorboard, absent
     here) into a bare class of the same name: the methods' own statements run unchanged, on the stand-ins `ns` gives their globals."""
@@ -605,6 +666,14 @@ def gen_badja_pck():
          **{k.replace("@", "_at_"): np.float64(v_) for k, v_ in res.items()})
 
 
+def gen_tracker_all():
+    gen_tracker_all_queries(False)
+
+
+def gen_tracker_trained():
+    gen_tracker_all_queries(True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate single fixtures: python gen_golden.py gen_hr_tracker ...
         for name in sys.argv[1:]:
@@ -620,3 +689,5 @@ if __name__ == "__main__":
         gen_tracker_8f()
         gen_jhmdb_pck()
         gen_badja_pck()
+        gen_tracker_all()
+        gen_tracker_trained()

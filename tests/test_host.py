@@ -442,3 +442,22 @@ def test_stream_kernels_use_no_scratch():
             assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
     for k, v in c256.items():                                   # one wave per SIMD: the whole register file, all accumulators in it
         assert v["vgpr_count"] in (376, 512) and v["agpr_count"] in (128, 256), (k, v)
+
+
+def test_production_library_refuses_the_ablation_switches():
+    """fgvc_set_option of libfgvc_hip.so takes the A/B switches, probes and the fault injection, and refuses every bit that makes a kernel
+    return wrong results (round-5 review: the production library shipped them); libfgvc_hip_ablations.so, built beside it from the same
+    objects, takes them.  Host only."""
+    from fgvc_amd import _lib
+    lib = _lib.load()
+    for name, v in (("pair_debug", 1), ("corr_debug", 1), ("conv_s2_debug", 2), ("corr6_debug", 1024), ("corr8_debug", 2), ("conv_debug", 4),
+                    ("pair_f16_debug", 2), ("pair_f16_debug", 4194304 + 1048576), ("pair_f16_debug", 2048)):
+        assert lib.fgvc_set_option(name.encode(), v) == _lib.ERR_UNSUPPORTED, (name, v)
+        assert b"ablation" in lib.fgvc_last_error()
+    for name, v in (("pair_f16_debug", 4096), ("pair_f16_debug", 4194304 + 2048 + 8), ("pair_f16_debug", 512 + 1024), ("conv_debug", 1024 + 16 + 8),
+                    ("corr6_debug", 4 + 8), ("conv64_variant", 16), ("readout_prune", 0)):
+        assert lib.fgvc_set_option(name.encode(), v) == _lib.FGVC_OK, (name, v)
+        assert lib.fgvc_set_option(name.encode(), 1 if name == "readout_prune" else 0) == _lib.FGVC_OK
+    with _lib.ablations() as ab:
+        assert ab is not lib and ab.fgvc_set_option(b"corr6_debug", 1024) == _lib.FGVC_OK and ab.fgvc_set_option(b"corr6_debug", 0) == _lib.FGVC_OK
+    assert _lib.load() is lib
