@@ -565,10 +565,11 @@ def main():
     rs = getattr(backend, "refine_stats", None)
     if "merge_refine" in kernels and rs is not None:
         worst = ops.refine_max_error(rs)
-        rs = rs.cpu().tolist()
+        smp_err, smp_n = ops.refine_sample_error(rs)
+        cnt = ops.refine_counts(rs)
         n_q = (Tc - 1) * HW if a.mode == "video" and world == 1 else None
-        kernels["merge_refine"].update(queries_rescored=rs[0], of_them_from_scratch=rs[1], candidates_rescored=rs[2], beyond_scan_queue=rs[3],
-                                       queries=n_q, eps=cfg.pair_refine_eps, max_pair_score_error_seen=worst)
+        kernels["merge_refine"].update(**cnt, queries=n_q, eps=cfg.pair_refine_eps, max_pair_score_error_seen=worst,
+                                       max_pair_score_error_unbiased_sample=smp_err, unbiased_sample_entries=smp_n)
         if worst > cfg.pair_refine_eps:
             raise SystemExit(f"bench.py: the pair kernel's score error reached {worst:.2e}, beyond the bound {cfg.pair_refine_eps:.2e} the exact re-scoring assumes")
     head = kernels.get("encoder_conv") or kernels.get("pair_topk")

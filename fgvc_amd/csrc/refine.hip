@@ -39,6 +39,7 @@ struct RefineItem {
 };
 static_assert(sizeof(RefineItem) == 144, "RefineItem");
 constexpr int RF_INLINE = 1 << 29;    // a scan item that found the queue full: recomputed inside the refine kernel (slow path)
+constexpr int RF_SAMPLE = 1 << 28;    // not a work item: a query whose lists are final, re-scored only to MEASURE the pair kernel's error (round 6)
 
 struct RefineParams {
   const int32_t* pair_idx;
@@ -57,7 +58,9 @@ struct RefineParams {
   float* logit_out;
   float* weight_out;
   int* counters;                      // [0] work items, [1] items recomputed from scratch, [2] candidates re-scored, [3] scan items beyond the queue,
-                                      // [4] the largest |approximate - exact| score among the re-scored candidates (f32 bits)
+                                      // [4] the largest |approximate - exact| score among the re-scored candidates (f32 bits),
+                                      // [5] the same over the UNBIASED sample: every listed entry (clustered or not, inside the window or not) of a
+                                      //     pseudo-random 1/64 of the queries whose order was proven without re-scoring, [6] entries in that sample, [7] queries in it ([0] counts them too: it is the number of queued items)
   RefineItem* items;
   int* scan_ids;                      // [scan_cap] work-item index of every queued scan item
   int* scan_done;                     // [scan_cap] workgroups of the item that have written their part
@@ -256,10 +259,19 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
     for (int j = 0; j < RF_KMAX; ++j) { sc[j] = top.v[j]; id[j] = top.ix[j]; }
     rf_write(p, f, q, sc, id);
   }
+  // The error word above is fed by re-scored candidates only -- clustered ones: a biased sample of what `eps` must bound (round-5 review).
+  // So a pseudo-random 1/64 of the queries that were NOT flagged (their lists are final and written) are queued as well, every listed
+  // entry of their 16 marked: the refine kernel re-scores them for the measurement alone and writes nothing.
+  const unsigned hsh = ((unsigned)q * 2654435761u) ^ ((unsigned)f * 0x9E3779B1u);
+  const bool sampled = valid && !flagged && ((hsh >> 11) & 63u) == 0u;
+  unsigned mask_all = 0;
+#pragma unroll
+  for (int j = 0; j < RF_KX; ++j) mask_all |= (top.ix[j] != IDX_EMPTY) ? (1u << j) : 0u;
+  const bool queued = flagged || (sampled && mask_all != 0u);
   // queue slots by ONE atomic per wave and counter (a tenth of the queries are flagged: 17 000 atomics on one address otherwise)
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const unsigned long long bf = __ballot(flagged), bb = __ballot(flagged && brute);
+  const unsigned long long bf = __ballot(queued), bb = __ballot(flagged && brute);
   if (bf == 0ull) return;                                                // (wave-uniform)
   int base_f = 0, base_b = 0;
   if (lane == __builtin_ctzll(bf)) base_f = atomicAdd(&p.counters[0], __popcll(bf));
@@ -272,9 +284,18 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(RefineParams p) {
 #pragma unroll
   for (int mm = 32; mm >= 1; mm >>= 1) n_resc += __shfl_xor(n_resc, mm);
   if (lane == __builtin_ctzll(bf) && n_resc) atomicAdd(&p.counters[2], n_resc);
-  if (!flagged) return;
+  int n_smp = (queued && !flagged) ? __popc(mask_all) : 0;
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) n_smp += __shfl_xor(n_smp, mm);
+  const int q_smp = __popcll(__ballot(queued && !flagged));
+  if (lane == __builtin_ctzll(bf) && n_smp) {
+    atomicAdd(&p.counters[6], n_smp);
+    atomicAdd(&p.counters[7], q_smp);
+  }
+  if (!queued) return;
   const int slot = base_f + __popcll(bf & lt);
-  int flags = (int)mask;
+  int flags = flagged ? (int)mask : (RF_SAMPLE | (int)mask_all);
+  if (!flagged) m = __popc(mask_all);
   if (brute) {
     const int b = base_b + __popcll(bb & lt);
     // which slots must be scanned: those whose own last entry lies inside the window (an unlisted candidate of theirs may belong to the
@@ -458,7 +479,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
   const int n_waves = (int)gridDim.x * 4;
   const int n_items = __builtin_amdgcn_readfirstlane(p.counters[0]);
   const int HWk = p.Hk * p.Wk;
-  float wave_err = 0.f;
+  float wave_err = 0.f, wave_err_s = 0.f;
   for (int base = 4 * wave; base < n_items; base += 4 * n_waves) {
     const int it = base + (lane >> 4);
     const bool active = it < n_items;
@@ -525,7 +546,9 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
         }
       }
     }
-    wave_err = fmaxf(wave_err, err);
+    const bool smp = mine && (flags & RF_SAMPLE) != 0;      // (the unbiased sample: measured, nothing written -- the query's lists are final)
+    wave_err_s = fmaxf(wave_err_s, smp ? err : 0.f);
+    wave_err = fmaxf(wave_err, smp ? 0.f : err);
     // rank of this lane's entry among the m entries of its item's window: (score desc, index asc)
     int rank = 0;
 #pragma unroll
@@ -534,7 +557,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
       const int gj = __shfl(gid, g0 + j);
       rank += (j < m && (sj > sc || (sj == sc && gj < gid))) ? 1 : 0;
     }
-    const bool inwin = mine && sub < m;
+    const bool inwin = mine && !smp && sub < m;
     float osc[RF_KMAX];
     int oid[RF_KMAX];
 #pragma unroll
@@ -547,11 +570,15 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineParams p) {
       osc[r] = grp ? v : -INFINITY;
       oid[r] = grp ? gi : IDX_EMPTY;
     }
-    if (mine && sub == 0) rf_write(p, row, q, osc, oid);
+    if (mine && !smp && sub == 0) rf_write(p, row, q, osc, oid);
   }
 #pragma unroll
-  for (int mm = 32; mm >= 1; mm >>= 1) wave_err = fmaxf(wave_err, __shfl_xor(wave_err, mm));
+  for (int mm = 32; mm >= 1; mm >>= 1) {
+    wave_err = fmaxf(wave_err, __shfl_xor(wave_err, mm));
+    wave_err_s = fmaxf(wave_err_s, __shfl_xor(wave_err_s, mm));
+  }
   if (lane == 0 && wave_err > 0.f) atomicMax(&p.counters[4], __builtin_bit_cast(int, wave_err));
+  if (lane == 0 && wave_err_s > 0.f) atomicMax(&p.counters[5], __builtin_bit_cast(int, wave_err_s));
 }
 
 // ... and the from-scratch items that found the scan queue full, one per wave (a launch that ends at once when there are none)

@@ -442,10 +442,11 @@ def merge_refine_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pai
     """merge_topk() behind the approximate scores of fgvc_pair_topk_f16f6, index-exact: candidates whose approximate scores are within
     2 eps of a neighbour are re-scored from the exact rows of `q_bank` / `k_bank` (f32 (frames, HW, 256), or split_f16f6x() banks),
     queries whose window the pair lists do not close are recomputed from every candidate under `mask`.
-    Returns idx, logit, weight as merge_topk(), and the int32 statistics {queries re-scored, of them from scratch, candidates re-scored,
-    from-scratch queries beyond the scan queue (slow path), f32 bits of the largest |approximate - exact| score among the re-scored
-    candidates} as a device tensor (5,) (a view of the workspace: read it before the next call that uses the same workspace;
-    refine_max_error() decodes the last word)."""
+    Returns idx, logit, weight as merge_topk(), and the int32 statistics {work items (queries re-scored + sampled), of them from scratch,
+    candidates re-scored, from-scratch queries beyond the scan queue (slow path), f32 bits of the largest |approximate - exact| score
+    among the re-scored candidates, the same over the UNBIASED sample (round 6: every listed entry of a pseudo-random 1/64 of the queries
+    whose order needed no re-scoring), entries in that sample, queries in it (counted in the first word too)} as a device tensor (8,) (a view of the workspace: read it before the next
+    call that uses the same workspace; refine_max_error() / refine_sample_error() decode words 4 and 5)."""
     pair_idx, pair_score = _chk(pair_idx, torch.int32, "pair_idx"), _chk(pair_score, torch.float32, "pair_score")
     slot_pair, pairs = _chk(slot_pair, torch.int32, "slot_pair"), _chk(pairs, torch.int32, "pairs")
     assert pair_idx.shape == pair_score.shape and pair_idx.shape[2] == topk and pair_idx.shape[1] == Hq * Wq and pairs.shape[0] == pair_idx.shape[0]
@@ -465,13 +466,31 @@ def merge_refine_topk(pair_idx: torch.Tensor, pair_score: torch.Tensor, slot_pai
               C.c_void_p(qb.data_ptr() + qo), C.c_int64(qfb), qrb, C.c_void_p(kb.data_ptr() + ko), C.c_int64(kfb), krb,
               n_out, T, Hq, Wq, Hk, Wk, 256, topk, float(temperature), wm, float(eps), mask.r2max, mask.ry, mask.rx,
               _ptr(idx), _ptr(logit), _ptr(weight), _ptr(workspace), _stream(pair_idx))
-    return idx, logit, weight, workspace.view(torch.int32)[:5]
+    return idx, logit, weight, workspace.view(torch.int32)[:8]
 
 
 def refine_max_error(stats: torch.Tensor) -> float:
     """The largest |approximate - exact| score (dot-product units) the refining merge saw among the candidates it re-scored: `eps` as
     measured on that call's data.  Synchronises (reads the device counters)."""
-    return float(stats[4:5].cpu().view(torch.float32)[0])
+    e = stats[4:6].cpu().view(torch.float32) if stats.numel() >= 6 else stats[4:5].cpu().view(torch.float32)
+    return float(e.max())                 # (both samples: the clustered candidates' and the unbiased one's -- the bound must hold for either)
+
+
+def refine_sample_error(stats: torch.Tensor):
+    """(largest |approximate - exact| over the unbiased sample, entries in it): refine_max_error() over candidates the refining merge did
+    NOT need to re-score -- every listed entry, inside the window or not, of 1/64 of the queries whose order was proven as it stood."""
+    if stats.numel() < 8:
+        return None, 0
+    c = stats[:8].cpu()
+    return float(c[5:6].view(torch.float32)[0]), int(c[6])
+
+
+def refine_counts(stats: torch.Tensor) -> dict:
+    """The refining merge's counters by name (synchronises)."""
+    c = stats.cpu().tolist()
+    smp_q = c[7] if len(c) >= 8 else 0
+    return dict(queries_rescored=c[0] - smp_q, of_them_from_scratch=c[1], candidates_rescored=c[2], beyond_scan_queue=c[3],
+                sampled_queries=smp_q, sampled_entries=c[6] if len(c) >= 7 else 0)
 
 
 def unsplit_f16f6p(split: torch.Tensor) -> torch.Tensor:

@@ -93,6 +93,7 @@ def test_refined_lists_equal_float64_topk(dev, case):
     tk = engine.merge_pairs(pl, cfg)
     assert not ops.pair_f16x3_timed_out()
     stats = tk.refine_stats.cpu().tolist()
+    stats[0] -= stats[7]                                     # (word 0 counts queued items: the unbiased sample's queries, word 7, are not re-scored queries)
     plain = engine.merge_pairs(engine.PairLists(pl.plan, pl.idx, pl.score, pl.HW, pl.channels), cfg)
     fc = f.cpu()
     HW = H * W
@@ -140,6 +141,8 @@ def test_refine_from_scratch_when_one_slot_owns_the_list(dev):
         assert all(sum(1 for p in sp if p >= 0) == 1 for sp in plan.slot_pair)
         tk = engine.run_affinity(f, H, W, plan, cfg)
         stats = tk.refine_stats.cpu().tolist()
+        stats[0] -= stats[7]
+    stats[0] -= stats[7]                                     # (word 0 counts queued items: the unbiased sample's queries, word 7, are not re-scored queries)
         assert stats[0] == stats[1] == len(plan.slot_pair) * H * W and stats[3] == 0, stats
         fc = f.cpu()
         for (s0, fr), row in plan.out_rows.items():
@@ -161,6 +164,7 @@ def test_refine_from_scratch_beyond_the_scan_queue(dev):
     plan = engine.plan_clip(Tn, [0], cfg)
     tk = engine.run_affinity(f, H, W, plan, cfg)
     stats = tk.refine_stats.cpu().tolist()
+    stats[0] -= stats[7]                                     # (word 0 counts queued items: the unbiased sample's queries, word 7, are not re-scored queries)
     assert stats[0] == stats[1] == H * W and stats[3] == H * W - 4096, stats
     fc = f.cpu()
     dense, ks = _dense_rows(fc, plan, 0, 12, "circle")
@@ -211,6 +215,7 @@ def test_refine_at_480p_size_sampled(dev):
     tk = engine.merge_pairs(pl, cfg)
     assert not ops.pair_f16x3_timed_out()
     stats = tk.refine_stats.cpu().tolist()
+    stats[0] -= stats[7]                                     # (word 0 counts queued items: the unbiased sample's queries, word 7, are not re-scored queries)
     HW = H * W
     sample = torch.randperm(HW, generator=g)[:2000].sort().values.to(dev)
     row = plan.out_rows[(0, 7)]
@@ -284,3 +289,52 @@ def test_tracker_holds_the_measured_score_error_against_eps(dev):
     tight = _tracker(dev, "VanillaTracker", (1, 1, 1, 4), dict(cfg, pair_refine_eps=1e-7), 5)
     with pytest.raises(RuntimeError, match="beyond the bound"):
         tight(test_mode=True, rgbs=rgbs, query_points=qp, trajectories=traj, visibilities=vis)
+
+
+def test_unbiased_error_sample_and_every_candidate_of_sampled_queries(dev):
+    """Round-5 review, "what's weak" 1b: the refining merge's bound `eps` was validated on the candidates it re-scores -- clustered ones --
+    while the proof needs it for every candidate.  Two measurements on a structured clip (smooth features: the case the merge was built
+    for), through the product route (run_pairs f16f6x + merge_refine):
+      (a) the UNBIASED sample the merge now takes on every call: every listed entry -- clustered or not, inside the window or not -- of a
+          pseudo-random 1/64 of the queries whose order was proven as it stood; counted, non-empty, within the bound, and no list of the
+          launch changes because of it (the sampled queries' lists are final before they are sampled);
+      (b) test-only: EVERY candidate inside the disc -- listed by the pair kernel or not -- of 512 sampled queries, scored by the model of
+          the kernel's arithmetic on the bank rows the kernel reads (oracle.f16f6p_decode: what the matrix instructions are fed, sums in
+          float64; the GPU tests of the pair kernel hold it to this model within 2e-6) against the exact float64 product of the f32 rows."""
+    import numpy as np
+    from fgvc_amd import engine, ops
+    H, W, Tn = 48, 64, 7
+    x = _feats(H, W, Tn, 3, "smooth")
+    f = ops.normalize_to_hwc(x.to(dev))
+    cfg = engine.TrackerConfig(neighbor_range=30, topk=10, precede_frames=5, pair_split_fmt="f16f6", pair_precision="split")
+    plan = engine.plan_clip(Tn, [0], cfg)
+    pl = engine.run_pairs(f, H, W, plan, cfg)
+    tk = engine.merge_pairs(pl, cfg)
+    torch.cuda.synchronize()
+    assert not ops.pair_f16x3_timed_out()
+    cnt = ops.refine_counts(tk.refine_stats)
+    smp_err, smp_n = ops.refine_sample_error(tk.refine_stats)
+    n_q = len(plan.slot_pair) * H * W
+    assert cnt["sampled_queries"] > 0.005 * n_q and smp_n >= 10 * cnt["sampled_queries"] and cnt["sampled_queries"] < 0.03 * n_q, cnt
+    assert 0.0 < smp_err < ops.REFINE_EPS and ops.refine_max_error(tk.refine_stats) >= smp_err, (smp_err, cnt)
+    # (b) every in-disc candidate of 512 sampled queries of the last frame's key slots
+    HW = H * W
+    rows = pl.exact.contiguous().view(torch.uint8).reshape(Tn, HW, -1)[:, :, :1024].cpu().numpy()
+    fc = f.double().cpu().numpy()
+    qf = Tn - 1
+    hq, h6q, l6q = O.f16f6p_decode(rows[qf])
+    g = np.random.default_rng(5)
+    qs = g.choice(HW, 512, replace=False)
+    yy, xx = np.arange(HW) // W, np.arange(HW) % W
+    worst, n_c = 0.0, 0
+    for kf in plan.slot_frame[plan.out_rows[(0, qf)]]:
+        hk, h6k, l6k = O.f16f6p_decode(rows[kf])
+        for q in qs:
+            cand = np.nonzero((yy - yy[q]) ** 2 + (xx - xx[q]) ** 2 < 15 * 15)[0]
+            approx = (hk[cand] @ hq[q] + (h6k[cand] @ l6q[q] + l6k[cand] @ h6q[q]) / 256.0) / 65536.0
+            exact = fc[kf][cand] @ fc[qf][q]
+            worst = max(worst, float(np.abs(approx - exact).max()))
+            n_c += len(cand)
+    print(f"unbiased sample: {cnt}, error {smp_err:.2e} over {smp_n} entries; every in-disc candidate of 512 queries x {len(plan.slot_frame[plan.out_rows[(0, qf)]])} key frames "
+          f"({n_c} candidates): model error {worst:.2e} (eps {ops.REFINE_EPS:.0e})")
+    assert worst < ops.REFINE_EPS and n_c > 512 * 500, (worst, n_c)
