@@ -619,9 +619,27 @@ def dense_propagate(aff: torch.Tensor, labels: torch.Tensor, topk: Optional[int]
 
 
 def local_corr_topk(qfeat: torch.Tensor, kfeat: torch.Tensor, H: int, W: int, R: int, topk: int,
-                    temperature: float, normalized: bool = False, split_fmt: str = "f16"):
+                    temperature: float, normalized: bool = False, split_fmt: str = "f16", presplit: bool = False):
     """A7: qfeat (1, HW, C), kfeat (K, HW, C) -> idx (HW,k) int32 = slot*(2R+1)^2 + tap, logit, weight.
-    normalized=True (rows are L2-normalised) lets C == 256 / k <= 10 run on the 16-bit matrix pipe (fgvc_local_corr_topk_f16x3)."""
+    normalized=True (rows are L2-normalised) lets C == 256 / k <= 10 run on the 16-bit matrix pipe (fgvc_local_corr_topk_f16x3).
+    presplit=True (round 6): qfeat / kfeat ARE split_f16x2() banks (1, HW, 2, 256) / (K, HW, 2, 256) int16 of normalised rows -- a tracker
+    splits a frame once when it enters its bank, not once per query frame that correlates with it (at 480 x 854 the split of seven frames
+    was 0.96 of the 4.2 ms this call took: tools/bench_cfg3.py)."""
+    if presplit:
+        qs, ks = _chk(qfeat, torch.int16, "qfeat"), _chk(kfeat, torch.int16, "kfeat")
+        assert qs.dim() == 4 and ks.dim() == 4 and qs.shape[2:] == (2, 256) and ks.shape[2:] == (2, 256) and qs.shape[1] == ks.shape[1] == H * W
+        if not split_path_ok(256, H, W, topk, True, None, MaskSpec(ry=R, rx=R), True):
+            raise ValueError("local_corr_topk(presplit=True): the 16-bit local-window path needs topk <= 10 and a window within its block list")
+        K, dev = ks.shape[0], qs.device
+        pairs = make_pairs([(0, t) for t in range(K)], dev)
+        ws_i = torch.empty((K, H * W, topk), device=dev, dtype=torch.int32)
+        ws_s = torch.empty((K, H * W, topk), device=dev, dtype=torch.float32)
+        idx = torch.empty((H * W, topk), device=dev, dtype=torch.int32)
+        logit = torch.empty((H * W, topk), device=dev, dtype=torch.float32)
+        weight = torch.empty_like(logit)
+        _lib.call("fgvc_local_corr_topk_f16x3", _ptr(qs), _ptr(ks), _ptr(pairs), K, 256, H, W, R, topk,
+                  float(temperature), _ptr(ws_i), _ptr(ws_s), _ptr(idx), _ptr(logit), _ptr(weight), _stream(qs))
+        return idx, logit, weight
     qfeat, kfeat = _chk(qfeat, torch.float32, "qfeat"), _chk(kfeat, torch.float32, "kfeat")
     K = kfeat.shape[0]
     dev = qfeat.device

@@ -54,7 +54,12 @@ for t in range(T + 1):                                            # frame by fra
 t_split = timeit(lambda: ops.local_corr_topk(big[:1], big[1:], H1, W1, R1, k, 0.07, normalized=True), reps=3)
 q16, k16 = ops.split_f16x2(big[:1]), ops.split_f16x2(big[1:])
 t_s = timeit(lambda: (ops.split_f16x2(big[:1]), ops.split_f16x2(big[1:])), reps=3)
+t_pre = timeit(lambda: ops.local_corr_topk(q16, k16, H1, W1, R1, k, 0.07, presplit=True), reps=3)
+a, b = ops.local_corr_topk(big[:1], big[1:], H1, W1, R1, k, 0.07, normalized=True), ops.local_corr_topk(q16, k16, H1, W1, R1, k, 0.07, presplit=True)
+assert all(torch.equal(x, y) for x, y in zip(a, b))
 fl = 2.0 * H1 * W1 * T * (2 * R1 + 1) ** 2 * C
-print(f"local window (A7) radius {R1}, {T} key slots at {H1}x{W1}x{C} (configs[2] as stated): f16x3 kernel {t_split:.2f} ms per query frame "
-      f"incl. {t_s:.2f} ms for splitting the 7 frames ({fl / 1e9:.0f} GFLOP windowed -> {fl / ((t_split - t_s) * 1e-3) / 1e12:.0f} TFLOP/s f32-grade "
-      f"without the split; features read: {(T + 1) * H1 * W1 * C * 4 / 1e9:.2f} GB)")
+gb = (T + 1) * H1 * W1 * C * 4 / 1e9
+print(f"local window (A7) radius {R1}, {T} key slots at {H1}x{W1}x{C} (configs[2] as stated): f16x3 kernel {t_split:.2f} ms per query frame from f32 rows "
+      f"(incl. {t_s:.2f} ms for splitting the 7 frames), {t_pre:.2f} ms on a bank split once (presplit=True: identical lists) = "
+      f"{fl / 1e9:.0f} GFLOP windowed -> {fl / (t_pre * 1e-3) / 1e12:.0f} TFLOP/s f32-grade; features read {gb:.2f} GB -> {gb / (t_pre * 1e-3) / 1e3:.2f} TB/s = "
+      f"{gb / (t_pre * 1e-3) / 8e3:.3f} of the 8 TB/s roofline (SURVEY 8(d): 0.37 ms at 8 TB/s)")

@@ -26,7 +26,8 @@ def per_kernel(d):
 
 
 fetch, write, tcc, mfma = (per_kernel(d) for d in sys.argv[1:5])
-names = {"fgvc_pair_topk_f16f6": "pair_topk_kernel_v7", "fgvc_pair_topk_f16x3": "pair_topk_kernel_v6", "fgvc_pair_topk_f32": "pair_topk_kernel_v2",
+names = {"fgvc_pair_topk_f16f6": "pair_topk_kernel_v7", "fgvc_pair_topk_f16f6[v8, opt-in]": "pair_topk_kernel_v8",
+         "fgvc_local_corr_topk_f16x3[merge]": "local_merge_kernel", "fgvc_c2f_refine_f32": "c2f_refine_kernel", "fgvc_pair_topk_f16x3": "pair_topk_kernel_v6", "fgvc_pair_topk_f32": "pair_topk_kernel_v2",
          "fgvc_corr_volume_f16f6": "corr_volume_f16f6_kernel", "fgvc_corr_volume_f16f8": "corr_volume_f16f8_v2_kernel", "fgvc_corr_volume_bf16x3": "corr_volume_bf16_kernel<256, 3",
          "fgvc_corr_volume_bf16": "corr_volume_bf16_kernel<256, 1", "fgvc_corr_volume_f32": "corr_volume_f32_kernel",
          "fgvc_conv_split_f32": "conv_split_kernel<3, 256, 1, 3, 4, true, 0, 2, false, false", "fgvc_conv_split_fmt_f32[f16f8]": "conv_split_kernel<3, 256, 1, 3, 4, false, 1, 2, false, false",

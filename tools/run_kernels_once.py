@@ -22,6 +22,9 @@ for _ in range(3):
     pl = engine.run_pairs(h6x_all, H, W, plan, cfg6)          # the default: fgvc_pair_topk_f16f6x on 2 KiB rows ...
     engine.merge_pairs(pl, cfg6)                              # ... + fgvc_merge_refine_topk_f32 (merge_mark / refine / refine_scan kernels)
     ops.pair_topk_split(h6_all, h6_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16f6")
+    ops.set_option("pair_f16_debug", 4194304)                 # round 6: the one-role kernel (opt-in), for its fetch / busy figures beside v7's
+    ops.pair_topk_split(h6_all, h6_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16f6")
+    ops.set_option("pair_f16_debug", 0)
     ops.pair_topk_split(h16_all, h16_all, pairs, H, W, H, W, cfg.mask, 10, validate=False, all_masked=True, fmt="f16")
     ops.pair_topk(feats, feats, pairs, H, W, H, W, cfg.mask, 10, validate=False)
     ops.corr_volume(sp6[1], sp6[0], 0.07, "f16f6", out=vol)
