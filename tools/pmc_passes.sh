@@ -10,4 +10,5 @@ run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum
 run mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
 python3 tools/pmc_report.py $OUT/fetch $OUT/write $OUT/tcc $OUT/mfma > $ROOT/gpurun_out/${TAG}_pmc.json
+rm -rf $OUT/fetch $OUT/write $OUT/tcc $OUT/mfma      # (raw counter databases: tens of MB each; gpurun_out is copied back only below 64 MiB)
 echo "wrote gpurun_out/${TAG}_pmc.json"

@@ -20,7 +20,13 @@ torch.cuda.empty_cache()
 H, W, scale, Cf, Rf, P = 120, 214, 4, 64, 6, 16
 fine = ops.normalize_to_hwc(torch.randn(T + 1, Cf, H * scale, W * scale, device=dev))
 vfine = torch.rand(T, H * scale * W * scale, P, device=dev)
-arg = torch.randint(0, H * W, (T, H * W), device=dev, dtype=torch.int32)
+# the fine windows' centres as the coarse stage gives them (bench_cfg3.py): the arg-max of the masked coarse affinity -- on these noise features
+# a uniformly random cell of the radius-15 disc, the WORST case for the fine stage's locality (a real video's motion is coherent)
+coarse = ops.normalize_to_hwc(torch.randn(T + 1, C, H, W, device=dev))
+cidx, _ = ops.pair_topk_auto(coarse, coarse, ops.make_pairs([(0, 1 + t, True) for t in range(T)], dev), H, W, H, W,
+                             ops.MaskSpec.from_neighbor_range(30), 1, normalized=True)
+arg = cidx[:, :, 0].clamp_min(0).contiguous()
+del coarse
 for _ in range(3):
     ops.c2f_refine(arg, fine[0], fine[1:], vfine, H, W, scale, Rf, k, 0.07)
 torch.cuda.synchronize()
