@@ -270,7 +270,7 @@ class KernelProbe:
         return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (None, 0)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -323,40 +323,12 @@ def main():
                     help="N > 1 ranks on ONE GPU over gloo (device tensors staged through the host by fgvc_amd.dist): exercises every "
                          "line of the multi-rank path on a one-GPU box; the number it prints is NOT a measurement (RCCL refuses two "
                          "ranks on one device, hence gloo)")
-    a = ap.parse_args()
+    return ap.parse_args()
 
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` on its own: this process (which has not touched the GPU and never will) starts the N ranks with the
-        # reference's launcher shape (tools/dist_test.sh:10-13: torch.distributed.launch --nproc_per_node) and hands on their exit code
-        raise SystemExit(self_launch(a.gpus))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU "
-                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus})")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    if a.rehearse_on_one_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    backend_name = None
-    if world > 1:
-        import datetime
-        # every collective is bounded: a rank that hangs in one makes the job exit non-zero (the process group's watchdog aborts
-        # the communicator and raises) instead of sitting at the closing barrier for ever
-        tmo = datetime.timedelta(seconds=a.comm_timeout)
-        if a.rehearse_on_one_gpu:
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            dist.init_process_group("gloo", timeout=tmo)
-        else:
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
-            dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # RCCL over xGMI
-        backend_name = dist.get_backend()
 
-    from fgvc_amd import _lib, dist as fdist, engine, ops
-    _lib.load()
+def setup_workload(L):
+    """model, data, kernel probe, backend of one run: everything the timed loop needs.  `L`: the run's namespace (main() threads one dict through the phases)."""
+    a, dev, engine, fdist, ops, rank, world = L.get("a"), L.get("dev"), L.get("engine"), L.get("fdist"), L.get("ops"), L.get("rank"), L.get("world")
     for kv in a.set_option:
         name, _, val = kv.partition("=")
         ops.set_option(name, int(val))
@@ -440,7 +412,14 @@ def main():
     plan1 = engine.plan_clip(Tc, [0], cfg)
     state = {}
     sched_cache = {}
+    _out = ('P', 'T', 'Tc', '_', 'arith', 'backend', 'cfg', 'e_lo', 'h', 'halo_why', 'hi', 'lo', 'model', 'name', 'pair_fmt', 'plan1', 'probe', 'pts', 'qp', 'rgbs', 'sched_cache', 'state', 'tail_stream', 'timing', 'w', 'wl')
+    L.update({k_: v_ for k_, v_ in locals().items() if k_ in _out})
 
+
+def timed_steps(L):
+    """warm-up, EXACTLY a.steps timed steps between barrier + synchronise (max over ranks), failure flags, the repeat blocks.  `L`: the run's namespace (main() threads one dict through the phases)."""
+    T, _, a, backend, cfg, dev, engine, fdist, h, model, ops, plan1 = L.get("T"), L.get("_"), L.get("a"), L.get("backend"), L.get("cfg"), L.get("dev"), L.get("engine"), L.get("fdist"), L.get("h"), L.get("model"), L.get("ops"), L.get("plan1")
+    probe, pts, qp, rgbs, sched_cache, state, tail_stream, timing, w, world = L.get("probe"), L.get("pts"), L.get("qp"), L.get("rgbs"), L.get("sched_cache"), L.get("state"), L.get("tail_stream"), L.get("timing"), L.get("w"), L.get("world")
     def step(timed: bool):
         if a.mode == "video":
             traj, _ = fdist.track_points_sharded(backend, rgbs, qp, cfg, device=dev, halo=a.halo, timing=timing if timed else None,
@@ -493,7 +472,14 @@ def main():
             step(False)
         barrier()
         rep.append((time.perf_counter() - t1) / 20 * 1e3)
+    _out = ('_', 'barrier', 'comm', 'elapsed', 'n_frames_total', 'out_coords', 'rep', 't', 't1')
+    L.update({k_: v_ for k_, v_ in locals().items() if k_ in _out})
 
+
+def roofline_objects(L):
+    """per-kernel roofline objects from the HIP events of the timed region and the committed PMC passes.  `L`: the run's namespace (main() threads one dict through the phases)."""
+    Tc, a, arith, backend, cfg, h, name, ops, pair_fmt, plan1, probe, t = L.get("Tc"), L.get("a"), L.get("arith"), L.get("backend"), L.get("cfg"), L.get("h"), L.get("name"), L.get("ops"), L.get("pair_fmt"), L.get("plan1"), L.get("probe"), L.get("t")
+    w, wl, world = L.get("w"), L.get("wl"), L.get("world")
     Hf, Wf = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     for s_ in wl["strides"][:wl["out_indices"][0] + 1]:
         Hf, Wf = (Hf - 1) // s_ + 1, (Wf - 1) // s_ + 1
@@ -576,7 +562,15 @@ def main():
     roofline = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "what", "executed_tflops",
                                      "frac_executed", "frac_of_f32_mfma_peak", "sustained_peak", "frac_executed_of_sustained", "sustained_note", "ms_per_launch", "mfma_util", "launch_note", "pmc_note")
                 if k in head} if head else None
+    _out = ('C', 'HW', 'Hf', 'Wf', 'kernels', 'n_', 'n_pairs_clip', 'name', 'pm', 'roofline')
+    L.update({k_: v_ for k_, v_ in locals().items() if k_ in _out})
 
+
+def assemble_record(L):
+    """the JSON line's fixed part: metric, value, config, distributed, sharding phases.  `L`: the run's namespace (main() threads one dict through the phases)."""
+    C, HW, Hf, P, T, Tc, Wf, _, a, arith, backend, backend_name = L.get("C"), L.get("HW"), L.get("Hf"), L.get("P"), L.get("T"), L.get("Tc"), L.get("Wf"), L.get("_"), L.get("a"), L.get("arith"), L.get("backend"), L.get("backend_name")
+    cfg, comm, dev, e_lo, elapsed, engine, fdist, h, hi, kernels, lo, local = L.get("cfg"), L.get("comm"), L.get("dev"), L.get("e_lo"), L.get("elapsed"), L.get("engine"), L.get("fdist"), L.get("h"), L.get("hi"), L.get("kernels"), L.get("lo"), L.get("local")
+    n_, n_frames_total, n_pairs_clip, pair_fmt, rank, rep, roofline, timing, w, wl, world = L.get("n_"), L.get("n_frames_total"), L.get("n_pairs_clip"), L.get("pair_fmt"), L.get("rank"), L.get("rep"), L.get("roofline"), L.get("timing"), L.get("w"), L.get("wl"), L.get("world")
     out = {
         "metric": "frames/sec + ms/corr-volume, 480p 8-frame clip, 1/2/4/8 MI355X",
         "value": n_frames_total / elapsed, "unit": "frames/s",
@@ -663,6 +657,14 @@ def main():
         out["comm_bytes_per_step_rank0"] = dict(comm, expected=exp, frame_bytes=frame_bytes, list_bytes_per_frame=list_bytes)
         for k_, v_ in exp.items():
             assert abs(comm[k_] - v_) <= 1e-6 * max(v_, 1), (k_, comm[k_], v_)
+    _out = ('out',)
+    L.update({k_: v_ for k_, v_ in locals().items() if k_ in _out})
+
+
+def clips_line(L):
+    """the same ranks on independent clips (no collective): what the exchange steps cost.  `L`: the run's namespace (main() threads one dict through the phases)."""
+    Tc, _, a, barrier, cfg, dev, engine, h, model, n_pairs_clip, out, plan1 = L.get("Tc"), L.get("_"), L.get("a"), L.get("barrier"), L.get("cfg"), L.get("dev"), L.get("engine"), L.get("h"), L.get("model"), L.get("n_pairs_clip"), L.get("out"), L.get("plan1")
+    pts, rank, t1, tail_stream, w, world = L.get("pts"), L.get("rank"), L.get("t1"), L.get("tail_stream"), L.get("w"), L.get("world")
     if a.mode == "video" and not a.no_clips_line:
         # the reference's own data parallelism on the same clips (`--mode clips`: independent 8-frame clips per rank, no data-path
         # collective), measured right here: separates "cost of the exchange steps" from "a longer video has more pairs per frame"
@@ -691,6 +693,14 @@ def main():
                                      "no halo, no all_gather), timed the same way right after the sharded-video steps",
                              "value": world * Tc * n_c / el_c, "unit": "frames/s", "ms_per_step": el_c / n_c * 1e3, "steps": n_c,
                              "pairs_per_rank": n_pairs_clip}
+    _out = ('_', 't1')
+    L.update({k_: v_ for k_, v_ in locals().items() if k_ in _out})
+
+
+def precision_lines(L):
+    """the same steps in the three-f16-product form and without the refining merge.  `L`: the run's namespace (main() threads one dict through the phases)."""
+    T, _, a, arith, backend, barrier, cfg, dev, fdist, model, out, out_coords = L.get("T"), L.get("_"), L.get("a"), L.get("arith"), L.get("backend"), L.get("barrier"), L.get("cfg"), L.get("dev"), L.get("fdist"), L.get("model"), L.get("out"), L.get("out_coords")
+    pair_fmt, qp, rgbs, t1, world = L.get("pair_fmt"), L.get("qp"), L.get("rgbs"), L.get("t1"), L.get("world")
     if a.mode == "video" and not a.no_f16x3_line and (arith != "f16x3" or pair_fmt != "f16"):
         # the price of precision, on the driver's record: the same steps with every matrix product in the three-f16-product form
         # (22 significand bits per operand: encoder f16x3 + fgvc_pair_topk_f16x3), timed the same way right here
@@ -754,6 +764,13 @@ def main():
         out["value_unrefined"] = {"what": "the same steps without the refining merge (pair_refine = False: round 4's default, lists exact at 1e-4 only)",
                                   "value": T * n4 / el4, "unit": "frames/s", "ms_per_step": el4 / n4 * 1e3, "steps": n4}
         model.test_cfg.pop("pair_refine")
+    _out = ('_',)
+    L.update({k_: v_ for k_, v_ in locals().items() if k_ in _out})
+
+
+def corr_volume_section(L):
+    """ms/corr-volume: the dense volume kernels round-robin, the store stream by itself.  `L`: the run's namespace (main() threads one dict through the phases)."""
+    C, HW, _, _lib, a, dev, name, ops, out, pm, rank = L.get("C"), L.get("HW"), L.get("_"), L.get("_lib"), L.get("a"), L.get("dev"), L.get("name"), L.get("ops"), L.get("out"), L.get("pm"), L.get("rank")
     if rank == 0 and not a.no_corr_volume:
         gq = torch.Generator(device=dev).manual_seed(5)
         feats2 = torch.nn.functional.normalize(torch.randn(2, HW, C, generator=gq, device=dev), dim=2)
@@ -830,6 +847,52 @@ def main():
                                    store_ceiling_gbps=vol_bytes / (min(sweep_ms.values()) * 1e-3),
                                    corr_volume_store_replay_gbps=(vol_bytes / (replay_ms * 1e-3)) if replay_ms else None)
         del vol
+
+
+def main():
+    a = parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process (which has not touched the GPU and never will) starts the N ranks with the
+        # reference's launcher shape (tools/dist_test.sh:10-13: torch.distributed.launch --nproc_per_node) and hands on their exit code
+        raise SystemExit(self_launch(a.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if a.rehearse_on_one_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    backend_name = None
+    if world > 1:
+        import datetime
+        # every collective is bounded: a rank that hangs in one makes the job exit non-zero (the process group's watchdog aborts
+        # the communicator and raises) instead of sitting at the closing barrier for ever
+        tmo = datetime.timedelta(seconds=a.comm_timeout)
+        if a.rehearse_on_one_gpu:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", timeout=tmo)
+        else:
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # RCCL over xGMI
+        backend_name = dist.get_backend()
+
+    from fgvc_amd import _lib, dist as fdist, engine, ops
+    _lib.load()
+    L = dict(locals())                                               # the run's namespace: every phase reads what it needs from it and adds what later ones need
+    setup_workload(L)
+    timed_steps(L)
+    roofline_objects(L)
+    assemble_record(L)
+    clips_line(L)
+    precision_lines(L)
+    corr_volume_section(L)
+    a, halo_why, out, rank, wl, world = L.get("a"), L.get("halo_why"), L.get("out"), L.get("rank"), L.get("wl"), L.get("world")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:          # reported at N = 1 only (the other ranks would sit at the barrier)
         out["cpu_baseline"] = cpu_baseline(wl)
     if halo_why is not None:
