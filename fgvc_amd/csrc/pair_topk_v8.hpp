@@ -1,32 +1,39 @@
-// pair_topk_kernel_v8 (round 6): fgvc_pair_topk_f16f6's windowed correlation + top-k as ONE kind of wave.  Included by pair_topk_v5.hip
-// behind pair_topk_v7.hpp (same translation unit: row format, bounded spins, timeout flag, poison lists are shared).
+// pair_topk_kernel_v8 (round 6, OPT-IN: pair_f16_debug & 4194304): fgvc_pair_topk_f16f6's windowed correlation + top-k as ONE kind of
+// wave.  Included by pair_topk_v5.hip behind pair_topk_v7.hpp (same translation unit: row format, bounded spins, timeout flag, poison lists).
 //
-// What round 5's profile said about pair_topk_kernel_v7 (27 pairs of a 480p clip, 1.17 ms, matrix pipe 24.5 % busy, 3.59 GB fetched):
-// a 32 x 32 tile is a chain of LDS round trips between three wave roles -- a consumer multiplies and hands its 4 KiB of sums to a
-// selector through the LDS, producers stage a 30 KiB key block through registers for FOUR query blocks (56 block loads per 8 x 16 query
-// tile) -- and no unit is busy.  Here:
-//   * 8 waves, two per SIMD, all alike.  A wave owns one 4 x 8 query block of a 16 x 16 query tile with ALL its operands resident (h 64
-//     + l6 24 + h6 24 registers: 256 registers per wave at two waves per SIMD), multiplies it with a key block as the LDS holds it
-//     (33 operand reads per tile instead of 43), keeps the sums and selects from them itself: no hand-over, no mailbox.  While one wave
-//     of a SIMD selects (vector unit), its partner multiplies (matrix pipe) -- the overlap the three roles were built for, without
-//     their round trips -- and from the second tile of a pair on a wave's own selection of tile t - 1 sits behind the matrix
-//     instructions of tile t (pair_v8.inc, tools/gen_pair_v8.py).
-//   * A key block is staged ONCE for eight query blocks: 68 block loads per 16 x 16 tile (8.5 per query block; v7: 14), by LDS-DMA
-//     (global_load_lds_dwordx4, 58 lanes = the 928 bytes of a row that carry something: tools/micro/probe_dma_exec.hip), four rows per
-//     wave and block, no registers, no ds_write.
-//   * The ring has no workgroup barrier: per slot `filled` counts the waves whose rows of the block have landed (8 per block: a wave
-//     posts block G + D - 1 as soon as only block G + D's rows are still in flight), `done` the waves that have finished with it (8 per
-//     block: also those whose query block does not reach it, at once).  A wave re-fills slot s with block G + D only when `done`
-//     shows block G + D - NSLOT released by everybody, so a wave runs at most one block ahead of the slowest -- enough, with the block
-//     list in an order that pairs a key row only the upper query blocks reach with one only the lower reach, for every SIMD to find
-//     work in every pair of steps (tools/sim_pair_ring.py's model: a barrier per step would idle 46 % of the tile slots).
-//     Every spin is bounded; a wave that gives up raises the workgroup's flag and the lists written from then on are POISON, as in v7.
+// What round 5's profile said about pair_topk_kernel_v7 (27 pairs of a 480p clip, 1.17 ms, matrix pipe 24.5 % busy, 3.59 GB fetched): a
+// 32 x 32 tile is a chain of LDS round trips between three wave roles -- a consumer multiplies and hands its 4 KiB of sums to a selector
+// through the LDS, producers stage a 30 KiB key block through registers for FOUR query blocks (56 block loads per 8 x 16 query tile).
+// This kernel is the review's proposal built and measured:
+//   * 8 waves, two per SIMD, all alike.  A wave owns one 4 x 8 query block of a 16 x 16 query tile with ALL its operands resident (h 64 +
+//     l6 24 + h6 24 registers), multiplies it with a key block as the LDS holds it (33 operand reads per tile; v7: 43 + the query's h6
+//     from the LDS), keeps the sums and selects from them itself: no hand-over, no mailbox.
+//   * A tile = ONE assembly statement (pair_v8.inc, tools/gen_pair_v8.py): the 24 matrix instructions of v7's chain -- same operands,
+//     same order: the scores are v7's bit for bit -- with the selection of the tile BEFORE it (212 vector operations) dealt behind them,
+//     the chain's buffers physical registers named in the text, the selection's values renamed in place by the generator's allocator
+//     (statement per instruction, the allocator rotated the 6-register operands through v_mov chains and spilled: 270 registers wanted).
+//   * A key block is staged ONCE for eight query blocks (68 block loads per 16 x 16 tile: 8.5 per query block, v7: 14) by LDS-DMA
+//     (global_load_lds_dwordx4 under an exec mask of 58 lanes = the 928 bytes of a row that carry something: tools/micro/
+//     probe_dma_exec.hip; four instructions per row, m0 and vcc the only registers), all 32 rows of block G by wave G mod 8, three
+//     blocks ahead; posted two steps later.
+//   * The ring has no workgroup barrier: per slot `filled` counts posted blocks, `done` the waves that have finished with one (also those
+//     whose query block does not reach it -- once it is complete: a release for a block that is not staged yet would be counted for the
+//     block before it).  The block list pairs a key row only the upper query blocks reach with one only the lower reach, step by step
+//     (row-major: 1.38 ms instead of 1.20).  Every spin is bounded; a wave that gives up raises the workgroup's flag and the lists
+//     written from then on are POISON, as in v7.
 //   * Selection keys are canonical: (22-bit score << 10) | tag, tag = the key pixel's rank in (row, column) order inside the window the
-//     query block can reach (9 x 4 pixel rows x 5 block columns x 4 columns: 720 values), so equal scores resolve to the LOWER pixel
-//     index whatever the order the blocks were visited in (v7: by list position).  Scores are v7's bit for bit (same instructions, same
-//     operands, same order); lists differ from v7's only where a score ties across the K-th place.
-// Limits: those of v7 (C = 256, k <= 10, normalised rows, every pair masked) and a mask reach of at most 16 pixels either way (the tag);
-// everything else stays on pair_topk_kernel_v7 / v6.
+//     query block can reach, so equal scores resolve to the LOWER pixel index whatever the order the blocks were visited in.
+// Measured (profiles/r06_pair_v8_cfg2.log, r06_pmc.json; same box as v7): bit-identical scores on 13 M lists, identical lists on every one
+// of them -- and 1-7 % SLOWER than v7 at every BASELINE shape (1.20 against 1.18 ms at 480p; cfg4 10.5 / 9.8, cfg5 13.2 / 12.6), matrix
+// pipe 21 % busy, 3.9 GB of L2 fills (fewer bytes reach each CU, but the tile order of this kernel hits its L2 only 42 % of the time:
+// v7's was tuned to 65 %).  Why the proposal does not pay here, from the ablations: with key blocks, chain and selection all switched
+// off the launch still takes 0.52 of its 1.20 ms -- a SIMD issues ONE instruction per ~4 cycles whatever number of its waves is ready
+// (the protocol of a step is ~150 instructions per wave), the selection is 212 + 32 vector instructions per tile that NO arrangement
+// makes fewer, so a tile costs >= 1 100 issue cycles per SIMD against 768 of matrix pipe: both kernels sit at 2 400-2 500 cycles per
+// tile and SIMD, bound by instruction issue, not by the pipe, the LDS or the bytes.  What would move them is fewer instructions per
+// candidate, not another arrangement of the same ones.  v7 stays the default; this kernel is kept, tested against
+// v7 on every run of the GPU suite, as the measured answer to the proposal.
+// Limits: those of v7 (C = 256, k <= 10, normalised rows, every pair masked) and a mask reach of at most 16 pixels either way (the tag).
 #pragma once
 
 namespace fgvc {

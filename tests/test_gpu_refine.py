@@ -141,8 +141,7 @@ def test_refine_from_scratch_when_one_slot_owns_the_list(dev):
         assert all(sum(1 for p in sp if p >= 0) == 1 for sp in plan.slot_pair)
         tk = engine.run_affinity(f, H, W, plan, cfg)
         stats = tk.refine_stats.cpu().tolist()
-        stats[0] -= stats[7]
-    stats[0] -= stats[7]                                     # (word 0 counts queued items: the unbiased sample's queries, word 7, are not re-scored queries)
+        stats[0] -= stats[7]                                 # (word 0 counts queued items: the unbiased sample's queries, word 7, are not re-scored queries)
         assert stats[0] == stats[1] == len(plan.slot_pair) * H * W and stats[3] == 0, stats
         fc = f.cpu()
         for (s0, fr), row in plan.out_rows.items():
