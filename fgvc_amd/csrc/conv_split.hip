@@ -1030,7 +1030,9 @@ void set_conv_cot_cap(int v) { g_conv_cot_cap = v; }
 // beside the loop's 140 000.
 // COT: output channels per workgroup, 256 (four 32-channel tiles per wave, 16 accumulators) or 128 (two tiles, 8 accumulators: the 128 -> 128
 // layers; conv128p_loop.inc -- a stage has 24 matrix instructions there).
-template <int COT, int OUT_FMT, bool RES, bool F32OUT, bool GENERIC, bool BANK = false>
+// CIN_TAG: no code depends on it -- the 128 -> 256 convolution of a stage's first block is launched as its own instance (1) so that a kernel
+// trace tells its launches (half the loop) from the 256 -> 256 ones (round-5 review: one symbol mixed both, 123-374 us)
+template <int COT, int OUT_FMT, bool RES, bool F32OUT, bool GENERIC, bool BANK = false, int CIN_TAG = 0>
 __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   constexpr int NA = COT / 64, PPW = NA * 2;
   constexpr int TROWS = 8, PATCHB = (TROWS + 2) * CV_PW * 128, SLOTB = COT * 128, NPIECE = (TROWS + 2) * 5;
@@ -1573,7 +1575,8 @@ int conv_split_launch(const uint16_t* x, const uint16_t* w, const float* bias, c
       Cin >= 32 && fits32 && !(g_conv_debug & 1024)) {
     if (y_bank) conv256p_kernel<256, -1, false, false, true, true><<<grid, 256, 0, s>>>(p);
     else if (cot_eff == 256) {
-      if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<256, 3, false, false, false><<<grid, 256, 0, s>>>(p);
+      if (y_split && out_fmt == 3 && !residual && !y_f32 && p.Cin == 128) conv256p_kernel<256, 3, false, false, false, false, 1><<<grid, 256, 0, s>>>(p);
+      else if (y_split && out_fmt == 3 && !residual && !y_f32) conv256p_kernel<256, 3, false, false, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && !residual && y_f32) conv256p_kernel<256, 3, false, true, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && residual && y_f32) conv256p_kernel<256, 3, true, true, false><<<grid, 256, 0, s>>>(p);
       else if (y_split && out_fmt == 3 && residual && !y_f32) conv256p_kernel<256, 3, true, false, false><<<grid, 256, 0, s>>>(p);

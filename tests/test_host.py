@@ -434,7 +434,7 @@ def test_stream_kernels_use_no_scratch():
     notes = kn.kernel_notes()
     c256 = {k: v for k, v in notes.items() if "conv256p_kernel" in k}
     assert len(c256) >= 10, sorted(notes)[:5]
-    for fam, want in (("conv256p_kernel", 10), ("conv64p_kernel", 3), ("pair_topk_kernel_v7ILi10ELb0", 1), ("pair_topk_kernel_v7ILi5ELb0", 1),
+    for fam, want in (("conv256p_kernel", 11), ("conv64p_kernel", 3), ("pair_topk_kernel_v7ILi10ELb0", 1), ("pair_topk_kernel_v7ILi5ELb0", 1),
                       ("pair_topk_kernel_v8ILi10ELb0", 1), ("pair_topk_kernel_v8ILi5ELb0", 1)):
         ks = {k: v for k, v in notes.items() if fam in k}
         assert len(ks) >= want, (fam, len(ks))
