@@ -295,7 +295,9 @@ def parse_args():
     ap.add_argument("--sync-tail", action="store_true",
                     help="label sweep + read-out on the main stream (default: on a side stream, so that the next step's encoder "
                          "overlaps this step's chain of small launches; every step is complete before the closing barrier)")
-    ap.add_argument("--tail-from", default="sweep", choices=["sweep", "pairs"],
+    ap.add_argument("--tail-priority", type=int, default=0, help="HIP priority of the side stream (lower = dispatched first; A/B)")
+    ap.add_argument("--lane-priority", type=int, default=0, help="HIP priority of the encoder's lane streams (ResNet.lane_priority; A/B)")
+    ap.add_argument("--tail-from", default="pairs", choices=["sweep", "pairs"],
                     help="what runs on the side stream: the label sweep + read-out only, or everything after the encoder (pair top-k, "
                          "merge, exchange steps, sweep): the next step's encoder then runs beside this step's pair kernel")
     ap.add_argument("--merge-on-main", action="store_true", help="the slot merge (+ exact re-scoring) behind the pair kernel on the main stream instead of "
@@ -341,6 +343,7 @@ def setup_workload(L):
         ResNet.split_lanes = a.encoder_lanes
     if a.no_conv64:
         ResNet.use_conv64 = False
+    ResNet.lane_priority = a.lane_priority
     if a.no_layer1_whole_batch:
         ResNet.layer1_whole_batch = False
     if a.encoder_graph:
@@ -403,7 +406,7 @@ def setup_workload(L):
     ops.merge_refine_topk = probe.wrap(ops.merge_refine_topk, lambda pi, *r, **kw: ("merge_refine", pi.shape[0]))
     ops.merge_topk = probe.wrap(ops.merge_topk, lambda pi, *r, **kw: ("merge", pi.shape[0]))
 
-    tail_stream = None if a.sync_tail else torch.cuda.Stream(dev)
+    tail_stream = None if a.sync_tail else torch.cuda.Stream(dev, priority=a.tail_priority)
     backend = fdist.HipBackend(model, tail_stream=tail_stream, tail_from=a.tail_from)
     backend.merge_on_tail = not a.merge_on_main
     if os.environ.get("FGVC_EARLY_HALO", "1") == "0":               # escape hatch: the halo posted after the whole encoder pass (round 2's order)
@@ -472,7 +475,16 @@ def timed_steps(L):
             step(False)
         barrier()
         rep.append((time.perf_counter() - t1) / 20 * 1e3)
-    _out = ('_', 'barrier', 'comm', 'elapsed', 'n_frames_total', 'out_coords', 'rep', 't', 't1')
+    # one step at a time (synchronised on both sides): what a caller with ONE clip waits for -- the timed region above overlaps each
+    # step's side-stream work (pair top-k, merge, sweep with --tail-from pairs) with the next step's encoder
+    lat = []
+    for _ in range(10 if a.repeats > 0 else 0):
+        barrier()
+        t1 = time.perf_counter()
+        step(False)
+        barrier()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    _out = ('_', 'barrier', 'comm', 'elapsed', 'lat', 'n_frames_total', 'out_coords', 'rep', 't', 't1')
     L.update({k_: v_ for k_, v_ in locals().items() if k_ in _out})
 
 
@@ -570,6 +582,7 @@ def assemble_record(L):
     """the JSON line's fixed part: metric, value, config, distributed, sharding phases.  `L`: the run's namespace (main() threads one dict through the phases)."""
     C, HW, Hf, P, T, Tc, Wf, _, a, arith, backend, backend_name = L.get("C"), L.get("HW"), L.get("Hf"), L.get("P"), L.get("T"), L.get("Tc"), L.get("Wf"), L.get("_"), L.get("a"), L.get("arith"), L.get("backend"), L.get("backend_name")
     cfg, comm, dev, e_lo, elapsed, engine, fdist, h, hi, kernels, lo, local = L.get("cfg"), L.get("comm"), L.get("dev"), L.get("e_lo"), L.get("elapsed"), L.get("engine"), L.get("fdist"), L.get("h"), L.get("hi"), L.get("kernels"), L.get("lo"), L.get("local")
+    lat = L.get("lat")
     n_, n_frames_total, n_pairs_clip, pair_fmt, rank, rep, roofline, timing, w, wl, world = L.get("n_"), L.get("n_frames_total"), L.get("n_pairs_clip"), L.get("pair_fmt"), L.get("rank"), L.get("rep"), L.get("roofline"), L.get("timing"), L.get("w"), L.get("wl"), L.get("world")
     out = {
         "metric": "frames/sec + ms/corr-volume, 480p 8-frame clip, 1/2/4/8 MI355X",
@@ -590,6 +603,11 @@ def assemble_record(L):
                                    f"{cfg.precede_frames}-frame halo ({a.halo}), all_gather of merged top-k lists, replicated sweep"
                                    if a.mode == "video" else f"dp{world} (independent clips per rank, no data-path collective)")},
         "timed_seconds": elapsed,
+        "single_step_latency_ms": (round(sorted(lat)[len(lat) // 2], 4) if lat else None),
+        "steps_overlap": (None if a.sync_tail else
+                          {"pairs": "each step's pair top-k, merge and sweep run on a side stream under the NEXT step's encoder (HipBackend(tail_from='pairs')); "
+                                    "all K steps are complete before the closing barrier; single_step_latency_ms is one step alone",
+                           "sweep": "each step's merge and sweep run on a side stream under the next step's encoder"}[a.tail_from]),
         "repeat_ms_per_step": rep,
         "roofline": roofline,
         "kernels": kernels,

@@ -342,11 +342,13 @@ class Timing:
 class HipBackend:
     """The product backend: encoder through the tracker model, kernels through fgvc_amd.engine.
     `tail_stream`: run the replicated sweep + read-out (a chain of small launches that leaves most CUs idle) on this side stream,
-    so that whatever the caller enqueues next -- the next video's encoder -- starts under it; `tail_from="pairs"` moves the pair
-    top-k, the merge and the exchange steps there as well.  The returned trajectories are then
+    so that whatever the caller enqueues next -- the next video's encoder -- starts under it; `tail_from="pairs"` (the default since
+    round 6: +3.7 % frames/s at 480p on one MI355X, A/B/A/B in `profiles/r06_ab_tail_from.log`; it changed nothing in round 3, before the
+    encoder's one-wave-per-SIMD kernels left tail rounds for the pair kernel's workgroups to fill) moves the pair top-k, the merge and the
+    exchange steps there as well; `"sweep"` keeps them on the caller's stream.  The returned trajectories are then
     produced on that stream: wait for `backend.tail_event` (or synchronise) before reading them."""
 
-    def __init__(self, model, tail_stream: Optional["torch.cuda.Stream"] = None, tail_from: str = "sweep"):
+    def __init__(self, model, tail_stream: Optional["torch.cuda.Stream"] = None, tail_from: str = "pairs"):
         if tail_from not in ("sweep", "pairs"):
             raise ValueError(f"tail_from={tail_from!r}")
         self.model = model

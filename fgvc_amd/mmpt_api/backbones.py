@@ -672,7 +672,7 @@ class ResNet(nn.Module):
             if n_lanes > 1:
                 skey = ("streams", dev, n_lanes)
                 if skey not in cache:
-                    cache[skey] = [torch.cuda.Stream(dev) for _ in range(n_lanes)]
+                    cache[skey] = [torch.cuda.Stream(dev, priority=int(getattr(self, "lane_priority", 0))) for _ in range(n_lanes)]
                 streams = cache[skey]
                 for s in streams:
                     s.wait_stream(main)
