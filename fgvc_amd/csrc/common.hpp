@@ -297,31 +297,36 @@ __device__ __forceinline__ void split_f16_4(const f32x4& x, float s, uint2& hw, 
 // (hw[g]: channels 8 g + 4 h ..+4) and the 2 x 16 bytes it stores at byte 80 - 16 h (main6) and 112 - 16 h (tail6) of the row.
 typedef int fgvc_i32x6 __attribute__((ext_vector_type(6)));
 typedef int fgvc_i32x16 __attribute__((ext_vector_type(16)));
+// Round 6, fewer instructions for the same bits (the conversion was 12.7 vector instructions per value in conv256p_kernel's epilogue):
+//   * ONE running maximum M = max |c| over the clamped values gives both the overflow flag (|s x| > 57344 <=> |c| > 57344: the clamp sits
+//     above the bound) and the block's largest |h| (rounding to f16 is monotonic and odd: max |f16(c)| = f16(max |c|));
+//   * the residual's maximum is taken over c - h (exact) and scaled by 2^11 once per block (exact);
+//   * `lo`: the clamp's lower bound -- a caller whose ReLU has no other reader passes 0 instead of applying it (v_med3 does both).
 __device__ __forceinline__ void split_f16f6_chunk(const f32x4 (&v)[4], float s, int h, uint2 (&hw)[4], fgvc_i32x4& main6, fgvc_i32x4& tail6,
-                                                  bool& ovf) {
+                                                  bool& ovf, float lo = -65504.f) {
   typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
   unsigned A[8], B[8];                 // A: packed h pairs, B: packed f16(2^11 l) pairs; register 2 g + j = channels 8 g + 4 h + 2 j, + 1
-  float mh = 0.f, ml = 0.f;
+  float mc = 0.f, md = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      const float c0 = __builtin_amdgcn_fmed3f(v[g][2 * j] * s, lo, 65504.f);
+      const float c1 = __builtin_amdgcn_fmed3f(v[g][2 * j + 1] * s, lo, 65504.f);
+      mc = fmaxf(fmaxf(mc, fabsf(c0)), fabsf(c1));
       f16x2 hp, lp;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float xs = v[g][2 * j + i] * s;
-        ovf |= fabsf(xs) > 57344.f;                      // (the bound of FMT 1, kept: one calibration rule for both formats)
-        const float c = __builtin_amdgcn_fmed3f(xs, -65504.f, 65504.f);
-        hp[i] = (_Float16)c;
-        const float hf = (float)hp[i];
-        const float lf = (c - hf) * 2048.f;
-        lp[i] = (_Float16)lf;
-        mh = fmaxf(mh, fabsf(hf));
-        ml = fmaxf(ml, fabsf(lf));
-      }
+      hp[0] = (_Float16)c0;
+      hp[1] = (_Float16)c1;
+      const float d0 = c0 - (float)hp[0], d1 = c1 - (float)hp[1];      // exact (the low bits of c)
+      md = fmaxf(fmaxf(md, fabsf(d0)), fabsf(d1));
+      lp[0] = (_Float16)(d0 * 2048.f);
+      lp[1] = (_Float16)(d1 * 2048.f);
       A[2 * g + j] = __builtin_bit_cast(unsigned, hp);
       B[2 * g + j] = __builtin_bit_cast(unsigned, lp);
     }
+  ovf |= mc > 57344.f;                                   // (the bound of FMT 1, kept: one calibration rule for both formats)
+  const float mh = (float)(_Float16)mc;
+  const float ml = md * 2048.f;                          // = max |2^11 (c - h)|: the scaling is exact
 #pragma unroll
   for (int g = 0; g < 4; ++g) hw[g] = {A[2 * g], A[2 * g + 1]};
   // upper lanes of A <-> lower lanes of B: lane (n, 0) then holds h of channels 8 g + k (A) and 8 g + 4 + k (B), lane (n, 1) the residuals

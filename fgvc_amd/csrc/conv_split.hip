@@ -1172,6 +1172,11 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
   {
   int lane = lane_e, n = lane & 31, h = lane >> 5;      // (not const: re-taken per pixel row below -- `row_fence`)
+  // (the padded width too: the prologue reads p.Wp under a lane predicate, the compiler kept that VECTOR copy, sign-extended, for the
+  // epilogue's pixel addresses -- two registers spilled around the loop in the plain instances once the conversion was rewritten in
+  // round 6; a scalar copy taken as new here is what the rows multiply by)
+  int Wp_e = __builtin_amdgcn_readfirstlane(p.Wp);
+  asm volatile("" : "+s"(Wp_e));
   constexpr int RPW = 4, CW = COT / 2, RB = CW * 4, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;
   static_assert(4 * 32 * RS <= PATCHB + 3 * SLOTB, "epilogue staging");
   __syncthreads();
@@ -1426,6 +1431,9 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
   // plain instances spill 36-45 registers into scratch inside the rows; from the LDS copy (16 ds_read_b128 per row) they spill none, at
   // +0.3 % of the launch -- tools/ab_bench.sh, same box.  Off.)
   constexpr bool HOIST_BIAS = false;
+  // round 6: where the split form is the only reader of the row (no f32 copy), the ReLU is the lower bound of the conversion's clamp
+  constexpr bool FUSE_RELU = !GENERIC && !F32OUT && OUT_FMT == 3;
+  const float clamp_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(FUSE_RELU && p.relu ? 0 : (int)0xC77FE000u));    // 0 or -65504
   f32x4 bvv[HOIST_BIAS ? NA : 1][4];
   if constexpr (HOIST_BIAS) {
 #pragma unroll
@@ -1438,7 +1446,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
     row_fence();
     const int y = y0 + RPW * pr + b;
     if (y >= p.H) continue;                       // wave-uniform
-    const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * p.Wp + (x0 + 1);
+    const size_t pix0 = ((size_t)nimg * p.Hp + (y + 1)) * Wp_e + (x0 + 1);
     const size_t fpix0 = ((size_t)nimg * p.H + y) * p.W + x0;
     if (has_res) residual_wait(b == 0 ? 0 : ((GENERIC ? p.y_f32 != nullptr : F32OUT) ? 32 / RPI : 0) + (p.y_split ? 32 / RPI : 0));
     f32x4 v[NA][4];
@@ -1451,7 +1459,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
         v[a][g] = {fmaf(acc[a][b][4 * g + 0], p.acc_scale, bv.x), fmaf(acc[a][b][4 * g + 1], p.acc_scale, bv.y),
                    fmaf(acc[a][b][4 * g + 2], p.acc_scale, bv.z), fmaf(acc[a][b][4 * g + 3], p.acc_scale, bv.w)};
         if (has_res) v[a][g] += residual_at(cw);
-        if (p.relu) {
+        if (p.relu && !FUSE_RELU) {
           v[a][g].x = fmaxf(v[a][g].x, 0.f); v[a][g].y = fmaxf(v[a][g].y, 0.f);
           v[a][g].z = fmaxf(v[a][g].z, 0.f); v[a][g].w = fmaxf(v[a][g].w, 0.f);
         }
@@ -1487,7 +1495,7 @@ __global__ __launch_bounds__(256, 1) void conv256p_kernel(ConvSplitParams p) {
         for (int a = 0; a < NA; ++a) {
           uint2 hw[4];
           i32x4 main6, tail6;
-          split_f16f6_chunk(v[a], p.out_scale, h, hw, main6, tail6, ovf);
+          split_f16f6_chunk(v[a], p.out_scale, h, hw, main6, tail6, ovf, clamp_lo);
           unsigned char* o = tile + n * RS + a * 128;
 #pragma unroll
           for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(o + (8 * g + 4 * h) * 2) = hw[g];
