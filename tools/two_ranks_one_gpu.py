@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--strides", type=int, nargs=4, default=(1, 2, 1, 1))
     ap.add_argument("--neighbor-range", type=int, default=12)
     ap.add_argument("--points", type=int, default=4)
-    ap.add_argument("--halos", nargs="+", default=["exchange", "recompute"], choices=["exchange", "recompute"])
+    ap.add_argument("--halos", nargs="+", default=["exchange", "recompute"], choices=["exchange", "recompute", "auto"])
     a = ap.parse_args()
     fd, path = tempfile.mkstemp(prefix="fgvc_rdzv_")
     os.close(fd)
