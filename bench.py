@@ -555,6 +555,32 @@ def roofline_objects(L):
             "frac_of_f32_mfma_peak": f32_tf / F32_MFMA_PEAK_TFLOPS,
             "ms_per_launch": pair_ms, "pairs_per_launch": pair_tag[1], "launches_timed": n_l,
             "mfma_util": pm.get("mfma_util"), "traffic": pm.get("hbm_bytes_per_launch")}
+        # In the step the launch runs on the side stream BESIDE the next step's encoder (--tail-from pairs): its in-step duration is
+        # stretched by what it shares the CUs with.  The kernel's own figure: the same launch alone on an idle chip, timed right here.
+        if split and a.mode == "video" and world == 1 and pair_tag[1] == n_pairs_clip and not a.sync_tail and a.tail_from == "pairs":
+            import torch
+            model, rgbs, engine = L.get("model"), L.get("rgbs"), L.get("engine")
+            torch.cuda.synchronize()
+            feats_, Hf_, Wf_ = model.get_feats_hwc(rgbs, split=True)
+            probe.on = False
+            for _ in range(3):
+                engine.run_pairs(feats_, Hf_, Wf_, plan1, cfg)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                engine.run_pairs(feats_, Hf_, Wf_, plan1, cfg)
+            e1.record()
+            torch.cuda.synchronize()
+            alone = e0.elapsed_time(e1) / 10
+            k_ = kernels["pair_topk"]
+            k_.update(ms_per_launch_in_step=pair_ms, ms_per_launch=alone, achieved=fl / (alone * 1e-3) / 1e12,
+                      frac=fl / (alone * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, executed_tflops=n_prod * fl / (alone * 1e-3) / 1e12,
+                      frac_executed=n_prod * fl / (alone * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                      frac_of_f32_mfma_peak=fl / (alone * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                      launch_note="ms_per_launch and the fractions: the launch ALONE (10 launches on an idle chip after the timed steps); "
+                                  "ms_per_launch_in_step: HIP events in the timed region, where it runs beside the next step's encoder")
+            del feats_
     for tag_ in [t for t in probe.ev if t[0] in ("merge_refine", "merge")]:
         ms_, n_ = probe.mean_ms(tag_)
         kernels[tag_[0]] = {"kernel": "fgvc_merge_refine_topk_f32" if tag_[0] == "merge_refine" else "fgvc_merge_topk_f32", "ms_per_launch": ms_,
