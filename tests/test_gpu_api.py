@@ -730,3 +730,44 @@ def test_two_ranks_one_gpu_hip_backend(dev, two_ranks):
         assert set(r) == {"exchange", "exchange+tail", "exchange+tail_from_pairs"}
         for v in r.values():
             assert v["order_equal"] and v["finite"] and v["max_abs_diff_px"] < 1e-3 and v["halo_early"] == 1
+
+
+def test_pipelined_videos_equal_videos_run_one_at_a_time(dev):
+    """Round 6: `HipBackend(tail_from="pairs")` (the default) lets the NEXT video's encoder start under this video's pair top-k, merge and
+    sweep.  The bench feeds the same clip every step, so a race between one video's side-stream work and the next video's encoder -- the
+    bank, the pair lists, the encoder's cached workspaces -- would not show there.  Here: nine DIFFERENT videos of three shapes enqueued back to
+    back without a synchronisation, trajectories read at the end, against the same videos run one at a time on the caller's stream
+    (no side stream): equal bit for bit.  Twice (the second round runs on cached schedules and recycled allocations)."""
+    import fgvc_amd.mmpt_api as api
+    from fgvc_amd import dist as fdist
+    torch.manual_seed(11)
+    model = api.build_model(dict(type="VanillaTracker", backbone=dict(type="ResNet", depth=18, strides=(1, 2, 1, 1), out_indices=(2,), pool_type="none")),
+                            train_cfg=None, test_cfg=api.ConfigDict(precede_frames=5, topk=10, temperature=0.07, neighbor_range=30,
+                                                                    with_first=True, with_first_neighbor=True)).to(dev).eval()
+    cfg = model.engine_config()
+    g = torch.Generator().manual_seed(3)
+    videos = []
+    for i in range(9):                                                        # ... and three at the bench's size, where the encoder is the long part
+        T_, h, w = (8, 480, 854) if i >= 6 else (8, 96, 128) if i % 2 == 0 else (6, 128, 96)
+        rgbs = (torch.rand(T_, 3, h, w, generator=g) * 255).to(dev)
+        pts = torch.stack([torch.zeros(5), torch.rand(5, generator=g) * (w - 1), torch.rand(5, generator=g) * (h - 1)], -1).to(dev)      # (t, x, y)
+        videos.append((rgbs, pts))
+    serial_be = fdist.HipBackend(model)                                       # no side stream: everything on the caller's stream
+    want = []
+    for rgbs, qp in videos:
+        traj, order = fdist.track_points_sharded(serial_be, rgbs, qp, cfg, device=dev)
+        torch.cuda.synchronize()
+        want.append((traj.clone(), order))
+    for tail_from in ("pairs", "sweep"):
+        be = fdist.HipBackend(model, tail_stream=torch.cuda.Stream(dev), tail_from=tail_from)
+        caches = [dict() for _ in videos]
+        for rnd in range(2):
+            got = []
+            for (rgbs, qp), cache in zip(videos, caches):                     # enqueued back to back: no synchronisation in between
+                traj, order = fdist.track_points_sharded(be, rgbs, qp, cfg, device=dev, cache=cache, check=False)
+                got.append((traj, order))
+            torch.cuda.synchronize()
+            for i, ((t, o), (tw, ow)) in enumerate(zip(got, want)):
+                assert torch.equal(torch.as_tensor(o).cpu(), torch.as_tensor(ow).cpu()), (tail_from, rnd, i)
+                assert torch.equal(t, tw), (tail_from, rnd, i, float((t - tw).abs().max()))
+    assert not any(be.failure_flags()) if hasattr(be, "failure_flags") else True
