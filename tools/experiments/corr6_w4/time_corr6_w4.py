@@ -3,7 +3,7 @@
     python tools/experiments/time_corr6_w4.py [HxW]"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from fgvc_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 shapes = [(37, 53), (120, 214)] if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1].split("x"))]
