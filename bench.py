@@ -971,6 +971,11 @@ def _driver_view(out):
         assert len(new) <= 24, len(new)
         out["roofline_notes"] = {k: v for k, v in r.items() if k not in new}
         out["roofline"] = new
+    # (what the timed region overlaps, and one step alone, where the driver keeps them)
+    out.setdefault("config", {}).update(steps_overlap=("next step's encoder under this step's pair top-k, merge and sweep (side stream); all steps "
+                                                       "complete before the closing barrier" if out.get("steps_overlap") and "pair top-k" in out["steps_overlap"]
+                                                       else "next step's encoder under this step's merge and sweep" if out.get("steps_overlap") else "none"),
+                                        single_step_latency_ms=out.get("single_step_latency_ms"))
     d = out.get("distributed") or {}
     out.setdefault("config", {}).update(world_size=d.get("world_size"), distinct_devices=d.get("distinct_devices", 1 if d.get("world_size") == 1 else None),
                                         rccl_version=d.get("rccl_version"), backend=d.get("backend"))
